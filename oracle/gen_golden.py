@@ -1,0 +1,204 @@
+"""Pin the oracle against the reference and write the golden vectors.
+
+TEST INFRASTRUCTURE -- BUILD CONTAINER ONLY (needs /root/reference).
+
+    python oracle/gen_golden.py [--skip-base]
+
+For each case the *reference's own* ``models/segofa`` code (imported through
+``oracle/_refshim.py``) and the restatement ``oracle/segofa_ref.py`` are given
+the same procedural weights (``procedural_state_dict``) and the same seeded
+inputs (``synthetic_batch``); the script asserts they agree to fp32 round-off
+and then stores the REFERENCE's outputs as the golden vectors:
+
+  tests/golden/fixture_train.npz   small config, B=2, causal + full-context
+                                   logits, bilinear-upsampled CE loss (computed by
+                                   the reference's SegCriterion.compute_loss),
+                                   area histograms, selected parameter grads
+  tests/golden/fixture_resize.npz  small config, 64x96 image (P=24 > orig 16):
+                                   the double-bilinear rel-pos resize path, eval
+  tests/golden/base_c1.npz         SegOFA-Base, B=1, 512x512, nseg 15, L=36
+                                   (BASELINE config 1 shapes): logits, loss,
+                                   grad norms
+
+Only data (inputs are regenerated from seeds; outputs are arrays) is written.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refshim  # noqa: E402
+import segofa_ref as O  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+GRAD_KEYS = [
+    "encoder.layers.0.self_attn.q_proj.weight",
+    "encoder.layers.0.self_attn.c_attn",
+    "encoder.layers.1.fc1.bias",
+    "encoder.image_rel_pos_table_list.0.weight",
+    "encoder.token_rel_pos_table_list.1.weight",
+    "encoder.pos_q_linear.weight",
+    "encoder.type_embedding.weight",
+    "encoder.layers.0.ffn_layernorm.weight",
+    "decoder.seg_rel_pos_table_list.0.weight",
+    "decoder.cross_pos_k_linear.weight",
+    "decoder.layers.1.encoder_attn.v_proj.weight",
+    "decoder.layers.0.self_attn_ln.bias",
+    "decoder.layer_norm.weight",
+    "decoder.embed_seg_positions.weight",
+]
+
+
+def build_reference(cfg, arch, overrides=None):
+    model, args = _refshim.build_reference_model(
+        arch, cfg.num_seg_tokens, cfg.vocab_size - 1, cfg.patch_image_size,
+        cfg.orig_patch_image_size, overrides)
+    sd = O.procedural_state_dict(cfg, seed=0)
+    ref_keys = set(model.state_dict().keys())
+    derived = {k for k in ref_keys if k.endswith(("_rp_bucket", ".version", "image_position_idx",
+                                                  "bin_id_offset", "seg_id_offset", "region_prefix"))}
+    assert ref_keys - derived == set(sd.keys()), (
+        sorted(ref_keys - derived - set(sd.keys()))[:10], sorted(set(sd.keys()) - (ref_keys - derived))[:10])
+    for k, v in model.state_dict().items():
+        if k in sd:
+            assert tuple(v.shape) == tuple(sd[k].shape), (k, v.shape, sd[k].shape)
+    missing, unexpected = torch.nn.Module.load_state_dict(model, sd, strict=False)
+    assert not unexpected and set(missing) <= derived, (missing, unexpected)
+    # bucket tables: the restatement's generators must reproduce the reference's buffers
+    rsd = model.state_dict()
+    n_img = (2 * cfg.image_bucket_size - 1) ** 2 + 3
+    assert torch.equal(rsd["encoder.image_rp_bucket"], O.make_image_bucket_position(cfg.image_bucket_size, n_img))
+    assert torch.equal(rsd["encoder.token_rp_bucket"], O.make_token_bucket_position(cfg.token_bucket_size))
+    sb = cfg.seg_bucket_size
+    assert torch.equal(rsd["decoder.seg_rp_bucket"], O.make_image_bucket_position(sb, (2 * sb - 1) ** 2 + 3))
+    return model, sd
+
+
+def build_criterion(cfg):
+    from criterions.seg_criterion import SegCriterion
+
+    class _Cfg:
+        num_seg_tokens = cfg.num_seg_tokens
+        category_list = ",".join("c%d" % i for i in range(cfg.num_seg_tokens))
+
+    d = _refshim.FakeDictionary(cfg.vocab_size - 1, cfg.num_seg_tokens)
+
+    class _Task:
+        cfg = _Cfg()
+        target_dictionary = d
+        tgt_dict = d
+
+    return SegCriterion(_Task(), sentence_avg=False, label_smoothing=0.0,
+                        unsupervised_segmentation="false", init_seg_with_text="false")
+
+
+def ref_forward(model, batch, full_ctx):
+    B, L = batch["src_tokens"].shape
+    return model(src_tokens=batch["src_tokens"], src_lengths=torch.full((B,), L),
+                 prev_output_tokens=batch["prev_output_tokens"], patch_images=batch["patch_images"],
+                 patch_masks=batch["patch_masks"], full_context_alignment=full_ctx)
+
+
+def oracle_train(cfg, sd, batch, grad_keys):
+    sdg = {k: v.clone() for k, v in sd.items()}
+    # restore aliases
+    for name, (_, kind) in O.state_dict_spec(cfg).items():
+        if kind.startswith("alias:"):
+            sdg[name] = sdg[kind[6:]]
+    for k in grad_keys:
+        sdg[k].requires_grad_(True)
+    logits, extra = O.segofa_forward(sdg, cfg, batch["src_tokens"], batch["patch_images"],
+                                     batch["prev_output_tokens"], batch["patch_masks"], False)
+    hp, wp = extra["encoder_returns"]["image_embed_shape"]
+    h, w = batch["patch_images"].shape[-2:]
+    loss, s, t = O.seg_loss(cfg, logits, batch["target"], hp, wp, h, w)
+    loss.backward()
+    return logits.detach(), loss.detach(), {k: sdg[k].grad for k in grad_keys}, O.seg_metric(s.detach(), t, cfg.num_seg_tokens)
+
+
+def case_train(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys, full_grads=True):
+    t0 = time.time()
+    model, sd = build_reference(cfg, arch, overrides)
+    crit = build_criterion(cfg)
+    batch = O.synthetic_batch(cfg, batch_size, src_len)
+    model.train()
+    params = dict(model.named_parameters())
+    for k in grad_keys:
+        params[k].requires_grad_(True)
+    out = ref_forward(model, batch, False)
+    sample = {"target": batch["target"], "net_input": {"patch_images": batch["patch_images"]}}
+    loss, metrics, _ = crit.compute_loss(model, out, sample, 0)
+    loss.backward()
+    ref_logits = out[0].detach()
+    with torch.no_grad():
+        ref_full = ref_forward(model, batch, True)[0]
+    print("[%s] reference done %.1fs loss=%.9f" % (out_name, time.time() - t0, loss.item()))
+
+    o_logits, o_loss, o_grads, o_metric = oracle_train(cfg, sd, batch, grad_keys)
+    with torch.no_grad():
+        o_full = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"], None,
+                                  batch["patch_masks"], True)[0]
+    err = (o_logits - ref_logits).abs().max().item()
+    errf = (o_full - ref_full).abs().max().item()
+    print("  oracle vs reference: logits max-abs %.3e (full-ctx %.3e)  loss diff %.3e"
+          % (err, errf, abs(o_loss.item() - loss.item())))
+    assert err <= 2e-5 and errf <= 2e-5, "oracle != reference"
+    assert abs(o_loss.item() - loss.item()) <= 2e-6
+    save = {"logits_causal": ref_logits.numpy(), "logits_full": ref_full.numpy(),
+            "loss": np.float64(loss.item()),
+            "batch_size": batch_size, "src_len": src_len}
+    for name in ("area_intersect", "area_pred_label", "area_label", "area_union"):
+        save[name] = metrics[name].numpy()
+    for a, b in zip(o_metric, (metrics["area_intersect"], metrics["area_pred_label"],
+                               metrics["area_label"], metrics["area_union"])):
+        assert torch.equal(a, b), "metric histograms differ"
+    for k in grad_keys:
+        g_ref = params[k].grad
+        g_o = o_grads[k]
+        rel = ((g_o - g_ref).norm() / (g_ref.norm() + 1e-30)).item()
+        print("  grad %-52s rel-L2 %.2e  |g|=%.4e" % (k, rel, g_ref.norm().item()))
+        assert rel <= 2e-5, k
+        save["gradnorm:" + k] = np.float64(g_ref.norm().item())
+        if full_grads or g_ref.numel() <= 16384:
+            save["grad:" + k] = g_ref.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, out_name), **save)
+    print("  wrote", out_name, "%.1fs" % (time.time() - t0))
+
+
+def case_resize(cfg, arch, overrides, out_name):
+    model, sd = build_reference(cfg, arch, overrides)
+    model.eval()
+    batch = O.synthetic_batch(cfg, 1, 12, image_hw=(64, 96), seed=4321)
+    with torch.no_grad():
+        ref = ref_forward(model, batch, False)[0]
+        ora = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"], None, batch["patch_masks"], False)[0]
+    err = (ora - ref).abs().max().item()
+    print("[%s] oracle vs reference logits max-abs %.3e  shape %s" % (out_name, err, tuple(ref.shape)))
+    assert err <= 2e-5
+    np.savez_compressed(os.path.join(GOLDEN, out_name), logits_causal=ref.numpy(), image_hw=np.array([64, 96]),
+                        seed=4321, src_len=12)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-base", action="store_true")
+    a = ap.parse_args()
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.manual_seed(0)
+    fx = O.fixture_config()
+    ov = dict(encoder_embed_dim=fx.embed_dim, encoder_ffn_embed_dim=fx.ffn_dim, encoder_layers=fx.enc_layers,
+              decoder_layers=fx.dec_layers, encoder_attention_heads=fx.heads, decoder_attention_heads=fx.heads)
+    case_train(fx, "tiny", ov, 2, 12, "fixture_train.npz", GRAD_KEYS)
+    case_resize(fx, "tiny", ov, "fixture_resize.npz")
+    if not a.skip_base:
+        case_train(O.base_config(), "base", None, 1, 36, "base_c1.npz", GRAD_KEYS, full_grads=False)
+
+
+if __name__ == "__main__":
+    main()

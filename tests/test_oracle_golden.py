@@ -1,0 +1,107 @@
+"""CPU: the oracle restatement against the reference-generated golden vectors.
+
+The vectors in tests/golden/*.npz are the REFERENCE's outputs (produced by
+oracle/gen_golden.py importing /root/reference in the build container); the
+oracle regenerates weights and inputs procedurally and must reproduce them.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import segofa_ref as O
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_fixture_logits_loss_and_grads(golden_dir):
+    g = _load(golden_dir, "fixture_train.npz")
+    cfg = O.fixture_config()
+    sd = O.procedural_state_dict(cfg)
+    batch = O.synthetic_batch(cfg, int(g["batch_size"]), int(g["src_len"]))
+    keys = [k[5:] for k in g.files if k.startswith("grad:")]
+    sd = dict(sd)
+    for k in keys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    logits, extra = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"], None, batch["patch_masks"], False)
+    hp, wp = extra["encoder_returns"]["image_embed_shape"]
+    loss, s, t = O.seg_loss(cfg, logits, batch["target"], hp, wp, 64, 64)
+    loss.backward()
+    assert np.abs(logits.detach().numpy() - g["logits_causal"]).max() <= 1e-5
+    assert abs(loss.item() - float(g["loss"])) <= 1e-6
+    for k in keys:
+        ref = torch.from_numpy(g["grad:" + k])
+        rel = (sd[k].grad - ref).norm() / ref.norm()
+        assert rel <= 1e-5, (k, rel)
+    ai, ap, al, au = O.seg_metric(s.detach(), t, cfg.num_seg_tokens)
+    assert np.array_equal(ai.numpy(), g["area_intersect"])
+    assert np.array_equal(ap.numpy(), g["area_pred_label"])
+    assert np.array_equal(al.numpy(), g["area_label"])
+    assert np.array_equal(au.numpy(), g["area_union"])
+    with torch.no_grad():
+        full = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"], None, batch["patch_masks"], True)[0]
+    assert np.abs(full.numpy() - g["logits_full"]).max() <= 1e-5
+    # causal and full-context must genuinely differ (mask is exercised)
+    assert np.abs(g["logits_full"] - g["logits_causal"]).max() > 1e-3
+
+
+def test_fixture_resize_path(golden_dir):
+    """P != orig grid: positional-embedding + double-bilinear rel-pos resize
+    (encoder_module.py:360-368,802-808; decoder_module.py:541-548,603-627)."""
+    g = _load(golden_dir, "fixture_resize.npz")
+    cfg = O.fixture_config()
+    sd = O.procedural_state_dict(cfg)
+    hw = tuple(int(v) for v in g["image_hw"])
+    batch = O.synthetic_batch(cfg, 1, int(g["src_len"]), image_hw=hw, seed=int(g["seed"]))
+    with torch.no_grad():
+        logits = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"], None, batch["patch_masks"], False)[0]
+    assert logits.shape == (1, (hw[0] // 16) * (hw[1] // 16) + 1, cfg.num_seg_tokens)
+    assert np.abs(logits.numpy() - g["logits_causal"]).max() <= 1e-5
+
+
+def test_bucket_tables_closed_form():
+    """The image bucket index is closed-form in (dy, dx) -- what the HIP kernels
+    compute in-register instead of reading an index tensor."""
+    for b in (4, 32, 42):
+        n = (2 * b - 1) ** 2 + 3
+        t = O.make_image_bucket_position(b, n)
+        ys, xs = torch.meshgrid(torch.arange(b), torch.arange(b), indexing="ij")
+        pid = (xs + ys * b + 1).reshape(-1)
+        yi, xi = ys.reshape(-1), xs.reshape(-1)
+        closed = (yi[:, None] - yi[None, :] + b - 1) * (2 * b - 1) + (xi[:, None] - xi[None, :] + b - 1)
+        assert torch.equal(t[pid][:, pid], closed)
+        assert (t[0, 1:] == n - 3).all() and (t[1:, 0] == n - 2).all() and t[0, 0] == n - 1
+    tok = O.make_token_bucket_position(256)
+    i = torch.arange(300)
+    d = i[:, None] - i[None, :]
+    near = d.abs() <= 128
+    assert torch.equal(tok[:300, :300][near], (d + 255)[near])
+    assert tok.min() >= 0 and tok.max() <= 510
+
+
+def test_padding_mask_changes_only_padded_keys():
+    cfg = O.fixture_config()
+    sd = O.procedural_state_dict(cfg)
+    batch = O.synthetic_batch(cfg, 2, 12)
+    src = batch["src_tokens"].clone()
+    src[1, -3:] = O.PAD
+    with torch.no_grad():
+        a = O.segofa_forward(sd, cfg, src, batch["patch_images"])[0]
+    assert torch.isfinite(a).all()
+
+
+@pytest.mark.slow
+def test_base_config1_against_reference(golden_dir):
+    """BASELINE config 1 shapes (B=1 here to stay in CPU-minutes): Base, 512x512, nseg 15."""
+    g = _load(golden_dir, "base_c1.npz")
+    cfg = O.base_config()
+    sd = O.procedural_state_dict(cfg)
+    batch = O.synthetic_batch(cfg, 1, int(g["src_len"]))
+    with torch.no_grad():
+        logits, extra = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"])
+        loss, _, _ = O.seg_loss(cfg, logits, batch["target"], 32, 32, 512, 512)
+    assert np.abs(logits.numpy() - g["logits_causal"]).max() <= 1e-4
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5
