@@ -1,0 +1,790 @@
+// Fused position-biased attention for SegOFA on gfx950 (forward + backward).
+//
+// Reference semantics (unify_multihead_attention.py:346,459-501 and the bias
+// construction in encoder_module.py:757-809 / decoder_module.py:335-366,601-631):
+//     S = (q*scaling) k^T + abs_pos_bias + rel_pos_bias (+ causal -inf mask)
+//     P = softmax_fp32(S);  O = P v
+// where abs_pos_bias[h] = (pos_q*pos_scaling) pos_k^T is batch invariant and
+// rel_pos_bias[h,i,j] = table[bucket(i,j), h].
+//
+// MI355X formulation: the abs-pos term is folded into the contraction,
+// S = [q | pos_q] . [k | pos_k]^T (head dim 64 -> 128), so neither the [H,T,S]
+// bias nor the [B*H,T,S] scores ever exist in HBM, and its gradient falls out of
+// the same dQ/dK MFMAs.  The rel-pos term is a per-head delta table held in LDS
+// and indexed arithmetically (image grid: code_i - code_j; text: i - j).
+// Everything is computed "swapped" (S^T = K Q^T, O^T = V^T P^T) so that a query
+// row lives in one lane: softmax statistics are per-lane scalars, P feeds the
+// second MFMA straight from registers, and V / K are consumed through
+// ds_read_b64_tr_b16 with a free choice of key order.
+//
+// Token order inside a sequence: [grid tokens 0..P-1 | tail tokens P..T-1].
+// Encoder: grid = image patches, tail = text.  Decoder: grid = patches, tail =
+// the single bos token (the host permutes bos to the end; `causal` uses
+// "tail-first" original order: a tail key is visible to every grid query).
+#include "common.h"
+#include "../../include/ifseg_hip.h"
+
+namespace {
+
+struct AttnArgs {
+  const bf16_t *q, *k, *v, *pq, *pk;
+  bf16_t* o;
+  float* lse;
+  int B, H, T, S;
+  long long q_bs, k_bs, v_bs, o_bs;
+  int ldq, ldk, ldv, ldo, ldpq, ldpk;
+  int rel_mode, P, code_bias, n2d, Lt, causal;
+  const int* gcode;
+  const float *rel2d, *rel1d, *relx, *dense;
+  // backward
+  const bf16_t* dO; long long do_bs; int lddo;
+  const float* delta;
+  bf16_t *dq, *dk, *dv; long long dq_bs, dk_bs, dv_bs; int lddq, lddk, lddv;
+  float *dpq, *dpk;          // [B, T, H*64] / [B, S, H*64] fp32 per-batch partials
+  float *drel2d_part, *drel1d_part, *drelx_part;  // [H][nparts][n]
+  int nparts;
+  const float* gain;          // [H] per-head output gain c_attn (may be null)
+  float dq_scale, dpq_scale;
+};
+
+constexpr int KT_BYTES = 64 * 256;  // K_ext tile  [64 keys][128] bf16
+constexpr int VT_BYTES = 64 * 128;  // V tile      [64 keys][64]  bf16
+constexpr float NEG_INF = -INFINITY;
+
+// K_ext tile: 256-byte rows, 16-byte chunk c (0..15) XOR (row & 15)
+__device__ __forceinline__ int kx_off(int r, int c) { return r * 256 + ((c ^ (r & 15)) << 4); }
+// V tile: 128-byte rows; 64-byte halves swapped on rows with bit1 set (tr-read bank spread)
+__device__ __forceinline__ int vx_off(int r, int colbyte) { return r * 128 + (colbyte ^ (((r >> 1) & 1) << 6)); }
+
+struct RelCtx {
+  const float* tbl;   // LDS copy of rel2d[h]
+  const int* gc;      // LDS copy of gcode
+  const float* rel1d; // global, rel1d[h]
+  float relx0, relx1;
+};
+
+// ---------------------------------------------------------------- forward
+template <bool HAS_POS>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  auto sKb = [&](int buf) { return smem + buf * (KT_BYTES + VT_BYTES); };
+  auto sVb = [&](int buf) { return smem + buf * (KT_BYTES + VT_BYTES) + KT_BYTES; };
+  float* sTbl = reinterpret_cast<float*>(smem + 2 * (KT_BYTES + VT_BYTES));
+  int* sGc = reinterpret_cast<int*>(sTbl + ((a.n2d + 3) & ~3));
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int nq = (a.T + 127) >> 7;
+  const int bid = xcd_remap(blockIdx.x, nq * a.H * a.B);
+  const int qt = bid % nq, h = (bid / nq) % a.H, b = bid / (nq * a.H);
+  const int q0 = qt * 128, qw = q0 + wave * 32;
+  const int qi = qw + (lane & 31);           // this lane's query row
+  const bool qvalid = qi < a.T;
+  const int qrow = qvalid ? qi : a.T - 1;
+  constexpr int NKS = HAS_POS ? 8 : 4;
+
+  // ---- Q_ext fragments (B operand of S^T = K Q^T): lane holds Q[qi][ks*16 + half*8 .. +8]
+  bf16x8 qf[NKS];
+  {
+    const bf16_t* qp = a.q + (long long)b * a.q_bs + (long long)qrow * a.ldq + h * 64 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { U128 u; u.v = *reinterpret_cast<const uint4*>(qp + ks * 16); qf[ks] = u.b; }
+    if (HAS_POS) {
+      const bf16_t* pp = a.pq + (long long)qrow * a.ldpq + h * 64 + half * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { U128 u; u.v = *reinterpret_cast<const uint4*>(pp + ks * 16); qf[4 + ks] = u.b; }
+    }
+  }
+  // ---- rel-pos tables into LDS
+  if (a.rel_mode) {
+    for (int i = tid; i < a.n2d; i += 256) sTbl[i] = a.rel2d[(long long)h * a.n2d + i];
+    for (int i = tid; i < a.P; i += 256) sGc[i] = a.gcode[i];
+  }
+  const bool q_grid = a.rel_mode && qi < a.P;
+  const int ci = q_grid ? a.gcode[qi] + a.code_bias : 0;
+  const int ti = qi - a.P;
+  const float relx0 = a.rel_mode ? a.relx[h * 2 + 0] : 0.f, relx1 = a.rel_mode ? a.relx[h * 2 + 1] : 0.f;
+  const float* rel1d = a.rel_mode ? a.rel1d + (long long)h * (2 * a.Lt - 1) + (a.Lt - 1) : nullptr;
+
+  // ---- tile schedule (causal: skip grid tiles wholly above the diagonal)
+  const int ntile = (a.S + 63) >> 6;
+  const int Pk = a.rel_mode || a.causal ? a.P : a.S;        // keys < Pk are "grid" keys
+  const int ngrid = Pk >> 6;                                 // P % 64 == 0 enforced by the host
+  int g_end = ngrid;
+  if (a.causal) {
+    int imax = (q0 < a.P) ? min(q0 + 127, a.P - 1) : -1;
+    g_end = imax >= 0 ? min(ngrid, (imax >> 6) + 1) : 0;
+  }
+  const int nsched = g_end + (ntile - ngrid);
+  auto tile_of = [&](int it) { return it < g_end ? it : ngrid + (it - g_end); };
+
+  // ---- staging registers
+  uint4 rk[4], rv[2];
+  const bf16_t* kb_ = a.k + (long long)b * a.k_bs + h * 64;
+  const bf16_t* vb_ = a.v + (long long)b * a.v_bs + h * 64;
+  const bf16_t* pkb_ = HAS_POS ? a.pk + h * 64 : nullptr;
+  auto load_kv = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (tid >> 3) + 32 * i, c = tid & 7, j = j0 + r;
+      rk[i] = make_uint4(0, 0, 0, 0); rk[2 + i] = make_uint4(0, 0, 0, 0); rv[i] = make_uint4(0, 0, 0, 0);
+      if (j < a.S) {
+        rk[i] = *reinterpret_cast<const uint4*>(kb_ + (long long)j * a.ldk + c * 8);
+        if (HAS_POS) rk[2 + i] = *reinterpret_cast<const uint4*>(pkb_ + (long long)j * a.ldpk + c * 8);
+        rv[i] = *reinterpret_cast<const uint4*>(vb_ + (long long)j * a.ldv + c * 8);
+      }
+    }
+  };
+  auto store_kv = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (tid >> 3) + 32 * i, c = tid & 7;
+      *reinterpret_cast<uint4*>(sKb(buf) + kx_off(r, c)) = rk[i];
+      if (HAS_POS) *reinterpret_cast<uint4*>(sKb(buf) + kx_off(r, 8 + c)) = rk[2 + i];
+      *reinterpret_cast<uint4*>(sVb(buf) + vx_off(r, c * 16)) = rv[i];
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
+  float m_run = NEG_INF, l_run = 0.f;
+
+  if (nsched > 0) { load_kv(tile_of(0) * 64); store_kv(0); }
+  __syncthreads();
+
+  for (int it = 0; it < nsched; ++it) {
+    const int cur = it & 1;
+    const int j0 = tile_of(it) * 64;
+    if (it + 1 < nsched) load_kv(tile_of(it + 1) * 64);
+    const bool tile_grid = j0 < Pk;
+    // wave-level causal skip: every key of a grid tile is beyond every query of this wave
+    const bool skip = a.causal && tile_grid && (j0 > qw + 31 || qw >= a.P);
+    if (!skip) {
+      f32x16 s[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          bf16x8 kf = lds_read_b128(sKb(cur) + kx_off(kb * 32 + (lane & 31), ks * 2 + half));
+          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+        }
+      }
+      // ---- bias + mask ; lane element (kb, r) <-> key j0 + kb*32 + (r&3) + 8*(r>>2) + 4*half
+      float mx = NEG_INF;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int jb = j0 + kb * 32 + 8 * rg + 4 * half;
+          int4 cj = make_int4(0, 0, 0, 0);
+          if (a.rel_mode && tile_grid) cj = *reinterpret_cast<const int4*>(sGc + jb);
+          const int cjs[4] = {cj.x, cj.y, cj.z, cj.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int j = jb + e;
+            float sv = s[kb][rg * 4 + e];
+            if (a.rel_mode) {
+              float bias;
+              if (tile_grid) bias = q_grid ? sTbl[ci - cjs[e]] : relx1;
+              else bias = q_grid ? relx0 : ((j < a.S && qvalid) ? rel1d[ti - (j - a.P)] : 0.f);
+              sv += bias;
+            }
+            if (a.dense && j < a.S) sv += a.dense[((long long)h * a.T + qrow) * a.S + j];
+            bool masked = j >= a.S;
+            if (a.causal) {
+              if (tile_grid) masked |= (qi >= a.P) || (j > qi);
+              else masked |= (qi >= a.P) && (j > qi);
+            }
+            sv = masked ? NEG_INF : sv;
+            s[kb][rg * 4 + e] = sv;
+            mx = fmaxf(mx, sv);
+          }
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+      const float alpha = __expf(m_run - m_use);   // m_run = -inf -> 0
+      float psum = 0.f;
+      bf16x8 pf[2][2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          U128 u;
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            float p0 = __expf(s[kb][s2 * 8 + e] - m_use), p1 = __expf(s[kb][s2 * 8 + e + 1] - m_use);
+            psum += p0 + p1;
+            u.w[e >> 1] = pack2bf(p0, p1);
+          }
+          pf[kb][s2] = u.b;
+        }
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
+      // ---- O^T += V^T P^T ; slot (kh, e) <-> key kb*32 + 16*s2 + 4*kh + (e&3) + 8*(e>>2)
+      const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const int colb = (db * 32 + g16 * 16 + (i16 & 3) * 4) * 2;
+            const int r0 = kb * 32 + 16 * s2 + 4 * half + (i16 >> 2);
+            U64 x, y;
+            x.s = lds_read_tr(sVb(cur) + vx_off(r0, colb));
+            y.s = lds_read_tr(sVb(cur) + vx_off(r0 + 8, colb));
+            U128 vf; vf.w[0] = x.w[0]; vf.w[1] = x.w[1]; vf.w[2] = y.w[0]; vf.w[3] = y.w[1];
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.b, pf[kb][s2], oacc[db], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (it + 1 < nsched) store_kv(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- finalize: lane (q, half) holds O[q][d = db*32 + (r&3) + 8*(r>>2) + 4*half]
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = (l_tot > 0.f ? 1.f / l_tot : 0.f) * (a.gain ? a.gain[h] : 1.f);
+  if (qvalid) {
+    bf16_t* op = a.o + (long long)b * a.o_bs + (long long)qi * a.ldo + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d = db * 32 + 8 * rg + 4 * half;
+        *reinterpret_cast<uint2*>(op + d) =
+            make_uint2(pack2bf(oacc[db][rg * 4] * inv, oacc[db][rg * 4 + 1] * inv),
+                       pack2bf(oacc[db][rg * 4 + 2] * inv, oacc[db][rg * 4 + 3] * inv));
+      }
+    if (half == 0) a.lse[((long long)b * a.H + h) * a.T + qi] = m_run + __logf(l_tot);
+  }
+}
+
+
+// ---------------------------------------------------------------- backward
+// Shared element logic: bias value for (query i, key j) is needed only to
+// recompute P; the gradient of the bias goes to LDS histograms.
+//
+// (1) dK/dV kernel: one workgroup owns 128 keys (wave = 32 keys, lane = key) and
+//     streams 64-query tiles of Q_ext / dO / lse / delta through LDS.
+//       S[q,key]  = Q_ext K_ext^T          (A = Q tile b128 reads, B = K regs)
+//       dP[q,key] = dO V^T                 (A = dO tile,           B = V regs)
+//       dS = P (gain*dP - delta)
+//       dV^T[d,key]   += dO^T P            (A = dO tile tr-reads,  B = P regs)
+//       dK^T[c,key]   += Q_ext^T dS        (A = Q tile tr-reads,   B = dS regs)
+//     so the key stays in the lane for S, P, dS and both accumulators.
+template <bool HAS_POS>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int STAGE = KT_BYTES + VT_BYTES + 512;   // Q tile, dO tile, lse[64], delta[64]
+  auto sQb = [&](int buf) { return smem + buf * STAGE; };
+  auto sOb = [&](int buf) { return smem + buf * STAGE + KT_BYTES; };
+  auto sLb = [&](int buf) { return reinterpret_cast<float*>(smem + buf * STAGE + KT_BYTES + VT_BYTES); };
+  float* sHist = reinterpret_cast<float*>(smem + 2 * STAGE);
+  const int n2dp = (a.n2d + 3) & ~3, n1d = a.rel_mode ? 2 * a.Lt - 1 : 0, n1dp = (n1d + 3) & ~3;
+  float* sHist1 = sHist + n2dp;
+  float* sX = sHist1 + n1dp;          // 4 floats: relx0, relx1 accumulators
+  int* sGc = reinterpret_cast<int*>(sX + 4);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int nkt = (a.S + 127) >> 7;
+  const int bid = xcd_remap(blockIdx.x, nkt * a.H * a.B);
+  const int kt = bid % nkt, h = (bid / nkt) % a.H, b = bid / (nkt * a.H);
+  const int k0 = kt * 128, kw = k0 + wave * 32;
+  const int kj = kw + (lane & 31);
+  const bool kvalid = kj < a.S;
+  const int krow = kvalid ? kj : a.S - 1;
+  constexpr int NKS = HAS_POS ? 8 : 4;
+  const float gain = a.gain ? a.gain[h] : 1.f;
+
+  bf16x8 kf[NKS], vf[4];
+  {
+    const bf16_t* kp = a.k + (long long)b * a.k_bs + (long long)krow * a.ldk + h * 64 + half * 8;
+    const bf16_t* vp = a.v + (long long)b * a.v_bs + (long long)krow * a.ldv + h * 64 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      U128 u; u.v = *reinterpret_cast<const uint4*>(kp + ks * 16); kf[ks] = u.b;
+      U128 w; w.v = *reinterpret_cast<const uint4*>(vp + ks * 16); vf[ks] = w.b;
+    }
+    if (HAS_POS) {
+      const bf16_t* pp = a.pk + (long long)krow * a.ldpk + h * 64 + half * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { U128 u; u.v = *reinterpret_cast<const uint4*>(pp + ks * 16); kf[4 + ks] = u.b; }
+    }
+  }
+  if (a.rel_mode) {
+    for (int i = tid; i < n2dp + n1dp + 4; i += 256) sHist[i] = 0.f;
+    for (int i = tid; i < a.P; i += 256) sGc[i] = a.gcode[i];
+  }
+  const bool k_grid = kj < a.P;
+  const int cj = (a.rel_mode && k_grid) ? a.gcode[kj] - a.code_bias : 0;   // idx = ci - cj
+  const int tj = kj - a.P;
+  const float* rel2d = a.rel_mode ? a.rel2d + (long long)h * a.n2d : nullptr;
+  const float* rel1d = a.rel_mode ? a.rel1d + (long long)h * n1d + (a.Lt - 1) : nullptr;
+  const float relx0 = a.rel_mode ? a.relx[h * 2 + 0] : 0.f, relx1 = a.rel_mode ? a.relx[h * 2 + 1] : 0.f;
+  float gx0 = 0.f, gx1 = 0.f;
+
+  // ---- q-tile schedule
+  const int nqt = (a.T + 63) >> 6;
+  int qs = 0, qe = nqt;
+  if (a.causal && k0 < a.P) { qs = k0 >> 6; qe = (k0 + 127 < a.P) ? (a.P >> 6) : nqt; }
+  const int nsched = qe - qs;
+
+  uint4 rq[4], ro[2];
+  float rl = 0.f, rd = 0.f;
+  const bf16_t* qb_ = a.q + (long long)b * a.q_bs + h * 64;
+  const bf16_t* pqb_ = HAS_POS ? a.pq + h * 64 : nullptr;
+  const bf16_t* dob_ = a.dO + (long long)b * a.do_bs + h * 64;
+  const float* lseb = a.lse + ((long long)b * a.H + h) * a.T;
+  const float* delb = a.delta + ((long long)b * a.H + h) * a.T;
+  auto load_q = [&](int i0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (tid >> 3) + 32 * i, c = tid & 7, qi = i0 + r;
+      rq[i] = make_uint4(0, 0, 0, 0); rq[2 + i] = make_uint4(0, 0, 0, 0); ro[i] = make_uint4(0, 0, 0, 0);
+      if (qi < a.T) {
+        rq[i] = *reinterpret_cast<const uint4*>(qb_ + (long long)qi * a.ldq + c * 8);
+        if (HAS_POS) rq[2 + i] = *reinterpret_cast<const uint4*>(pqb_ + (long long)qi * a.ldpq + c * 8);
+        ro[i] = *reinterpret_cast<const uint4*>(dob_ + (long long)qi * a.lddo + c * 8);
+      }
+    }
+    if (tid < 64) { const int qi = i0 + tid; rl = qi < a.T ? lseb[qi] : INFINITY; }
+    else if (tid < 128) { const int qi = i0 + tid - 64; rd = qi < a.T ? delb[qi] : 0.f; }
+  };
+  auto store_q = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (tid >> 3) + 32 * i, c = tid & 7;
+      *reinterpret_cast<uint4*>(sQb(buf) + kx_off(r, c)) = rq[i];
+      if (HAS_POS) *reinterpret_cast<uint4*>(sQb(buf) + kx_off(r, 8 + c)) = rq[2 + i];
+      *reinterpret_cast<uint4*>(sOb(buf) + vx_off(r, c * 16)) = ro[i];
+    }
+    if (tid < 64) sLb(buf)[tid] = rl;
+    else if (tid < 128) sLb(buf)[tid] = rd;     // delta at [64..127]
+  };
+
+  f32x16 dv[2], dk[NKS / 2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    dv[0][e] = 0.f; dv[1][e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NKS / 2; ++c) dk[c][e] = 0.f;
+  }
+
+  if (nsched > 0) { load_q(qs * 64); store_q(0); }
+  __syncthreads();
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+
+  for (int it = 0; it < nsched; ++it) {
+    const int cur = it & 1;
+    const int i0 = (qs + it) * 64;
+    if (it + 1 < nsched) load_q(i0 + 64);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int ib = i0 + qb * 32;
+      const bool skip = (ib >= a.T) || (a.causal && (kw + 31 < a.P) && ((ib + 31 < kw) || (ib >= a.P)));
+      if (skip) continue;
+      const bool qb_grid = ib < a.P;
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        bf16x8 qf = lds_read_b128(sQb(cur) + kx_off(qb * 32 + (lane & 31), ks * 2 + half));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 of = lds_read_b128(sOb(cur) + vx_off(qb * 32 + (lane & 31), (ks * 2 + half) * 16));
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vf[ks], dp, 0, 0, 0);
+      }
+      // element r <-> query ib + (r&3) + 8*(r>>2) + 4*half ; key = kj (lane)
+      bf16x8 pfr[2], dsf[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        U128 up, ud;
+#pragma unroll
+        for (int rg2 = 0; rg2 < 2; ++rg2) {
+          const int rg = s2 * 2 + rg2;
+          const int iq = ib + 8 * rg + 4 * half, il = qb * 32 + 8 * rg + 4 * half;
+          const float4 l4 = *reinterpret_cast<const float4*>(sLb(cur) + il);
+          const float4 d4 = *reinterpret_cast<const float4*>(sLb(cur) + 64 + il);
+          const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+          int4 c4 = make_int4(0, 0, 0, 0);
+          if (a.rel_mode && qb_grid) c4 = *reinterpret_cast<const int4*>(sGc + iq);
+          const int cis[4] = {c4.x, c4.y, c4.z, c4.w};
+          float pv[4], dsv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = iq + e;
+            float sv = s[rg * 4 + e];
+            int hidx = -1;
+            if (a.rel_mode) {
+              float bias;
+              if (qb_grid) {
+                if (k_grid) { hidx = cis[e] - cj; bias = rel2d[hidx]; }
+                else bias = relx0;
+              } else {
+                if (k_grid) bias = relx1;
+                else { hidx = (kvalid && i < a.T) ? (i - a.P) - tj + a.Lt - 1 : 0; bias = (kvalid && i < a.T) ? rel1d[(i - a.P) - tj] : 0.f; }
+              }
+              sv += bias;
+            }
+            bool masked = !kvalid;
+            if (a.causal) {
+              if (k_grid) masked |= (i >= a.P) || (kj > i);
+              else masked |= (i >= a.P) && (kj > i);
+            }
+            const float p = masked ? 0.f : __expf(sv - ls[e]);
+            const float ds = p * (gain * dp[rg * 4 + e] - dl[e]);
+            pv[e] = p; dsv[e] = ds;
+            if (a.rel_mode) {
+              if (qb_grid) { if (k_grid) atomicAdd(&sHist[hidx], ds); else gx0 += ds; }
+              else { if (k_grid) gx1 += ds; else if (kvalid && i < a.T) atomicAdd(&sHist1[hidx], ds); }
+            }
+          }
+          up.w[rg2 * 2] = pack2bf(pv[0], pv[1]); up.w[rg2 * 2 + 1] = pack2bf(pv[2], pv[3]);
+          ud.w[rg2 * 2] = pack2bf(dsv[0], dsv[1]); ud.w[rg2 * 2 + 1] = pack2bf(dsv[2], dsv[3]);
+        }
+        pfr[s2] = up.b; dsf[s2] = ud.b;
+      }
+      // dV^T += dO^T P ; dK^T += Q^T dS ; slot (kh,e) <-> query ib + 16*s2 + 4*kh + (e&3) + 8*(e>>2)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int r0 = qb * 32 + 16 * s2 + 4 * half + (i16 >> 2);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const int colb = (db * 32 + g16 * 16 + (i16 & 3) * 4) * 2;
+          U64 x, y;
+          x.s = lds_read_tr(sOb(cur) + vx_off(r0, colb));
+          y.s = lds_read_tr(sOb(cur) + vx_off(r0 + 8, colb));
+          U128 f; f.w[0] = x.w[0]; f.w[1] = x.w[1]; f.w[2] = y.w[0]; f.w[3] = y.w[1];
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, pfr[s2], dv[db], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cb = 0; cb < NKS / 2; ++cb) {
+          const int col = cb * 32 + g16 * 16 + (i16 & 3) * 4;
+          U64 x, y;
+          x.s = lds_read_tr(sQb(cur) + kx_off(r0, col >> 3) + (col & 7) * 2);
+          y.s = lds_read_tr(sQb(cur) + kx_off(r0 + 8, col >> 3) + (col & 7) * 2);
+          U128 f; f.w[0] = x.w[0]; f.w[1] = x.w[1]; f.w[2] = y.w[0]; f.w[3] = y.w[1];
+          dk[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, dsf[s2], dk[cb], 0, 0, 0);
+        }
+      }
+    }
+    if (it + 1 < nsched) store_q(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- write dV, dK, dpos_k partial: lane = key, reg r <-> column (r&3) + 8*(r>>2) + 4*half
+  if (kvalid) {
+    bf16_t* dvp = a.dv + (long long)b * a.dv_bs + (long long)kj * a.lddv + h * 64;
+    bf16_t* dkp = a.dk + (long long)b * a.dk_bs + (long long)kj * a.lddk + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d = db * 32 + 8 * rg + 4 * half;
+        *reinterpret_cast<uint2*>(dvp + d) =
+            make_uint2(pack2bf(dv[db][rg * 4] * gain, dv[db][rg * 4 + 1] * gain),
+                       pack2bf(dv[db][rg * 4 + 2] * gain, dv[db][rg * 4 + 3] * gain));
+        *reinterpret_cast<uint2*>(dkp + d) =
+            make_uint2(pack2bf(dk[db][rg * 4], dk[db][rg * 4 + 1]), pack2bf(dk[db][rg * 4 + 2], dk[db][rg * 4 + 3]));
+      }
+    if (HAS_POS) {
+      float* pp = a.dpk + ((long long)b * a.S + kj) * (a.H * 64) + h * 64;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int d = db * 32 + 8 * rg + 4 * half;
+          *reinterpret_cast<float4*>(pp + d) = make_float4(dk[2 + db][rg * 4], dk[2 + db][rg * 4 + 1],
+                                                           dk[2 + db][rg * 4 + 2], dk[2 + db][rg * 4 + 3]);
+        }
+    }
+  }
+  if (a.rel_mode) {
+    gx0 = warp_sum(gx0); gx1 = warp_sum(gx1);
+    if (lane == 0) { atomicAdd(&sX[0], gx0); atomicAdd(&sX[1], gx1); }
+    __syncthreads();
+    const int part = b * nkt + kt;
+    float* o2 = a.drel2d_part + ((long long)h * a.nparts + part) * a.n2d;
+    for (int i = tid; i < a.n2d; i += 256) o2[i] = sHist[i];
+    float* o1 = a.drel1d_part + ((long long)h * a.nparts + part) * n1d;
+    for (int i = tid; i < n1d; i += 256) o1[i] = sHist1[i];
+    if (tid < 2) a.drelx_part[((long long)h * a.nparts + part) * 2 + tid] = sX[tid];
+  }
+}
+
+// (2) dQ kernel: same shape as the forward (lane = query):
+//       S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (gain*dP^T - delta),
+//       dQ_ext^T[c,q] += K_ext^T dS^T  (A = K tile tr-reads, B = dS regs)
+template <bool HAS_POS>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  auto sKb = [&](int buf) { return smem + buf * (KT_BYTES + VT_BYTES); };
+  auto sVb = [&](int buf) { return smem + buf * (KT_BYTES + VT_BYTES) + KT_BYTES; };
+  float* sTbl = reinterpret_cast<float*>(smem + 2 * (KT_BYTES + VT_BYTES));
+  int* sGc = reinterpret_cast<int*>(sTbl + ((a.n2d + 3) & ~3));
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  const int nq = (a.T + 127) >> 7;
+  const int bid = xcd_remap(blockIdx.x, nq * a.H * a.B);
+  const int qt = bid % nq, h = (bid / nq) % a.H, b = bid / (nq * a.H);
+  const int q0 = qt * 128, qw = q0 + wave * 32;
+  const int qi = qw + (lane & 31);
+  const bool qvalid = qi < a.T;
+  const int qrow = qvalid ? qi : a.T - 1;
+  constexpr int NKS = HAS_POS ? 8 : 4;
+  const float gain = a.gain ? a.gain[h] : 1.f;
+
+  bf16x8 qf[NKS], dof[4];
+  {
+    const bf16_t* qp = a.q + (long long)b * a.q_bs + (long long)qrow * a.ldq + h * 64 + half * 8;
+    const bf16_t* op = a.dO + (long long)b * a.do_bs + (long long)qrow * a.lddo + h * 64 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      U128 u; u.v = *reinterpret_cast<const uint4*>(qp + ks * 16); qf[ks] = u.b;
+      U128 w; w.v = qvalid ? *reinterpret_cast<const uint4*>(op + ks * 16) : make_uint4(0, 0, 0, 0); dof[ks] = w.b;
+    }
+    if (HAS_POS) {
+      const bf16_t* pp = a.pq + (long long)qrow * a.ldpq + h * 64 + half * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { U128 u; u.v = *reinterpret_cast<const uint4*>(pp + ks * 16); qf[4 + ks] = u.b; }
+    }
+  }
+  const float lse_q = qvalid ? a.lse[((long long)b * a.H + h) * a.T + qi] : INFINITY;
+  const float del_q = qvalid ? a.delta[((long long)b * a.H + h) * a.T + qi] : 0.f;
+  if (a.rel_mode) {
+    for (int i = tid; i < a.n2d; i += 256) sTbl[i] = a.rel2d[(long long)h * a.n2d + i];
+    for (int i = tid; i < a.P; i += 256) sGc[i] = a.gcode[i];
+  }
+  const bool q_grid = a.rel_mode && qi < a.P;
+  const int ci = q_grid ? a.gcode[qi] + a.code_bias : 0;
+  const int ti = qi - a.P;
+  const float relx0 = a.rel_mode ? a.relx[h * 2 + 0] : 0.f, relx1 = a.rel_mode ? a.relx[h * 2 + 1] : 0.f;
+  const float* rel1d = a.rel_mode ? a.rel1d + (long long)h * (2 * a.Lt - 1) + (a.Lt - 1) : nullptr;
+
+  const int ntile = (a.S + 63) >> 6;
+  const int Pk = a.rel_mode || a.causal ? a.P : a.S;
+  const int ngrid = Pk >> 6;
+  int g_end = ngrid;
+  if (a.causal) {
+    int imax = (q0 < a.P) ? min(q0 + 127, a.P - 1) : -1;
+    g_end = imax >= 0 ? min(ngrid, (imax >> 6) + 1) : 0;
+  }
+  const int nsched = g_end + (ntile - ngrid);
+  auto tile_of = [&](int it) { return it < g_end ? it : ngrid + (it - g_end); };
+
+  uint4 rk[4], rv[2];
+  const bf16_t* kb_ = a.k + (long long)b * a.k_bs + h * 64;
+  const bf16_t* vb_ = a.v + (long long)b * a.v_bs + h * 64;
+  const bf16_t* pkb_ = HAS_POS ? a.pk + h * 64 : nullptr;
+  auto load_kv = [&](int j0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (tid >> 3) + 32 * i, c = tid & 7, j = j0 + r;
+      rk[i] = make_uint4(0, 0, 0, 0); rk[2 + i] = make_uint4(0, 0, 0, 0); rv[i] = make_uint4(0, 0, 0, 0);
+      if (j < a.S) {
+        rk[i] = *reinterpret_cast<const uint4*>(kb_ + (long long)j * a.ldk + c * 8);
+        if (HAS_POS) rk[2 + i] = *reinterpret_cast<const uint4*>(pkb_ + (long long)j * a.ldpk + c * 8);
+        rv[i] = *reinterpret_cast<const uint4*>(vb_ + (long long)j * a.ldv + c * 8);
+      }
+    }
+  };
+  auto store_kv = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (tid >> 3) + 32 * i, c = tid & 7;
+      *reinterpret_cast<uint4*>(sKb(buf) + kx_off(r, c)) = rk[i];
+      if (HAS_POS) *reinterpret_cast<uint4*>(sKb(buf) + kx_off(r, 8 + c)) = rk[2 + i];
+      *reinterpret_cast<uint4*>(sVb(buf) + vx_off(r, c * 16)) = rv[i];
+    }
+  };
+
+  f32x16 dq[NKS / 2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+#pragma unroll
+    for (int c = 0; c < NKS / 2; ++c) dq[c][e] = 0.f;
+
+  if (nsched > 0) { load_kv(tile_of(0) * 64); store_kv(0); }
+  __syncthreads();
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+
+  for (int it = 0; it < nsched; ++it) {
+    const int cur = it & 1;
+    const int j0 = tile_of(it) * 64;
+    if (it + 1 < nsched) load_kv(tile_of(it + 1) * 64);
+    const bool tile_grid = j0 < Pk;
+    const bool skip = a.causal && tile_grid && (j0 > qw + 31 || qw >= a.P);
+    if (!skip) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          bf16x8 kf = lds_read_b128(sKb(cur) + kx_off(kb * 32 + (lane & 31), ks * 2 + half));
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          bf16x8 vfr = lds_read_b128(sVb(cur) + vx_off(kb * 32 + (lane & 31), (ks * 2 + half) * 16));
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, dof[ks], dp, 0, 0, 0);
+        }
+        bf16x8 dsf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          U128 ud;
+#pragma unroll
+          for (int rg2 = 0; rg2 < 2; ++rg2) {
+            const int rg = s2 * 2 + rg2;
+            const int jb = j0 + kb * 32 + 8 * rg + 4 * half;
+            int4 cj = make_int4(0, 0, 0, 0);
+            if (a.rel_mode && tile_grid) cj = *reinterpret_cast<const int4*>(sGc + jb);
+            const int cjs[4] = {cj.x, cj.y, cj.z, cj.w};
+            float dsv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int j = jb + e;
+              float sv = s[rg * 4 + e];
+              if (a.rel_mode) {
+                float bias;
+                if (tile_grid) bias = q_grid ? sTbl[ci - cjs[e]] : relx1;
+                else bias = q_grid ? relx0 : ((j < a.S && qvalid) ? rel1d[ti - (j - a.P)] : 0.f);
+                sv += bias;
+              }
+              bool masked = j >= a.S;
+              if (a.causal) {
+                if (tile_grid) masked |= (qi >= a.P) || (j > qi);
+                else masked |= (qi >= a.P) && (j > qi);
+              }
+              const float p = masked ? 0.f : __expf(sv - lse_q);
+              dsv[e] = p * (gain * dp[rg * 4 + e] - del_q);
+            }
+            ud.w[rg2 * 2] = pack2bf(dsv[0], dsv[1]); ud.w[rg2 * 2 + 1] = pack2bf(dsv[2], dsv[3]);
+          }
+          dsf[s2] = ud.b;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int r0 = kb * 32 + 16 * s2 + 4 * half + (i16 >> 2);
+#pragma unroll
+          for (int cb = 0; cb < NKS / 2; ++cb) {
+            const int col = cb * 32 + g16 * 16 + (i16 & 3) * 4;
+            U64 x, y;
+            x.s = lds_read_tr(sKb(cur) + kx_off(r0, col >> 3) + (col & 7) * 2);
+            y.s = lds_read_tr(sKb(cur) + kx_off(r0 + 8, col >> 3) + (col & 7) * 2);
+            U128 f; f.w[0] = x.w[0]; f.w[1] = x.w[1]; f.w[2] = y.w[0]; f.w[3] = y.w[1];
+            dq[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, dsf[s2], dq[cb], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (it + 1 < nsched) store_kv(cur ^ 1);
+    __syncthreads();
+  }
+
+  if (qvalid) {
+    bf16_t* dqp = a.dq + (long long)b * a.dq_bs + (long long)qi * a.lddq + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d = db * 32 + 8 * rg + 4 * half;
+        *reinterpret_cast<uint2*>(dqp + d) =
+            make_uint2(pack2bf(dq[db][rg * 4] * a.dq_scale, dq[db][rg * 4 + 1] * a.dq_scale),
+                       pack2bf(dq[db][rg * 4 + 2] * a.dq_scale, dq[db][rg * 4 + 3] * a.dq_scale));
+      }
+    if (HAS_POS) {
+      float* pp = a.dpq + ((long long)b * a.T + qi) * (a.H * 64) + h * 64;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int d = db * 32 + 8 * rg + 4 * half;
+          *reinterpret_cast<float4*>(pp + d) =
+              make_float4(dq[2 + db][rg * 4] * a.dpq_scale, dq[2 + db][rg * 4 + 1] * a.dpq_scale,
+                          dq[2 + db][rg * 4 + 2] * a.dpq_scale, dq[2 + db][rg * 4 + 3] * a.dpq_scale);
+        }
+    }
+  }
+}
+
+// delta[b,h,t] = sum_d dO[b,t,h,d] * O[b,t,h,d]   (8 lanes per (row, head))
+__global__ void attn_delta_kernel(const bf16_t* o, const bf16_t* dO, float* delta, int B, int H, int T,
+                                  long long o_bs, int ldo, long long do_bs, int lddo) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long grp = gid >> 3;
+  const int sub = (int)(gid & 7);
+  const long long total = (long long)B * T * H;
+  float acc = 0.f;
+  if (grp < total) {
+    const int hh = (int)(grp % H);
+    const long long bt = grp / H;
+    const int t = (int)(bt % T), bb = (int)(bt / T);
+    U128 x, y;
+    x.v = *reinterpret_cast<const uint4*>(o + bb * o_bs + (long long)t * ldo + hh * 64 + sub * 8);
+    y.v = *reinterpret_cast<const uint4*>(dO + bb * do_bs + (long long)t * lddo + hh * 64 + sub * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc += bflo(x.w[e]) * bflo(y.w[e]) + bfhi(x.w[e]) * bfhi(y.w[e]);
+  }
+  acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+  if (grp < total && sub == 0) {
+    const int hh = (int)(grp % H);
+    const long long bt = grp / H;
+    delta[((bt / T) * H + hh) * T + (bt % T)] = acc;
+  }
+}
+
+}  // namespace
+
+static int attn_check(const AttnArgs& a) {
+  if (a.rel_mode || a.causal) {
+    if (a.P % 64 || a.P > a.T || a.P > a.S) return IFSEG_ERR_BAD_SHAPE;
+  }
+  if ((a.ldq | a.ldk | a.ldv | a.ldo) & 7) return IFSEG_ERR_BAD_SHAPE;
+  return 0;
+}
+
+extern "C" int ifseg_attn_fwd(const void* q, const void* k, const void* v, const void* pos_q, const void* pos_k,
+                              void* out, float* lse, int B, int H, int T, int S, int ldq, int ldk, int ldv,
+                              int ldo, int ldpq, int ldpk, long long q_bs, long long k_bs, long long v_bs,
+                              long long o_bs, int rel_mode, int P, const int* gcode, int code_bias, int n2d,
+                              const float* rel2d, const float* rel1d, const float* relx, int causal,
+                              const float* dense_bias, void* stream) {
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
+  a.pq = (const bf16_t*)pos_q; a.pk = (const bf16_t*)pos_k; a.o = (bf16_t*)out; a.lse = lse;
+  a.B = B; a.H = H; a.T = T; a.S = S; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.ldpq = ldpq; a.ldpk = ldpk; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
+  a.rel_mode = rel_mode; a.P = P; a.gcode = gcode; a.code_bias = code_bias; a.n2d = rel_mode ? n2d : 0;
+  a.Lt = T - P; a.rel2d = rel2d; a.rel1d = rel1d; a.relx = relx; a.causal = causal; a.dense = dense_bias;
+  if (!rel_mode && !causal) a.P = S;
+  int rc = attn_check(a);
+  if (rc) return rc;
+  const int nq = (T + 127) / 128;
+  size_t lds = 2 * (KT_BYTES + VT_BYTES) + (rel_mode ? (((size_t)a.n2d + 3) & ~3) * 4 + (size_t)P * 4 : 0);
+  if (lds > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
+  dim3 grid(nq * H * B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (pos_q) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, lds, s, a);
+  } else {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, lds, s, a);
+  }
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}

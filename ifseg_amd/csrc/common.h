@@ -1,0 +1,111 @@
+// Shared device helpers for the ifseg_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+typedef unsigned short bf16_t;  // raw storage type
+
+#define IFSEG_CHECK_LAUNCH()                         \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    if (e__ != hipSuccess) return (int)e__;          \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+
+// round-to-nearest-even float -> bf16 (NaN kept quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+union U128 {
+  uint4 v;
+  bf16x8 b;
+  uint32_t w[4];
+  bf16_t h[8];
+};
+union U64 {
+  uint2 v;
+  s16x4 s;
+  uint32_t w[2];
+  bf16_t h[4];
+};
+
+// ---- LDS tile images (16 KiB each: 128 x 64 bf16) -------------------------
+// "KC" tile: [128 rows][64 k], k contiguous in global.  16-byte chunks are
+// XOR-swizzled inside 256-byte lines (two rows per line) so that the 16 rows a
+// ds_read_b128 lane group touches at one k-chunk land on 16 distinct slots.
+__device__ __forceinline__ int kc_off(int r, int c /*0..7*/) {
+  int line = r >> 1;
+  int s = (((r & 1) << 3) | c) ^ (line & 15);
+  return line * 256 + s * 16;
+}
+// "KS" tile: [64 k rows][128 cols], cols contiguous in global (the reduction
+// index is the row).  64-byte granules XOR-swizzled by (k & 3) so the four k
+// rows one ds_read_b64_tr_b16 touches sit on four different bank quarters.
+__device__ __forceinline__ int ks_off(int kr, int col /*0..127*/) {
+  int c = col >> 3;
+  return kr * 256 + ((((c >> 2) ^ (kr & 3))) << 6) + ((c & 3) << 4) + ((col & 7) << 1);
+}
+
+__device__ __forceinline__ bf16x8 lds_read_b128(const unsigned char* p) {
+  U128 u;
+  u.v = *reinterpret_cast<const uint4*>(p);
+  return u.b;
+}
+// transposed 4x(16 lanes) read: lane i of a 16-lane group passes the address of
+// chunk i (row i>>2, 4-col chunk i&3) of a [4][16] bf16 block and receives
+// column i (4 rows).
+__device__ __forceinline__ s16x4 lds_read_tr(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4 __attribute__((address_space(3)))*)(p));
+}
+
+// MFMA fragment (8 bf16 along k) for rows rb..rb+31 of a KC tile at k-step ks (16 k each)
+__device__ __forceinline__ bf16x8 frag_kc(const unsigned char* tile, int rb, int ks, int lane) {
+  return lds_read_b128(tile + kc_off(rb + (lane & 31), ks * 2 + (lane >> 5)));
+}
+// same fragment for columns cb..cb+31 of a KS tile
+__device__ __forceinline__ bf16x8 frag_ks(const unsigned char* tile, int cb, int ks, int lane) {
+  int i = lane & 15, g = (lane >> 4) & 1, kh = lane >> 5;
+  int col = cb + g * 16 + (i & 3) * 4;
+  int kr = ks * 16 + kh * 8 + (i >> 2);
+  U64 a, b;
+  a.s = lds_read_tr(tile + ks_off(kr, col));
+  b.s = lds_read_tr(tile + ks_off(kr + 4, col));
+  U128 u;
+  u.w[0] = a.w[0]; u.w[1] = a.w[1]; u.w[2] = b.w[0]; u.w[3] = b.w[1];
+  return u.b;
+}
+
+__device__ __forceinline__ float warp_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float warp_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// bijective XCD-aware remap of a linear block id: XCD x (= id % 8 as observed)
+// gets one contiguous chunk of the tile space so neighbours share L2 panels.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + loc;
+}
