@@ -345,30 +345,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   const bf16_t* dob_ = a.dO + (long long)b * a.do_bs + h * 64;
   const float* lseb = a.lse + ((long long)b * a.H + h) * a.T;
   const float* delb = a.delta + ((long long)b * a.H + h) * a.T;
-  auto load_q = [&](int i0) {
+  const int aT = a.T, aldq = a.ldq, aldpq = a.ldpq, alddo = a.lddo;
+  auto load_q = [&rq, &ro, &rl, &rd, tid, aT, aldq, aldpq, alddo, qb_, pqb_, dob_, lseb, delb](int i0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = (tid >> 3) + 32 * i, c = tid & 7, qi = i0 + r;
       rq[i] = make_uint4(0, 0, 0, 0); rq[2 + i] = make_uint4(0, 0, 0, 0); ro[i] = make_uint4(0, 0, 0, 0);
-      if (qi < a.T) {
-        rq[i] = *reinterpret_cast<const uint4*>(qb_ + (long long)qi * a.ldq + c * 8);
-        if (HAS_POS) rq[2 + i] = *reinterpret_cast<const uint4*>(pqb_ + (long long)qi * a.ldpq + c * 8);
-        ro[i] = *reinterpret_cast<const uint4*>(dob_ + (long long)qi * a.lddo + c * 8);
+      if (qi < aT) {
+        rq[i] = *reinterpret_cast<const uint4*>(qb_ + (long long)qi * aldq + c * 8);
+        if (HAS_POS) rq[2 + i] = *reinterpret_cast<const uint4*>(pqb_ + (long long)qi * aldpq + c * 8);
+        ro[i] = *reinterpret_cast<const uint4*>(dob_ + (long long)qi * alddo + c * 8);
       }
     }
-    if (tid < 64) { const int qi = i0 + tid; rl = qi < a.T ? lseb[qi] : INFINITY; }
-    else if (tid < 128) { const int qi = i0 + tid - 64; rd = qi < a.T ? delb[qi] : 0.f; }
+    if (tid < 64) { const int qi = i0 + tid; rl = qi < aT ? lseb[qi] : INFINITY; }
+    else if (tid < 128) { const int qi = i0 + tid - 64; rd = qi < aT ? delb[qi] : 0.f; }
   };
-  auto store_q = [&](int buf) {
+  auto store_q = [&rq, &ro, &rl, &rd, tid](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = (tid >> 3) + 32 * i, c = tid & 7;
-      *reinterpret_cast<uint4*>(sQb(buf) + kx_off(r, c)) = rq[i];
-      if (HAS_POS) *reinterpret_cast<uint4*>(sQb(buf) + kx_off(r, 8 + c)) = rq[2 + i];
-      *reinterpret_cast<uint4*>(sOb(buf) + vx_off(r, c * 16)) = ro[i];
+      unsigned char* base = smem + buf * STAGE;
+      *reinterpret_cast<uint4*>(base + kx_off(r, c)) = rq[i];
+      if (HAS_POS) *reinterpret_cast<uint4*>(base + kx_off(r, 8 + c)) = rq[2 + i];
+      *reinterpret_cast<uint4*>(base + KT_BYTES + vx_off(r, c * 16)) = ro[i];
     }
-    if (tid < 64) sLb(buf)[tid] = rl;
-    else if (tid < 128) sLb(buf)[tid] = rd;     // delta at [64..127]
+    float* lb = reinterpret_cast<float*>(smem + buf * STAGE + KT_BYTES + VT_BYTES);
+    if (tid < 64) lb[tid] = rl;
+    else if (tid < 128) lb[tid] = rd;     // delta at [64..127]
   };
 
   f32x16 dv[2], dk[NKS / 2];
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         *reinterpret_cast<uint2*>(dkp + d) =
             make_uint2(pack2bf(dk[db][rg * 4], dk[db][rg * 4 + 1]), pack2bf(dk[db][rg * 4 + 2], dk[db][rg * 4 + 3]));
       }
-    if (HAS_POS) {
+    if constexpr (HAS_POS) {
       float* pp = a.dpk + ((long long)b * a.S + kj) * (a.H * 64) + h * 64;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             make_uint2(pack2bf(dq[db][rg * 4] * a.dq_scale, dq[db][rg * 4 + 1] * a.dq_scale),
                        pack2bf(dq[db][rg * 4 + 2] * a.dq_scale, dq[db][rg * 4 + 3] * a.dq_scale));
       }
-    if (HAS_POS) {
+    if constexpr (HAS_POS) {
       float* pp = a.dpq + ((long long)b * a.T + qi) * (a.H * 64) + h * 64;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -762,14 +765,14 @@ extern "C" int ifseg_attn_fwd(const void* q, const void* k, const void* v, const
                               int ldo, int ldpq, int ldpk, long long q_bs, long long k_bs, long long v_bs,
                               long long o_bs, int rel_mode, int P, const int* gcode, int code_bias, int n2d,
                               const float* rel2d, const float* rel1d, const float* relx, int causal,
-                              const float* dense_bias, void* stream) {
+                              const float* dense_bias, const float* gain, void* stream) {
   AttnArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
   a.pq = (const bf16_t*)pos_q; a.pk = (const bf16_t*)pos_k; a.o = (bf16_t*)out; a.lse = lse;
   a.B = B; a.H = H; a.T = T; a.S = S; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.ldpq = ldpq; a.ldpk = ldpk; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
   a.rel_mode = rel_mode; a.P = P; a.gcode = gcode; a.code_bias = code_bias; a.n2d = rel_mode ? n2d : 0;
-  a.Lt = T - P; a.rel2d = rel2d; a.rel1d = rel1d; a.relx = relx; a.causal = causal; a.dense = dense_bias;
+  a.Lt = T - P; a.rel2d = rel2d; a.rel1d = rel1d; a.relx = relx; a.causal = causal; a.dense = dense_bias; a.gain = gain;
   if (!rel_mode && !causal) a.P = S;
   int rc = attn_check(a);
   if (rc) return rc;
@@ -784,6 +787,54 @@ extern "C" int ifseg_attn_fwd(const void* q, const void* k, const void* v, const
   } else {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, lds, s, a);
+  }
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
+  AttnArgs a{};
+  a.q = (const bf16_t*)x->q; a.k = (const bf16_t*)x->k; a.v = (const bf16_t*)x->v;
+  a.pq = (const bf16_t*)x->pos_q; a.pk = (const bf16_t*)x->pos_k; a.lse = (float*)x->lse;
+  a.B = x->B; a.H = x->H; a.T = x->T; a.S = x->S;
+  a.ldq = x->ldq; a.ldk = x->ldk; a.ldv = x->ldv; a.ldpq = x->ldpq; a.ldpk = x->ldpk;
+  a.q_bs = x->q_bs; a.k_bs = x->k_bs; a.v_bs = x->v_bs;
+  a.rel_mode = x->rel_mode; a.P = x->P; a.gcode = x->gcode; a.code_bias = x->code_bias;
+  a.n2d = x->rel_mode ? x->n2d : 0; a.Lt = x->T - x->P;
+  a.rel2d = x->rel2d; a.rel1d = x->rel1d; a.relx = x->relx; a.causal = x->causal;
+  a.dO = (const bf16_t*)x->dout; a.do_bs = x->do_bs; a.lddo = x->lddo; a.delta = x->delta;
+  a.dq = (bf16_t*)x->dq; a.dk = (bf16_t*)x->dk; a.dv = (bf16_t*)x->dv;
+  a.dq_bs = x->dq_bs; a.dk_bs = x->dk_bs; a.dv_bs = x->dv_bs; a.lddq = x->lddq; a.lddk = x->lddk; a.lddv = x->lddv;
+  a.dpq = x->dpos_q_part; a.dpk = x->dpos_k_part;
+  a.drel2d_part = x->drel2d_part; a.drel1d_part = x->drel1d_part; a.drelx_part = x->drelx_part;
+  a.nparts = x->nparts; a.gain = x->gain; a.dq_scale = x->dq_scale; a.dpq_scale = x->dpq_scale;
+  if (!a.rel_mode && !a.causal) a.P = a.S;
+  int rc = attn_check(a);
+  if (rc) return rc;
+  if ((x->lddo | x->lddq | x->lddk | x->lddv | x->ldout) & 7) return IFSEG_ERR_BAD_SHAPE;
+  const int nkt = (a.S + 127) / 128, nq = (a.T + 127) / 128;
+  if (a.rel_mode && a.nparts != a.B * nkt) return IFSEG_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  {  // delta = rowsum(dO * O)
+    const long long threads = (long long)a.B * a.T * a.H * 8;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
+                       (const bf16_t*)x->out, a.dO, x->delta, a.B, a.H, a.T, x->out_bs, x->ldout, a.do_bs, a.lddo);
+  }
+  const size_t n2dp = ((size_t)a.n2d + 3) & ~(size_t)3;
+  const size_t n1dp = a.rel_mode ? (((size_t)(2 * a.Lt - 1) + 3) & ~(size_t)3) : 0;
+  const size_t lds_kv = 2 * (KT_BYTES + VT_BYTES + 512) + (a.rel_mode ? (n2dp + n1dp + 4) * 4 + (size_t)a.P * 4 : 0);
+  const size_t lds_q = 2 * (KT_BYTES + VT_BYTES) + (a.rel_mode ? n2dp * 4 + (size_t)a.P * 4 : 0);
+  if (lds_kv > 160 * 1024 || lds_q > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
+  if (x->pos_q) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(nkt * a.H * a.B), dim3(256), lds_kv, s, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(nq * a.H * a.B), dim3(256), lds_q, s, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(nkt * a.H * a.B), dim3(256), lds_kv, s, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(nq * a.H * a.B), dim3(256), lds_q, s, a);
   }
   IFSEG_CHECK_LAUNCH();
   return 0;

@@ -1,0 +1,392 @@
+// HBM-bound row kernels for the SegOFA blocks (gfx950): LayerNorm forward/backward
+// with fused GELU input and residual output, partial-sum reductions, bias-gradient
+// column sums, embedding gathers.  16-byte vector accesses, one wave per row,
+// wave shuffles for the row statistics; no global atomics (deterministic).
+//
+// Reference ops replaced: fairseq LayerNorm (modules/layer_norm.py:30-35, eps 1e-5)
+// at every *_layer_norm / attn_ln / ffn_layernorm / layernorm_embedding site of
+// unify_transformer_layer.py:256-292,463-568, encoder_module.py:405-424,757-760,829,
+// decoder_module.py:342-346,575-576,668; GELU in fp32 (modules/gelu.py:24-25);
+// residual_connection (unify_transformer_layer.py:196); their autograd.
+#include "common.h"
+#include "../../include/ifseg_hip.h"
+
+namespace {
+
+struct RowMap {  // logical row r -> element offset  (r / rpb) * bs + (r % rpb) * ld
+  int rpb; long long bs; int ld;
+  __device__ __forceinline__ long long off(int r) const {
+    return rpb > 0 ? (long long)(r / rpb) * bs + (long long)(r % rpb) * ld : (long long)r * ld;
+  }
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = bflo(v.x); f[1] = bfhi(v.x); f[2] = bflo(v.y); f[3] = bfhi(v.y);
+  f[4] = bflo(v.z); f[5] = bfhi(v.z); f[6] = bflo(v.w); f[7] = bfhi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+
+// y = [resid +] LN(act(x)) * gamma + beta ; one wave per row, NCH 8-element chunks per lane
+template <int NCH, bool GELU>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const bf16_t* gamma, const bf16_t* beta,
+                                                     const bf16_t* resid, bf16_t* y, float* mean, float* rstd,
+                                                     int rows, int C, float eps, RowMap mx, RowMap my, RowMap mr) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = C >> 3;
+  const bf16_t* xp = x + mx.off(row);
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) {
+      uint4 u = *reinterpret_cast<const uint4*>(xp + c * 8);
+      unpack8(u, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { if (GELU) v[i][e] = gelu_f(v[i][e]); s += v[i][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mu = warp_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (lane + i * 64 < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
+    }
+  const float rs = rsqrtf(warp_sum(q) / C + eps);
+  if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+  bf16_t* yp = y + my.off(row);
+  const bf16_t* rp = resid ? resid + mr.off(row) : nullptr;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) {
+      float g[8], b[8], o[8];
+      unpack8(*reinterpret_cast<const uint4*>(gamma + c * 8), g);
+      unpack8(*reinterpret_cast<const uint4*>(beta + c * 8), b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+      if (rp) {
+        float r[8];
+        unpack8(*reinterpret_cast<const uint4*>(rp + c * 8), r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += r[e];
+      }
+      *reinterpret_cast<uint4*>(yp + c * 8) = pack8(o);
+    }
+  }
+}
+
+// backward: dx = [dx_add +] act'(x) * rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma
+// dgamma/dbeta: per-block partial sums over the rows the block visited -> [nblk][C]
+template <int NCH, bool GELU>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
+                                                     const float* mean, const float* rstd, const bf16_t* dx_add,
+                                                     bf16_t* dx, float* dgamma_part, float* dbeta_part, int rows, int C,
+                                                     RowMap mdy, RowMap mx, RowMap mdx, RowMap madd) {
+  __shared__ float red[4][64 * 8 + 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  float gam[NCH][8], dg[NCH][8], db[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) unpack8(*reinterpret_cast<const uint4*>(gamma + c * 8), gam[i]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; if (c >= nch) gam[i][e] = 0.f; }
+  }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const bf16_t* xp = x + mx.off(row);
+    const bf16_t* dyp = dy + mdy.off(row);
+    const float mu = mean[row], rs = rstd[row];
+    float xr[NCH][8], gv[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        float d[8];
+        unpack8(*reinterpret_cast<const uint4*>(xp + c * 8), xr[i]);
+        unpack8(*reinterpret_cast<const uint4*>(dyp + c * 8), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = GELU ? gelu_f(xr[i][e]) : xr[i][e];
+          const float xh = (a - mu) * rs;
+          const float g = d[e] * gam[i][e];
+          dg[i][e] += d[e] * xh; db[i][e] += d[e];
+          s1 += g; s2 += g * xh;
+          gv[i][e] = g;
+          if (GELU) { /* keep pre-activation in xr, xhat recomputed below */ } else xr[i][e] = xh;
+        }
+      }
+    }
+    s1 = warp_sum(s1) / C; s2 = warp_sum(s2) / C;
+    bf16_t* dxp = dx + mdx.off(row);
+    const bf16_t* ap = dx_add ? dx_add + madd.off(row) : nullptr;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xh, dact = 1.f;
+          if (GELU) { xh = (gelu_f(xr[i][e]) - mu) * rs; dact = gelu_grad_f(xr[i][e]); }
+          else xh = xr[i][e];
+          o[e] = rs * (gv[i][e] - s1 - xh * s2) * dact;
+        }
+        if (ap) {
+          float r[8];
+          unpack8(*reinterpret_cast<const uint4*>(ap + c * 8), r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += r[e];
+        }
+        *reinterpret_cast<uint4*>(dxp + c * 8) = pack8(o);
+      }
+    }
+  }
+  // cross-wave reduction of dgamma / dbeta partials (chunk by chunk through LDS)
+  if (dgamma_part) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = pass ? db[i][e] : dg[i][e];
+        __syncthreads();
+        for (int t = threadIdx.x; t < 512; t += 256) {
+          const int c = (t >> 3) + i * 64;
+          if (c < nch) {
+            const float sum = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+            (pass ? dbeta_part : dgamma_part)[(long long)blockIdx.x * C + c * 8 + (t & 7)] = sum;
+          }
+        }
+      }
+    }
+  }
+}
+
+// out[o][i] (+)= sum_p in[o][p][i]
+template <bool OUT_BF16>
+__global__ void reduce_parts_kernel(const float* in, void* out, int outer, int parts, long long n, int accumulate,
+                                    float scale) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long long)outer * n) return;
+  const long long o = gid / n, i = gid % n;
+  const float* p = in + o * parts * n + i;
+  float s = 0.f;
+  for (int k = 0; k < parts; ++k) s += p[(long long)k * n];
+  s *= scale;
+  if (OUT_BF16) {
+    bf16_t* op = reinterpret_cast<bf16_t*>(out) + gid;
+    if (accumulate) s += bf2f(*op);
+    *op = f2bf(s);
+  } else {
+    float* op = reinterpret_cast<float*>(out) + gid;
+    if (accumulate) s += *op;
+    *op = s;
+  }
+}
+
+// column sums of a bf16 matrix: part[blockIdx.y][n] = sum over the block's row slab
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, float* part, int M, int N, RowMap mx,
+                                                     int rows_per_blk) {
+  const int c = blockIdx.x * 256 + threadIdx.x;  // 8-column chunk
+  if (c * 8 >= N) return;
+  const int r0 = blockIdx.y * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = r0; r < r1; ++r) {
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + mx.off(r) + c * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += f[e];
+  }
+  float* o = part + (long long)blockIdx.y * N + c * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = acc[e];
+}
+
+// out[r] = table[ids[r]] + add   (ids int64, C % 8 == 0)
+__global__ void embed_rows_kernel(const bf16_t* table, const long long* ids, const bf16_t* add, bf16_t* out, int n,
+                                  int C, RowMap mo) {
+  const int nch = C >> 3;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long long)n * nch) return;
+  const int r = (int)(gid / nch), c = (int)(gid % nch);
+  float f[8];
+  unpack8(*reinterpret_cast<const uint4*>(table + ids[r] * C + c * 8), f);
+  if (add) {
+    float a[8];
+    unpack8(*reinterpret_cast<const uint4*>(add + c * 8), a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += a[e];
+  }
+  *reinterpret_cast<uint4*>(out + mo.off(r) + c * 8) = pack8(f);
+}
+
+// elementwise helpers -------------------------------------------------------
+__global__ void cast_f32_to_bf16_kernel(const float* in, bf16_t* out, long long n, float scale) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 v = *reinterpret_cast<const float4*>(in + i);
+    *reinterpret_cast<uint2*>(out + i) = make_uint2(pack2bf(v.x * scale, v.y * scale), pack2bf(v.z * scale, v.w * scale));
+  } else {
+    for (long long k = i; k < n; ++k) out[k] = f2bf(in[k] * scale);
+  }
+}
+__global__ void add_bf16_kernel(const bf16_t* a, const bf16_t* b, bf16_t* out, long long n) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 7 < n) {
+    float x[8], y[8];
+    unpack8(*reinterpret_cast<const uint4*>(a + i), x);
+    unpack8(*reinterpret_cast<const uint4*>(b + i), y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] += y[e];
+    *reinterpret_cast<uint4*>(out + i) = pack8(x);
+  } else {
+    for (long long k = i; k < n; ++k) out[k] = f2bf(bf2f(a[k]) + bf2f(b[k]));
+  }
+}
+// NCHW (fp32 or bf16) -> NHWC bf16 with channel padding to Cp (zeros)
+template <typename TIN>
+__global__ void nchw_to_nhwc_kernel(const TIN* in, bf16_t* out, int B, int Cc, int H, int W, int Cp) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)B * H * W * Cp;
+  if (gid >= total) return;
+  const int c = (int)(gid % Cp);
+  const long long p = gid / Cp;
+  const int xw = (int)(p % W), yh = (int)((p / W) % H), b = (int)(p / ((long long)W * H));
+  float v = 0.f;
+  if (c < Cc) {
+    const long long src = (((long long)b * Cc + c) * H + yh) * W + xw;
+    if (sizeof(TIN) == 4) v = reinterpret_cast<const float*>(in)[src];
+    else v = bf2f(reinterpret_cast<const bf16_t*>(in)[src]);
+  }
+  out[gid] = f2bf(v);
+}
+
+template <int NCH>
+int launch_ln_fwd(bool gelu, dim3 g, hipStream_t s, const bf16_t* x, const bf16_t* gamma, const bf16_t* beta,
+                  const bf16_t* resid, bf16_t* y, float* mean, float* rstd, int rows, int C, float eps, RowMap mx,
+                  RowMap my, RowMap mr) {
+  if (gelu) hipLaunchKernelGGL((ln_fwd_kernel<NCH, true>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr);
+  else hipLaunchKernelGGL((ln_fwd_kernel<NCH, false>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr);
+  return 0;
+}
+template <int NCH>
+int launch_ln_bwd(bool gelu, dim3 g, hipStream_t s, const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
+                  const float* mean, const float* rstd, const bf16_t* add, bf16_t* dx, float* dgp, float* dbp, int rows,
+                  int C, RowMap mdy, RowMap mx, RowMap mdx, RowMap madd) {
+  if (gelu) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true>), g, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgp, dbp, rows, C, mdy, mx, mdx, madd);
+  else hipLaunchKernelGGL((ln_bwd_kernel<NCH, false>), g, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgp, dbp, rows, C, mdy, mx, mdx, madd);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int ifseg_ln_fwd(const void* x, const void* gamma, const void* beta, const void* resid, void* y,
+                            float* mean, float* rstd, int rows, int C, float eps, int act_gelu, int rpb,
+                            long long x_bs, int ldx, long long y_bs, int ldy, long long r_bs, int ldr, void* stream) {
+  if (rows <= 0) return 0;
+  if ((C & 7) || C > 4096 || (ldx & 7) || (ldy & 7) || (resid && (ldr & 7))) return IFSEG_ERR_BAD_SHAPE;
+  RowMap mx{rpb, x_bs, ldx}, my{rpb, y_bs, ldy}, mr{rpb, r_bs, ldr};
+  dim3 g((rows + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  const bf16_t *X = (const bf16_t*)x, *G = (const bf16_t*)gamma, *Bt = (const bf16_t*)beta, *R = (const bf16_t*)resid;
+  if (C <= 1024) launch_ln_fwd<2>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr);
+  else if (C <= 3072) launch_ln_fwd<6>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr);
+  else launch_ln_fwd<8>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                            const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, int nblocks,
+                            int rows, int C, int act_gelu, int rpb, long long dy_bs, int lddy, long long x_bs,
+                            int ldx, long long dx_bs, int lddx, long long add_bs, int ldadd, void* stream) {
+  if (rows <= 0) return 0;
+  if ((C & 7) || C > 4096 || nblocks <= 0) return IFSEG_ERR_BAD_SHAPE;
+  RowMap mdy{rpb, dy_bs, lddy}, mx{rpb, x_bs, ldx}, mdx{rpb, dx_bs, lddx}, madd{rpb, add_bs, ldadd};
+  dim3 g(nblocks);
+  hipStream_t s = (hipStream_t)stream;
+  const bf16_t *DY = (const bf16_t*)dy, *X = (const bf16_t*)x, *G = (const bf16_t*)gamma, *A = (const bf16_t*)dx_add;
+  if (C <= 1024) launch_ln_bwd<2>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd);
+  else if (C <= 3072) launch_ln_bwd<6>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd);
+  else launch_ln_bwd<8>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_reduce_parts(const float* in, void* out, int outer, int parts, long long n, int accumulate,
+                                  int out_bf16, float scale, void* stream) {
+  const long long total = (long long)outer * n;
+  if (total <= 0) return 0;
+  dim3 g((unsigned)((total + 255) / 256));
+  if (out_bf16) hipLaunchKernelGGL(reduce_parts_kernel<true>, g, dim3(256), 0, (hipStream_t)stream, in, out, outer, parts, n, accumulate, scale);
+  else hipLaunchKernelGGL(reduce_parts_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, in, out, outer, parts, n, accumulate, scale);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_colsum_bf16(const void* x, float* part, int nblk_rows, int M, int N, int rpb, long long x_bs,
+                                 int ldx, void* stream) {
+  if (M <= 0) return 0;
+  if (N & 7) return IFSEG_ERR_BAD_SHAPE;
+  RowMap mx{rpb, x_bs, ldx};
+  const int rows_per_blk = (M + nblk_rows - 1) / nblk_rows;
+  dim3 g((N / 8 + 255) / 256, nblk_rows);
+  hipLaunchKernelGGL(colsum_kernel, g, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, part, M, N, mx, rows_per_blk);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_embed_rows(const void* table, const long long* ids, const void* add, void* out, int n, int C,
+                                int rpb, long long o_bs, int ldo, void* stream) {
+  if (n <= 0) return 0;
+  if (C & 7) return IFSEG_ERR_BAD_SHAPE;
+  RowMap mo{rpb, o_bs, ldo};
+  const long long total = (long long)n * (C / 8);
+  hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)table, ids, (const bf16_t*)add, (bf16_t*)out, n, C, mo);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_cast_f32_bf16(const float* in, void* out, long long n, float scale, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, n, scale);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_add_bf16(const void* a, const void* b, void* out, long long n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)((n / 8 + 256) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_nchw_to_nhwc_bf16(const void* in, int in_is_f32, void* out, int B, int C, int H, int W, int Cpad,
+                                       void* stream) {
+  const long long total = (long long)B * H * W * Cpad;
+  if (total <= 0) return 0;
+  dim3 g((unsigned)((total + 255) / 256));
+  if (in_is_f32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, (const float*)in, (bf16_t*)out, B, C, H, W, Cpad);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, g, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, B, C, H, W, Cpad);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}

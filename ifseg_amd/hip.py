@@ -112,8 +112,30 @@ class RelBias:
         self.rel2d, self.rel1d, self.relx = rel2d, rel1d, relx   # fp32 [H,n2d], [H,2Lt-1], [H,2]
 
 
-def attn_fwd(q, k, v, pos_q, pos_k, out, lse, B, H, T, S, rel=None, causal=False, P=None, dense_bias=None):
+def attn_fwd(q, k, v, pos_q, pos_k, out, lse, B, H, T, S, rel=None, causal=False, P=None, dense_bias=None,
+             gain=None):
     """q/k/v/out: [B, T|S, *] bf16 row-strided views (head h at cols h*64..); pos_q/pos_k: [T|S, H*64]."""
+    return attn_fwd_gain(q, k, v, pos_q, pos_k, out, lse, B, H, T, S, rel, causal, P, dense_bias, gain)
+
+
+class _AttnBwdArgs(ctypes.Structure):
+    _fields_ = ([(n, c_void_p) for n in ("q", "k", "v", "pos_q", "pos_k", "out", "dout", "lse", "delta", "dq", "dk",
+                                          "dv", "dpos_q_part", "dpos_k_part")]
+                + [(n, c_int) for n in ("B", "H", "T", "S", "ldq", "ldk", "ldv", "ldpq", "ldpk", "ldout", "lddo",
+                                        "lddq", "lddk", "lddv")]
+                + [(n, c_ll) for n in ("q_bs", "k_bs", "v_bs", "out_bs", "do_bs", "dq_bs", "dk_bs", "dv_bs")]
+                + [(n, c_int) for n in ("rel_mode", "P", "code_bias", "n2d", "causal", "nparts")]
+                + [(n, c_void_p) for n in ("gcode", "rel2d", "rel1d", "relx", "gain", "drel2d_part", "drel1d_part",
+                                           "drelx_part")]
+                + [("dq_scale", c_float), ("dpq_scale", c_float)])
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def attn_fwd_gain(q, k, v, pos_q, pos_k, out, lse, B, H, T, S, rel=None, causal=False, P=None, dense_bias=None,
+                  gain=None):
     L = lib()
     if rel is not None:
         P = rel.P
@@ -128,6 +150,153 @@ def attn_fwd(q, k, v, pos_q, pos_k, out, lse, B, H, T, S, rel=None, causal=False
                           c_int(rel.rel2d.shape[1] if rel is not None else 0),
                           _ptr(rel.rel2d) if rel is not None else None, _ptr(rel.rel1d) if rel is not None else None,
                           _ptr(rel.relx) if rel is not None else None, c_int(1 if causal else 0), _ptr(dense_bias),
-                          _stream())
+                          _ptr(gain), _stream())
     _check(rc, "attn_fwd")
     return out
+
+
+def attn_bwd(q, k, v, pos_q, pos_k, out, dout, lse, delta, dq, dk, dv, dpq_part, dpk_part, B, H, T, S, rel=None,
+             causal=False, P=None, gain=None, dq_scale=1.0, dpq_scale=1.0, drel2d_part=None, drel1d_part=None,
+             drelx_part=None, nparts=0):
+    a = _AttnBwdArgs()
+    if rel is not None:
+        P = rel.P
+    if P is None:
+        P = S
+    for name, t in (("q", q), ("k", k), ("v", v), ("pos_q", pos_q), ("pos_k", pos_k), ("out", out), ("dout", dout),
+                    ("lse", lse), ("delta", delta), ("dq", dq), ("dk", dk), ("dv", dv), ("dpos_q_part", dpq_part),
+                    ("dpos_k_part", dpk_part), ("gain", gain), ("drel2d_part", drel2d_part),
+                    ("drel1d_part", drel1d_part), ("drelx_part", drelx_part)):
+        setattr(a, name, _p(t))
+    a.B, a.H, a.T, a.S = B, H, T, S
+    a.ldq, a.ldk, a.ldv = q.stride(1), k.stride(1), v.stride(1)
+    a.ldpq = pos_q.stride(0) if pos_q is not None else 0
+    a.ldpk = pos_k.stride(0) if pos_k is not None else 0
+    a.ldout, a.lddo, a.lddq, a.lddk, a.lddv = out.stride(1), dout.stride(1), dq.stride(1), dk.stride(1), dv.stride(1)
+    a.q_bs, a.k_bs, a.v_bs, a.out_bs = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.do_bs, a.dq_bs, a.dk_bs, a.dv_bs = dout.stride(0), dq.stride(0), dk.stride(0), dv.stride(0)
+    a.rel_mode = 1 if rel is not None else 0
+    a.P, a.causal, a.nparts = P, 1 if causal else 0, nparts
+    if rel is not None:
+        a.code_bias, a.n2d = rel.code_bias, rel.rel2d.shape[1]
+        a.gcode, a.rel2d, a.rel1d, a.relx = _p(rel.gcode), _p(rel.rel2d), _p(rel.rel1d), _p(rel.relx)
+    a.dq_scale, a.dpq_scale = dq_scale, dpq_scale
+    rc = lib().ifseg_attn_bwd(ctypes.byref(a), _stream())
+    _check(rc, "attn_bwd")
+
+
+# ------------------------------------------------------------------------ row ops
+def _map(t, rpb):
+    """(bs, ld) of a [rows, C] or [B, rpb, C] view"""
+    if t is None:
+        return 0, 0
+    if t.dim() == 3:
+        return t.stride(0), t.stride(1)
+    return 0, t.stride(0)
+
+
+def ln_fwd(x, gamma, beta, y, mean=None, rstd=None, resid=None, gelu=False, eps=1e-5):
+    """x, y, resid: [rows, C] or [B, rpb, C] (strided views allowed, last dim contiguous)."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    rpb = x.shape[1] if x.dim() == 3 else 0
+    xb, xl = _map(x, rpb)
+    yb, yl = _map(y, rpb)
+    rb, rl = _map(resid, rpb)
+    rc = lib().ifseg_ln_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(resid), _ptr(y), _ptr(mean), _ptr(rstd),
+                            c_int(rows), c_int(C), c_float(eps), c_int(1 if gelu else 0), c_int(rpb), c_ll(xb),
+                            c_int(xl), c_ll(yb), c_int(yl), c_ll(rb), c_int(rl), _stream())
+    _check(rc, "ln_fwd")
+    return y
+
+
+LN_BWD_BLOCKS = 256
+
+
+def ln_bwd(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx_add=None, gelu=False):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    rpb = x.shape[1] if x.dim() == 3 else 0
+    db_, dl = _map(dy, rpb)
+    xb, xl = _map(x, rpb)
+    ob, ol = _map(dx, rpb)
+    ab, al = _map(dx_add, rpb)
+    rc = lib().ifseg_ln_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx_add), _ptr(dx),
+                            _ptr(dgamma_part), _ptr(dbeta_part), c_int(LN_BWD_BLOCKS), c_int(rows), c_int(C),
+                            c_int(1 if gelu else 0), c_int(rpb), c_ll(db_), c_int(dl), c_ll(xb), c_int(xl), c_ll(ob),
+                            c_int(ol), c_ll(ab), c_int(al), _stream())
+    _check(rc, "ln_bwd")
+    return dx
+
+
+def reduce_parts(inp, out, outer, parts, n, accumulate=False, scale=1.0):
+    rc = lib().ifseg_reduce_parts(_ptr(inp), _ptr(out), c_int(outer), c_int(parts), c_ll(n),
+                                  c_int(1 if accumulate else 0), c_int(1 if out.dtype == torch.bfloat16 else 0),
+                                  c_float(scale), _stream())
+    _check(rc, "reduce_parts")
+    return out
+
+
+COLSUM_BLOCKS = 64
+
+
+def colsum(x, part):
+    """x [M,N] (or [B,rpb,N]) bf16 -> part [COLSUM_BLOCKS, N] fp32 partial column sums"""
+    N = x.shape[-1]
+    M = x.numel() // N
+    rpb = x.shape[1] if x.dim() == 3 else 0
+    xb, xl = _map(x, rpb)
+    rc = lib().ifseg_colsum_bf16(_ptr(x), _ptr(part), c_int(COLSUM_BLOCKS), c_int(M), c_int(N), c_int(rpb), c_ll(xb),
+                                 c_int(xl), _stream())
+    _check(rc, "colsum")
+    return part
+
+
+def embed_rows(table, ids, add, out):
+    C = table.shape[1]
+    n = ids.numel()
+    rpb = out.shape[1] if out.dim() == 3 else 0
+    ob, ol = _map(out, rpb)
+    rc = lib().ifseg_embed_rows(_ptr(table), _ptr(ids), _ptr(add), _ptr(out), c_int(n), c_int(C), c_int(rpb),
+                                c_ll(ob), c_int(ol), _stream())
+    _check(rc, "embed_rows")
+    return out
+
+
+def cast_f32_bf16(x, out, scale=1.0):
+    _check(lib().ifseg_cast_f32_bf16(_ptr(x), _ptr(out), c_ll(x.numel()), c_float(scale), _stream()), "cast")
+    return out
+
+
+def add_bf16(a, b, out):
+    _check(lib().ifseg_add_bf16(_ptr(a), _ptr(b), _ptr(out), c_ll(a.numel()), _stream()), "add")
+    return out
+
+
+def nchw_to_nhwc(x, out, Cpad):
+    B, C, H, W = x.shape
+    _check(lib().ifseg_nchw_to_nhwc_bf16(_ptr(x), c_int(1 if x.dtype == torch.float32 else 0), _ptr(out), c_int(B),
+                                         c_int(C), c_int(H), c_int(W), c_int(Cpad), _stream()), "nchw_to_nhwc")
+    return out
+
+
+def stem_conv(x4, w, shift, out, B, H, W):
+    _check(lib().ifseg_stem_conv7x7(_ptr(x4), _ptr(w), _ptr(shift), _ptr(out), c_int(B), c_int(H), c_int(W),
+                                    _stream()), "stem_conv")
+    return out
+
+
+def maxpool(x, out, B, H, W, C):
+    _check(lib().ifseg_maxpool3x3s2(_ptr(x), _ptr(out), c_int(B), c_int(H), c_int(W), c_int(C), _stream()), "maxpool")
+    return out
+
+
+def grad_sumsq(g, workspace, out):
+    _check(lib().ifseg_grad_sumsq_bf16(_ptr(g), c_ll(g.numel()), _ptr(workspace), _ptr(out), _stream()), "sumsq")
+    return out
+
+
+def adam_step(p32, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, max_norm=0.0, sumsq=None):
+    _check(lib().ifseg_adam_step(_ptr(p32), _ptr(g), _ptr(m), _ptr(v), _ptr(p16), c_ll(p32.numel()), c_float(lr),
+                                 c_float(beta1), c_float(beta2), c_float(eps), c_float(wd), c_int(step),
+                                 c_float(grad_scale), c_float(max_norm), _ptr(sumsq), _stream()), "adam")

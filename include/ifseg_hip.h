@@ -77,7 +77,91 @@ int ifseg_attn_fwd(const void* q, const void* k, const void* v, const void* pos_
                    void* out, float* lse, int B, int H, int T, int S, int ldq, int ldk, int ldv, int ldo,
                    int ldpq, int ldpk, long long q_bs, long long k_bs, long long v_bs, long long o_bs,
                    int rel_mode, int P, const int* gcode, int code_bias, int n2d, const float* rel2d,
-                   const float* rel1d, const float* relx, int causal, const float* dense_bias, void* stream);
+                   const float* rel1d, const float* relx, int causal, const float* dense_bias,
+                   const float* gain, void* stream);
+
+/* Backward of ifseg_attn_fwd (autograd of the same reference lines).  Launches
+ *   delta[b,h,t] = sum_d dout*out;  a key-stationary dK/dV kernel that also
+ *   histograms d(rel2d/rel1d/relx) in LDS;  a query-stationary dQ kernel.
+ * `gain` [H] fp32 is the per-head c_attn applied to `out` by the forward
+ * (unify_multihead_attention.py:509-512); d(gain)[h] = sum_{b,t} delta / gain[h].
+ * dq is scaled by dq_scale (the reference's q scaling), the abs-pos halves of
+ * dQ_ext / dK_ext are written as fp32 per-batch partials dpos_q_part [B,T,H*64]
+ * (scaled by dpq_scale) and dpos_k_part [B,S,H*64]; rel-table gradients as
+ * per-workgroup partials [H][nparts][n] with nparts = B*ceil(S/128) (sum them with
+ * ifseg_reduce_parts).  No atomics on global memory: results are deterministic. */
+typedef struct ifseg_attn_bwd_args {
+  const void *q, *k, *v, *pos_q, *pos_k, *out, *dout;
+  const float* lse;
+  float* delta;               /* workspace [B,H,T] */
+  void *dq, *dk, *dv;
+  float *dpos_q_part, *dpos_k_part;
+  int B, H, T, S;
+  int ldq, ldk, ldv, ldpq, ldpk, ldout, lddo, lddq, lddk, lddv;
+  long long q_bs, k_bs, v_bs, out_bs, do_bs, dq_bs, dk_bs, dv_bs;
+  int rel_mode, P, code_bias, n2d, causal, nparts;
+  const int* gcode;
+  const float *rel2d, *rel1d, *relx, *gain;
+  float *drel2d_part, *drel1d_part, *drelx_part;
+  float dq_scale, dpq_scale;
+} ifseg_attn_bwd_args;
+int ifseg_attn_bwd(const ifseg_attn_bwd_args* args, void* stream);
+
+/* -------------------------------------------------------------- row ops */
+/* Row addressing used below: logical row r lives at element offset
+ *   (r / rpb) * bs + (r % rpb) * ld      (rpb = rows per batch segment; rpb<=0: r*ld)
+ * which lets a kernel read / write a token range of a [B, T, C] buffer in place
+ * (the reference's torch.cat of image|text tokens, encoder_module.py:427, and of
+ * bos|patch tokens, decoder_module.py:537). */
+
+/* y = [resid +] LayerNorm(act(x)) * gamma + beta, act = identity | GELU(fp32).
+ * mean/rstd (fp32 [rows]) are saved for the backward when non-NULL.
+ * Replaces fairseq LayerNorm (modules/layer_norm.py:30-35) at the sites
+ * unify_transformer_layer.py:258,270,278,282,465,513,522,546,554,559 and
+ * encoder_module.py:408,423,757-759,829 / decoder_module.py:344,576,668, fused with
+ * activation_fn GELU (modules/gelu.py:24-25) and residual_connection (:196). */
+int ifseg_ln_fwd(const void* x, const void* gamma, const void* beta, const void* resid, void* y, float* mean,
+                 float* rstd, int rows, int C, float eps, int act_gelu, int rpb, long long x_bs, int ldx,
+                 long long y_bs, int ldy, long long r_bs, int ldr, void* stream);
+/* dx = [dx_add +] d/dx of the above; per-block partials of dgamma / dbeta are
+ * written to dgamma_part / dbeta_part [nblocks][C] (sum with ifseg_reduce_parts). */
+int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                 const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, int nblocks, int rows,
+                 int C, int act_gelu, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx,
+                 long long dx_bs, int lddx, long long add_bs, int ldadd, void* stream);
+/* out[o][i] (+)= scale * sum_p in[o][p][i]   (fp32 in; fp32 or bf16 out) */
+int ifseg_reduce_parts(const float* in, void* out, int outer, int parts, long long n, int accumulate,
+                       int out_bf16, float scale, void* stream);
+/* part[k][n] = column sums of the k-th row slab of x[M,N] (bias gradients; autograd of
+ * the bias add in F.linear). */
+int ifseg_colsum_bf16(const void* x, float* part, int nblk_rows, int M, int N, int rpb, long long x_bs, int ldx,
+                      void* stream);
+/* out[r] = table[ids[r]] + add  (embed_tokens + type_embedding, encoder_module.py:400-406) */
+int ifseg_embed_rows(const void* table, const long long* ids, const void* add, void* out, int n, int C, int rpb,
+                     long long o_bs, int ldo, void* stream);
+int ifseg_cast_f32_bf16(const float* in, void* out, long long n, float scale, void* stream);
+int ifseg_add_bf16(const void* a, const void* b, void* out, long long n, void* stream);
+/* NCHW (fp32 / bf16) image -> NHWC bf16 with channels zero-padded to Cpad */
+int ifseg_nchw_to_nhwc_bf16(const void* in, int in_is_f32, void* out, int B, int C, int H, int W, int Cpad,
+                            void* stream);
+
+/* ------------------------------------------------------------ ResNet stem */
+/* conv1 7x7/2 (3->64) + folded FrozenBN + ReLU on an NHWC(4) bf16 image; w fp32
+ * [7][7][3][64] with the BN scale folded, shift fp32 [64] (resnet.py:215-218). */
+int ifseg_stem_conv7x7(const void* in_nhwc4, const float* w, const float* shift, void* out, int B, int H, int W,
+                       void* stream);
+/* MaxPool2d(3, 2, 1) on NHWC bf16 (resnet.py:219). */
+int ifseg_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, void* stream);
+
+/* -------------------------------------------------------------- optimizer */
+/* sum of squares of a bf16 gradient arena -> out_sumsq[0] (device). */
+int ifseg_grad_sumsq_bf16(const void* g, long long n, float* workspace, float* out_sumsq, void* stream);
+/* Fused grad scaling + clip-by-global-norm + Adam with decoupled weight decay over a
+ * flat arena; writes the bf16 model copy.  Mirrors trainer.py:874-907 +
+ * fairseq/optim/adam.py:158-240 + fp16_optimizer.py (fp32 masters). */
+int ifseg_adam_step(float* p32, const void* g, float* m, float* v, void* p16, long long n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, float grad_scale, float max_norm,
+                    const float* sumsq, void* stream);
 
 #ifdef __cplusplus
 }
