@@ -1,0 +1,101 @@
+"""seg_criterion -- caller of the hot path (mirror of criterions/seg_criterion.py).
+
+Supervised branch of the reference criterion (seg_criterion.py:188-192 ->
+compute_loss :269-347 -> upsample_logits :237-244, compute_metric :349-362,
+reduce_metrics mIoU :533-572): bilinear upsample of the per-patch logits to pixel
+resolution, masked cross entropy, per-class area histograms.  ``sample_size`` is 1 per
+rank (``ntokens = 1``, :345) exactly like the reference, so after the trainer's
+``multiply_grads(world / sum(sample_size))`` the gradient is the mean over ranks.
+
+Round 1: the loss math runs as stock PyTorch ops on the GPU (SURVEY.md 8f row 2 --
+the fused upsample+CE+histogram kernel -- is "next"); the model call is the HIP path.
+"""
+import torch
+import torch.nn.functional as F
+
+from ..registry import register_criterion
+
+PAD, EOS = 1, 2
+
+
+@register_criterion("seg_criterion")
+class SegCriterion:
+    def __init__(self, task=None, label_smoothing=0.0, upscale_lprobs=True, unsupervised_segmentation=False,
+                 full_context_alignment=False, num_seg_tokens=None, seg_id_offset=None):
+        self.task = task
+        self.eps = label_smoothing
+        self.upscale_lprobs = upscale_lprobs
+        self.unsupervised_segmentation = unsupervised_segmentation
+        self.full_context_alignment = full_context_alignment
+        cfg = getattr(task, "cfg", None)
+        self.num_seg = num_seg_tokens if num_seg_tokens is not None else cfg.num_seg_tokens
+        self.seg_id_offset = seg_id_offset if seg_id_offset is not None else task.seg_id_offset
+        self.padding_idx = PAD
+        self.iter = -1
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    def forward(self, model, sample, update_num=0, reduce=True, ema_model=None):
+        """seg_criterion.py:165-235 (supervised train branch / eval branch)."""
+        self.iter += 1
+        if self.unsupervised_segmentation and model.training:
+            raise NotImplementedError("image-free training branch (seg_criterion.py:179-186): SURVEY 8f row 1")
+        net_output = model(**sample["net_input"], full_context_alignment=self.full_context_alignment)
+        loss, metrics, ntokens = self.compute_loss(model, net_output, sample, update_num, reduce=reduce)
+        sample_size = ntokens
+        logging_output = {"loss": loss.data, "imfree_loss": loss.data.new_zeros(1), "seg_loss": loss.data,
+                          "ntokens": sample["ntokens"], "nsentences": sample["nsentences"],
+                          "sample_size": sample_size}
+        logging_output.update({k: (v.data if isinstance(v, torch.Tensor) else v) for k, v in metrics.items()})
+        return loss, sample_size, logging_output
+
+    @staticmethod
+    def upsample_logits(logits, hp=32, wp=32, h=512, w=512):
+        """seg_criterion.py:237-244 (mmseg.ops.resize == F.interpolate)."""
+        lo = logits[:, :-1]
+        B, _, n = lo.shape
+        lo = lo.transpose(1, 2).reshape(B, n, hp, wp)
+        lo = F.interpolate(lo, size=(h, w), mode="bilinear", align_corners=False)
+        lo = lo.reshape(B, n, h * w).transpose(1, 2)
+        return torch.cat([lo, logits[:, -1:]], dim=1)
+
+    def compute_loss(self, model, net_output, sample, update_num, reduce=True):
+        scores_low, extra = net_output
+        scores_low = scores_low.float()
+        target = sample["target"]
+        hp, wp = extra["encoder_returns"]["image_embed_shape"][0]
+        h, w = sample["net_input"]["patch_images"].shape[-2:]
+        scores = self.upsample_logits(scores_low, hp, wp, h, w)
+        mask = (target == self.padding_idx) | (target == self.seg_id_offset + self.num_seg) | (target == EOS)
+        t = target[~mask] - self.seg_id_offset
+        s = scores[~mask]
+        metrics = dict(zip(("area_intersect", "area_pred_label", "area_label", "area_union"),
+                           self.compute_metric(s.detach(), t.detach())))
+        loss = F.cross_entropy(s, t, label_smoothing=self.eps)
+        metrics["nll_loss"] = loss
+        return loss, metrics, 1
+
+    @staticmethod
+    def compute_metric(lprobs, target):
+        """seg_criterion.py:349-362."""
+        n = lprobs.size(-1)
+        pred = lprobs.argmax(-1)
+        inter = pred[pred == target]
+        a_i = torch.histc(inter.float(), bins=n, min=0, max=n - 1)
+        a_p = torch.histc(pred.float(), bins=n, min=0, max=n - 1)
+        a_l = torch.histc(target.float(), bins=n, min=0, max=n - 1)
+        return a_i, a_p, a_l, a_p + a_l - a_i
+
+    @staticmethod
+    def reduce_metrics(logging_outputs):
+        """mIoU = nanmean(sum intersect / sum union) (seg_criterion.py:533-572)."""
+        ai = sum(l["area_intersect"] for l in logging_outputs)
+        au = sum(l["area_union"] for l in logging_outputs)
+        out = {"loss": sum(float(l["loss"]) for l in logging_outputs) / max(1, len(logging_outputs)),
+               "mIoU": float(torch.nanmean(ai / au))}
+        return out
+
+    @staticmethod
+    def logging_outputs_can_be_summed():
+        return True

@@ -390,3 +390,37 @@ extern "C" int ifseg_nchw_to_nhwc_bf16(const void* in, int in_is_f32, void* out,
   IFSEG_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- rel-pos table <-> per-head delta tables ------------------------------------
+namespace {
+// out[h][i] = table[idx[i]][h] (idx < 0 -> 0)
+__global__ void rel_gather_kernel(const bf16_t* table, const int* idx, float* out, int n, int H) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * H) return;
+  const int h = gid / n, i = gid % n;
+  const int r = idx[i];
+  out[gid] = r >= 0 ? bf2f(table[(long long)r * H + h]) : 0.f;
+}
+// acc[idx[i]][h] += d[h][i]   (fp32 accumulation buffer, tiny; duplicates allowed)
+__global__ void rel_scatter_kernel(const float* d, const int* idx, float* acc, int n, int H) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * H) return;
+  const int h = gid / n, i = gid % n;
+  const int r = idx[i];
+  if (r >= 0) atomicAdd(&acc[(long long)r * H + h], d[gid]);
+}
+}  // namespace
+
+extern "C" int ifseg_rel_gather(const void* table, const int* idx, float* out, int n, int H, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(rel_gather_kernel, dim3((n * H + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)table, idx, out, n, H);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int ifseg_rel_scatter_add(const float* d, const int* idx, float* acc, int n, int H, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(rel_scatter_kernel, dim3((n * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, idx, acc, n, H);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}

@@ -300,3 +300,15 @@ def adam_step(p32, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0
     _check(lib().ifseg_adam_step(_ptr(p32), _ptr(g), _ptr(m), _ptr(v), _ptr(p16), c_ll(p32.numel()), c_float(lr),
                                  c_float(beta1), c_float(beta2), c_float(eps), c_float(wd), c_int(step),
                                  c_float(grad_scale), c_float(max_norm), _ptr(sumsq), _stream()), "adam")
+
+
+def rel_gather(table, idx, out):
+    n, H = idx.numel(), table.shape[1]
+    _check(lib().ifseg_rel_gather(_ptr(table), _ptr(idx), _ptr(out), c_int(n), c_int(H), _stream()), "rel_gather")
+    return out
+
+
+def rel_scatter_add(d, idx, acc):
+    n, H = idx.numel(), acc.shape[1]
+    _check(lib().ifseg_rel_scatter_add(_ptr(d), _ptr(idx), _ptr(acc), c_int(n), c_int(H), _stream()), "rel_scatter")
+    return acc

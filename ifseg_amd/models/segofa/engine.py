@@ -1,0 +1,790 @@
+"""HIP execution engine for SegOFA: explicit forward + backward on MI355X.
+
+This is the host side of the hot path.  It owns
+  * one flat bf16 parameter arena and one flat bf16 gradient arena (the
+    nn.Parameters of the module tree are views into the arena, so the reference's
+    state_dict keys / load_state_dict keep working; q|k|v weights are laid out
+    contiguously so one GEMM serves the three projections),
+  * a static activation workspace (allocated once per input shape, reused every
+    step: no allocator traffic inside the step, hipGraph-capturable),
+  * the launch sequence of the hand-written kernels in csrc/ through the C ABI
+    (ifseg_amd.hip).  No torch compute op touches an activation; torch is used for
+    memory, streams and a handful of <=H-element scalar fix-ups.
+
+Reference call graph reproduced:
+  SegOFAModel.forward            models/segofa/segofa.py:69-153
+  TransformerEncoder.encode      models/segofa/encoder_module.py:677-851
+  TransformerEncoderLayer        models/segofa/unify_transformer_layer.py:222-292
+  extract_features_..surrogate   models/segofa/decoder_module.py:486-677
+  TransformerDecoderLayer        models/segofa/unify_transformer_layer.py:431-581
+  MultiheadAttention             models/segofa/unify_multihead_attention.py:327-513
+  ResNet / FrozenBatchNorm2d     models/segofa/resnet.py:215-229, frozen_bn.py:36-57
+and their autograd.  Internal token order of the decoder is [patches..., bos]
+(bos moved to the end so the seg grid is tile aligned); logits are produced in the
+reference order [bos, patches...].
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from ... import hip
+from .config import image_rp_bucket, token_bucket_of_delta
+
+BF = torch.bfloat16
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+class HipEngine:
+    def __init__(self, model):
+        self.model = model
+        self.cfg = model.cfg
+        self.packed = False
+        self.device = None
+        self.ws = {}
+        self.geo = {}
+        self.ctx = None
+        self.grad_ready_hook = None      # callable(lo, hi) on arena slices once their grads are final
+
+    # ------------------------------------------------------------------ packing
+    def _arena_order(self):
+        cfg = self.cfg
+        names = dict(self.model.named_parameters())   # unique tensors (ties appear once)
+        order, fused = [], {}
+
+        def add(n):
+            if n in names and n not in order:
+                order.append(n)
+
+        def mha(p):
+            add(p + ".c_attn")
+            for suf in (".weight", ".bias"):
+                for pr in ("q_proj", "k_proj", "v_proj"):
+                    add("%s.%s%s" % (p, pr, suf))
+            add(p + ".out_proj.weight"); add(p + ".out_proj.bias")
+
+        def lnp(p):
+            add(p + ".weight"); add(p + ".bias")
+
+        e = "encoder."
+        for p in ("layernorm_embedding", "patch_layernorm_embedding", "pos_ln", "image_pos_ln", "layer_norm"):
+            lnp(e + p)
+        add(e + "type_embedding.weight"); add(e + "embed_positions.weight"); add(e + "embed_image_positions.weight")
+        for suf in (".weight", ".bias"):
+            add(e + "pos_q_linear" + suf); add(e + "pos_k_linear" + suf)
+        for i in range(cfg.enc_layers):
+            p = "%slayers.%d." % (e, i)
+            mha(p + "self_attn")
+            for q in ("self_attn_layer_norm", "attn_ln", "final_layer_norm", "ffn_layernorm"):
+                lnp(p + q)
+            for q in ("fc1", "fc2"):
+                add(p + q + ".weight"); add(p + q + ".bias")
+            add("%stoken_rel_pos_table_list.%d.weight" % (e, i)); add("%simage_rel_pos_table_list.%d.weight" % (e, i))
+        d = "decoder."
+        for p in ("layernorm_embedding", "seg_pos_ln", "layer_norm"):
+            lnp(d + p)
+        add(d + "embed_seg_positions.weight")
+        for suf in (".weight", ".bias"):
+            add(d + "self_pos_q_linear" + suf); add(d + "self_pos_k_linear" + suf)
+        for n in ("cross_pos_q_linear", "cross_pos_k_linear"):
+            add(d + n + ".weight"); add(d + n + ".bias")
+        for i in range(cfg.dec_layers):
+            p = "%slayers.%d." % (d, i)
+            mha(p + "self_attn"); mha(p + "encoder_attn")
+            for q in ("self_attn_layer_norm", "self_attn_ln", "encoder_attn_layer_norm", "cross_attn_ln",
+                      "final_layer_norm", "ffn_layernorm"):
+                lnp(p + q)
+            for q in ("fc1", "fc2"):
+                add(p + q + ".weight"); add(p + q + ".bias")
+            add("%sseg_rel_pos_table_list.%d.weight" % (d, i))
+        # trainable parameters the path never touches (no grad in the reference either)
+        rest_train = [n for n, p in names.items() if n not in order and p.requires_grad and "embed_images" not in n]
+        order += rest_train
+        n_train_names = len(order)
+        frozen = [n for n in names if n not in order and "embed_images" not in n]
+        order += frozen
+        return order, n_train_names
+
+    def pack(self, device):
+        """(Re)build the arenas on `device` from the current parameter values."""
+        m = self.model
+        names = dict(m.named_parameters())
+        order, n_train_names = self._arena_order()
+        unsupported = [n for n in order[n_train_names:] if names[n].requires_grad]
+        unsupported += [n for n, p in names.items() if "embed_images" in n and p.requires_grad]
+        if unsupported:
+            raise NotImplementedError(
+                "ifseg_amd HIP engine: gradients for %s are not implemented (the shipped IFSeg recipe freezes "
+                "them: coco_unseen.sh:31-33,76)" % unsupported[:4])
+        offs, off = {}, 0
+        for n in order:
+            offs[n] = off
+            off += _pad8(names[n].numel())
+        total = off
+        n_train = offs[order[n_train_names]] if n_train_names < len(order) else total
+        p16 = torch.zeros(total, dtype=BF, device=device)
+        g16 = torch.zeros(n_train, dtype=BF, device=device)
+        master = torch.zeros(n_train, dtype=torch.float32, device=device)
+        for n in order:
+            p = names[n]
+            v = p.data.detach().to(device=device, dtype=torch.float32).reshape(-1)
+            o = offs[n]
+            if o < n_train:
+                master[o:o + v.numel()] = v
+            p16[o:o + v.numel()] = v.to(BF)
+            p.data = p16[o:o + v.numel()].view(p.shape)
+        self.p16, self.g16, self.master_init = p16, g16, master
+        self.offs, self.n_train, self.order = offs, n_train, order
+        self.shapes = {n: tuple(names[n].shape) for n in order}
+        self.names = names
+        # everything else (ResNet trunk, buffers) just moves to the device
+        for n, p in names.items():
+            if "embed_images" in n:
+                p.data = p.data.to(device)
+        for b_name, b in m.named_buffers():
+            if b.device != device:
+                b.data = b.data.to(device)
+        self.device = device
+        self._pack_resnet()
+        self._pack_misc()
+        self.packed = True
+        self.ws.clear()
+        self.geo.clear()
+
+    def trainable_names(self):
+        return [n for n in self.order if self.offs[n] < self.n_train and self.names[n].requires_grad]
+
+    def trainable_params(self):
+        return tuple(self.names[n] for n in self.trainable_names())
+
+    def W(self, n):
+        o = self.offs[n]
+        sh = self.shapes[n]
+        return self.p16[o:o + math.prod(sh)].view(sh)
+
+    def G(self, n):
+        o = self.offs[n]
+        sh = self.shapes[n]
+        return self.g16[o:o + math.prod(sh)].view(sh)
+
+    def _fused(self, arena, first, rows, cols=None):
+        """view of `rows` x cols starting at parameter `first` (parameters laid out contiguously)"""
+        o = self.offs[first]
+        n = rows * (cols or 1)
+        v = arena[o:o + n]
+        return v.view(rows, cols) if cols else v
+
+    def _pack_resnet(self):
+        """Fold FrozenBN into the conv weights (frozen_bn.py:39-40: scale = w*rsqrt(var+eps),
+        bias = b - mean*scale) and lay the kernels out [Cout][KH][KW][Cin] bf16."""
+        sd = {k: v for k, v in self.model.state_dict().items() if k.startswith("encoder.embed_images.")}
+        pre = "encoder.embed_images."
+        dev = self.device
+
+        def fold(conv, bn):
+            w = sd[pre + conv + ".weight"].float()
+            scale = sd[pre + bn + ".weight"].float() * torch.rsqrt(sd[pre + bn + ".running_var"].float() + 1e-5)
+            shift = sd[pre + bn + ".bias"].float() - sd[pre + bn + ".running_mean"].float() * scale
+            return w * scale.view(-1, 1, 1, 1), shift
+
+        w, sh = fold("conv1", "bn1")
+        self.stem_w = w.permute(2, 3, 1, 0).contiguous().to(dev)          # [7][7][3][64] fp32
+        self.stem_shift = sh.contiguous().to(dev)
+        self.rn_blocks = []
+        for li, nb in enumerate(self.cfg.resnet_layers, start=1):
+            for b in range(nb):
+                p = "layer%d.%d." % (li, b)
+                blk = {"stride": 2 if (b == 0 and li > 1) else 1}
+                for cn, bnn in (("conv1", "bn1"), ("conv2", "bn2"), ("conv3", "bn3")):
+                    w, sh = fold(p + cn, p + bnn)
+                    blk[cn] = (w.permute(0, 2, 3, 1).contiguous().to(dev, BF), sh.to(dev, BF))
+                if b == 0:
+                    w, sh = fold(p + "downsample.0", p + "downsample.1")
+                    blk["down"] = (w.permute(0, 2, 3, 1).contiguous().to(dev, BF), sh.to(dev, BF))
+                self.rn_blocks.append(blk)
+
+    def _pack_misc(self):
+        cfg, dev = self.cfg, self.device
+        C = cfg.embed_dim
+        npad = _pad8(cfg.num_seg_tokens)
+        self.npad = npad
+        self.wseg_pad = torch.zeros(npad, C, dtype=BF, device=dev)
+        self.refresh_frozen()
+
+    def refresh_frozen(self):
+        """Re-derive packed copies of frozen tensors (call after they are modified in place,
+        e.g. seg_criterion._lazy_initialization writes seg_embed_tokens)."""
+        w = self.model.decoder.seg_projection.weight.data
+        self.wseg_pad.zero_()
+        self.wseg_pad[: w.shape[0]] = w.to(self.wseg_pad.device, BF)
+
+    # --------------------------------------------------------------- workspace
+    def buf(self, name, shape, dtype=BF):
+        t = self.ws.get(name)
+        shape = tuple(int(s) for s in shape)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self.ws[name] = t
+        return t
+
+    def _geometry(self, h, w, L):
+        """index tables for a (h, w) feature grid and L text tokens (device tensors, cached)."""
+        key = (h, w, L)
+        g = self.geo.get(key)
+        if g is not None:
+            return g
+        cfg, dev = self.cfg, self.device
+        P = h * w
+        g = {"P": P}
+        ys = torch.arange(h).repeat_interleave(w)
+        xs = torch.arange(w).repeat(h)
+        g["gcode"] = (ys * (2 * w - 1) + xs).int().to(dev)
+        g["code_bias"] = (h - 1) * (2 * w - 1) + (w - 1)
+        g["n2d"] = (2 * h - 1) * (2 * w - 1)
+        dy = torch.arange(-(h - 1), h).repeat_interleave(2 * w - 1)
+        dx = torch.arange(-(w - 1), w).repeat(2 * h - 1)
+        b = cfg.image_bucket_size
+        g["enc_idx2d"] = ((dy + b - 1) * (2 * b - 1) + (dx + b - 1)).int().to(dev)      # encoder_module.py:87-104
+        tb = token_bucket_of_delta(cfg.token_bucket_size, cfg.max_source_positions)
+        dl = torch.arange(-(L - 1), L)
+        g["enc_idx1d"] = tb[dl + cfg.max_source_positions - 1].int().to(dev)
+        g["enc_idxx"] = torch.tensor([-1, -1], dtype=torch.int32, device=dev)
+        sb = cfg.seg_bucket_size
+        nseg_rel = (2 * sb - 1) ** 2 + 3
+        g["dec_idx2d"] = ((dy + sb - 1) * (2 * sb - 1) + (dx + sb - 1)).int().to(dev)
+        g["dec_idx1d"] = torch.tensor([nseg_rel - 1], dtype=torch.int32, device=dev)        # [0,0] corner
+        # relx[0]: grid query x bos key = column 0 -> N-2 ; relx[1]: bos query x grid key = row 0 -> N-3
+        g["dec_idxx"] = torch.tensor([nseg_rel - 2, nseg_rel - 3], dtype=torch.int32, device=dev)
+        self.geo[key] = g
+        return g
+
+    # ------------------------------------------------------------------ ResNet
+    def _resnet(self, images):
+        B, _, Hh, Ww = images.shape
+        x4 = self.buf("rn_x4", (B, Hh, Ww, 4))
+        hip.nchw_to_nhwc(images.contiguous(), x4, 4)
+        H1, W1 = (Hh + 6 - 7) // 2 + 1, (Ww + 6 - 7) // 2 + 1
+        s = self.buf("rn_stem", (B, H1, W1, 64))
+        hip.stem_conv(x4, self.stem_w, self.stem_shift, s, B, Hh, Ww)
+        H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
+        maxel = B * H2 * W2 * 256
+        pool = [self.buf("rn_p%d" % i, (maxel,)) for i in range(4)]
+        cur = pool[0][: B * H2 * W2 * 64].view(B, H2, W2, 64)
+        hip.maxpool(s, cur, B, H1, W1, 64)
+        curi, Hc, Wc, Cc = 0, H2, W2, 64
+
+        def take(busy):
+            for i in range(4):
+                if i not in busy:
+                    return i
+            raise RuntimeError("resnet buffer pool exhausted")
+
+        for blk in self.rn_blocks:
+            st = blk["stride"]
+            w1, s1 = blk["conv1"]; w2, s2 = blk["conv2"]; w3, s3 = blk["conv3"]
+            mid, cout = w1.shape[0], w3.shape[0]
+            Ho, Wo = (Hc + 2 - 3) // st + 1, (Wc + 2 - 3) // st + 1
+            i1 = take({curi})
+            o1 = pool[i1][: B * Hc * Wc * mid].view(B, Hc, Wc, mid)
+            hip.conv2d_nhwc(cur, w1, s1, None, o1, B, Hc, Wc, Cc, mid, 1, 1, 1, 0, True)
+            i2 = take({curi, i1})
+            o2 = pool[i2][: B * Ho * Wo * mid].view(B, Ho, Wo, mid)
+            hip.conv2d_nhwc(o1, w2, s2, None, o2, B, Hc, Wc, mid, mid, 3, 3, st, 1, True)
+            if "down" in blk:
+                wd, sd_ = blk["down"]
+                i3 = take({curi, i1, i2})
+                idt = pool[i3][: B * Ho * Wo * cout].view(B, Ho, Wo, cout)
+                hip.conv2d_nhwc(cur, wd, sd_, None, idt, B, Hc, Wc, Cc, cout, 1, 1, st, 0, False)
+                io = i1
+            else:
+                i3, idt = curi, cur
+                io = i1
+            out = pool[io][: B * Ho * Wo * cout].view(B, Ho, Wo, cout)
+            hip.conv2d_nhwc(o2, w3, s3, idt, out, B, Ho, Wo, mid, cout, 1, 1, 1, 0, True)
+            cur, curi, Hc, Wc, Cc = out, io, Ho, Wo, cout
+        feat = self.buf("rn_feat", (B, Hc * Wc, Cc))
+        feat.copy_(cur.view(B, Hc * Wc, Cc))
+        return feat, Hc, Wc
+
+    # ------------------------------------------------------------ small helpers
+    def _rel_tables(self, tag, tables_idx):
+        """gather (table, idx) pairs into fp32 [H, n] delta tables"""
+        out = []
+        H = self.cfg.heads
+        for k, (tab, idx) in enumerate(tables_idx):
+            o = self.buf("%s_rel%d" % (tag, k), (H, idx.numel()), torch.float32)
+            if tab is None:
+                o.zero_()
+            else:
+                hip.rel_gather(tab, idx, o)
+            out.append(o)
+        return out
+
+    def _ln_stats(self, tag, rows):
+        return self.buf(tag + "_mu", (rows,), torch.float32), self.buf(tag + "_rs", (rows,), torch.float32)
+
+    def _gain32(self, tag, name):
+        g = self.buf(tag + "_gain", (self.cfg.heads,), torch.float32)
+        g.copy_(self.W(name))
+        return g
+
+    # ----------------------------------------------------------------- forward
+    def forward(self, src_tokens, patch_images, prev_output_tokens=None, full_context_alignment=False,
+                need_grad=True):
+        cfg = self.cfg
+        dev = patch_images.device
+        if not self.packed or self.device != dev:
+            self.pack(dev)
+        key = (src_tokens.data_ptr(), src_tokens._version, tuple(src_tokens.shape))
+        if getattr(self, "_checked_src", None) != key:
+            self._checked_src = key if not bool(src_tokens.eq(1).any()) else None
+        if self._checked_src is None:
+            raise NotImplementedError("ifseg_amd HIP engine: padded source tokens are not supported "
+                                      "(every IFSeg sample carries the same unpadded prompt)")
+        B, L = src_tokens.shape
+        C, Fd, H = cfg.embed_dim, cfg.ffn_dim, cfg.heads
+        scaling = float(cfg.head_dim * cfg.attn_scale_factor) ** -0.5
+        W, buf = self.W, self.buf
+        feat, h, w = self._resnet(patch_images)
+        P = h * w
+        oh = cfg.orig_patch_image_size // 16
+        if (h, w) != (oh, oh) or (h, w) != (cfg.seg_bucket_size,) * 2 or P % 64:
+            raise NotImplementedError(
+                "ifseg_amd HIP engine: feature grid %dx%d differs from the trained grid %dx%d (or is not a "
+                "multiple of 64 tokens); the resized-bias slow path is not built yet" % (h, w, oh, oh))
+        g = self._geometry(h, w, L)
+        T, Td = P + L, P + 1
+        ctx = {"B": B, "L": L, "P": P, "T": T, "Td": Td, "h": h, "w": w, "full": bool(full_context_alignment),
+               "src_tokens": src_tokens, "feat": feat}
+        e = "encoder."
+        # ---- embeddings (forward_embedding, encoder_module.py:388-446)
+        bias_img = buf("bias_img", (C,))
+        hip.add_bf16(W(e + "image_proj.bias"), W(e + "type_embedding.weight")[1], bias_img)
+        img_pre = buf("img_pre", (B * P, C))
+        hip.linear_fwd(feat.view(B * P, 1024), W(e + "image_proj.weight"), bias_img, out=img_pre)
+        x = buf("e_x_in", (B, T, C))
+        mu, rs = self._ln_stats("img_ln", B * P)
+        hip.ln_fwd(img_pre.view(B, P, C), W(e + "patch_layernorm_embedding.weight"),
+                   W(e + "patch_layernorm_embedding.bias"), x[:, :P], mu, rs)
+        tok_pre = buf("tok_pre", (B * L, C))
+        hip.embed_rows(W(e + "embed_tokens.weight"), src_tokens.reshape(-1).contiguous(),
+                       W(e + "type_embedding.weight")[0], tok_pre)
+        mu, rs = self._ln_stats("tok_ln", B * L)
+        hip.ln_fwd(tok_pre.view(B, L, C), W(e + "layernorm_embedding.weight"), W(e + "layernorm_embedding.bias"),
+                   x[:, P:], mu, rs)
+        # ---- abs-pos operands (encoder_module.py:757-771): LN over the table rows in place
+        bsz = cfg.image_bucket_size
+        img_pos_view = W(e + "embed_image_positions.weight")[1:1 + bsz * h].view(h, bsz, C)[:, :w]
+        pos_all = buf("e_pos_all", (T, C))
+        mu, rs = self._ln_stats("ipos_ln", P)
+        hip.ln_fwd(img_pos_view, W(e + "image_pos_ln.weight"), W(e + "image_pos_ln.bias"), pos_all[:P].view(h, w, C), mu, rs)
+        mu, rs = self._ln_stats("tpos_ln", L)
+        hip.ln_fwd(W(e + "embed_positions.weight")[:L], W(e + "pos_ln.weight"), W(e + "pos_ln.bias"), pos_all[P:], mu, rs)
+        pqk = buf("e_pqk", (T, 2 * C))
+        hip.linear_fwd(pos_all, self._fused(self.p16, e + "pos_q_linear.weight", 2 * C, C),
+                       self._fused(self.p16, e + "pos_q_linear.bias", 2 * C), out=pqk, alpha=scaling, alpha_ncols=C)
+        ctx["e_pq"], ctx["e_pk"] = pqk[:, :C], pqk[:, C:]
+        # ---- encoder layers
+        for l in range(cfg.enc_layers):
+            p = "%slayers.%d." % (e, l)
+            tg = "e%d" % l
+            r2, r1, rx = self._rel_tables(tg, [
+                (W("%simage_rel_pos_table_list.%d.weight" % (e, l)), g["enc_idx2d"]),
+                (W("%stoken_rel_pos_table_list.%d.weight" % (e, l)), g["enc_idx1d"]),
+                (None, g["enc_idxx"])])
+            rel = hip.RelBias(P, g["gcode"], g["code_bias"], r2, r1, rx)
+            x = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", x, B, T,
+                                     ctx["e_pq"], ctx["e_pk"], rel, False, scaling)
+            x = self._ffn_fwd(tg, p, x, B * T)
+        enc_out = buf("enc_out", (B, T, C))
+        mu, rs = self._ln_stats("e_final_ln", B * T)
+        hip.ln_fwd(x.view(B * T, C), W(e + "layer_norm.weight"), W(e + "layer_norm.bias"), enc_out.view(B * T, C), mu, rs)
+        ctx["e_x_final"] = x
+        ctx["enc_out"] = enc_out
+
+        # ---- decoder (extract_features_scriptable_surrogate, decoder_module.py:486-677)
+        d = "decoder."
+        y0b = buf("d_bos", (B, 1, C))
+        bos = (prev_output_tokens[:, :1] if prev_output_tokens is not None
+               else torch.zeros(B, 1, dtype=torch.long, device=dev))
+        hip.embed_rows(W(e + "embed_tokens.weight"), bos.reshape(-1).contiguous(), None, y0b)
+        y = buf("d_y_in", (B, Td, C))
+        mu, rs = self._ln_stats("d_emb_ln_p", B * P)
+        hip.ln_fwd(enc_out[:, :P], W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), y[:, :P], mu, rs)
+        mu, rs = self._ln_stats("d_emb_ln_b", B)
+        hip.ln_fwd(y0b, W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), y[:, P:], mu, rs)
+        # positions: internal order [grid cells 1..P | slot 0]
+        sb = cfg.seg_bucket_size
+        segtab = W(d + "embed_seg_positions.weight")
+        tp = buf("d_tp", (Td, C))
+        mu, rs = self._ln_stats("d_tp_ln_p", P)
+        hip.ln_fwd(segtab[1:1 + P], W(d + "seg_pos_ln.weight"), W(d + "seg_pos_ln.bias"), tp[:P], mu, rs)
+        mu, rs = self._ln_stats("d_tp_ln_b", 1)
+        hip.ln_fwd(segtab[:1], W(d + "seg_pos_ln.weight"), W(d + "seg_pos_ln.bias"), tp[P:], mu, rs)
+        spqk = buf("d_spqk", (Td, 2 * C))
+        hip.linear_fwd(tp, self._fused(self.p16, d + "self_pos_q_linear.weight", 2 * C, C),
+                       self._fused(self.p16, d + "self_pos_q_linear.bias", 2 * C), out=spqk, alpha=scaling, alpha_ncols=C)
+        cpq = buf("d_cpq", (Td, C))
+        hip.linear_fwd(tp, W(d + "cross_pos_q_linear.weight"), W(d + "cross_pos_q_linear.bias"), out=cpq, alpha=scaling)
+        cpk = buf("d_cpk", (T, C))
+        hip.linear_fwd(pos_all, W(d + "cross_pos_k_linear.weight"), W(d + "cross_pos_k_linear.bias"), out=cpk)
+        ctx.update(d_spq=spqk[:, :C], d_spk=spqk[:, C:], d_cpq=cpq, d_cpk=cpk)
+        causal = not full_context_alignment
+        for l in range(cfg.dec_layers):
+            p = "%slayers.%d." % (d, l)
+            tg = "d%d" % l
+            tab = W("%sseg_rel_pos_table_list.%d.weight" % (d, l))
+            r2, r1, rx = self._rel_tables(tg, [(tab, g["dec_idx2d"]), (tab, g["dec_idx1d"]), (tab, g["dec_idxx"])])
+            rel = hip.RelBias(P, g["gcode"], g["code_bias"], r2, r1, rx)
+            y = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", y, B, Td,
+                                     ctx["d_spq"], ctx["d_spk"], rel, causal, scaling)
+            y = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling)
+            y = self._ffn_fwd(tg, p, y, B * Td)
+        ctx["d_y_final"] = y
+        # final LN written in reference order [bos, patches] (decoder_module.py:668-675)
+        featb = buf("d_feat", (B, Td, C))
+        mu, rs = self._ln_stats("d_final_ln_p", B * P)
+        hip.ln_fwd(y[:, :P], W(d + "layer_norm.weight"), W(d + "layer_norm.bias"), featb[:, 1:], mu, rs)
+        mu, rs = self._ln_stats("d_final_ln_b", B)
+        hip.ln_fwd(y[:, P:], W(d + "layer_norm.weight"), W(d + "layer_norm.bias"), featb[:, :1], mu, rs)
+        logits = buf("logits_pad", (B, Td, self.npad))
+        hip.linear_fwd(featb.view(B * Td, C), self.wseg_pad, out=logits.view(B * Td, self.npad))   # :290-294
+        self.ctx = ctx
+        return logits, ctx
+
+    def _self_block_fwd(self, tg, p, attn, ln1, ln2, x, B, T, pq, pk, rel, causal, scaling):
+        C, H = self.cfg.embed_dim, self.cfg.heads
+        W, buf = self.W, self.buf
+        a_ = p + attn
+        xn = buf(tg + "_xn", (B * T, C))
+        mu, rs = self._ln_stats(tg + "_ln1", B * T)
+        hip.ln_fwd(x.view(B * T, C), W(p + ln1 + ".weight"), W(p + ln1 + ".bias"), xn, mu, rs)
+        qkv = buf(tg + "_qkv", (B, T, 3 * C))
+        hip.linear_fwd(xn, self._fused(self.p16, a_ + ".q_proj.weight", 3 * C, C),
+                       self._fused(self.p16, a_ + ".q_proj.bias", 3 * C), out=qkv.view(B * T, 3 * C),
+                       alpha=scaling, alpha_ncols=C)
+        o = buf(tg + "_o", (B, T, C))
+        lse = buf(tg + "_lse", (B, H, T), torch.float32)
+        gain = self._gain32(tg + "_sa", a_ + ".c_attn")
+        hip.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], pq, pk, o, lse, B, H, T, T, rel=rel,
+                     causal=causal, gain=gain)
+        a = buf(tg + "_a", (B * T, C))
+        hip.linear_fwd(o.view(B * T, C), W(a_ + ".out_proj.weight"), W(a_ + ".out_proj.bias"), out=a)
+        x1 = buf(tg + "_x1", (B, T, C))
+        mu, rs = self._ln_stats(tg + "_ln2", B * T)
+        hip.ln_fwd(a, W(p + ln2 + ".weight"), W(p + ln2 + ".bias"), x1.view(B * T, C), mu, rs, resid=x.view(B * T, C))
+        self.ctx_tmp = None
+        self._save(tg + "_sa", x=x, xn=xn, qkv=qkv, o=o, lse=lse, a=a, rel=rel, gain=gain, causal=causal)
+        return x1
+
+    def _cross_block_fwd(self, tg, p, y1, enc_out, B, Td, Te, cpq, cpk, scaling):
+        C, H = self.cfg.embed_dim, self.cfg.heads
+        W, buf = self.W, self.buf
+        a_ = p + "encoder_attn"
+        yn = buf(tg + "_cyn", (B * Td, C))
+        mu, rs = self._ln_stats(tg + "_cln1", B * Td)
+        hip.ln_fwd(y1.view(B * Td, C), W(p + "encoder_attn_layer_norm.weight"), W(p + "encoder_attn_layer_norm.bias"), yn, mu, rs)
+        q = buf(tg + "_cq", (B, Td, C))
+        hip.linear_fwd(yn, W(a_ + ".q_proj.weight"), W(a_ + ".q_proj.bias"), out=q.view(B * Td, C), alpha=scaling)
+        kv = buf(tg + "_ckv", (B, Te, 2 * C))
+        hip.linear_fwd(enc_out.view(B * Te, C), self._fused(self.p16, a_ + ".k_proj.weight", 2 * C, C),
+                       self._fused(self.p16, a_ + ".k_proj.bias", 2 * C), out=kv.view(B * Te, 2 * C))
+        o = buf(tg + "_co", (B, Td, C))
+        lse = buf(tg + "_clse", (B, H, Td), torch.float32)
+        gain = self._gain32(tg + "_ca", a_ + ".c_attn")
+        hip.attn_fwd(q, kv[:, :, :C], kv[:, :, C:], cpq, cpk, o, lse, B, H, Td, Te, gain=gain)
+        a = buf(tg + "_ca_a", (B * Td, C))
+        hip.linear_fwd(o.view(B * Td, C), W(a_ + ".out_proj.weight"), W(a_ + ".out_proj.bias"), out=a)
+        y2 = buf(tg + "_y2", (B, Td, C))
+        mu, rs = self._ln_stats(tg + "_cln2", B * Td)
+        hip.ln_fwd(a, W(p + "cross_attn_ln.weight"), W(p + "cross_attn_ln.bias"), y2.view(B * Td, C), mu, rs,
+                   resid=y1.view(B * Td, C))
+        self._save(tg + "_ca", x=y1, xn=yn, q=q, kv=kv, o=o, lse=lse, a=a, gain=gain)
+        return y2
+
+    def _ffn_fwd(self, tg, p, x1, rows):
+        C, Fd = self.cfg.embed_dim, self.cfg.ffn_dim
+        W, buf = self.W, self.buf
+        xn = buf(tg + "_fxn", (rows, C))
+        mu, rs = self._ln_stats(tg + "_fln1", rows)
+        hip.ln_fwd(x1.view(rows, C), W(p + "final_layer_norm.weight"), W(p + "final_layer_norm.bias"), xn, mu, rs)
+        u = buf(tg + "_u", (rows, Fd))
+        hip.linear_fwd(xn, W(p + "fc1.weight"), W(p + "fc1.bias"), out=u)
+        z = buf(tg + "_z", (rows, Fd))
+        mu, rs = self._ln_stats(tg + "_fln2", rows)
+        hip.ln_fwd(u, W(p + "ffn_layernorm.weight"), W(p + "ffn_layernorm.bias"), z, mu, rs, gelu=True)
+        x2 = buf(tg + "_x2", x1.shape)
+        hip.linear_fwd(z, W(p + "fc2.weight"), W(p + "fc2.bias"), out=x2.view(rows, C), resid=x1.view(rows, C))
+        self._save(tg + "_ffn", x1=x1, xn=xn, u=u, z=z)
+        return x2
+
+    def _save(self, key, **kw):
+        if not hasattr(self, "saved"):
+            self.saved = {}
+        self.saved[key] = kw
+
+    # ---------------------------------------------------------------- backward
+    def _ln_param_grads(self, pname, C, accumulate=False):
+        hip.reduce_parts(self._dgp(C), self.G(pname + ".weight"), 1, hip.LN_BWD_BLOCKS, C, accumulate=accumulate)
+        hip.reduce_parts(self._dbp(C), self.G(pname + ".bias"), 1, hip.LN_BWD_BLOCKS, C, accumulate=accumulate)
+
+    def _dgp(self, C):
+        return self.buf("ln_dgp_%d" % C, (hip.LN_BWD_BLOCKS, C), torch.float32)
+
+    def _dbp(self, C):
+        return self.buf("ln_dbp_%d" % C, (hip.LN_BWD_BLOCKS, C), torch.float32)
+
+    def _ln_bwd(self, dy, x, pname, stats_tag, dx, dx_add=None, gelu=False, accumulate=False):
+        C = x.shape[-1]
+        rows = x.numel() // C
+        mu, rs = self._ln_stats(stats_tag, rows)
+        hip.ln_bwd(dy, x, self.W(pname + ".weight"), mu, rs, dx, self._dgp(C), self._dbp(C), dx_add=dx_add, gelu=gelu)
+        self._ln_param_grads(pname, C, accumulate)
+        return dx
+
+    def _bias_grad(self, dy2d, gout, accumulate=False):
+        N = dy2d.shape[-1]
+        part = self.buf("colsum_%d" % N, (hip.COLSUM_BLOCKS, N), torch.float32)
+        hip.colsum(dy2d, part)
+        hip.reduce_parts(part, gout, 1, hip.COLSUM_BLOCKS, N, accumulate=accumulate)
+
+    def _linear_bwd(self, dy, x, wname_or_view, gw, gb, dx_out=None, dx_resid=None, dx_accumulate=False, need_dx=True):
+        """dy [M,N], x [M,K]: writes dW -> gw, db -> gb, returns dx [M,K]"""
+        hip.linear_dw(dy, x, gw)
+        if gb is not None:
+            self._bias_grad(dy, gb)
+        if need_dx:
+            return hip.linear_dx(dy, wname_or_view, out=dx_out, resid=dx_resid, accumulate=dx_accumulate)
+        return None
+
+    def _ffn_bwd(self, tg, p, dx2, rows):
+        """dx2: grad of the block output [rows, C]; returns grad of x1 (block input)"""
+        C, Fd = self.cfg.embed_dim, self.cfg.ffn_dim
+        s = self.saved[tg + "_ffn"]
+        W, G, buf = self.W, self.G, self.buf
+        dz = buf("g_dz_%d" % rows, (rows, Fd))
+        self._linear_bwd(dx2, s["z"], W(p + "fc2.weight"), G(p + "fc2.weight"), G(p + "fc2.bias"), dx_out=dz)
+        du = buf("g_du_%d" % rows, (rows, Fd))
+        self._ln_bwd(dz, s["u"], p + "ffn_layernorm", tg + "_fln2", du, gelu=True)
+        dxn = buf("g_dxn_%d" % rows, (rows, C))
+        self._linear_bwd(du, s["xn"], W(p + "fc1.weight"), G(p + "fc1.weight"), G(p + "fc1.bias"), dx_out=dxn)
+        dx1 = buf("g_dx1_%d" % rows, (rows, C))
+        self._ln_bwd(dxn, s["x1"].view(rows, C), p + "final_layer_norm", tg + "_fln1", dx1, dx_add=dx2)
+        return dx1
+
+    def _attn_core_bwd(self, tag, q, k, v, pq, pk, o, lse, do, dq, dk, dv, B, T, S, rel, causal, gain, gain_name,
+                       scaling, dpq_acc, dpk_acc, first_pos, rel_grads):
+        cfg = self.cfg
+        C, H = cfg.embed_dim, cfg.heads
+        buf = self.buf
+        delta = buf("g_delta_%d" % T, (B, H, T), torch.float32)
+        dpq_part = buf("g_dpq_part_%d" % T, (B, T, C), torch.float32)
+        dpk_part = buf("g_dpk_part_%d" % S, (B, S, C), torch.float32)
+        nparts = B * ((S + 127) // 128)
+        parts = [None, None, None]
+        if rel is not None:
+            parts = [buf("g_relp%d_%d" % (i, t.shape[1]), (H, nparts, t.shape[1]), torch.float32)
+                     for i, t in enumerate((rel.rel2d, rel.rel1d, rel.relx))]
+        hip.attn_bwd(q, k, v, pq, pk, o, do, lse, delta, dq, dk, dv, dpq_part, dpk_part, B, H, T, S, rel=rel,
+                     causal=causal, gain=gain, dq_scale=scaling, dpq_scale=scaling, drel2d_part=parts[0],
+                     drel1d_part=parts[1], drelx_part=parts[2], nparts=nparts)
+        hip.reduce_parts(dpq_part, dpq_acc, 1, B, T * C, accumulate=not first_pos)
+        hip.reduce_parts(dpk_part, dpk_acc, 1, B, S * C, accumulate=not first_pos)
+        # d c_attn[h] = sum_{b,t} delta / c_attn[h]   (H scalars)
+        hip.reduce_parts(delta.view(B, H * T), buf("g_dsum_bt", (H * T,), torch.float32), 1, B, H * T)
+        self.G(gain_name).copy_((self.ws["g_dsum_bt"].view(H, T).sum(1) / gain))
+        if rel is not None:
+            for (tabname, idx), part in zip(rel_grads, parts):
+                if tabname is None:
+                    continue
+                n = part.shape[2]
+                red = buf("g_relred_%d" % n, (H, n), torch.float32)
+                hip.reduce_parts(part, red, H, nparts, n)
+                acc = self._table_acc(tabname)
+                hip.rel_scatter_add(red, idx, acc)
+
+    def _table_acc(self, tabname):
+        key = "g_tabacc_" + tabname
+        if key not in self._tab_touched:
+            t = self.buf(key, self.shapes[tabname], torch.float32)
+            t.zero_()
+            self._tab_touched[key] = tabname
+        return self.ws[key]
+
+    def _self_block_bwd(self, tg, p, attn, ln1, ln2, dx1, B, T, pq, pk, scaling, dpq_acc, dpk_acc, first_pos, rel_grads):
+        C = self.cfg.embed_dim
+        s = self.saved[tg + "_sa"]
+        W, G, buf = self.W, self.G, self.buf
+        a_ = p + attn
+        rows = B * T
+        da = buf("g_da_%d" % rows, (rows, C))
+        self._ln_bwd(dx1, s["a"], p + ln2, tg + "_ln2", da)
+        do = buf("g_do_%d" % rows, (B, T, C))
+        self._linear_bwd(da, s["o"].view(rows, C), W(a_ + ".out_proj.weight"), G(a_ + ".out_proj.weight"),
+                         G(a_ + ".out_proj.bias"), dx_out=do.view(rows, C))
+        dqkv = buf("g_dqkv_%d" % rows, (B, T, 3 * C))
+        qkv = s["qkv"]
+        self._attn_core_bwd(tg, qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], pq, pk, s["o"], s["lse"], do,
+                            dqkv[:, :, :C], dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:], B, T, T, s["rel"], s["causal"],
+                            s["gain"], a_ + ".c_attn", scaling, dpq_acc, dpk_acc, first_pos, rel_grads)
+        dxn = buf("g_dxn_%d" % rows, (rows, C))
+        self._linear_bwd(dqkv.view(rows, 3 * C), s["xn"], self._fused(self.p16, a_ + ".q_proj.weight", 3 * C, C),
+                         self._fused(self.g16, a_ + ".q_proj.weight", 3 * C, C),
+                         self._fused(self.g16, a_ + ".q_proj.bias", 3 * C), dx_out=dxn)
+        dx = buf("g_dx0_%d" % rows, (rows, C))
+        self._ln_bwd(dxn, s["x"].view(rows, C), p + ln1, tg + "_ln1", dx, dx_add=dx1)
+        return dx
+
+    def _cross_block_bwd(self, tg, p, dy2, B, Td, Te, cpq, cpk, scaling, d_enc_out, first_cross, dcpq_acc, dcpk_acc):
+        C = self.cfg.embed_dim
+        s = self.saved[tg + "_ca"]
+        W, G, buf = self.W, self.G, self.buf
+        a_ = p + "encoder_attn"
+        rows = B * Td
+        da = buf("g_da_%d" % rows, (rows, C))
+        self._ln_bwd(dy2, s["a"], p + "cross_attn_ln", tg + "_cln2", da)
+        do = buf("g_do_%d" % rows, (B, Td, C))
+        self._linear_bwd(da, s["o"].view(rows, C), W(a_ + ".out_proj.weight"), G(a_ + ".out_proj.weight"),
+                         G(a_ + ".out_proj.bias"), dx_out=do.view(rows, C))
+        dq = buf("g_cdq", (B, Td, C))
+        dkv = buf("g_cdkv", (B, Te, 2 * C))
+        kv = s["kv"]
+        self._attn_core_bwd(tg + "c", s["q"], kv[:, :, :C], kv[:, :, C:], cpq, cpk, s["o"], s["lse"], do, dq,
+                            dkv[:, :, :C], dkv[:, :, C:], B, Td, Te, None, False, s["gain"], a_ + ".c_attn", scaling,
+                            dcpq_acc, dcpk_acc, first_cross, None)
+        dyn = buf("g_dxn_%d" % rows, (rows, C))
+        self._linear_bwd(dq.view(rows, C), s["xn"], W(a_ + ".q_proj.weight"), G(a_ + ".q_proj.weight"),
+                         G(a_ + ".q_proj.bias"), dx_out=dyn)
+        # K/V projections read the encoder output: accumulate into d_enc_out
+        enc2d = self.ctx["enc_out"].view(B * Te, C)
+        self._linear_bwd(dkv.view(B * Te, 2 * C), enc2d, self._fused(self.p16, a_ + ".k_proj.weight", 2 * C, C),
+                         self._fused(self.g16, a_ + ".k_proj.weight", 2 * C, C),
+                         self._fused(self.g16, a_ + ".k_proj.bias", 2 * C), dx_out=d_enc_out.view(B * Te, C),
+                         dx_accumulate=not first_cross)
+        dy1 = buf("g_dy1c_%d" % rows, (rows, C))
+        self._ln_bwd(dyn, s["x"].view(rows, C), p + "encoder_attn_layer_norm", tg + "_cln1", dy1, dx_add=dy2)
+        return dy1
+
+    def backward(self, dlogits):
+        """dlogits: [B, P+1, nseg] (any float dtype) in reference order.  Fills the gradient arena."""
+        cfg, ctx = self.cfg, self.ctx
+        B, L, P, T, Td, h, w = (ctx[k] for k in ("B", "L", "P", "T", "Td", "h", "w"))
+        C, H = cfg.embed_dim, cfg.heads
+        scaling = float(cfg.head_dim * cfg.attn_scale_factor) ** -0.5
+        W, G, buf = self.W, self.G, self.buf
+        g = self._geometry(h, w, L)
+        self.g16.zero_()
+        self._tab_touched = {}
+        e, d = "encoder.", "decoder."
+        # ---- seg projection (frozen, tied to seg_embed_tokens: no weight grad)
+        dl = buf("g_dlogits", (B * Td, self.npad))
+        dl.zero_()
+        dl.view(B, Td, self.npad)[:, :, : cfg.num_seg_tokens].copy_(dlogits)
+        dfeat = buf("g_dfeat", (B, Td, C))
+        hip.linear_dx(dl, self.wseg_pad, out=dfeat.view(B * Td, C))
+        y = ctx["d_y_final"]
+        dy = buf("g_dy_final", (B, Td, C))
+        self._ln_bwd(dfeat[:, 1:], y[:, :P], d + "layer_norm", "d_final_ln_p", dy[:, :P])
+        self._ln_bwd(dfeat[:, :1], y[:, P:], d + "layer_norm", "d_final_ln_b", dy[:, P:], accumulate=True)
+        dy = dy.view(B * Td, C)
+        d_enc_out = buf("g_d_enc_out", (B, T, C))
+        dspq, dspk = buf("g_dspq", (Td, C), torch.float32), buf("g_dspk", (Td, C), torch.float32)
+        dcpq, dcpk = buf("g_dcpq", (Td, C), torch.float32), buf("g_dcpk", (T, C), torch.float32)
+        for l in reversed(range(cfg.dec_layers)):
+            p = "%slayers.%d." % (d, l)
+            tg = "d%d" % l
+            first = l == cfg.dec_layers - 1
+            dy = self._ffn_bwd(tg, p, dy, B * Td)
+            dy = self._cross_block_bwd(tg, p, dy, B, Td, T, ctx["d_cpq"], ctx["d_cpk"], scaling, d_enc_out, first, dcpq, dcpk)
+            tabn = "%sseg_rel_pos_table_list.%d.weight" % (d, l)
+            dy = self._self_block_bwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", dy, B, Td,
+                                      ctx["d_spq"], ctx["d_spk"], scaling, dspq, dspk, first,
+                                      [(tabn, g["dec_idx2d"]), (tabn, g["dec_idx1d"]), (tabn, g["dec_idxx"])])
+            self._flush_tables()
+            self._notify(p)
+        # ---- decoder embedding LN (input = [enc_out[:, :P] | embed(bos)])
+        dy3 = dy.view(B, Td, C)
+        enc_out = ctx["enc_out"]
+        self._ln_bwd(dy3[:, :P], enc_out[:, :P], d + "layernorm_embedding", "d_emb_ln_p", d_enc_out[:, :P],
+                     dx_add=d_enc_out[:, :P])
+        scratch = buf("g_bos_scratch", (B, 1, C))
+        self._ln_bwd(dy3[:, P:], self.ws["d_bos"], d + "layernorm_embedding", "d_emb_ln_b", scratch, accumulate=True)
+        # ---- decoder position operands
+        dspqk = buf("g_dspqk", (Td, 2 * C))
+        hip.cast_f32_bf16(dspq, buf("g_tmp_tc", (Td, C)))
+        dspqk[:, :C].copy_(self.ws["g_tmp_tc"])
+        hip.cast_f32_bf16(dspk, self.ws["g_tmp_tc"])
+        dspqk[:, C:].copy_(self.ws["g_tmp_tc"])
+        tp = self.ws["d_tp"]
+        dtp = buf("g_dtp", (Td, C))
+        self._linear_bwd(dspqk, tp, self._fused(self.p16, d + "self_pos_q_linear.weight", 2 * C, C),
+                         self._fused(self.g16, d + "self_pos_q_linear.weight", 2 * C, C),
+                         self._fused(self.g16, d + "self_pos_q_linear.bias", 2 * C), dx_out=dtp)
+        dcpq16 = buf("g_dcpq16", (Td, C))
+        hip.cast_f32_bf16(dcpq, dcpq16)
+        self._linear_bwd(dcpq16, tp, W(d + "cross_pos_q_linear.weight"), G(d + "cross_pos_q_linear.weight"),
+                         G(d + "cross_pos_q_linear.bias"), dx_out=dtp, dx_accumulate=True)
+        segG = G(d + "embed_seg_positions.weight")
+        segtab = W(d + "embed_seg_positions.weight")
+        self._ln_bwd(dtp[:P], segtab[1:1 + P], d + "seg_pos_ln", "d_tp_ln_p", segG[1:1 + P])
+        self._ln_bwd(dtp[P:], segtab[:1], d + "seg_pos_ln", "d_tp_ln_b", segG[:1], accumulate=True)
+        pos_all = self.ws["e_pos_all"]
+        dcpk16 = buf("g_dcpk16", (T, C))
+        hip.cast_f32_bf16(dcpk, dcpk16)
+        dpos_all = buf("g_dpos_all", (T, C))
+        self._linear_bwd(dcpk16, pos_all, W(d + "cross_pos_k_linear.weight"), G(d + "cross_pos_k_linear.weight"),
+                         G(d + "cross_pos_k_linear.bias"), dx_out=dpos_all)
+        self._notify(d)
+        # ---- encoder
+        dx = buf("g_dx_enc", (B * T, C))
+        self._ln_bwd(d_enc_out.view(B * T, C), ctx["e_x_final"].view(B * T, C), e + "layer_norm", "e_final_ln", dx)
+        depq, depk = buf("g_depq", (T, C), torch.float32), buf("g_depk", (T, C), torch.float32)
+        for l in reversed(range(cfg.enc_layers)):
+            p = "%slayers.%d." % (e, l)
+            tg = "e%d" % l
+            first = l == cfg.enc_layers - 1
+            dx = self._ffn_bwd(tg, p, dx, B * T)
+            dx = self._self_block_bwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", dx, B, T, ctx["e_pq"],
+                                      ctx["e_pk"], scaling, depq, depk, first,
+                                      [("%simage_rel_pos_table_list.%d.weight" % (e, l), g["enc_idx2d"]),
+                                       ("%stoken_rel_pos_table_list.%d.weight" % (e, l), g["enc_idx1d"]),
+                                       (None, None)])
+            self._flush_tables()
+            self._notify(p)
+        # ---- encoder abs-pos operands
+        depqk = buf("g_depqk", (T, 2 * C))
+        tmp = buf("g_tmp_ec", (T, C))
+        hip.cast_f32_bf16(depq, tmp); depqk[:, :C].copy_(tmp)
+        hip.cast_f32_bf16(depk, tmp); depqk[:, C:].copy_(tmp)
+        self._linear_bwd(depqk, pos_all, self._fused(self.p16, e + "pos_q_linear.weight", 2 * C, C),
+                         self._fused(self.g16, e + "pos_q_linear.weight", 2 * C, C),
+                         self._fused(self.g16, e + "pos_q_linear.bias", 2 * C), dx_out=dpos_all, dx_accumulate=True)
+        bsz = cfg.image_bucket_size
+        ipos_view = W(e + "embed_image_positions.weight")[1:1 + bsz * h].view(h, bsz, C)[:, :w]
+        ipos_grad = G(e + "embed_image_positions.weight")[1:1 + bsz * h].view(h, bsz, C)[:, :w]
+        self._ln_bwd(dpos_all[:P].view(h, w, C), ipos_view, e + "image_pos_ln", "ipos_ln", ipos_grad)
+        self._ln_bwd(dpos_all[P:], W(e + "embed_positions.weight")[:L], e + "pos_ln", "tpos_ln",
+                     G(e + "embed_positions.weight")[:L])
+        # ---- encoder embeddings (embed_tokens / image_proj / ResNet frozen -> stop here)
+        dx3 = dx.view(B, T, C)
+        dimg = buf("g_dimg_pre", (B, P, C))
+        self._ln_bwd(dx3[:, :P], self.ws["img_pre"].view(B, P, C), e + "patch_layernorm_embedding", "img_ln", dimg)
+        dtok = buf("g_dtok_pre", (B, L, C))
+        self._ln_bwd(dx3[:, P:], self.ws["tok_pre"].view(B, L, C), e + "layernorm_embedding", "tok_ln", dtok)
+        gt = G(e + "type_embedding.weight")
+        self._bias_grad(dtok.view(B * L, C), gt[0])
+        self._bias_grad(dimg.view(B * P, C), gt[1])
+        self._notify(e)
+        return self.g16
+
+    def _flush_tables(self):
+        for key, tabname in self._tab_touched.items():
+            hip.cast_f32_bf16(self.ws[key].view(-1), self.G(tabname).view(-1))
+        self._tab_touched = {}
+
+    def _notify(self, prefix):
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(prefix)

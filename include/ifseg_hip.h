@@ -145,6 +145,13 @@ int ifseg_add_bf16(const void* a, const void* b, void* out, long long n, void* s
 int ifseg_nchw_to_nhwc_bf16(const void* in, int in_is_f32, void* out, int B, int C, int H, int W, int Cpad,
                             void* stream);
 
+/* out[h][i] = table[idx[i]][h] (fp32; idx<0 -> 0): turns a rel-pos bucket table
+ * [num_buckets, H] into the per-head delta table the attention kernels index
+ * (F.embedding(rp_bucket, table) of encoder_module.py:313-331, decoder_module.py:327-333).
+ * ifseg_rel_scatter_add is its adjoint (embedding_dense_backward) into an fp32 buffer. */
+int ifseg_rel_gather(const void* table, const int* idx, float* out, int n, int H, void* stream);
+int ifseg_rel_scatter_add(const float* d, const int* idx, float* acc, int n, int H, void* stream);
+
 /* ------------------------------------------------------------ ResNet stem */
 /* conv1 7x7/2 (3->64) + folded FrozenBN + ReLU on an NHWC(4) bf16 image; w fp32
  * [7][7][3][64] with the BN scale folded, shift fp32 [64] (resnet.py:215-218). */

@@ -14,7 +14,7 @@ and then stores the REFERENCE's outputs as the golden vectors:
                                    logits, bilinear-upsampled CE loss (computed by
                                    the reference's SegCriterion.compute_loss),
                                    area histograms, selected parameter grads
-  tests/golden/fixture_resize.npz  small config, 64x96 image (P=24 > orig 16):
+  tests/golden/fixture_resize.npz  small config, 128x192 image (P=96 > orig 64):
                                    the double-bilinear rel-pos resize path, eval
   tests/golden/base_c1.npz         SegOFA-Base, B=1, 512x512, nseg 15, L=36
                                    (BASELINE config 1 shapes): logits, loss,
@@ -174,14 +174,14 @@ def case_train(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys, f
 def case_resize(cfg, arch, overrides, out_name):
     model, sd = build_reference(cfg, arch, overrides)
     model.eval()
-    batch = O.synthetic_batch(cfg, 1, 12, image_hw=(64, 96), seed=4321)
+    batch = O.synthetic_batch(cfg, 1, 12, image_hw=(128, 192), seed=4321)
     with torch.no_grad():
         ref = ref_forward(model, batch, False)[0]
         ora = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"], None, batch["patch_masks"], False)[0]
     err = (ora - ref).abs().max().item()
     print("[%s] oracle vs reference logits max-abs %.3e  shape %s" % (out_name, err, tuple(ref.shape)))
     assert err <= 2e-5
-    np.savez_compressed(os.path.join(GOLDEN, out_name), logits_causal=ref.numpy(), image_hw=np.array([64, 96]),
+    np.savez_compressed(os.path.join(GOLDEN, out_name), logits_causal=ref.numpy(), image_hw=np.array([128, 192]),
                         seed=4321, src_len=12)
 
 

