@@ -1,0 +1,136 @@
+"""Benchmark of the SegOFA fwd+bwd hot path (BASELINE.json metric: images/sec, 512x512,
+SegOFA-Base, bf16).  One "step" = criterion forward (HIP model + upsample/CE loss) +
+backward (HIP) + gradient all-reduce (N>1) + clip + Adam, on one batch of 8 synthetic
+images per GPU that is already resident in HBM.
+
+    python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  "roofline":     dominant kernel family, algorithmic FLOP / measured kernel time (HIP events on
+                  the launch stream inside the timed region) vs the 2.5 PFLOP/s dense bf16 MFMA peak
+  "cpu_baseline": the CPU oracle (oracle/segofa_ref.py, fp32, all host cores) timed on a bounded
+                  sample (1 image) of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+GF_PER_IMG = {15: 912.0, 150: 1003.2}      # algorithmic fwd+bwd GFLOP / image, frozen ResNet
+MFMA_PEAK_TF = 2500.0                      # dense bf16 (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(nseg, src_len):
+    """oracle fwd+bwd on ONE image of the same workload, fp32, all host threads"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import segofa_ref as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = O.base_config(num_seg_tokens=nseg)
+    sd = O.procedural_state_dict(cfg)
+    spec = O.state_dict_spec(cfg)
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "embed_images" not in k and not spec[k][1].startswith("alias"):
+            v.requires_grad_(k.startswith(("encoder.layers", "decoder.layers")))
+    batch = O.synthetic_batch(cfg, 1, src_len)
+    t0 = time.time()
+    logits, extra = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"])
+    loss, _, _ = O.seg_loss(cfg, logits, batch["target"], 32, 32, 512, 512)
+    loss.backward()
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 image of the 8-image batch: 1 fwd+bwd step of oracle/segofa_ref.py (fp32, %.1f s)" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--nseg", type=int, default=15)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from ifseg_amd import hip
+    from ifseg_amd.criterions import SegCriterion
+    from ifseg_amd.tasks.mm_tasks import SegmentationTask
+    from ifseg_amd.trainer import Trainer
+
+    torch.manual_seed(0)
+    task = SegmentationTask(num_seg_tokens=a.nseg, patch_image_size=512, arch="segofa_base")
+    model = task.build_model()
+    crit = SegCriterion(task)
+    trainer = Trainer(model, crit, task, device=dev)
+    sample = task.synthetic_sample(a.batch, dev, seed=1234 + rank)
+    sample["net_input"]["patch_images"] = sample["net_input"]["patch_images"].to(torch.bfloat16)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        if i == a.warmup - 1:
+            hip.prof_reset(); hip.prof_enable(0x1FF)      # discovery pass: every family
+        trainer.train_step([sample])
+    torch.cuda.synchronize()
+    fam = [hip.prof_read(k) for k in range(len(hip.PROF_KINDS))]
+    dominant = max(range(len(fam)), key=lambda k: fam[k]["ms"]) if a.warmup > 0 else 0
+    hip.prof_reset(); hip.prof_enable(1 << dominant)
+    sync()
+    t0 = time.time()
+    for _ in range(a.steps):
+        logs = trainer.train_step([sample])
+    sync()
+    dt = time.time() - t0
+    tt = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = tt.item()
+    dom = hip.prof_read(dominant)
+    hip.prof_enable(0)
+    loss = float(logs[-1]["loss"])
+    if rank == 0:
+        imgs = a.batch * world * a.steps
+        value = imgs / dt
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        out = {
+            "metric": "images/sec (512x512, SegOFA-Base fwd+bwd)", "value": round(value, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: SegOFA-Base bf16, batch %d/GPU, 512x512, %d classes (L=%d), "
+                                   "frozen ResNet-101 trunk; step = fwd + upsample/CE loss + bwd + clip + Adam"
+                                   % (a.batch, a.nseg, task.src_len),
+                       "global_batch": a.batch * world, "parallelism": "dp%d" % world, "loss": round(loss, 4)},
+            "roofline": {"bound": "mfma", "kernel": dom["kind"], "achieved": round(ach, 2), "peak": MFMA_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": None,
+                         "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(1, dom["launches"]), 2),
+                         "whole_step_frac": round(value / world * GF_PER_IMG.get(a.nseg, 912.0) / 1e3 / MFMA_PEAK_TF, 4)},
+            "kernel_families_ms_per_step": {f["kind"]: round(f["ms"], 3) for f in fam},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a.nseg, task.src_len)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

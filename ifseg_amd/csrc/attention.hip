@@ -22,6 +22,7 @@
 // the single bos token (the host permutes bos to the end; `causal` uses
 // "tail-first" original order: a tail key is visible to every grid query).
 #include "common.h"
+#include "prof.h"
 #include "../../include/ifseg_hip.h"
 
 namespace {
@@ -781,6 +782,8 @@ extern "C" int ifseg_attn_fwd(const void* q, const void* k, const void* v, const
   if (lds > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
   dim3 grid(nq * H * B), block(256);
   hipStream_t s = (hipStream_t)stream;
+  // algorithmic flops of the reference: QK^T + PV at head dim 64 (dense), 4*T*S*64 per (b,h)
+  ifseg_prof_begin(IFSEG_K_ATTN_FWD, s, 4.0 * 64 * (double)T * S * B * H, 0);
   if (pos_q) {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, lds, s, a);
@@ -788,6 +791,7 @@ extern "C" int ifseg_attn_fwd(const void* q, const void* k, const void* v, const
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, lds, s, a);
   }
+  ifseg_prof_end(IFSEG_K_ATTN_FWD, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }
@@ -828,8 +832,12 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   if (x->pos_q) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    ifseg_prof_begin(IFSEG_K_ATTN_DKV, s, 6.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);   // dV, dP, dK of the reference
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(nkt * a.H * a.B), dim3(256), lds_kv, s, a);
+    ifseg_prof_end(IFSEG_K_ATTN_DKV, s);
+    ifseg_prof_begin(IFSEG_K_ATTN_DQ, s, 2.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);    // dQ of the reference
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(nq * a.H * a.B), dim3(256), lds_q, s, a);
+    ifseg_prof_end(IFSEG_K_ATTN_DQ, s);
   } else {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);

@@ -14,6 +14,7 @@
 // no operand is ever transposed in HBM.  The MFMA is issued "swapped"
 // (D[n][m]) so each lane owns 4 consecutive output columns -> 8/16-byte stores.
 #include "common.h"
+#include "prof.h"
 #include "../../include/ifseg_hip.h"
 
 namespace {
@@ -255,12 +256,15 @@ extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   dim3 grid(tiles, batch > 0 ? batch : 1), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (layout < 0 || layout > 2) return IFSEG_ERR_BAD_ARG;
+  const double nb = batch > 0 ? batch : 1;
+  ifseg_prof_begin(IFSEG_K_GEMM_NT + layout, s, 2.0 * M * N * K * nb, 2.0 * nb * ((double)M * K + (double)N * K + (double)M * N));
   switch (layout) {
     case IFSEG_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<A_KC, false>), grid, block, 0, s, g); break;
     case IFSEG_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<A_KC, true>), grid, block, 0, s, g); break;
     case IFSEG_GEMM_TN: hipLaunchKernelGGL((gemm_kernel<A_KS, true>), grid, block, 0, s, g); break;
-    default: return IFSEG_ERR_BAD_ARG;
   }
+  ifseg_prof_end(IFSEG_K_GEMM_NT + layout, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }
@@ -282,7 +286,9 @@ extern "C" int ifseg_conv2d_nhwc_bf16(const void* in, const void* w, const void*
   g.alpha = 1.f; g.alpha_ncols = 0; g.flags = relu ? IFSEG_GEMM_RELU : 0;
   g.cH = H; g.cW = W; g.cC = Cin; g.cKW = KW; g.cStride = stride; g.cPad = pad; g.cOH = OH; g.cOW = OW;
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  ifseg_prof_begin(IFSEG_K_CONV, (hipStream_t)stream, 2.0 * g.M * g.N * g.K, 2.0 * ((double)B * H * W * Cin + (double)g.N * g.K + (double)g.M * g.N));
   hipLaunchKernelGGL((gemm_kernel<A_CONV, false>), dim3(tiles, 1), dim3(256), 0, (hipStream_t)stream, g);
+  ifseg_prof_end(IFSEG_K_CONV, (hipStream_t)stream);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

@@ -9,6 +9,7 @@
 // decoder_module.py:342-346,575-576,668; GELU in fp32 (modules/gelu.py:24-25);
 // residual_connection (unify_transformer_layer.py:196); their autograd.
 #include "common.h"
+#include "prof.h"
 #include "../../include/ifseg_hip.h"
 
 namespace {
@@ -306,9 +307,11 @@ extern "C" int ifseg_ln_fwd(const void* x, const void* gamma, const void* beta, 
   dim3 g((rows + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
   const bf16_t *X = (const bf16_t*)x, *G = (const bf16_t*)gamma, *Bt = (const bf16_t*)beta, *R = (const bf16_t*)resid;
+  ifseg_prof_begin(IFSEG_K_LN_FWD, s, 0, (double)rows * C * (resid ? 6.0 : 4.0));
   if (C <= 1024) launch_ln_fwd<2>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr);
   else if (C <= 3072) launch_ln_fwd<6>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr);
   else launch_ln_fwd<8>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr);
+  ifseg_prof_end(IFSEG_K_LN_FWD, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }
@@ -323,9 +326,11 @@ extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, co
   dim3 g(nblocks);
   hipStream_t s = (hipStream_t)stream;
   const bf16_t *DY = (const bf16_t*)dy, *X = (const bf16_t*)x, *G = (const bf16_t*)gamma, *A = (const bf16_t*)dx_add;
+  ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 8.0 : 6.0));
   if (C <= 1024) launch_ln_bwd<2>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd);
   else if (C <= 3072) launch_ln_bwd<6>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd);
   else launch_ln_bwd<8>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd);
+  ifseg_prof_end(IFSEG_K_LN_BWD, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

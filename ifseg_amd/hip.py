@@ -312,3 +312,20 @@ def rel_scatter_add(d, idx, acc):
     n, H = idx.numel(), acc.shape[1]
     _check(lib().ifseg_rel_scatter_add(_ptr(d), _ptr(idx), _ptr(acc), c_int(n), c_int(H), _stream()), "rel_scatter")
     return acc
+
+
+PROF_KINDS = ("gemm_nt", "gemm_nn", "gemm_tn", "conv", "attn_fwd", "attn_bwd_dkv", "attn_bwd_dq", "ln_fwd", "ln_bwd")
+
+
+def prof_enable(mask):
+    lib().ifseg_prof_enable(ctypes.c_uint(mask))
+
+
+def prof_reset():
+    lib().ifseg_prof_reset()
+
+
+def prof_read(kind):
+    ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+    _check(lib().ifseg_prof_read(c_int(kind), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n)), "prof_read")
+    return {"kind": PROF_KINDS[kind], "ms": ms.value, "flops": fl.value, "bytes": by.value, "launches": n.value}

@@ -1,0 +1,117 @@
+"""Minimal train-step harness standing in for the reference's train.py / trainer.py on a
+box without fairseq (last row).  One process per GPU.
+
+train_step semantics reproduced (trainer.py:745-1050):
+  seed = seed + num_updates (:1297) -> criterion(model, sample) -> backward ->
+  gradient SUM over ranks (DDP, distributed_fairseq_model.py:57-67) ->
+  multiply_grads(world / sum(sample_size)) (:874-879; sample_size == 1 per rank, so the
+  result is the mean over ranks) -> clip_grad_norm(1.0) (:886) -> Adam(0.9, 0.999,
+  eps 1e-8, decoupled wd 0.1) on fp32 masters (fp16_optimizer.py) -> cosine LR (:962).
+
+MI355X realisation: gradients live in one flat bf16 arena (engine.g16); RCCL all-reduce
+is issued per layer slice from inside the backward (engine.grad_ready_hook) so it rides
+the xGMI links while the remaining backward kernels run; scaling, clipping, Adam and the
+bf16 write-back are ONE kernel over the arena with the norm kept on the device.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import hip
+
+
+class Trainer:
+    def __init__(self, model, criterion, task, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1,
+                 clip_norm=1.0, max_update=2000, min_lr=0.0, seed=1, device=None):
+        self.model, self.criterion, self.task = model, criterion, task
+        self.lr0, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip_norm
+        self.max_update, self.min_lr, self.seed = max_update, min_lr, seed
+        self.num_updates = 0
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        model.autograd_mode = "arena"
+        eng = model.engine
+        if not eng.packed or eng.device != self.device:
+            model.to(self.device)
+            eng.pack(self.device)
+        self.eng = eng
+        n = eng.n_train
+        self.p32 = eng.master_init                         # fp32 masters (taken over from pack())
+        self.m = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.v = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.ws = torch.zeros(1024, dtype=torch.float32, device=self.device)
+        self._works = []
+        self._slices = self._layer_slices()
+        if self.world > 1:
+            eng.grad_ready_hook = self._on_grads_ready
+            # same start on every rank (DDP broadcasts rank 0's parameters at construction)
+            dist.broadcast(eng.p16, 0)
+            dist.broadcast(self.p32, 0)
+
+    # -- DDP over the flat arena ---------------------------------------------------------
+    def _layer_slices(self):
+        eng = self.eng
+        sl = {}
+        for n in eng.trainable_names():
+            parts = n.split(".")
+            key = ".".join(parts[:3]) + "." if parts[1] == "layers" else parts[0] + "."
+            lo, hi = eng.offs[n], eng.offs[n] + math.prod(eng.shapes[n])
+            a, b = sl.get(key, (lo, hi))
+            sl[key] = (min(a, lo), max(b, hi))
+        return sl
+
+    def _on_grads_ready(self, prefix):
+        """called by the engine when every gradient under `prefix` is final"""
+        if prefix not in self._slices:
+            return
+        lo, hi = self._slices[prefix]
+        if prefix in ("encoder.", "decoder."):
+            # top-level tensors are interleaved with nothing else but are only final at the very
+            # end of their half of the backward; layer slices inside the range were reduced already
+            return
+        self._works.append(dist.all_reduce(self.eng.g16[lo:hi], async_op=True))
+
+    def _reduce_rest(self):
+        eng = self.eng
+        done = [self._slices[k] for k in self._slices if k not in ("encoder.", "decoder.")]
+        done.sort()
+        cur = 0
+        for lo, hi in done + [(eng.n_train, eng.n_train)]:
+            if lo > cur:
+                self._works.append(dist.all_reduce(eng.g16[cur:lo], async_op=True))
+            cur = max(cur, hi)
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    # -- schedule -------------------------------------------------------------------------
+    def get_lr(self):
+        """fairseq cosine schedule without warm-up / restarts (cosine_lr_scheduler.py:52)."""
+        t = min(self.num_updates, self.max_update)
+        return self.min_lr + 0.5 * (self.lr0 - self.min_lr) * (1 + math.cos(math.pi * t / self.max_update))
+
+    # -- steps ------------------------------------------------------------------------------
+    def train_step(self, samples):
+        torch.manual_seed(self.seed + self.num_updates)
+        self.model.train()
+        logs, sample_sizes = [], []
+        for sample in samples:            # update_freq > 1 would accumulate; the shipped recipe uses 1
+            loss, ss, lg = self.task.train_step(sample, self.model, self.criterion, None, self.num_updates)
+            logs.append(lg)
+            sample_sizes.append(ss)
+        total_ss = float(sum(sample_sizes))
+        if self.world > 1:
+            self._reduce_rest()
+            total_ss *= self.world          # every rank reports sample_size 1 (seg_criterion.py:345)
+        gscale = 1.0 / total_ss             # sum over ranks * (world / total) / world
+        eng = self.eng
+        hip.grad_sumsq(eng.g16, self.ws, self.sumsq)
+        self.num_updates += 1
+        hip.adam_step(self.p32, eng.g16, self.m, self.v, eng.p16[: eng.n_train], self.get_lr(), self.betas[0],
+                      self.betas[1], self.eps, self.wd, self.num_updates, gscale, self.clip, self.sumsq)
+        return logs
+
+    def valid_step(self, sample):
+        return self.task.valid_step(sample, self.model, self.criterion)

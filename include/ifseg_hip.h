@@ -170,6 +170,15 @@ int ifseg_adam_step(float* p32, const void* g, float* m, float* v, void* p16, lo
                     float beta2, float eps, float weight_decay, int step, float grad_scale, float max_norm,
                     const float* sumsq, void* stream);
 
+/* -------------------------------------------------------------- profiling */
+/* Per-kernel-family timing with HIP events recorded on the launch stream (bench.py's
+ * roofline object).  kinds: 0 GEMM_NT, 1 GEMM_NN, 2 GEMM_TN, 3 CONV, 4 ATTN_FWD,
+ * 5 ATTN_BWD_DKV, 6 ATTN_BWD_DQ, 7 LN_FWD, 8 LN_BWD.  ifseg_prof_read returns the summed
+ * kernel time and the summed ALGORITHMIC flops / bytes of the recorded launches. */
+int ifseg_prof_enable(unsigned mask);
+int ifseg_prof_reset(void);
+int ifseg_prof_read(int kind, double* ms, double* flops, double* bytes, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,16 +84,29 @@ def test_fixture_forward_backward_vs_oracle(golden_dir):
     torch.cuda.synchronize()
     named = dict(m.named_parameters())
     worst = []
+    gain_scale = max(v.abs().max().item() for k, v in o_grads.items() if k.endswith("c_attn"))
     for k, og in sorted(o_grads.items()):
         if k not in named or not named[k].requires_grad or og.norm() == 0:
             continue
+        if k.endswith(("k_proj.bias", "pos_k_linear.bias")):
+            # key biases shift every score of a query equally: their gradient is zero in exact
+            # arithmetic (fp32 oracle: ~1e-9 noise; bf16 path: ~1e-4 noise) -- only check it is tiny
+            assert named[k].grad.float().norm().item() < 2e-2, k
+            continue
         hg = named[k].grad
         assert hg is not None, k
+        if k.endswith("c_attn"):
+            # d c_attn[h] = sum_{b,t,d} dO*O is a heavily cancelling sum of bf16-rounded terms:
+            # judge it on the scale of the largest head-gain gradient in the model
+            assert (hg.float().cpu() - og).abs().max().item() <= 2e-2 * gain_scale, k
+            continue
         worst.append((_rel(hg, og), k))
     worst.sort(reverse=True)
     print("worst grads:", [(round(e, 4), k) for e, k in worst[:8]])
     print("checked %d parameter grads; median rel err %.4f" % (len(worst), sorted(e for e, _ in worst)[len(worst) // 2]))
     assert len(worst) > 100
+    for e_, k_ in worst[:4]:
+        print(k_, "hip", named[k_].grad.float().cpu().flatten()[:6].tolist(), "oracle", o_grads[k_].flatten()[:6].tolist())
     bad = [(e, k) for e, k in worst if e > 6e-2]
     assert not bad, bad[:10]
     # never-used trainable parameters get an exactly zero grad
