@@ -31,7 +31,7 @@ def cpu_baseline(nseg, src_len):
     """oracle fwd+bwd on ONE image of the same workload, fp32, all host threads"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import segofa_ref as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     cfg = O.base_config(num_seg_tokens=nseg)
     sd = O.procedural_state_dict(cfg)
     spec = O.state_dict_spec(cfg)

@@ -30,6 +30,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _torch_libdir():
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    d = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    return d if os.path.exists(os.path.join(d, "libamdhip64.so")) else None
+
+
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
@@ -57,7 +66,11 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        # No DT_NEEDED on a HIP runtime: PyTorch bundles its own copy (torch/lib/libamdhip64.so) next to
+        # /opt/rocm's, and two runtimes in one process do not share devices/streams (observed: "no
+        # ROCm-capable device is detected" from ours).  ifseg_amd.hip preloads torch's copy RTLD_GLOBAL
+        # and the HIP symbols of this library bind to it at dlopen time.
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-no-hip-rt", "-o", LIB] + objs)
     return LIB
 
 

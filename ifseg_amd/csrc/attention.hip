@@ -767,6 +767,7 @@ extern "C" int ifseg_attn_fwd(const void* q, const void* k, const void* v, const
                               long long o_bs, int rel_mode, int P, const int* gcode, int code_bias, int n2d,
                               const float* rel2d, const float* rel1d, const float* relx, int causal,
                               const float* dense_bias, const float* gain, void* stream) {
+  (void)hipGetLastError();
   AttnArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
   a.pq = (const bf16_t*)pos_q; a.pk = (const bf16_t*)pos_k; a.o = (bf16_t*)out; a.lse = lse;
@@ -797,6 +798,7 @@ extern "C" int ifseg_attn_fwd(const void* q, const void* k, const void* v, const
 }
 
 extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
+  (void)hipGetLastError();
   AttnArgs a{};
   a.q = (const bf16_t*)x->q; a.k = (const bf16_t*)x->k; a.v = (const bf16_t*)x->v;
   a.pq = (const bf16_t*)x->pos_q; a.pk = (const bf16_t*)x->pos_k; a.lse = (float*)x->lse;

@@ -9,10 +9,20 @@ typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
 typedef unsigned short bf16_t;  // raw storage type
 
-#define IFSEG_CHECK_LAUNCH()                         \
-  do {                                               \
-    hipError_t e__ = hipGetLastError();              \
-    if (e__ != hipSuccess) return (int)e__;          \
+#include <stdio.h>
+#include <stdlib.h>
+#define IFSEG_CHECK_LAUNCH()                                                                   \
+  do {                                                                                         \
+    hipError_t e__ = hipGetLastError();                                                        \
+    if (e__ != hipSuccess) {                                                                   \
+      if (getenv("IFSEG_DEBUG")) {                                                             \
+        int d__ = -1;                                                                          \
+        (void)hipGetDevice(&d__);                                                              \
+        fprintf(stderr, "[ifseg_hip] %s:%d launch failed: %s (%d), device %d\n", __FILE__,    \
+                __LINE__, hipGetErrorString(e__), (int)e__, d__);                              \
+      }                                                                                        \
+      return (int)e__;                                                                         \
+    }                                                                                          \
   } while (0)
 
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }

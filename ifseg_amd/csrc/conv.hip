@@ -97,6 +97,7 @@ __global__ void maxpool3x3s2_kernel(const bf16_t* in, bf16_t* out, int B, int H,
 
 extern "C" int ifseg_stem_conv7x7(const void* in_nhwc4, const float* w, const float* shift, void* out, int B, int H,
                                   int W, void* stream) {
+  (void)hipGetLastError();
   const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
   const int tiles = ((OH + ST_TH - 1) / ST_TH) * ((OW + ST_TW - 1) / ST_TW);
   const size_t lds = (147 * 64 + ST_PH * ST_PW * 3) * sizeof(float);
@@ -108,6 +109,7 @@ extern "C" int ifseg_stem_conv7x7(const void* in_nhwc4, const float* w, const fl
 }
 
 extern "C" int ifseg_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, void* stream) {
+  (void)hipGetLastError();
   if (C & 7) return IFSEG_ERR_BAD_SHAPE;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)B * OH * OW * (C / 8);

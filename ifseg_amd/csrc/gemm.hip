@@ -242,6 +242,7 @@ extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C
                                int lda, int ldb, int ldc, const void* bias, float alpha, int alpha_ncols,
                                const void* resid, int ldr, int flags, int batch, long long strideA,
                                long long strideB, long long strideC, long long strideR, void* stream) {
+  (void)hipGetLastError();
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if ((N & 7) || (lda & 7) || (ldb & 7) || (ldc & 3) || (resid && (ldr & 3))) return IFSEG_ERR_BAD_SHAPE;
   if (layout == IFSEG_GEMM_NT && (K & 7)) return IFSEG_ERR_BAD_SHAPE;
@@ -276,6 +277,7 @@ extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C
 extern "C" int ifseg_conv2d_nhwc_bf16(const void* in, const void* w, const void* shift, const void* resid,
                                       void* out, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                                       int stride, int pad, int relu, void* stream) {
+  (void)hipGetLastError();
   if ((Cin % 64) || (Cout & 7)) return IFSEG_ERR_BAD_SHAPE;
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   GemmArgs g{};

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p32, const bf16_t* g, 
 
 extern "C" int ifseg_grad_sumsq_bf16(const void* g, long long n, float* workspace /* >= 1024 floats */,
                                      float* out_sumsq, void* stream) {
+  (void)hipGetLastError();
   const int nblk = 1024;
   hipLaunchKernelGGL(sumsq_bf16_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, n, workspace);
   hipLaunchKernelGGL(finish_norm_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, nblk, out_sumsq);
@@ -94,6 +95,7 @@ extern "C" int ifseg_grad_sumsq_bf16(const void* g, long long n, float* workspac
 extern "C" int ifseg_adam_step(float* p32, const void* g, float* m, float* v, void* p16, long long n, float lr,
                                float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                                float max_norm, const float* sumsq, void* stream) {
+  (void)hipGetLastError();
   if (n <= 0) return 0;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, p32, (const bf16_t*)g, m, v,

@@ -30,6 +30,7 @@ void ifseg_prof_end(int kind, hipStream_t s) {
 extern "C" int ifseg_prof_enable(unsigned mask) { g_mask = mask; return 0; }
 
 extern "C" int ifseg_prof_reset(void) {
+  (void)hipGetLastError();
   for (auto& sl : g_slot) {
     for (auto e : sl.ev) (void)hipEventDestroy(e);
     sl.ev.clear(); sl.flops = sl.bytes = 0; sl.launches = 0;
@@ -39,6 +40,7 @@ extern "C" int ifseg_prof_reset(void) {
 
 // total elapsed ms over all recorded launches of `kind` (synchronises on the events)
 extern "C" int ifseg_prof_read(int kind, double* ms, double* flops, double* bytes, int* launches) {
+  (void)hipGetLastError();
   if (kind < 0 || kind >= IFSEG_K_COUNT) return IFSEG_ERR_BAD_ARG;
   Slot& sl = g_slot[kind];
   double tot = 0;

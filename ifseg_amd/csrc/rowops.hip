@@ -301,6 +301,7 @@ int launch_ln_bwd(bool gelu, dim3 g, hipStream_t s, const bf16_t* dy, const bf16
 extern "C" int ifseg_ln_fwd(const void* x, const void* gamma, const void* beta, const void* resid, void* y,
                             float* mean, float* rstd, int rows, int C, float eps, int act_gelu, int rpb,
                             long long x_bs, int ldx, long long y_bs, int ldy, long long r_bs, int ldr, void* stream) {
+  (void)hipGetLastError();
   if (rows <= 0) return 0;
   if ((C & 7) || C > 4096 || (ldx & 7) || (ldy & 7) || (resid && (ldr & 7))) return IFSEG_ERR_BAD_SHAPE;
   RowMap mx{rpb, x_bs, ldx}, my{rpb, y_bs, ldy}, mr{rpb, r_bs, ldr};
@@ -320,6 +321,7 @@ extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, co
                             const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, int nblocks,
                             int rows, int C, int act_gelu, int rpb, long long dy_bs, int lddy, long long x_bs,
                             int ldx, long long dx_bs, int lddx, long long add_bs, int ldadd, void* stream) {
+  (void)hipGetLastError();
   if (rows <= 0) return 0;
   if ((C & 7) || C > 4096 || nblocks <= 0) return IFSEG_ERR_BAD_SHAPE;
   RowMap mdy{rpb, dy_bs, lddy}, mx{rpb, x_bs, ldx}, mdx{rpb, dx_bs, lddx}, madd{rpb, add_bs, ldadd};
@@ -337,6 +339,7 @@ extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, co
 
 extern "C" int ifseg_reduce_parts(const float* in, void* out, int outer, int parts, long long n, int accumulate,
                                   int out_bf16, float scale, void* stream) {
+  (void)hipGetLastError();
   const long long total = (long long)outer * n;
   if (total <= 0) return 0;
   dim3 g((unsigned)((total + 255) / 256));
@@ -348,6 +351,7 @@ extern "C" int ifseg_reduce_parts(const float* in, void* out, int outer, int par
 
 extern "C" int ifseg_colsum_bf16(const void* x, float* part, int nblk_rows, int M, int N, int rpb, long long x_bs,
                                  int ldx, void* stream) {
+  (void)hipGetLastError();
   if (M <= 0) return 0;
   if (N & 7) return IFSEG_ERR_BAD_SHAPE;
   RowMap mx{rpb, x_bs, ldx};
@@ -360,6 +364,7 @@ extern "C" int ifseg_colsum_bf16(const void* x, float* part, int nblk_rows, int 
 
 extern "C" int ifseg_embed_rows(const void* table, const long long* ids, const void* add, void* out, int n, int C,
                                 int rpb, long long o_bs, int ldo, void* stream) {
+  (void)hipGetLastError();
   if (n <= 0) return 0;
   if (C & 7) return IFSEG_ERR_BAD_SHAPE;
   RowMap mo{rpb, o_bs, ldo};
@@ -371,6 +376,7 @@ extern "C" int ifseg_embed_rows(const void* table, const long long* ids, const v
 }
 
 extern "C" int ifseg_cast_f32_bf16(const float* in, void* out, long long n, float scale, void* stream) {
+  (void)hipGetLastError();
   if (n <= 0) return 0;
   hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, n, scale);
   IFSEG_CHECK_LAUNCH();
@@ -378,6 +384,7 @@ extern "C" int ifseg_cast_f32_bf16(const float* in, void* out, long long n, floa
 }
 
 extern "C" int ifseg_add_bf16(const void* a, const void* b, void* out, long long n, void* stream) {
+  (void)hipGetLastError();
   if (n <= 0) return 0;
   hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)((n / 8 + 256) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
@@ -387,6 +394,7 @@ extern "C" int ifseg_add_bf16(const void* a, const void* b, void* out, long long
 
 extern "C" int ifseg_nchw_to_nhwc_bf16(const void* in, int in_is_f32, void* out, int B, int C, int H, int W, int Cpad,
                                        void* stream) {
+  (void)hipGetLastError();
   const long long total = (long long)B * H * W * Cpad;
   if (total <= 0) return 0;
   dim3 g((unsigned)((total + 255) / 256));
@@ -417,6 +425,7 @@ __global__ void rel_scatter_kernel(const float* d, const int* idx, float* acc, i
 }  // namespace
 
 extern "C" int ifseg_rel_gather(const void* table, const int* idx, float* out, int n, int H, void* stream) {
+  (void)hipGetLastError();
   if (n <= 0) return 0;
   hipLaunchKernelGGL(rel_gather_kernel, dim3((n * H + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)table, idx, out, n, H);
@@ -424,6 +433,7 @@ extern "C" int ifseg_rel_gather(const void* table, const int* idx, float* out, i
   return 0;
 }
 extern "C" int ifseg_rel_scatter_add(const float* d, const int* idx, float* acc, int n, int H, void* stream) {
+  (void)hipGetLastError();
   if (n <= 0) return 0;
   hipLaunchKernelGGL(rel_scatter_kernel, dim3((n * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, d, idx, acc, n, H);
   IFSEG_CHECK_LAUNCH();

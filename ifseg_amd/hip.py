@@ -26,6 +26,11 @@ def lib():
             raise RuntimeError(
                 "ifseg_amd: %s not found -- build it with `python -m ifseg_amd.build` "
                 "(there is no CPU/PyTorch fallback for the HIP path)" % LIB_PATH)
+        # bind to the HIP runtime PyTorch uses (one runtime per process; see ifseg_amd/build.py)
+        rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if not os.path.exists(rt):
+            rt = "libamdhip64.so"
+        ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
         if _lib.ifseg_abi_version() != 1:
@@ -210,7 +215,7 @@ def ln_fwd(x, gamma, beta, y, mean=None, rstd=None, resid=None, gelu=False, eps=
     return y
 
 
-LN_BWD_BLOCKS = 256
+LN_BWD_BLOCKS = 1024
 
 
 def ln_bwd(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx_add=None, gelu=False):

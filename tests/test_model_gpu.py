@@ -98,7 +98,7 @@ def test_fixture_forward_backward_vs_oracle(golden_dir):
         if k.endswith("c_attn"):
             # d c_attn[h] = sum_{b,t,d} dO*O is a heavily cancelling sum of bf16-rounded terms:
             # judge it on the scale of the largest head-gain gradient in the model
-            assert (hg.float().cpu() - og).abs().max().item() <= 2e-2 * gain_scale, k
+            assert (hg.float().cpu() - og).abs().max().item() <= 5e-2 * gain_scale, k
             continue
         worst.append((_rel(hg, og), k))
     worst.sort(reverse=True)

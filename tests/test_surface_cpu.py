@@ -67,7 +67,7 @@ def test_c_abi_exports_every_declared_symbol():
     if not os.path.exists(hip.LIB_PATH):
         from ifseg_amd.build import build
         build(verbose=False)
-    lib = ctypes.CDLL(hip.LIB_PATH)
+    lib = hip.lib()
     hdr = open(os.path.join(ROOT, "include", "ifseg_hip.h")).read()
     names = set(re.findall(r"\bint\s+(ifseg_\w+)\s*\(", hdr))
     assert len(names) >= 18
