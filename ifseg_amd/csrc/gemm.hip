@@ -29,6 +29,7 @@ struct GemmArgs {
   float alpha; int alpha_ncols; int flags;
   int cH, cW, cC, cKW, cStride, cPad, cOH, cOW;
   long long sA, sB, sC, sR;
+  int splitk, kchunk; long long sCsplit;
 };
 
 template <int AMODE, bool B_KS>
@@ -151,12 +152,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nk = (g.K + BK - 1) / BK;
-  load_tiles(0);
+  // split-K: slice blockIdx.z reduces k in [kbeg, kend) into its own fp32 slab of C
+  const int kbeg = g.splitk > 1 ? blockIdx.z * g.kchunk : 0;
+  const int kend = g.splitk > 1 ? min(g.K, kbeg + g.kchunk) : g.K;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (g.splitk > 1) g.K = kend;       // loaders zero-fill beyond the slice
+  load_tiles(kbeg);
   store_tiles();
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tiles((kt + 1) * BK);  // in flight under the MFMAs below
+    if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);  // in flight under the MFMAs below
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 fa[2], fb[2];
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (out_f32) {
-          float* cp = reinterpret_cast<float*>(g.C) + (long long)blockIdx.y * g.sC + (long long)m * g.ldc + n;
+          float* cp = reinterpret_cast<float*>(g.C) + (long long)blockIdx.y * g.sC + (long long)blockIdx.z * g.sCsplit +
+                      (long long)m * g.ldc + n;
           float4 o = make_float4(v[0], v[1], v[2], v[3]);
           if (accum) {
             float4 p = *reinterpret_cast<float4*>(cp);
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C, int M, int N, int K,
                                int lda, int ldb, int ldc, const void* bias, float alpha, int alpha_ncols,
                                const void* resid, int ldr, int flags, int batch, long long strideA,
-                               long long strideB, long long strideC, long long strideR, void* stream) {
+                               long long strideB, long long strideC, long long strideR, int splitk, void* stream) {
   (void)hipGetLastError();
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if ((N & 7) || (lda & 7) || (ldb & 7) || (ldc & 3) || (resid && (ldr & 3))) return IFSEG_ERR_BAD_SHAPE;
@@ -254,8 +260,17 @@ extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C
   g.bias = (const bf16_t*)bias; g.resid = (const bf16_t*)resid; g.ldr = ldr;
   g.alpha = alpha; g.alpha_ncols = (alpha == 1.0f) ? 0 : (alpha_ncols < 0 ? N : alpha_ncols);
   g.flags = flags; g.sA = strideA; g.sB = strideB; g.sC = strideC; g.sR = strideR;
+  g.splitk = 1;
+  if (splitk > 1) {
+    // C must be an fp32 workspace [splitk][M][ldc]; epilogue extras are not applied to partial sums
+    if (!(flags & IFSEG_GEMM_OUT_F32) || (flags & IFSEG_GEMM_ACCUMULATE) || bias || resid || alpha != 1.0f)
+      return IFSEG_ERR_BAD_ARG;
+    g.kchunk = (((K + splitk - 1) / splitk) + BK - 1) / BK * BK;
+    g.splitk = (K + g.kchunk - 1) / g.kchunk;
+    g.sCsplit = (long long)M * ldc;
+  }
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  dim3 grid(tiles, batch > 0 ? batch : 1), block(256);
+  dim3 grid(tiles, batch > 0 ? batch : 1, g.splitk), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (layout < 0 || layout > 2) return IFSEG_ERR_BAD_ARG;
   const double nb = batch > 0 ? batch : 1;

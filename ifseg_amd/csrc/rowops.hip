@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
     const bf16_t* xp = x + mx.off(row);
     const bf16_t* dyp = dy + mdy.off(row);
     const float mu = mean[row], rs = rstd[row];
-    float xr[NCH][8], gv[NCH][8];
+    float xr[NCH][8], gv[NCH][8], da[GELU ? NCH : 1][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -123,13 +123,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
         unpack8(*reinterpret_cast<const uint4*>(dyp + c * 8), d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float a = GELU ? gelu_f(xr[i][e]) : xr[i][e];
+          float a = xr[i][e];
+          if (GELU) {
+            const float xv = xr[i][e], er = erff(xv * 0.70710678118654752f);
+            a = 0.5f * xv * (1.f + er);
+            da[i][e] = 0.5f * (1.f + er) + xv * 0.39894228040143268f * __expf(-0.5f * xv * xv);
+          }
           const float xh = (a - mu) * rs;
           const float g = d[e] * gam[i][e];
           dg[i][e] += d[e] * xh; db[i][e] += d[e];
           s1 += g; s2 += g * xh;
           gv[i][e] = g;
-          if (GELU) { /* keep pre-activation in xr, xhat recomputed below */ } else xr[i][e] = xh;
+          xr[i][e] = xh;
         }
       }
     }
@@ -143,9 +148,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float xh, dact = 1.f;
-          if (GELU) { xh = (gelu_f(xr[i][e]) - mu) * rs; dact = gelu_grad_f(xr[i][e]); }
-          else xh = xr[i][e];
+          const float xh = xr[i][e], dact = GELU ? da[i][e] : 1.f;
           o[e] = rs * (gv[i][e] - s1 - xh * s2) * dact;
         }
         if (ap) {
@@ -199,6 +202,40 @@ __global__ void reduce_parts_kernel(const float* in, void* out, int outer, int p
     float* op = reinterpret_cast<float*>(out) + gid;
     if (accumulate) s += *op;
     *op = s;
+  }
+}
+
+// same reduction for many parts / few columns: 32 columns x 8 part-groups per block
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void reduce_parts2d_kernel(const float* in, void* out, int outer, int parts,
+                                                             long long n, int accumulate, float scale) {
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const long long nchunk = (n + 31) / 32;
+  const long long o = blockIdx.x / nchunk, i = (blockIdx.x % nchunk) * 32 + c;
+  float s = 0.f;
+  if (i < n) {
+    const float* p = in + o * parts * n + i;
+#pragma unroll 8
+    for (int k = g; k < parts; k += 8) s += p[(long long)k * n];
+  }
+  red[g][c] = s;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][c];
+    t *= scale;
+    const long long gid = o * n + i;
+    if (OUT_BF16) {
+      bf16_t* op = reinterpret_cast<bf16_t*>(out) + gid;
+      if (accumulate) t += bf2f(*op);
+      *op = f2bf(t);
+    } else {
+      float* op = reinterpret_cast<float*>(out) + gid;
+      if (accumulate) t += *op;
+      *op = t;
+    }
   }
 }
 
@@ -342,6 +379,13 @@ extern "C" int ifseg_reduce_parts(const float* in, void* out, int outer, int par
   (void)hipGetLastError();
   const long long total = (long long)outer * n;
   if (total <= 0) return 0;
+  if (parts >= 32) {
+    dim3 g2((unsigned)(outer * ((n + 31) / 32)));
+    if (out_bf16) hipLaunchKernelGGL(reduce_parts2d_kernel<true>, g2, dim3(256), 0, (hipStream_t)stream, in, out, outer, parts, n, accumulate, scale);
+    else hipLaunchKernelGGL(reduce_parts2d_kernel<false>, g2, dim3(256), 0, (hipStream_t)stream, in, out, outer, parts, n, accumulate, scale);
+    IFSEG_CHECK_LAUNCH();
+    return 0;
+  }
   dim3 g((unsigned)((total + 255) / 256));
   if (out_bf16) hipLaunchKernelGGL(reduce_parts_kernel<true>, g, dim3(256), 0, (hipStream_t)stream, in, out, outer, parts, n, accumulate, scale);
   else hipLaunchKernelGGL(reduce_parts_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, in, out, outer, parts, n, accumulate, scale);

@@ -61,11 +61,11 @@ def _bf(t):
 
 # --------------------------------------------------------------------------- GEMM
 def gemm(layout, A, B, C, M, N, K, lda, ldb, ldc, bias=None, alpha=1.0, alpha_ncols=-1, resid=None, ldr=0,
-         flags=0, batch=1, sA=0, sB=0, sC=0, sR=0):
+         flags=0, batch=1, sA=0, sB=0, sC=0, sR=0, splitk=1):
     rc = lib().ifseg_gemm_bf16(c_int(layout), _ptr(A), _ptr(B), _ptr(C), c_int(M), c_int(N), c_int(K),
                                c_int(lda), c_int(ldb), c_int(ldc), _ptr(bias), c_float(alpha), c_int(alpha_ncols),
                                _ptr(resid), c_int(ldr), c_int(flags), c_int(batch), c_ll(sA), c_ll(sB), c_ll(sC),
-                               c_ll(sR), _stream())
+                               c_ll(sR), c_int(splitk), _stream())
     _check(rc, "gemm")
 
 
@@ -91,10 +91,27 @@ def linear_dx(dy, w, out=None, resid=None, accumulate=False):
     return out
 
 
+_splitk_ws = {}
+
+
 def linear_dw(dy, x, out, accumulate=False):
-    """dw[N,K] = dy[M,N]^T @ x[M,K]   (out bf16 or fp32 decided by out.dtype)"""
+    """dw[N,K] = dy[M,N]^T @ x[M,K]   (out bf16 or fp32 decided by out.dtype).
+    The reduction runs over the M tokens; with few output tiles it is split over
+    workgroups (split-K into an fp32 workspace, then one reduction pass)."""
     M, N = dy.shape
     K = x.shape[1]
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    splitk = max(1, min(16, 512 // max(1, tiles), M // 512))
+    if splitk > 1 and out.is_contiguous():
+        kchunk = (((M + splitk - 1) // splitk) + 63) // 64 * 64
+        nsl = (M + kchunk - 1) // kchunk
+        ws = _splitk_ws.get(dy.device)
+        if ws is None or ws.numel() < nsl * N * K:
+            ws = torch.empty(max(nsl * N * K, 16 * 3072 * 768), dtype=torch.float32, device=dy.device)
+            _splitk_ws[dy.device] = ws
+        gemm(GEMM_TN, _bf(dy), _bf(x), ws, N, K, M, dy.stride(0), x.stride(0), K, flags=GEMM_OUT_F32, splitk=splitk)
+        reduce_parts(ws, out, 1, nsl, N * K, accumulate=accumulate)
+        return out
     flags = (GEMM_OUT_F32 if out.dtype == torch.float32 else 0) | (GEMM_ACCUMULATE if accumulate else 0)
     gemm(GEMM_TN, _bf(dy), _bf(x), out, N, K, M, dy.stride(0), x.stride(0), out.stride(0), flags=flags)
     return out
@@ -215,7 +232,7 @@ def ln_fwd(x, gamma, beta, y, mean=None, rstd=None, resid=None, gelu=False, eps=
     return y
 
 
-LN_BWD_BLOCKS = 1024
+LN_BWD_BLOCKS = 512
 
 
 def ln_bwd(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx_add=None, gelu=False):
@@ -242,7 +259,7 @@ def reduce_parts(inp, out, outer, parts, n, accumulate=False, scale=1.0):
     return out
 
 
-COLSUM_BLOCKS = 64
+COLSUM_BLOCKS = 256
 
 
 def colsum(x, part):

@@ -42,11 +42,15 @@ int ifseg_abi_version(void);
  * decoder_module.py:350-363); `alpha` carries the reference's `q *= scaling`
  * (unify_multihead_attention.py:346) and `* pos_scaling`; `resid` the
  * residual_connection (unify_transformer_layer.py:196,289).
- * N, lda, ldb must be multiples of 8 (16-byte rows); bias/resid bf16. */
+ * N, lda, ldb must be multiples of 8 (16-byte rows); bias/resid bf16.
+ * splitk > 1: the reduction is cut into ceil(K/kchunk) slices (kchunk = K/splitk rounded up
+ * to 64); slice z writes its partial product to the fp32 workspace C + z*M*ldc (requires
+ * IFSEG_GEMM_OUT_F32, no epilogue terms); the caller sums the slices (ifseg_reduce_parts).
+ * Used for the weight-gradient GEMMs whose K is the token count. */
 int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C, int M, int N, int K, int lda,
                     int ldb, int ldc, const void* bias, float alpha, int alpha_ncols,
                     const void* resid, int ldr, int flags, int batch, long long strideA,
-                    long long strideB, long long strideC, long long strideR, void* stream);
+                    long long strideB, long long strideC, long long strideR, int splitk, void* stream);
 
 /* Implicit-GEMM conv on NHWC bf16 with folded FrozenBatchNorm (+residual, +ReLU).
  * `w` is [Cout][KH][KW][Cin] with the BN scale already folded in, `shift` the
