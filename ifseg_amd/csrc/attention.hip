@@ -174,33 +174,60 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       }
       // ---- bias + mask ; lane element (kb, r) <-> key j0 + kb*32 + (r&3) + 8*(r>>2) + 4*half
       float mx = NEG_INF;
+      const bool wave_grid = __builtin_amdgcn_readfirstlane(qw) + 31 < a.P;
+      if (a.rel_mode && tile_grid && wave_grid && !a.dense) {
+        // grid x grid (the bulk of every self-attention): branch-free table lookup
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int jb = j0 + kb * 32 + 8 * rg + 4 * half;
-          int4 cj = make_int4(0, 0, 0, 0);
-          if (a.rel_mode && tile_grid) cj = *reinterpret_cast<const int4*>(sGc + jb);
-          const int cjs[4] = {cj.x, cj.y, cj.z, cj.w};
+          for (int rg = 0; rg < 4; ++rg) {
+            const int jb = j0 + kb * 32 + 8 * rg + 4 * half;
+            const int4 cj = *reinterpret_cast<const int4*>(sGc + jb);
+            const int dj = jb - qi;
+            const int cjs[4] = {cj.x, cj.y, cj.z, cj.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int j = jb + e;
-            float sv = s[kb][rg * 4 + e];
-            if (a.rel_mode) {
-              float bias;
-              if (tile_grid) bias = q_grid ? sTbl[ci - cjs[e]] : relx1;
-              else bias = q_grid ? relx0 : ((j < a.S && qvalid) ? rel1d[ti - (j - a.P)] : 0.f);
-              sv += bias;
+            for (int e = 0; e < 4; ++e) {
+              float sv = s[kb][rg * 4 + e] + sTbl[ci - cjs[e]];
+              if (a.causal) sv = (dj + e > 0) ? NEG_INF : sv;
+              s[kb][rg * 4 + e] = sv;
+              mx = fmaxf(mx, sv);
             }
-            if (a.dense && j < a.S) sv += a.dense[((long long)h * a.T + qrow) * a.S + j];
-            bool masked = j >= a.S;
-            if (a.causal) {
-              if (tile_grid) masked |= (qi >= a.P) || (j > qi);
-              else masked |= (qi >= a.P) && (j > qi);
+          }
+        }
+      } else if (!a.rel_mode && !a.causal && !a.dense && j0 + 64 <= a.S) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kb][e]);
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int jb = j0 + kb * 32 + 8 * rg + 4 * half;
+            int4 cj = make_int4(0, 0, 0, 0);
+            if (a.rel_mode && tile_grid) cj = *reinterpret_cast<const int4*>(sGc + jb);
+            const int cjs[4] = {cj.x, cj.y, cj.z, cj.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int j = jb + e;
+              float sv = s[kb][rg * 4 + e];
+              if (a.rel_mode) {
+                float bias;
+                if (tile_grid) bias = q_grid ? sTbl[ci - cjs[e]] : relx1;
+                else bias = q_grid ? relx0 : ((j < a.S && qvalid) ? rel1d[ti - (j - a.P)] : 0.f);
+                sv += bias;
+              }
+              if (a.dense && j < a.S) sv += a.dense[((long long)h * a.T + qrow) * a.S + j];
+              bool masked = j >= a.S;
+              if (a.causal) {
+                if (tile_grid) masked |= (qi >= a.P) || (j > qi);
+                else masked |= (qi >= a.P) && (j > qi);
+              }
+              sv = masked ? NEG_INF : sv;
+              s[kb][rg * 4 + e] = sv;
+              mx = fmaxf(mx, sv);
             }
-            sv = masked ? NEG_INF : sv;
-            s[kb][rg * 4 + e] = sv;
-            mx = fmaxf(mx, sv);
           }
         }
       }
@@ -283,23 +310,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 //       dK^T[c,key]   += Q_ext^T dS        (A = Q tile tr-reads,   B = dS regs)
 //     so the key stays in the lane for S, P, dS and both accumulators.
 template <bool HAS_POS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int STAGE = KT_BYTES + VT_BYTES + 512;   // Q tile, dO tile, lse[64], delta[64]
-  auto sQb = [&](int buf) { return smem + buf * STAGE; };
-  auto sOb = [&](int buf) { return smem + buf * STAGE + KT_BYTES; };
-  auto sLb = [&](int buf) { return reinterpret_cast<float*>(smem + buf * STAGE + KT_BYTES + VT_BYTES); };
-  float* sHist = reinterpret_cast<float*>(smem + 2 * STAGE);
+  // single staging buffer: Q_ext tile [64][128], dO tile [64][64], lse[64], delta[64]
+  unsigned char* sQ = smem;
+  unsigned char* sO = smem + KT_BYTES;
+  float* sL = reinterpret_cast<float*>(smem + KT_BYTES + VT_BYTES);
   const int n2dp = (a.n2d + 3) & ~3, n1d = a.rel_mode ? 2 * a.Lt - 1 : 0, n1dp = (n1d + 3) & ~3;
+  float* sTbl = reinterpret_cast<float*>(smem + KT_BYTES + VT_BYTES + 512);   // rel2d[h]
+  float* sHist = sTbl + n2dp;                                                  // d rel2d[h]
   float* sHist1 = sHist + n2dp;
-  float* sX = sHist1 + n1dp;          // 4 floats: relx0, relx1 accumulators
+  float* sX = sHist1 + n1dp;          // relx0 / relx1 gradient accumulators
   int* sGc = reinterpret_cast<int*>(sX + 4);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int nkt = (a.S + 127) >> 7;
   const int bid = xcd_remap(blockIdx.x, nkt * a.H * a.B);
   const int kt = bid % nkt, h = (bid / nkt) % a.H, b = bid / (nkt * a.H);
-  const int k0 = kt * 128, kw = k0 + wave * 32;
+  const int k0 = kt * 128;
+  const int kw = __builtin_amdgcn_readfirstlane(k0 + wave * 32);
   const int kj = kw + (lane & 31);
   const bool kvalid = kj < a.S;
   const int krow = kvalid ? kj : a.S - 1;
@@ -315,20 +344,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       U128 u; u.v = *reinterpret_cast<const uint4*>(kp + ks * 16); kf[ks] = u.b;
       U128 w; w.v = *reinterpret_cast<const uint4*>(vp + ks * 16); vf[ks] = w.b;
     }
-    if (HAS_POS) {
+    if constexpr (HAS_POS) {
       const bf16_t* pp = a.pk + (long long)krow * a.ldpk + h * 64 + half * 8;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) { U128 u; u.v = *reinterpret_cast<const uint4*>(pp + ks * 16); kf[4 + ks] = u.b; }
     }
   }
   if (a.rel_mode) {
-    for (int i = tid; i < n2dp + n1dp + 4; i += 256) sHist[i] = 0.f;
+    for (int i = tid; i < a.n2d; i += 256) { sTbl[i] = a.rel2d[(long long)h * a.n2d + i]; sHist[i] = 0.f; }
+    for (int i = tid; i < n1dp + 4; i += 256) sHist1[i] = 0.f;
     for (int i = tid; i < a.P; i += 256) sGc[i] = a.gcode[i];
   }
   const bool k_grid = kj < a.P;
-  const int cj = (a.rel_mode && k_grid) ? a.gcode[kj] - a.code_bias : 0;   // idx = ci - cj
+  const bool wave_kgrid = kw + 31 < a.P;
+  const int cj = (a.rel_mode && k_grid) ? a.gcode[kj] - a.code_bias : 0;   // table index = ci - cj
   const int tj = kj - a.P;
-  const float* rel2d = a.rel_mode ? a.rel2d + (long long)h * a.n2d : nullptr;
   const float* rel1d = a.rel_mode ? a.rel1d + (long long)h * n1d + (a.Lt - 1) : nullptr;
   const float relx0 = a.rel_mode ? a.relx[h * 2 + 0] : 0.f, relx1 = a.rel_mode ? a.relx[h * 2 + 1] : 0.f;
   float gx0 = 0.f, gx1 = 0.f;
@@ -339,41 +369,41 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   if (a.causal && k0 < a.P) { qs = k0 >> 6; qe = (k0 + 127 < a.P) ? (a.P >> 6) : nqt; }
   const int nsched = qe - qs;
 
-  uint4 rq[4], ro[2];
-  float rl = 0.f, rd = 0.f;
+  uint4 rq0, rq1, rq2, rq3, ro0, ro1;
+  float rl = 0.f;
   const bf16_t* qb_ = a.q + (long long)b * a.q_bs + h * 64;
   const bf16_t* pqb_ = HAS_POS ? a.pq + h * 64 : nullptr;
   const bf16_t* dob_ = a.dO + (long long)b * a.do_bs + h * 64;
   const float* lseb = a.lse + ((long long)b * a.H + h) * a.T;
   const float* delb = a.delta + ((long long)b * a.H + h) * a.T;
-  const int aT = a.T, aldq = a.ldq, aldpq = a.ldpq, alddo = a.lddo;
-  auto load_q = [&rq, &ro, &rl, &rd, tid, aT, aldq, aldpq, alddo, qb_, pqb_, dob_, lseb, delb](int i0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (tid >> 3) + 32 * i, c = tid & 7, qi = i0 + r;
-      rq[i] = make_uint4(0, 0, 0, 0); rq[2 + i] = make_uint4(0, 0, 0, 0); ro[i] = make_uint4(0, 0, 0, 0);
-      if (qi < aT) {
-        rq[i] = *reinterpret_cast<const uint4*>(qb_ + (long long)qi * aldq + c * 8);
-        if (HAS_POS) rq[2 + i] = *reinterpret_cast<const uint4*>(pqb_ + (long long)qi * aldpq + c * 8);
-        ro[i] = *reinterpret_cast<const uint4*>(dob_ + (long long)qi * alddo + c * 8);
-      }
-    }
-    if (tid < 64) { const int qi = i0 + tid; rl = qi < aT ? lseb[qi] : INFINITY; }
-    else if (tid < 128) { const int qi = i0 + tid - 64; rd = qi < aT ? delb[qi] : 0.f; }
-  };
-  auto store_q = [&rq, &ro, &rl, &rd, tid](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (tid >> 3) + 32 * i, c = tid & 7;
-      unsigned char* base = smem + buf * STAGE;
-      *reinterpret_cast<uint4*>(base + kx_off(r, c)) = rq[i];
-      if (HAS_POS) *reinterpret_cast<uint4*>(base + kx_off(r, 8 + c)) = rq[2 + i];
-      *reinterpret_cast<uint4*>(base + KT_BYTES + vx_off(r, c * 16)) = ro[i];
-    }
-    float* lb = reinterpret_cast<float*>(smem + buf * STAGE + KT_BYTES + VT_BYTES);
-    if (tid < 64) lb[tid] = rl;
-    else if (tid < 128) lb[tid] = rd;     // delta at [64..127]
-  };
+  const int sr = tid >> 3, sc = tid & 7;
+#define DKV_LOAD(i0_)                                                                                   \
+  {                                                                                                     \
+    const int qa_ = (i0_) + sr, qb2_ = (i0_) + sr + 32;                                                 \
+    const uint4 z_ = make_uint4(0, 0, 0, 0);                                                            \
+    rq0 = qa_ < a.T ? *reinterpret_cast<const uint4*>(qb_ + (long long)qa_ * a.ldq + sc * 8) : z_;      \
+    rq1 = qb2_ < a.T ? *reinterpret_cast<const uint4*>(qb_ + (long long)qb2_ * a.ldq + sc * 8) : z_;    \
+    if (HAS_POS) {                                                                                      \
+      rq2 = qa_ < a.T ? *reinterpret_cast<const uint4*>(pqb_ + (long long)qa_ * a.ldpq + sc * 8) : z_;  \
+      rq3 = qb2_ < a.T ? *reinterpret_cast<const uint4*>(pqb_ + (long long)qb2_ * a.ldpq + sc * 8) : z_;\
+    }                                                                                                   \
+    ro0 = qa_ < a.T ? *reinterpret_cast<const uint4*>(dob_ + (long long)qa_ * a.lddo + sc * 8) : z_;    \
+    ro1 = qb2_ < a.T ? *reinterpret_cast<const uint4*>(dob_ + (long long)qb2_ * a.lddo + sc * 8) : z_;  \
+    if (tid < 64) { const int qi_ = (i0_) + tid; rl = qi_ < a.T ? lseb[qi_] : INFINITY; }               \
+    else if (tid < 128) { const int qi_ = (i0_) + tid - 64; rl = qi_ < a.T ? delb[qi_] : 0.f; }         \
+  }
+#define DKV_STORE()                                                                   \
+  {                                                                                   \
+    *reinterpret_cast<uint4*>(sQ + kx_off(sr, sc)) = rq0;                             \
+    *reinterpret_cast<uint4*>(sQ + kx_off(sr + 32, sc)) = rq1;                        \
+    if (HAS_POS) {                                                                    \
+      *reinterpret_cast<uint4*>(sQ + kx_off(sr, 8 + sc)) = rq2;                       \
+      *reinterpret_cast<uint4*>(sQ + kx_off(sr + 32, 8 + sc)) = rq3;                  \
+    }                                                                                 \
+    *reinterpret_cast<uint4*>(sO + vx_off(sr, sc * 16)) = ro0;                        \
+    *reinterpret_cast<uint4*>(sO + vx_off(sr + 32, sc * 16)) = ro1;                   \
+    if (tid < 128) sL[tid] = rl; /* lse at [0..63], delta at [64..127] */             \
+  }
 
   f32x16 dv[2], dk[NKS / 2];
 #pragma unroll
@@ -382,35 +412,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
     for (int c = 0; c < NKS / 2; ++c) dk[c][e] = 0.f;
   }
-
-  if (nsched > 0) { load_q(qs * 64); store_q(0); }
-  __syncthreads();
   const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+  if (nsched > 0) DKV_LOAD(qs * 64);
 
   for (int it = 0; it < nsched; ++it) {
-    const int cur = it & 1;
     const int i0 = (qs + it) * 64;
-    if (it + 1 < nsched) load_q(i0 + 64);
+    __syncthreads();              // everyone is done reading the previous tile (and the table init)
+    DKV_STORE();
+    __syncthreads();
+    if (it + 1 < nsched) DKV_LOAD(i0 + 64);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       const int ib = i0 + qb * 32;
-      const bool skip = (ib >= a.T) || (a.causal && (kw + 31 < a.P) && ((ib + 31 < kw) || (ib >= a.P)));
+      const bool skip = (ib >= a.T) || (a.causal && wave_kgrid && ((ib + 31 < kw) || (ib >= a.P)));
       if (skip) continue;
-      const bool qb_grid = ib < a.P;
+      const bool qb_grid = ib + 31 < a.P;
       f32x16 s, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        bf16x8 qf = lds_read_b128(sQb(cur) + kx_off(qb * 32 + (lane & 31), ks * 2 + half));
+        bf16x8 qf = lds_read_b128(sQ + kx_off(qb * 32 + (lane & 31), ks * 2 + half));
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 of = lds_read_b128(sOb(cur) + vx_off(qb * 32 + (lane & 31), (ks * 2 + half) * 16));
+        bf16x8 of = lds_read_b128(sO + vx_off(qb * 32 + (lane & 31), (ks * 2 + half) * 16));
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vf[ks], dp, 0, 0, 0);
       }
       // element r <-> query ib + (r&3) + 8*(r>>2) + 4*half ; key = kj (lane)
+      const int fast = (a.rel_mode && qb_grid && wave_kgrid) ? 1 : ((!a.rel_mode && !a.causal) ? 2 : 0);
       bf16x8 pfr[2], dsf[2];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -419,40 +450,66 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         for (int rg2 = 0; rg2 < 2; ++rg2) {
           const int rg = s2 * 2 + rg2;
           const int iq = ib + 8 * rg + 4 * half, il = qb * 32 + 8 * rg + 4 * half;
-          const float4 l4 = *reinterpret_cast<const float4*>(sLb(cur) + il);
-          const float4 d4 = *reinterpret_cast<const float4*>(sLb(cur) + 64 + il);
+          const float4 l4 = *reinterpret_cast<const float4*>(sL + il);
+          const float4 d4 = *reinterpret_cast<const float4*>(sL + 64 + il);
           const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
-          int4 c4 = make_int4(0, 0, 0, 0);
-          if (a.rel_mode && qb_grid) c4 = *reinterpret_cast<const int4*>(sGc + iq);
-          const int cis[4] = {c4.x, c4.y, c4.z, c4.w};
           float pv[4], dsv[4];
+          if (fast == 1) {
+            const int4 c4 = *reinterpret_cast<const int4*>(sGc + iq);
+            const int cis[4] = {c4.x, c4.y, c4.z, c4.w};
+            const int di = kj - iq;                // masked (causal) iff kj > i  <=>  di > e
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int i = iq + e;
-            float sv = s[rg * 4 + e];
-            int hidx = -1;
-            if (a.rel_mode) {
-              float bias;
-              if (qb_grid) {
-                if (k_grid) { hidx = cis[e] - cj; bias = rel2d[hidx]; }
-                else bias = relx0;
-              } else {
-                if (k_grid) bias = relx1;
-                else { hidx = (kvalid && i < a.T) ? (i - a.P) - tj + a.Lt - 1 : 0; bias = (kvalid && i < a.T) ? rel1d[(i - a.P) - tj] : 0.f; }
+            for (int e = 0; e < 4; ++e) {
+              const int hidx = cis[e] - cj;
+              float p = __expf(s[rg * 4 + e] + sTbl[hidx] - ls[e]);
+              if (a.causal) p = (di > e) ? 0.f : p;
+              const float ds = p * (gain * dp[rg * 4 + e] - dl[e]);
+              pv[e] = p; dsv[e] = ds;
+              atomicAdd(&sHist[hidx], ds);
+            }
+          } else if (fast == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float p = kvalid ? __expf(s[rg * 4 + e] - ls[e]) : 0.f;
+              pv[e] = p; dsv[e] = p * (gain * dp[rg * 4 + e] - dl[e]);
+            }
+          } else {
+            int4 c4 = make_int4(0, 0, 0, 0);
+            const bool qg = ib < a.P;            // P % 32 == 0: whole block on one side
+            if (a.rel_mode && qg) c4 = *reinterpret_cast<const int4*>(sGc + iq);
+            const int cis[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int i = iq + e;
+              float sv = s[rg * 4 + e];
+              int hidx = 0;
+              if (a.rel_mode) {
+                float bias;
+                if (qg) {
+                  if (k_grid) { hidx = cis[e] - cj; bias = sTbl[hidx]; }
+                  else bias = relx0;
+                } else {
+                  if (k_grid) bias = relx1;
+                  else {
+                    const bool ok = kvalid && i < a.T;
+                    hidx = ok ? (i - a.P) - tj + a.Lt - 1 : 0;
+                    bias = ok ? rel1d[(i - a.P) - tj] : 0.f;
+                  }
+                }
+                sv += bias;
               }
-              sv += bias;
-            }
-            bool masked = !kvalid;
-            if (a.causal) {
-              if (k_grid) masked |= (i >= a.P) || (kj > i);
-              else masked |= (i >= a.P) && (kj > i);
-            }
-            const float p = masked ? 0.f : __expf(sv - ls[e]);
-            const float ds = p * (gain * dp[rg * 4 + e] - dl[e]);
-            pv[e] = p; dsv[e] = ds;
-            if (a.rel_mode) {
-              if (qb_grid) { if (k_grid) atomicAdd(&sHist[hidx], ds); else gx0 += ds; }
-              else { if (k_grid) gx1 += ds; else if (kvalid && i < a.T) atomicAdd(&sHist1[hidx], ds); }
+              bool masked = !kvalid;
+              if (a.causal) {
+                if (k_grid) masked |= (i >= a.P) || (kj > i);
+                else masked |= (i >= a.P) && (kj > i);
+              }
+              const float p = masked ? 0.f : __expf(sv - ls[e]);
+              const float ds = p * (gain * dp[rg * 4 + e] - dl[e]);
+              pv[e] = p; dsv[e] = ds;
+              if (a.rel_mode) {
+                if (qg) { if (k_grid) atomicAdd(&sHist[hidx], ds); else gx0 += ds; }
+                else { if (k_grid) gx1 += ds; else if (kvalid && i < a.T) atomicAdd(&sHist1[hidx], ds); }
+              }
             }
           }
           up.w[rg2 * 2] = pack2bf(pv[0], pv[1]); up.w[rg2 * 2 + 1] = pack2bf(pv[2], pv[3]);
@@ -468,8 +525,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         for (int db = 0; db < 2; ++db) {
           const int colb = (db * 32 + g16 * 16 + (i16 & 3) * 4) * 2;
           U64 x, y;
-          x.s = lds_read_tr(sOb(cur) + vx_off(r0, colb));
-          y.s = lds_read_tr(sOb(cur) + vx_off(r0 + 8, colb));
+          x.s = lds_read_tr(sO + vx_off(r0, colb));
+          y.s = lds_read_tr(sO + vx_off(r0 + 8, colb));
           U128 f; f.w[0] = x.w[0]; f.w[1] = x.w[1]; f.w[2] = y.w[0]; f.w[3] = y.w[1];
           dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, pfr[s2], dv[db], 0, 0, 0);
         }
@@ -477,16 +534,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         for (int cb = 0; cb < NKS / 2; ++cb) {
           const int col = cb * 32 + g16 * 16 + (i16 & 3) * 4;
           U64 x, y;
-          x.s = lds_read_tr(sQb(cur) + kx_off(r0, col >> 3) + (col & 7) * 2);
-          y.s = lds_read_tr(sQb(cur) + kx_off(r0 + 8, col >> 3) + (col & 7) * 2);
+          x.s = lds_read_tr(sQ + kx_off(r0, col >> 3) + (col & 7) * 2);
+          y.s = lds_read_tr(sQ + kx_off(r0 + 8, col >> 3) + (col & 7) * 2);
           U128 f; f.w[0] = x.w[0]; f.w[1] = x.w[1]; f.w[2] = y.w[0]; f.w[3] = y.w[1];
           dk[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, dsf[s2], dk[cb], 0, 0, 0);
         }
       }
     }
-    if (it + 1 < nsched) store_q(cur ^ 1);
-    __syncthreads();
   }
+#undef DKV_LOAD
+#undef DKV_STORE
 
   // ---- write dV, dK, dpos_k partial: lane = key, reg r <-> column (r&3) + 8*(r>>2) + 4*half
   if (kvalid) {
@@ -647,6 +704,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, dof[ks], dp, 0, 0, 0);
         }
         bf16x8 dsf[2];
+        const bool wave_grid = __builtin_amdgcn_readfirstlane(qw) + 31 < a.P;
+        const int fast = (a.rel_mode && tile_grid && wave_grid) ? 1 : ((!a.rel_mode && !a.causal && j0 + 64 <= a.S) ? 2 : 0);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           U128 ud;
@@ -654,27 +713,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
           for (int rg2 = 0; rg2 < 2; ++rg2) {
             const int rg = s2 * 2 + rg2;
             const int jb = j0 + kb * 32 + 8 * rg + 4 * half;
-            int4 cj = make_int4(0, 0, 0, 0);
-            if (a.rel_mode && tile_grid) cj = *reinterpret_cast<const int4*>(sGc + jb);
-            const int cjs[4] = {cj.x, cj.y, cj.z, cj.w};
             float dsv[4];
+            if (fast == 1) {
+              const int4 cj = *reinterpret_cast<const int4*>(sGc + jb);
+              const int dj = jb - qi;
+              const int cjs[4] = {cj.x, cj.y, cj.z, cj.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int j = jb + e;
-              float sv = s[rg * 4 + e];
-              if (a.rel_mode) {
-                float bias;
-                if (tile_grid) bias = q_grid ? sTbl[ci - cjs[e]] : relx1;
-                else bias = q_grid ? relx0 : ((j < a.S && qvalid) ? rel1d[ti - (j - a.P)] : 0.f);
-                sv += bias;
+              for (int e = 0; e < 4; ++e) {
+                float p = __expf(s[rg * 4 + e] + sTbl[ci - cjs[e]] - lse_q);
+                if (a.causal) p = (dj + e > 0) ? 0.f : p;
+                dsv[e] = p * (gain * dp[rg * 4 + e] - del_q);
               }
-              bool masked = j >= a.S;
-              if (a.causal) {
-                if (tile_grid) masked |= (qi >= a.P) || (j > qi);
-                else masked |= (qi >= a.P) && (j > qi);
+            } else if (fast == 2) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dsv[e] = __expf(s[rg * 4 + e] - lse_q) * (gain * dp[rg * 4 + e] - del_q);
+            } else {
+              int4 cj = make_int4(0, 0, 0, 0);
+              if (a.rel_mode && tile_grid) cj = *reinterpret_cast<const int4*>(sGc + jb);
+              const int cjs[4] = {cj.x, cj.y, cj.z, cj.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int j = jb + e;
+                float sv = s[rg * 4 + e];
+                if (a.rel_mode) {
+                  float bias;
+                  if (tile_grid) bias = q_grid ? sTbl[ci - cjs[e]] : relx1;
+                  else bias = q_grid ? relx0 : ((j < a.S && qvalid) ? rel1d[ti - (j - a.P)] : 0.f);
+                  sv += bias;
+                }
+                bool masked = j >= a.S;
+                if (a.causal) {
+                  if (tile_grid) masked |= (qi >= a.P) || (j > qi);
+                  else masked |= (qi >= a.P) && (j > qi);
+                }
+                const float p = masked ? 0.f : __expf(sv - lse_q);
+                dsv[e] = p * (gain * dp[rg * 4 + e] - del_q);
               }
-              const float p = masked ? 0.f : __expf(sv - lse_q);
-              dsv[e] = p * (gain * dp[rg * 4 + e] - del_q);
             }
             ud.w[rg2 * 2] = pack2bf(dsv[0], dsv[1]); ud.w[rg2 * 2 + 1] = pack2bf(dsv[2], dsv[3]);
           }
@@ -828,7 +902,7 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   }
   const size_t n2dp = ((size_t)a.n2d + 3) & ~(size_t)3;
   const size_t n1dp = a.rel_mode ? (((size_t)(2 * a.Lt - 1) + 3) & ~(size_t)3) : 0;
-  const size_t lds_kv = 2 * (KT_BYTES + VT_BYTES + 512) + (a.rel_mode ? (n2dp + n1dp + 4) * 4 + (size_t)a.P * 4 : 0);
+  const size_t lds_kv = (KT_BYTES + VT_BYTES + 512) + (a.rel_mode ? (2 * n2dp + n1dp + 4) * 4 + (size_t)a.P * 4 : 0);
   const size_t lds_q = 2 * (KT_BYTES + VT_BYTES) + (a.rel_mode ? n2dp * 4 + (size_t)a.P * 4 : 0);
   if (lds_kv > 160 * 1024 || lds_q > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
   if (x->pos_q) {
