@@ -46,6 +46,7 @@ struct AttnArgs {
   int nparts;
   const float* gain;          // [H] per-head output gain c_attn (may be null)
   float dq_scale, dpq_scale;
+  int grid_w;                 // width of the token grid (row-aligned diagonal reduction when 32)
 };
 
 constexpr int KT_BYTES = 64 * 256;  // K_ext tile  [64 keys][128] bf16
@@ -362,6 +363,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
   const float* rel1d = a.rel_mode ? a.rel1d + (long long)h * n1d + (a.Lt - 1) : nullptr;
   const float relx0 = a.rel_mode ? a.relx[h * 2 + 0] : 0.f, relx1 = a.rel_mode ? a.relx[h * 2 + 1] : 0.f;
   float gx0 = 0.f, gx1 = 0.f;
+  const bool row32 = a.rel_mode && a.grid_w == 32;
+  const int cj0 = __builtin_amdgcn_readfirstlane(cj);     // code of the wave's first key (x = 0 when row32)
+  const int xl = (lane & 31) + 4 * half;
 
   // ---- q-tile schedule
   const int nqt = (a.T + 63) >> 6;
@@ -442,6 +446,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
       }
       // element r <-> query ib + (r&3) + 8*(r>>2) + 4*half ; key = kj (lane)
       const int fast = (a.rel_mode && qb_grid && wave_kgrid) ? 1 : ((!a.rel_mode && !a.causal) ? 2 : 0);
+      float accA = 0.f, accB = 0.f;
       bf16x8 pfr[2], dsf[2];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -465,7 +470,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
               if (a.causal) p = (di > e) ? 0.f : p;
               const float ds = p * (gain * dp[rg * 4 + e] - dl[e]);
               pv[e] = p; dsv[e] = ds;
-              atomicAdd(&sHist[hidx], ds);
+              if (row32) {
+                // 32-wide grid, row-aligned blocks: this wave's keys are one grid row (x_j = lane&31) and
+                // the block's queries another (x_i = e + 8*rg + 4*half).  Rotate each register by x_i so
+                // that lane u holds the term of bin dx = x_i - x_j with u = (x_j - x_i) mod 32, and sum
+                // the 16 registers in place: 2 half-wave LDS adds per block instead of 16 full ones.
+                const int xs = xl + (e + 8 * rg);                 // (lane&31) + x_i
+                const float val = __shfl(ds, (xs & 31) | (lane & 32));
+                if (xs <= 31) accA += val; else accB += val;
+              } else {
+                atomicAdd(&sHist[hidx], ds);
+              }
             }
           } else if (fast == 2) {
 #pragma unroll
@@ -516,6 +531,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
           ud.w[rg2 * 2] = pack2bf(dsv[0], dsv[1]); ud.w[rg2 * 2 + 1] = pack2bf(dsv[2], dsv[3]);
         }
         pfr[s2] = up.b; dsf[s2] = ud.b;
+      }
+      if (row32 && fast == 1) {
+        accA += __shfl_xor(accA, 32);
+        accB += __shfl_xor(accB, 32);
+        const int base = sGc[ib] - cj0;        // bin of dx = 0 for this (query row, key row) pair
+        if (lane < 32) {
+          atomicAdd(&sHist[base - lane], accA);                     // dx = -u
+          if (lane > 0) atomicAdd(&sHist[base + 32 - lane], accB);  // dx = 32 - u
+        }
       }
       // dV^T += dO^T P ; dK^T += Q^T dS ; slot (kh,e) <-> query ib + 16*s2 + 4*kh + (e&3) + 8*(e>>2)
 #pragma unroll
@@ -888,6 +912,7 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   a.dpq = x->dpos_q_part; a.dpk = x->dpos_k_part;
   a.drel2d_part = x->drel2d_part; a.drel1d_part = x->drel1d_part; a.drelx_part = x->drelx_part;
   a.nparts = x->nparts; a.gain = x->gain; a.dq_scale = x->dq_scale; a.dpq_scale = x->dpq_scale;
+  a.grid_w = x->grid_w;
   if (!a.rel_mode && !a.causal) a.P = a.S;
   int rc = attn_check(a);
   if (rc) return rc;

@@ -129,8 +129,8 @@ def conv2d_nhwc(x, w, shift, resid, out, B, H, W, Cin, Cout, KH, KW, stride, pad
 class RelBias:
     """Per-(layer) rel-pos bias operands of the attention kernels (all device tensors)."""
 
-    def __init__(self, P, gcode, code_bias, rel2d, rel1d, relx):
-        self.P, self.gcode, self.code_bias = P, gcode, code_bias
+    def __init__(self, P, gcode, code_bias, rel2d, rel1d, relx, grid_w=0):
+        self.P, self.gcode, self.code_bias, self.grid_w = P, gcode, code_bias, grid_w
         self.rel2d, self.rel1d, self.relx = rel2d, rel1d, relx   # fp32 [H,n2d], [H,2Lt-1], [H,2]
 
 
@@ -149,7 +149,7 @@ class _AttnBwdArgs(ctypes.Structure):
                 + [(n, c_int) for n in ("rel_mode", "P", "code_bias", "n2d", "causal", "nparts")]
                 + [(n, c_void_p) for n in ("gcode", "rel2d", "rel1d", "relx", "gain", "drel2d_part", "drel1d_part",
                                            "drelx_part")]
-                + [("dq_scale", c_float), ("dpq_scale", c_float)])
+                + [("dq_scale", c_float), ("dpq_scale", c_float), ("grid_w", c_int)])
 
 
 def _p(t):
@@ -202,6 +202,7 @@ def attn_bwd(q, k, v, pos_q, pos_k, out, dout, lse, delta, dq, dk, dv, dpq_part,
     if rel is not None:
         a.code_bias, a.n2d = rel.code_bias, rel.rel2d.shape[1]
         a.gcode, a.rel2d, a.rel1d, a.relx = _p(rel.gcode), _p(rel.rel2d), _p(rel.rel1d), _p(rel.relx)
+        a.grid_w = rel.grid_w
     a.dq_scale, a.dpq_scale = dq_scale, dpq_scale
     rc = lib().ifseg_attn_bwd(ctypes.byref(a), _stream())
     _check(rc, "attn_bwd")

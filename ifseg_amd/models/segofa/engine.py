@@ -395,7 +395,7 @@ class HipEngine:
                 (W("%simage_rel_pos_table_list.%d.weight" % (e, l)), g["enc_idx2d"]),
                 (W("%stoken_rel_pos_table_list.%d.weight" % (e, l)), g["enc_idx1d"]),
                 (None, g["enc_idxx"])])
-            rel = hip.RelBias(P, g["gcode"], g["code_bias"], r2, r1, rx)
+            rel = hip.RelBias(P, g["gcode"], g["code_bias"], r2, r1, rx, grid_w=w)
             x = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", x, B, T,
                                      ctx["e_pq"], ctx["e_pk"], rel, False, scaling)
             x = self._ffn_fwd(tg, p, x, B * T)
@@ -438,7 +438,7 @@ class HipEngine:
             tg = "d%d" % l
             tab = W("%sseg_rel_pos_table_list.%d.weight" % (d, l))
             r2, r1, rx = self._rel_tables(tg, [(tab, g["dec_idx2d"]), (tab, g["dec_idx1d"]), (tab, g["dec_idxx"])])
-            rel = hip.RelBias(P, g["gcode"], g["code_bias"], r2, r1, rx)
+            rel = hip.RelBias(P, g["gcode"], g["code_bias"], r2, r1, rx, grid_w=w)
             y = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", y, B, Td,
                                      ctx["d_spq"], ctx["d_spk"], rel, causal, scaling)
             y = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling)

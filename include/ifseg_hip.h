@@ -108,6 +108,7 @@ typedef struct ifseg_attn_bwd_args {
   const float *rel2d, *rel1d, *relx, *gain;
   float *drel2d_part, *drel1d_part, *drelx_part;
   float dq_scale, dpq_scale;
+  int grid_w; /* width of the token grid (0 if unknown); 32 enables the row-aligned bias-gradient reduction */
 } ifseg_attn_bwd_args;
 int ifseg_attn_bwd(const ifseg_attn_bwd_args* args, void* stream);
 

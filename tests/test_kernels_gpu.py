@@ -226,7 +226,7 @@ def test_attn_bwd(case):
         gcode, code_bias, n2d = _grid_codes(gh, gw)
         g = torch.Generator().manual_seed(30)
         tabs = [torch.randn(H, n2d, generator=g), torch.randn(H, 2 * Lt - 1, generator=g), torch.randn(H, 2, generator=g)]
-        rel = hip.RelBias(P, gcode.to(dev), code_bias, tabs[0].to(dev), tabs[1].to(dev), tabs[2].to(dev))
+        rel = hip.RelBias(P, gcode.to(dev), code_bias, tabs[0].to(dev), tabs[1].to(dev), tabs[2].to(dev), grid_w=gw)
     # ---- fp32 autograd reference
     qf, kf, vf, pqf, pkf = [t.float().clone().requires_grad_(True) for t in (q, k, v, pq, pk)]
     gf = gain.clone().requires_grad_(True)
