@@ -7,13 +7,47 @@ resolution, masked cross entropy, per-class area histograms.  ``sample_size`` is
 rank (``ntokens = 1``, :345) exactly like the reference, so after the trainer's
 ``multiply_grads(world / sum(sample_size))`` the gradient is the mean over ranks.
 
-Round 1: the loss math runs as stock PyTorch ops on the GPU (SURVEY.md 8f row 2 --
-the fused upsample+CE+histogram kernel -- is "next"); the model call is the HIP path.
+The loss math is one fused HIP kernel pair (csrc/loss.hip: upsample + CE + gradient +
+histograms) whenever the image is exactly 16x the feature grid and
+label smoothing is off; otherwise the same math runs as stock PyTorch ops (eval on odd
+image sizes).  ``compute_loss_torch`` is kept as the in-framework reference of the kernel.
 """
 import torch
 import torch.nn.functional as F
 
+from .. import hip
 from ..registry import register_criterion
+
+
+class _FusedSegLossFn(torch.autograd.Function):
+    """loss = mean CE(bilinear_x16(logits[:, :P]), target); backward hands out the gradient the
+    forward kernel already produced."""
+
+    @staticmethod
+    def forward(ctx, logits, logits_pad, target, hp, wp, H, W, nseg, seg0, bufs):
+        B = logits_pad.shape[0]
+        dev = logits_pad.device
+        n_tiles = B * hp * wp
+        nstat = 2 + 3 * nseg
+        key = (B, hp, wp, nseg, logits_pad.shape[2], dev)
+        if bufs.get("key") != key:
+            bufs.clear()
+            bufs["key"] = key
+            bufs["tile"] = torch.empty(n_tiles * 9 * nseg, dtype=torch.float32, device=dev)
+            bufs["sp"] = torch.empty(n_tiles * nstat, dtype=torch.float32, device=dev)
+            bufs["stats"] = torch.empty(nstat, dtype=torch.float32, device=dev)
+            bufs["dl"] = torch.empty_like(logits_pad)
+            bufs["loss"] = torch.empty(1, dtype=torch.float32, device=dev)
+        hip.seg_loss(logits_pad, target, hp, wp, H, W, nseg, seg0, bufs["tile"], bufs["sp"], bufs["stats"],
+                     bufs["dl"], bufs["loss"])
+        ctx.dl = bufs["dl"]
+        ctx.nseg = nseg
+        return bufs["loss"][0], bufs["stats"]
+
+    @staticmethod
+    def backward(ctx, gloss, gstats):
+        g = ctx.dl[:, :, : ctx.nseg]
+        return g * gloss.to(g.dtype), None, None, None, None, None, None, None, None, None
 
 PAD, EOS = 1, 2
 
@@ -61,6 +95,25 @@ class SegCriterion:
         return torch.cat([lo, logits[:, -1:]], dim=1)
 
     def compute_loss(self, model, net_output, sample, update_num, reduce=True):
+        scores_low, extra = net_output
+        target = sample["target"]
+        hp, wp = extra["encoder_returns"]["image_embed_shape"][0]
+        h, w = sample["net_input"]["patch_images"].shape[-2:]
+        pad = extra.get("logits_padded")
+        if (pad is not None and self.eps == 0.0 and self.upscale_lprobs and h == 16 * hp and w == 16 * wp
+                and self.num_seg <= 192 and target.shape[1] == h * w + 1):
+            if not hasattr(self, "_bufs"):
+                self._bufs = {}
+            loss, stats = _FusedSegLossFn.apply(scores_low, pad, target.contiguous(), hp, wp, h, w, self.num_seg,
+                                                self.seg_id_offset, self._bufs)
+            n = self.num_seg
+            ai, ap, al = stats[2:2 + n], stats[2 + n:2 + 2 * n], stats[2 + 2 * n:2 + 3 * n]
+            metrics = {"area_intersect": ai, "area_pred_label": ap, "area_label": al, "area_union": ap + al - ai,
+                       "nll_loss": loss}
+            return loss, metrics, 1
+        return self.compute_loss_torch(model, net_output, sample, update_num, reduce)
+
+    def compute_loss_torch(self, model, net_output, sample, update_num, reduce=True):
         scores_low, extra = net_output
         scores_low = scores_low.float()
         target = sample["target"]

@@ -1,0 +1,183 @@
+// Fused criterion kernel for the segmentation loss (gfx950, HBM-bound):
+//   bilinear upsample (align_corners=False) of per-patch logits [B, hp*wp, nseg] to pixel
+//   resolution, masked mean cross entropy, its gradient w.r.t. the per-patch logits, argmax
+//   and the per-class intersect / pred / label area histograms -- without ever materialising
+//   the [B, H*W, nseg] fp32 score tensor (1.26 GB at B=8, 150 classes).
+// Reference: criterions/seg_criterion.py:237-244 (upsample_logits), :269-347 (compute_loss),
+//            :349-362 (compute_metric).  Scale factor H/hp == W/wp == 16 (every shipped config).
+//
+// One workgroup per low-res cell = one 16x16 pixel tile.  The tile reads the 3x3 cells its
+// pixels interpolate from, each thread owns one pixel (online softmax over the classes), and
+// the adjoint of the interpolation is applied separably (over x, then over y) in LDS, giving
+// a [3][3][nseg] partial per tile; a second kernel gathers the <=9 partials of every cell.
+// No global atomics: deterministic.
+#include "common.h"
+#include "prof.h"
+#include "../../include/ifseg_hip.h"
+
+namespace {
+
+constexpr int TS = 16;       // pixels per cell side
+constexpr int CH = 16;       // classes per gradient chunk
+constexpr int NS_MAX = 192;  // max classes
+
+__global__ __launch_bounds__(256) void seg_loss_tile_kernel(const bf16_t* logits, int ldl, long long lbs,
+                                                            const long long* target, long long tbs, int hp, int wp,
+                                                            int W, int nseg, long long seg0, long long pad_id,
+                                                            long long eos_id, float* tile_partial, float* stats_part) {
+  __shared__ float sLog[9][NS_MAX];
+  __shared__ float sWY[TS][3], sWX[TS][3];
+  __shared__ float sD[256][CH + 1];
+  __shared__ float sE[TS][3][CH];
+  __shared__ int sHist[3][NS_MAX];
+  __shared__ float sRed[8];
+  const int tid = threadIdx.x;
+  const int ncell = hp * wp;
+  const int b = blockIdx.x / ncell, cell = blockIdx.x % ncell;
+  const int cy = cell / wp, cx = cell % wp;
+  const int nstat = 2 + 3 * nseg;
+
+  for (int i = tid; i < 9 * nseg; i += 256) {
+    const int k = i / nseg, c = i % nseg;
+    const int ry = cy - 1 + k / 3, rx = cx - 1 + k % 3;
+    float v = 0.f;
+    if (ry >= 0 && ry < hp && rx >= 0 && rx < wp) v = bf2f(logits[b * lbs + (long long)(ry * wp + rx) * ldl + c]);
+    sLog[k][c] = v;
+  }
+  for (int i = tid; i < 3 * nseg; i += 256) sHist[i / nseg][i % nseg] = 0;
+  if (tid < 2 * TS) {
+    // source index of F.interpolate(mode='bilinear', align_corners=False): max((dst+0.5)/s-0.5, 0)
+    const bool isx = tid >= TS;
+    const int t = tid & (TS - 1);
+    const int c0 = isx ? cx : cy, lim = isx ? wp : hp;
+    float src = ((c0 * TS + t) + 0.5f) * (1.f / TS) - 0.5f;
+    src = fmaxf(src, 0.f);
+    const int i0 = (int)src;
+    const int i1 = min(i0 + 1, lim - 1);
+    const float l1 = src - i0, l0 = 1.f - l1;
+    const int s0 = i0 - (c0 - 1), s1 = i1 - (c0 - 1);
+    float* wrow = isx ? sWX[t] : sWY[t];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wrow[k] = (k == s0 ? l0 : 0.f) + (k == s1 ? l1 : 0.f);
+  }
+  __syncthreads();
+
+  const int py = tid >> 4, px = tid & 15;
+  const float wy0 = sWY[py][0], wy1 = sWY[py][1], wy2 = sWY[py][2];
+  const float wx0 = sWX[px][0], wx1 = sWX[px][1], wx2 = sWX[px][2];
+  float w9[9] = {wy0 * wx0, wy0 * wx1, wy0 * wx2, wy1 * wx0, wy1 * wx1, wy1 * wx2, wy2 * wx0, wy2 * wx1, wy2 * wx2};
+  auto value = [&](int c) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v += w9[k] * sLog[k][c];
+    return v;
+  };
+  const long long tg = target[b * tbs + (long long)(cy * TS + py) * W + (cx * TS + px)];
+  const bool valid = !(tg == pad_id || tg == eos_id || tg == seg0 + nseg);
+  const int label = valid ? (int)(tg - seg0) : 0;
+  float m = -INFINITY, sum = 0.f, vl = 0.f;
+  int pred = 0;
+  for (int c = 0; c < nseg; ++c) {
+    const float v = value(c);
+    if (v > m) { sum = sum * __expf(m - v) + 1.f; m = v; pred = c; }
+    else sum += __expf(v - m);
+    if (c == label) vl = v;
+  }
+  const float lse = m + __logf(sum);
+  float lpix = valid ? (lse - vl) : 0.f, cnt = valid ? 1.f : 0.f;
+  if (valid) {
+    atomicAdd(&sHist[1][pred], 1);
+    atomicAdd(&sHist[2][label], 1);
+    if (pred == label) atomicAdd(&sHist[0][label], 1);
+  }
+  lpix = warp_sum(lpix); cnt = warp_sum(cnt);
+  if ((tid & 63) == 0) { sRed[tid >> 6] = lpix; sRed[4 + (tid >> 6)] = cnt; }
+
+  // ---- gradient: d value[c] = softmax - onehot (masked); adjoint of the interpolation
+  float* tp = tile_partial + (long long)blockIdx.x * 9 * nseg;
+  for (int c0 = 0; c0 < nseg; c0 += CH) {
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+      const int c = c0 + cc;
+      float d = 0.f;
+      if (valid && c < nseg) d = __expf(value(c) - lse) - (c == label ? 1.f : 0.f);
+      sD[tid][cc] = d;
+    }
+    __syncthreads();
+    for (int i = tid; i < TS * 3 * CH; i += 256) {          // E[py][kx][cc] = sum_px WX[px][kx] D[py,px][cc]
+      const int cc = i % CH, kx = (i / CH) % 3, yy = i / (3 * CH);
+      float e = 0.f;
+#pragma unroll
+      for (int xx = 0; xx < TS; ++xx) e += sWX[xx][kx] * sD[yy * TS + xx][cc];
+      sE[yy][kx][cc] = e;
+    }
+    __syncthreads();
+    if (tid < 9 * CH) {                                      // G[ky][kx][cc] = sum_py WY[py][ky] E[py][kx][cc]
+      const int cc = tid % CH, k = tid / CH, ky = k / 3, kx = k % 3;
+      float gsum = 0.f;
+#pragma unroll
+      for (int yy = 0; yy < TS; ++yy) gsum += sWY[yy][ky] * sE[yy][kx][cc];
+      if (c0 + cc < nseg) tp[k * nseg + c0 + cc] = gsum;
+    }
+    __syncthreads();
+  }
+  float* sp = stats_part + (long long)blockIdx.x * nstat;
+  if (tid == 0) { sp[0] = sRed[0] + sRed[1] + sRed[2] + sRed[3]; sp[1] = sRed[4] + sRed[5] + sRed[6] + sRed[7]; }
+  for (int i = tid; i < 3 * nseg; i += 256) sp[2 + i] = (float)sHist[i / nseg][i % nseg];
+}
+
+// dlogits[b, cell, c] = (1/Nvalid) * sum over the <=9 tiles whose 3x3 stencil contains `cell`
+__global__ void seg_loss_gather_kernel(const float* tile_partial, const float* stats, bf16_t* dlogits, int ldl,
+                                       long long dbs, int B, int hp, int wp, int nseg, float* loss_out) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int ncell = hp * wp;
+  const long long total = (long long)B * (ncell + 1) * ldl;
+  if (gid == 0) loss_out[0] = stats[1] > 0.f ? stats[0] / stats[1] : 0.f;
+  if (gid >= total) return;
+  const int c = (int)(gid % ldl);
+  const long long r = gid / ldl;
+  const int cell = (int)(r % (ncell + 1)), b = (int)(r / (ncell + 1));
+  float g = 0.f;
+  if (cell < ncell && c < nseg) {
+    const int cy = cell / wp, cx = cell % wp;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ty = cy - (ky - 1);
+      if (ty < 0 || ty >= hp) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int tx = cx - (kx - 1);
+        if (tx < 0 || tx >= wp) continue;
+        g += tile_partial[(((long long)b * ncell + ty * wp + tx) * 9 + ky * 3 + kx) * nseg + c];
+      }
+    }
+    g *= stats[1] > 0.f ? 1.f / stats[1] : 0.f;
+  }
+  dlogits[b * dbs + (long long)cell * ldl + c] = f2bf(g);
+}
+
+}  // namespace
+
+extern "C" int ifseg_seg_loss_tiles(const void* logits, int ldl, long long logits_bs, const long long* target,
+                                    long long target_bs, int B, int hp, int wp, int H, int W, int nseg,
+                                    long long seg_id_offset, long long pad_id, long long eos_id,
+                                    float* tile_partial, float* stats_part, void* stream) {
+  (void)hipGetLastError();
+  if (H != hp * TS || W != wp * TS || nseg > NS_MAX || nseg < 1) return IFSEG_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(seg_loss_tile_kernel, dim3(B * hp * wp), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)logits, ldl, logits_bs, target, target_bs, hp, wp, W, nseg, seg_id_offset, pad_id,
+                     eos_id, tile_partial, stats_part);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_seg_loss_gather(const float* tile_partial, const float* stats, void* dlogits, int ldl,
+                                     long long dlogits_bs, int B, int hp, int wp, int nseg, float* loss_out,
+                                     void* stream) {
+  (void)hipGetLastError();
+  const long long total = (long long)B * (hp * wp + 1) * ldl;
+  hipLaunchKernelGGL(seg_loss_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     tile_partial, stats, (bf16_t*)dlogits, ldl, dlogits_bs, B, hp, wp, nseg, loss_out);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}

@@ -352,3 +352,19 @@ def prof_read(kind):
     ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
     _check(lib().ifseg_prof_read(c_int(kind), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n)), "prof_read")
     return {"kind": PROF_KINDS[kind], "ms": ms.value, "flops": fl.value, "bytes": by.value, "launches": n.value}
+
+
+def seg_loss(logits_pad, target, hp, wp, H, W, nseg, seg_id_offset, tile_partial, stats_part, stats, dlogits_pad,
+             loss_out, pad_id=1, eos_id=2):
+    """fused upsample + CE + grad + histograms; logits_pad / dlogits_pad: bf16 [B, P+1, ldl]"""
+    B = logits_pad.shape[0]
+    ldl = logits_pad.stride(1)
+    _check(lib().ifseg_seg_loss_tiles(_ptr(logits_pad), c_int(ldl), c_ll(logits_pad.stride(0)), _ptr(target),
+                                      c_ll(target.stride(0)), c_int(B), c_int(hp), c_int(wp), c_int(H), c_int(W),
+                                      c_int(nseg), c_ll(seg_id_offset), c_ll(pad_id), c_ll(eos_id),
+                                      _ptr(tile_partial), _ptr(stats_part), _stream()), "seg_loss_tiles")
+    reduce_parts(stats_part, stats, 1, B * hp * wp, 2 + 3 * nseg)
+    _check(lib().ifseg_seg_loss_gather(_ptr(tile_partial), _ptr(stats), _ptr(dlogits_pad), c_int(dlogits_pad.stride(1)),
+                                       c_ll(dlogits_pad.stride(0)), c_int(B), c_int(hp), c_int(wp), c_int(nseg),
+                                       _ptr(loss_out), _stream()), "seg_loss_gather")
+    return loss_out

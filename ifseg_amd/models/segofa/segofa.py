@@ -176,6 +176,7 @@ class SegOFAModel(nn.Module):
                 "encoder_padding_mask": [torch.zeros(B, T, dtype=torch.bool, device=logits.device)],
             },
             "attn": [None],
+            "logits_padded": eng.ws["logits_pad"],
         }
         return logits, extra
 

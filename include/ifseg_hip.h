@@ -165,6 +165,25 @@ int ifseg_stem_conv7x7(const void* in_nhwc4, const float* w, const float* shift,
 /* MaxPool2d(3, 2, 1) on NHWC bf16 (resnet.py:219). */
 int ifseg_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, void* stream);
 
+/* ------------------------------------------------------------- criterion */
+/* Fused segmentation loss: bilinear x16 upsample of the per-patch logits
+ * (logits[:, :P] viewed as [hp, wp]; align_corners=False), masked mean cross entropy, its
+ * gradient w.r.t. the logits, argmax and the per-class area histograms, replacing
+ * upsample_logits + F.cross_entropy + compute_metric (criterions/seg_criterion.py:237-244,
+ * :269-347, :349-362) and their autograd.  Step 1 (one workgroup per 16x16 pixel tile) writes
+ *   tile_partial [B*hp*wp][3][3][nseg]  gradient of the tile w.r.t. its 3x3 stencil cells
+ *   stats_part   [B*hp*wp][2 + 3*nseg]  loss sum, valid-pixel count, intersect|pred|label hist
+ * the caller sums stats_part over tiles (ifseg_reduce_parts) into stats[2+3*nseg]; step 2
+ * gathers dlogits (bf16 [B, P+1, ldl], eos row and padding columns zero) scaled by 1/valid and
+ * writes the mean loss.  target: int64 [B, H*W+1] dictionary ids; a pixel is ignored when its
+ * target is pad, eos or <seg_nseg>.  Requires H == 16*hp, W == 16*wp, label_smoothing == 0. */
+int ifseg_seg_loss_tiles(const void* logits, int ldl, long long logits_bs, const long long* target,
+                         long long target_bs, int B, int hp, int wp, int H, int W, int nseg,
+                         long long seg_id_offset, long long pad_id, long long eos_id, float* tile_partial,
+                         float* stats_part, void* stream);
+int ifseg_seg_loss_gather(const float* tile_partial, const float* stats, void* dlogits, int ldl,
+                          long long dlogits_bs, int B, int hp, int wp, int nseg, float* loss_out, void* stream);
+
 /* -------------------------------------------------------------- optimizer */
 /* sum of squares of a bf16 gradient arena -> out_sumsq[0] (device). */
 int ifseg_grad_sumsq_bf16(const void* g, long long n, float* workspace, float* out_sumsq, void* stream);

@@ -417,3 +417,46 @@ def test_adam_and_gradnorm():
     torch.cuda.synchronize()
     assert (p32 - pr).abs().max().item() < 1e-6
     assert _rel(p16, pr) < 5e-3
+
+
+@pytest.mark.parametrize("nseg,B,hp,wp", [(15, 2, 8, 8), (150, 1, 4, 6), (5, 2, 32, 32)])
+def test_fused_seg_loss(nseg, B, hp, wp):
+    """fused upsample+CE+grad+histogram kernel vs the PyTorch composition of the reference ops
+    (seg_criterion.py:237-244,269-362)."""
+    from ifseg_amd import hip
+    from ifseg_amd.criterions import SegCriterion
+    import torch.nn.functional as F
+    dev = _dev()
+    P, H, W = hp * wp, hp * 16, wp * 16
+    npad = (nseg + 7) // 8 * 8
+    seg0 = 1000
+    g = torch.Generator().manual_seed(7)
+    lp = torch.zeros(B, P + 1, npad, dtype=torch.bfloat16, device=dev)
+    lp[:, :, :nseg] = (torch.randn(B, P + 1, nseg, generator=g) * 2).to(dev)
+    tgt = torch.randint(0, nseg + 1, (B, H * W), generator=g) + seg0        # includes the ignore label seg0+nseg
+    tgt = torch.cat([tgt, torch.full((B, 1), 2)], 1).to(dev)
+    tile = torch.empty(B * P * 9 * nseg, device=dev)
+    sp = torch.empty(B * P * (2 + 3 * nseg), device=dev)
+    stats = torch.empty(2 + 3 * nseg, device=dev)
+    dl = torch.full((B, P + 1, npad), 3.0, dtype=torch.bfloat16, device=dev)
+    loss = torch.empty(1, device=dev)
+    hip.seg_loss(lp, tgt, hp, wp, H, W, nseg, seg0, tile, sp, stats, dl, loss)
+    # reference
+    lf = lp[:, :, :nseg].float().clone().requires_grad_(True)
+    scores = SegCriterion.upsample_logits(lf, hp, wp, H, W)
+    mask = (tgt == 1) | (tgt == seg0 + nseg) | (tgt == 2)
+    t = tgt[~mask] - seg0
+    sc = scores[~mask]
+    ref = F.cross_entropy(sc, t)
+    ref.backward()
+    ai, ap, al, au = SegCriterion.compute_metric(sc.detach(), t)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref.item()) < 2e-4 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    assert _rel(dl[:, :, :nseg], lf.grad) < 6e-3, _rel(dl[:, :, :nseg], lf.grad)
+    assert dl[:, :, nseg:].abs().sum() == 0 and dl[:, P].abs().sum() == 0
+    assert stats[1].item() == (~mask).sum().item()
+    n = nseg
+    # argmax can flip on near ties between fp orders of summation: allow a handful of pixels
+    assert (stats[2 + n:2 + 2 * n] - ap).abs().sum().item() <= 1e-4 * H * W * B + 2
+    assert torch.equal(stats[2 + 2 * n:2 + 3 * n], al)
+    assert (stats[2:2 + n] - ai).abs().sum().item() <= 1e-4 * H * W * B + 2
