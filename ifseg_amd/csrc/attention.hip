@@ -53,10 +53,21 @@ constexpr int KT_BYTES = 64 * 256;  // K_ext tile  [64 keys][128] bf16
 constexpr int VT_BYTES = 64 * 128;  // V tile      [64 keys][64]  bf16
 constexpr float NEG_INF = -INFINITY;
 
-// K_ext tile: 256-byte rows, 16-byte chunk c (0..15) XOR (row & 15)
-__device__ __forceinline__ int kx_off(int r, int c) { return r * 256 + ((c ^ (r & 15)) << 4); }
-// V tile: 128-byte rows; 64-byte halves swapped on rows with bit1 set (tr-read bank spread)
-__device__ __forceinline__ int vx_off(int r, int colbyte) { return r * 128 + (colbyte ^ (((r >> 1) & 1) << 6)); }
+// LDS images that are read BOTH row-wise (ds_read_b128: 16 rows x one 16-byte chunk per lane
+// group) and transposed (ds_read_b64_tr_b16: 4 consecutive rows x one 64-byte granule):
+// the chunk index is XOR-ed with a bit-rotated row id so that 16 consecutive rows hit 16
+// different 16-byte slots of the 256-byte bank line AND 4 consecutive rows hit 4 different
+// 64-byte bank quarters.
+// K_ext / Q_ext tile: 256-byte rows (16 chunks)
+__device__ __forceinline__ int kx_off(int r, int c) {
+  const int f = ((r & 3) << 2) | ((r >> 2) & 3);
+  return r * 256 + ((c ^ f) << 4);
+}
+// V / dO tile: 128-byte rows (8 chunks, two rows per bank line)
+__device__ __forceinline__ int vx_off(int r, int colbyte) {
+  const int u = r >> 1, hsw = ((u & 1) << 2) | ((u >> 1) & 3);
+  return r * 128 + ((((colbyte >> 4) ^ hsw) & 7) << 4) + (colbyte & 15);
+}
 
 struct RelCtx {
   const float* tbl;   // LDS copy of rel2d[h]
