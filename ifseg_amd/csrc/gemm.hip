@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BK = 64;   // BN is a template parameter (128, or 64 for narrow / few-tile outputs)
 enum { A_KC = 0, A_KS = 1, A_CONV = 2 };
 
 struct GemmArgs {
@@ -32,8 +32,11 @@ struct GemmArgs {
   int splitk, kchunk; long long sCsplit;
 };
 
-template <int AMODE, bool B_KS>
+template <int AMODE, bool B_KS, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+  static_assert(BN == 128 || (BN == 64 && !B_KS), "64-wide tiles only for k-contiguous B");
+  constexpr int NJ = BN / 64;        // 32-column MFMA tiles per wave along N
+  constexpr int NBI = BN / 32;       // B staging chunks per thread
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];
   unsigned char* sA = smem;
   unsigned char* sB = smem + 16384;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   long long b_rowbase[4];
   if (!B_KS) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NBI; ++i) {
       int n = n0 + (tid >> 3) + 32 * i;
       b_rowbase[i] = (n < g.N) ? (long long)n * g.ldb : -1;
     }
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     if (!B_KS) {
       const int kc = k0 + (tid & 7) * 8;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NBI; ++i) {
         rb[i] = make_uint4(0, 0, 0, 0);
         if (b_rowbase[i] >= 0 && kc < g.K)
           rb[i] = *reinterpret_cast<const uint4*>(Bb + b_rowbase[i] + kc);
@@ -139,16 +142,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         *reinterpret_cast<uint4*>(sA + kc_off((tid >> 3) + 32 * i, tid & 7)) = ra[i];
       if (B_KS)
         *reinterpret_cast<uint4*>(sB + ks_off((tid >> 4) + 16 * i, (tid & 15) * 8)) = rb[i];
-      else
+      else if (i < NBI)
         *reinterpret_cast<uint4*>(sB + kc_off((tid >> 3) + 32 * i, tid & 7)) = rb[i];
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -164,16 +167,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);  // in flight under the MFMAs below
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 fa[2], fb[2];
+      bf16x8 fa[2], fb[NJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 2; ++i)
         fa[i] = (AMODE == A_KS) ? frag_ks(sA, wm * 64 + i * 32, ks, lane) : frag_kc(sA, wm * 64 + i * 32, ks, lane);
-        fb[i] = B_KS ? frag_ks(sB, wn * 64 + i * 32, ks, lane) : frag_kc(sB, wn * 64 + i * 32, ks, lane);
-      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        fb[j] = B_KS ? frag_ks(sB, wn * (BN / 2) + j * 32, ks, lane) : frag_kc(sB, wn * (BN / 2) + j * 32, ks, lane);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
@@ -192,10 +196,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     const int m = m0 + wm * 64 + i * 32 + (lane & 31);
     if (m >= g.M) continue;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int n = n0 + wn * 64 + j * 32 + 8 * rg + 4 * (lane >> 5);
+        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * rg + 4 * (lane >> 5);
         if (n >= g.N) continue;
         float v[4];
 #pragma unroll
@@ -269,16 +273,22 @@ extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C
     g.splitk = (K + g.kchunk - 1) / g.kchunk;
     g.sCsplit = (long long)M * ldc;
   }
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int tiles128 = ((M + BM - 1) / BM) * ((N + 127) / 128);
+  // narrow tiles when the output is narrow or there are too few 128-wide tiles to fill 256 CUs
+  const bool narrow = layout == IFSEG_GEMM_NT && g.splitk == 1 && (N <= 64 || tiles128 < 384);
+  const int tiles = narrow ? ((M + BM - 1) / BM) * ((N + 63) / 64) : tiles128;
   dim3 grid(tiles, batch > 0 ? batch : 1, g.splitk), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (layout < 0 || layout > 2) return IFSEG_ERR_BAD_ARG;
   const double nb = batch > 0 ? batch : 1;
   ifseg_prof_begin(IFSEG_K_GEMM_NT + layout, s, 2.0 * M * N * K * nb, 2.0 * nb * ((double)M * K + (double)N * K + (double)M * N));
   switch (layout) {
-    case IFSEG_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<A_KC, false>), grid, block, 0, s, g); break;
-    case IFSEG_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<A_KC, true>), grid, block, 0, s, g); break;
-    case IFSEG_GEMM_TN: hipLaunchKernelGGL((gemm_kernel<A_KS, true>), grid, block, 0, s, g); break;
+    case IFSEG_GEMM_NT:
+      if (narrow) hipLaunchKernelGGL((gemm_kernel<A_KC, false, 64>), grid, block, 0, s, g);
+      else hipLaunchKernelGGL((gemm_kernel<A_KC, false, 128>), grid, block, 0, s, g);
+      break;
+    case IFSEG_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<A_KC, true, 128>), grid, block, 0, s, g); break;
+    case IFSEG_GEMM_TN: hipLaunchKernelGGL((gemm_kernel<A_KS, true, 128>), grid, block, 0, s, g); break;
   }
   ifseg_prof_end(IFSEG_K_GEMM_NT + layout, s);
   IFSEG_CHECK_LAUNCH();
@@ -302,9 +312,12 @@ extern "C" int ifseg_conv2d_nhwc_bf16(const void* in, const void* w, const void*
   g.bias = (const bf16_t*)shift; g.resid = (const bf16_t*)resid; g.ldr = Cout;
   g.alpha = 1.f; g.alpha_ncols = 0; g.flags = relu ? IFSEG_GEMM_RELU : 0;
   g.cH = H; g.cW = W; g.cC = Cin; g.cKW = KW; g.cStride = stride; g.cPad = pad; g.cOH = OH; g.cOW = OW;
-  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  const int tiles128 = ((g.M + BM - 1) / BM) * ((g.N + 127) / 128);
+  const bool narrow = g.N <= 64 || tiles128 < 384;
+  const int tiles = narrow ? ((g.M + BM - 1) / BM) * ((g.N + 63) / 64) : tiles128;
   ifseg_prof_begin(IFSEG_K_CONV, (hipStream_t)stream, 2.0 * g.M * g.N * g.K, 2.0 * ((double)B * H * W * Cin + (double)g.N * g.K + (double)g.M * g.N));
-  hipLaunchKernelGGL((gemm_kernel<A_CONV, false>), dim3(tiles, 1), dim3(256), 0, (hipStream_t)stream, g);
+  if (narrow) hipLaunchKernelGGL((gemm_kernel<A_CONV, false, 64>), dim3(tiles, 1), dim3(256), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL((gemm_kernel<A_CONV, false, 128>), dim3(tiles, 1), dim3(256), 0, (hipStream_t)stream, g);
   ifseg_prof_end(IFSEG_K_CONV, (hipStream_t)stream);
   IFSEG_CHECK_LAUNCH();
   return 0;
