@@ -21,6 +21,49 @@ import torch.distributed as dist
 from . import hip
 
 
+def layer_slices(eng):
+    """prefix -> (lo, hi) element range of the gradient arena (layers are contiguous)"""
+    sl = {}
+    for n in eng.trainable_names():
+        parts = n.split(".")
+        key = ".".join(parts[:3]) + "." if parts[1] == "layers" else parts[0] + "."
+        lo, hi = eng.offs[n], eng.offs[n] + math.prod(eng.shapes[n])
+        a, b = sl.get(key, (lo, hi))
+        sl[key] = (min(a, lo), max(b, hi))
+    return sl
+
+
+class ArenaReducer:
+    """Gradient SUM over ranks on a flat arena, overlapped with the backward pass.
+
+    ``on_ready(prefix)`` is called (in backward order) as soon as every gradient of a layer is
+    final: the layer's contiguous slice is all-reduced asynchronously (RCCL on its own stream,
+    xGMI busy while later backward kernels run).  ``finish()`` reduces whatever ranges were
+    not covered (top-level tensors) and waits.  The reference gets the same effect from
+    torch DDP's 25 MB buckets (distributed_fairseq_model.py:57-67)."""
+
+    def __init__(self, flat, slices, n):
+        self.flat, self.slices, self.n = flat, slices, n
+        self.works, self.done = [], []
+
+    def on_ready(self, prefix):
+        if prefix not in self.slices or prefix in ("encoder.", "decoder."):
+            return      # top-level tensors become final only at the end of their half of the backward
+        lo, hi = self.slices[prefix]
+        self.done.append((lo, hi))
+        self.works.append(dist.all_reduce(self.flat[lo:hi], async_op=True))
+
+    def finish(self):
+        cur = 0
+        for lo, hi in sorted(self.done) + [(self.n, self.n)]:
+            if lo > cur:
+                self.works.append(dist.all_reduce(self.flat[cur:lo], async_op=True))
+            cur = max(cur, hi)
+        for w in self.works:
+            w.wait()
+        self.works, self.done = [], []
+
+
 class Trainer:
     def __init__(self, model, criterion, task, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1,
                  clip_norm=1.0, max_update=2000, min_lr=0.0, seed=1, device=None):
@@ -42,8 +85,7 @@ class Trainer:
         self.v = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.ws = torch.zeros(1024, dtype=torch.float32, device=self.device)
-        self._works = []
-        self._slices = self._layer_slices()
+        self.reducer = ArenaReducer(eng.g16, layer_slices(eng), eng.n_train)
         if self.world > 1:
             eng.grad_ready_hook = self._on_grads_ready
             # same start on every rank (DDP broadcasts rank 0's parameters at construction)
@@ -51,40 +93,8 @@ class Trainer:
             dist.broadcast(self.p32, 0)
 
     # -- DDP over the flat arena ---------------------------------------------------------
-    def _layer_slices(self):
-        eng = self.eng
-        sl = {}
-        for n in eng.trainable_names():
-            parts = n.split(".")
-            key = ".".join(parts[:3]) + "." if parts[1] == "layers" else parts[0] + "."
-            lo, hi = eng.offs[n], eng.offs[n] + math.prod(eng.shapes[n])
-            a, b = sl.get(key, (lo, hi))
-            sl[key] = (min(a, lo), max(b, hi))
-        return sl
-
     def _on_grads_ready(self, prefix):
-        """called by the engine when every gradient under `prefix` is final"""
-        if prefix not in self._slices:
-            return
-        lo, hi = self._slices[prefix]
-        if prefix in ("encoder.", "decoder."):
-            # top-level tensors are interleaved with nothing else but are only final at the very
-            # end of their half of the backward; layer slices inside the range were reduced already
-            return
-        self._works.append(dist.all_reduce(self.eng.g16[lo:hi], async_op=True))
-
-    def _reduce_rest(self):
-        eng = self.eng
-        done = [self._slices[k] for k in self._slices if k not in ("encoder.", "decoder.")]
-        done.sort()
-        cur = 0
-        for lo, hi in done + [(eng.n_train, eng.n_train)]:
-            if lo > cur:
-                self._works.append(dist.all_reduce(eng.g16[cur:lo], async_op=True))
-            cur = max(cur, hi)
-        for w in self._works:
-            w.wait()
-        self._works = []
+        self.reducer.on_ready(prefix)
 
     # -- schedule -------------------------------------------------------------------------
     def get_lr(self):
@@ -103,7 +113,7 @@ class Trainer:
             sample_sizes.append(ss)
         total_ss = float(sum(sample_sizes))
         if self.world > 1:
-            self._reduce_rest()
+            self.reducer.finish()
             total_ss *= self.world          # every rank reports sample_size 1 (seg_criterion.py:345)
         gscale = 1.0 / total_ss             # sum over ranks * (world / total) / world
         eng = self.eng

@@ -1,0 +1,61 @@
+"""CPU, world_size 2 over gloo: the flat-arena gradient reducer of the bundled trainer
+(the N>1 path of bench.py) -- coverage of every element exactly once, overlap-order
+independence, and the reference's gradient scaling (trainer.py:874-879 with sample_size 1
+per rank => mean over ranks)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ifseg_amd.trainer import ArenaReducer
+    n = 10_000
+    # layer slices with gaps before / between / after (top-level tensors), like the real arena
+    slices = {"encoder.": (0, 700), "encoder.layers.0.": (700, 3000), "encoder.layers.1.": (3000, 5200),
+              "decoder.": (5200, 5600), "decoder.layers.0.": (5600, 9000)}
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(n, generator=g)
+    mine = flat.clone()
+    red = ArenaReducer(flat, slices, n)
+    # backward order: decoder layers first, then "decoder.", encoder layers, "encoder."
+    for p in ("decoder.layers.0.", "decoder.", "encoder.layers.1.", "encoder.layers.0.", "encoder."):
+        red.on_ready(p)
+    red.finish()
+    gathered = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    expect = sum(gathered)
+    ok = torch.allclose(flat, expect, atol=1e-6)
+    # scaling: sum over ranks * (world / sum(sample_size)) / world with sample_size == 1 per rank -> mean
+    mean = flat * (1.0 / world)
+    ok = ok and torch.allclose(mean, expect / world, atol=1e-6)
+    if rank == 0:
+        out.put(bool(ok))
+    dist.destroy_process_group()
+
+
+def test_arena_reducer_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
