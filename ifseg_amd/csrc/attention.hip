@@ -195,17 +195,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
           for (int rg = 0; rg < 4; ++rg) {
             const int jb = j0 + kb * 32 + 8 * rg + 4 * half;
             const int4 cj = *reinterpret_cast<const int4*>(sGc + jb);
-            const int dj = jb - qi;
-            const int cjs[4] = {cj.x, cj.y, cj.z, cj.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float sv = s[kb][rg * 4 + e] + sTbl[ci - cjs[e]];
-              if (a.causal) sv = (dj + e > 0) ? NEG_INF : sv;
-              s[kb][rg * 4 + e] = sv;
-              mx = fmaxf(mx, sv);
-            }
+            s[kb][rg * 4 + 0] += sTbl[ci - cj.x];
+            s[kb][rg * 4 + 1] += sTbl[ci - cj.y];
+            s[kb][rg * 4 + 2] += sTbl[ci - cj.z];
+            s[kb][rg * 4 + 3] += sTbl[ci - cj.w];
           }
         }
+        if (a.causal) {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int dj = j0 + kb * 32 + 8 * rg + 4 * half - qi;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) s[kb][rg * 4 + e] = (dj + e > 0) ? NEG_INF : s[kb][rg * 4 + e];
+            }
+        }
+        float m4[4] = {NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) m4[e & 3] = fmaxf(m4[e & 3], s[kb][e]);
+        mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
       } else if (!a.rel_mode && !a.causal && !a.dense && j0 + 64 <= a.S) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       const float m_new = fmaxf(m_run, mx);
       const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
       const float alpha = __expf(m_run - m_use);   // m_run = -inf -> 0
-      float psum = 0.f;
+      float ps4[4] = {0.f, 0.f, 0.f, 0.f};
       bf16x8 pf[2][2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -257,12 +268,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
           for (int e = 0; e < 8; e += 2) {
             float p0 = __expf(s[kb][s2 * 8 + e] - m_use), p1 = __expf(s[kb][s2 * 8 + e + 1] - m_use);
-            psum += p0 + p1;
+            ps4[(e >> 1) & 3] += p0 + p1;
             u.w[e >> 1] = pack2bf(p0, p1);
           }
           pf[kb][s2] = u.b;
         }
       }
+      const float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
       l_run = l_run * alpha + psum;
       m_run = m_new;
 #pragma unroll

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libifseg_hip.so")
+LIB_PATH = os.environ.get("IFSEG_LIB", os.path.join(_HERE, "lib", "libifseg_hip.so"))
 _lib = None
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2

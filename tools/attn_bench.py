@@ -8,7 +8,7 @@ def main(kind="enc", iters=5):
     dev = torch.device("cuda:0")
     B, H, C = 8, 12, 768
     gh = gw = 32; P = 1024
-    Lt = 36 if kind == "enc" else 1
+    Lt = 1 if kind == "dec" else 36
     T = S = P + Lt
     causal = kind == "dec"
     g = torch.Generator().manual_seed(0)
@@ -19,12 +19,14 @@ def main(kind="enc", iters=5):
     n2d = (2 * gh - 1) * (2 * gw - 1)
     rel = hip.RelBias(P, gcode, (gh - 1) * (2 * gw - 1) + gw - 1, torch.randn(H, n2d, generator=g).to(dev),
                       torch.randn(H, 2 * Lt - 1, generator=g).to(dev), torch.randn(H, 2, generator=g).to(dev), grid_w=gw)
+    if kind == "cross":
+        rel = None
     gain = torch.ones(H, device=dev)
     out = torch.zeros(B, T, C, dtype=torch.bfloat16, device=dev); lse = torch.zeros(B, H, T, device=dev)
     dqkv = torch.zeros_like(qkv); delta = torch.zeros(B, H, T, device=dev)
     dpq = torch.zeros(B, T, C, device=dev); dpk = torch.zeros(B, S, C, device=dev)
     nparts = B * ((S + 127) // 128)
-    parts = [torch.zeros(H, nparts, n, device=dev) for n in (n2d, 2 * Lt - 1, 2)]
+    parts = [torch.zeros(H, nparts, n, device=dev) for n in (n2d, 2 * Lt - 1, 2)] if rel is not None else [None] * 3
     q, k, v = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
     def step():
         hip.attn_fwd(q, k, v, pq, pk, out, lse, B, H, T, S, rel=rel, causal=causal, gain=gain)
