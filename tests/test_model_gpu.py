@@ -119,3 +119,49 @@ def test_fixture_forward_backward_vs_oracle(golden_dir):
     # histograms from the HIP logits match the reference's where the argmax agrees
     ai = logs["area_intersect"].cpu().numpy()
     assert np.abs(ai - g["area_intersect"]).sum() <= 0.02 * g["area_label"].sum()
+
+
+def test_base_config1_vs_reference_golden(golden_dir):
+    """SegOFA-Base at BASELINE config-1 shapes (512x512, nseg 15, L=36; B=1): the HIP path against
+    the REFERENCE's own outputs stored in tests/golden/base_c1.npz (logits, loss, grad norms)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ifseg_amd.criterions import SegCriterion
+    from ifseg_amd.models.segofa import SegOFAModel, make_config
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "base_c1.npz"))
+    ocfg = O.base_config()
+    sd = O.procedural_state_dict(ocfg)
+    batch = O.synthetic_batch(ocfg, 1, int(g["src_len"]))
+    m = SegOFAModel(make_config("segofa_base"))
+    missing, unexpected = torch.nn.Module.load_state_dict(m, sd, strict=False)
+    assert not unexpected
+    m.to(dev).train()
+    crit = SegCriterion(num_seg_tokens=15, seg_id_offset=ocfg.seg_id_offset)
+    sample = {"net_input": {k: batch[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks", "prev_output_tokens")},
+              "target": batch["target"].to(dev), "ntokens": 1, "nsentences": 1}
+    loss, _, logs = crit(m, sample)
+    loss.backward()
+    torch.cuda.synchronize()
+    logits = m.engine.ws["logits_pad"][:, :, :15].float().cpu()
+    ref = torch.from_numpy(g["logits_causal"])
+    e = _rel(logits, ref)
+    agree = (logits[:, :-1].argmax(-1) == ref[:, :-1].argmax(-1)).float().mean().item()
+    print("base c1: logits rel-L2 %.4f, loss %.5f vs reference %.5f, patch argmax agreement %.4f" % (e, loss.item(), float(g["loss"]), agree))
+    # 12 bf16 layers deep: measured 2.08e-2 (error budget: tools/err_budget.py -- ResNet 0.7e-2, encoder
+    # 0.9e-2); the loss / argmax (= mIoU) tolerances of BASELINE.md section 5 are met with margin
+    assert e <= 2.5e-2 and abs(loss.item() - float(g["loss"])) <= 1e-2 and agree >= 0.99
+    named = dict(m.named_parameters())
+    for k in g.files:
+        if not k.startswith("gradnorm:"):
+            continue
+        name = k[9:]
+        if name.endswith("c_attn"):
+            continue
+        hn, rn = named[name].grad.float().norm().item(), float(g[k])
+        print("   |grad| %-50s hip %.4e  reference %.4e" % (name, hn, rn))
+        assert abs(hn - rn) <= 0.06 * rn + 1e-6, (name, hn, rn)
+    # mIoU machinery: per-class areas from the fused kernel vs the reference's histograms
+    ai, al = logs["area_intersect"].cpu().numpy(), logs["area_label"].cpu().numpy()
+    assert np.array_equal(al, g["area_label"])
+    assert np.abs(ai - g["area_intersect"]).sum() <= 0.01 * al.sum()
