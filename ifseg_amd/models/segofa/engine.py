@@ -351,10 +351,15 @@ class HipEngine:
         feat, h, w = self._resnet(patch_images)
         P = h * w
         oh = cfg.orig_patch_image_size // 16
-        if (h, w) != (oh, oh) or (h, w) != (cfg.seg_bucket_size,) * 2 or P % 64:
-            raise NotImplementedError(
-                "ifseg_amd HIP engine: feature grid %dx%d differs from the trained grid %dx%d (or is not a "
-                "multiple of 64 tokens); the resized-bias slow path is not built yet" % (h, w, oh, oh))
+        slow = (h, w) != (oh, oh) or (h, w) != (cfg.seg_bucket_size,) * 2 or P % 64 != 0
+        if slow:
+            # eval-time images whose feature grid differs from the trained one (seg_criterion.py:194-217,
+            # batch 1, native aspect ratio): position tables / rel-pos biases are bilinear-resized exactly
+            # like the reference and handed to the attention kernel as a dense fp32 bias.  Forward only.
+            if need_grad:
+                raise NotImplementedError("ifseg_amd HIP engine: training on a feature grid (%dx%d) other than the "
+                                          "trained one (%dx%d) is not supported (eval-only slow path)" % (h, w, oh, oh))
+            return self._forward_resized(src_tokens, feat, h, w, prev_output_tokens, full_context_alignment)
         g = self._geometry(h, w, L)
         T, Td = P + L, P + 1
         ctx = {"B": B, "L": L, "P": P, "T": T, "Td": Td, "h": h, "w": w, "full": bool(full_context_alignment),
@@ -455,7 +460,127 @@ class HipEngine:
         self.ctx = ctx
         return logits, ctx
 
-    def _self_block_fwd(self, tg, p, attn, ln1, ln2, x, B, T, pq, pk, rel, causal, scaling):
+    # ---------------------------------------------------------- resized-grid slow path (eval)
+    @staticmethod
+    def _resize_hw(t, src_hw, dst_hw):
+        """bilinear resize of the trailing flattened grid dim (F.interpolate, align_corners=False)"""
+        lead = t.shape[:-1]
+        t4 = t.reshape(1, -1, src_hw[0], src_hw[1])
+        t4 = F.interpolate(t4, size=tuple(dst_hw), mode="bilinear")
+        return t4.reshape(*lead, dst_hw[0] * dst_hw[1])
+
+    def _forward_resized(self, src_tokens, feat, h, w, prev_output_tokens, full_context_alignment):
+        """encoder_module.py:360-368,802-808 and decoder_module.py:541-548,603-627 when (h, w) differs from
+        the trained grid.  The dense biases are built with a few PyTorch ops on PARAMETER-sized tensors
+        (no activation is touched); every activation op is still a HIP kernel."""
+        cfg, dev = self.cfg, self.device
+        W, buf = self.W, self.buf
+        B, L = src_tokens.shape
+        C, H = cfg.embed_dim, cfg.heads
+        P, T, Td = h * w, h * w + L, h * w + 1
+        scaling = float(cfg.head_dim * cfg.attn_scale_factor) ** -0.5
+        oh = cfg.orig_patch_image_size // 16
+        bsz, sb = cfg.image_bucket_size, cfg.seg_bucket_size
+        e, d = "encoder.", "decoder."
+        ids = lambda hh, ww, b: (torch.arange(ww, device=dev)[None, :] + torch.arange(hh, device=dev)[:, None] * b + 1).reshape(-1)
+        ctx = {"B": B, "L": L, "P": P, "T": T, "Td": Td, "h": h, "w": w, "full": bool(full_context_alignment),
+               "src_tokens": src_tokens, "feat": feat, "resized": True}
+        # ---- embeddings (same kernels as the fast path)
+        bias_img = buf("bias_img", (C,))
+        hip.add_bf16(W(e + "image_proj.bias"), W(e + "type_embedding.weight")[1], bias_img)
+        img_pre = buf("img_pre", (B * P, C))
+        hip.linear_fwd(feat.view(B * P, 1024), W(e + "image_proj.weight"), bias_img, out=img_pre)
+        x = buf("e_x_in", (B, T, C))
+        hip.ln_fwd(img_pre.view(B, P, C), W(e + "patch_layernorm_embedding.weight"),
+                   W(e + "patch_layernorm_embedding.bias"), x[:, :P])
+        tok_pre = buf("tok_pre", (B * L, C))
+        hip.embed_rows(W(e + "embed_tokens.weight"), src_tokens.reshape(-1).contiguous(),
+                       W(e + "type_embedding.weight")[0], tok_pre)
+        hip.ln_fwd(tok_pre.view(B, L, C), W(e + "layernorm_embedding.weight"), W(e + "layernorm_embedding.bias"), x[:, P:])
+        # ---- position embeddings (get_patch_images_info :358-370)
+        itab = W(e + "embed_image_positions.weight")
+        if P > oh * oh:
+            old = itab[ids(oh, oh, bsz)].float()
+            ipos = self._resize_hw(old.t(), (oh, oh), (h, w)).t().to(BF).contiguous()
+        else:
+            ipos = itab[ids(h, w, bsz)].contiguous()
+        pos_all = buf("e_pos_all", (T, C))
+        hip.ln_fwd(ipos, W(e + "image_pos_ln.weight"), W(e + "image_pos_ln.bias"), pos_all[:P])
+        hip.ln_fwd(W(e + "embed_positions.weight")[:L], W(e + "pos_ln.weight"), W(e + "pos_ln.bias"), pos_all[P:])
+        pqk = buf("e_pqk", (T, 2 * C))
+        hip.linear_fwd(pos_all, self._fused(self.p16, e + "pos_q_linear.weight", 2 * C, C),
+                       self._fused(self.p16, e + "pos_q_linear.bias", 2 * C), out=pqk, alpha=scaling, alpha_ncols=C)
+        tokb = self.model.encoder.token_rp_bucket[:L, :L].to(dev)
+        imgb = self.model.encoder.image_rp_bucket.to(dev)
+        i0 = ids(oh, oh, bsz)
+        rp = imgb[i0][:, i0]
+        for l in range(cfg.enc_layers):
+            p = "%slayers.%d." % (e, l)
+            tg = "e%d" % l
+            dense = torch.zeros(H, T, T, dtype=torch.float32, device=dev)
+            dense[:, P:, P:] = W("%stoken_rel_pos_table_list.%d.weight" % (e, l)).float()[tokb].permute(2, 0, 1)
+            img = W("%simage_rel_pos_table_list.%d.weight" % (e, l)).float()[rp].permute(2, 0, 1)      # [H,P0,P0]
+            if (h, w) != (oh, oh):
+                img = self._resize_hw(img, (oh, oh), (h, w))
+                img = self._resize_hw(img.transpose(1, 2), (oh, oh), (h, w)).transpose(1, 2)
+            dense[:, :P, :P] = img
+            x = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", x, B, T, pqk[:, :C],
+                                     pqk[:, C:], None, False, scaling, dense=dense.contiguous())
+            x = self._ffn_fwd(tg, p, x, B * T)
+        enc_out = buf("enc_out", (B, T, C))
+        hip.ln_fwd(x.view(B * T, C), W(e + "layer_norm.weight"), W(e + "layer_norm.bias"), enc_out.view(B * T, C))
+        ctx["enc_out"] = enc_out
+        # ---- decoder
+        y0b = buf("d_bos", (B, 1, C))
+        bos = (prev_output_tokens[:, :1] if prev_output_tokens is not None
+               else torch.zeros(B, 1, dtype=torch.long, device=dev))
+        hip.embed_rows(W(e + "embed_tokens.weight"), bos.reshape(-1).contiguous(), None, y0b)
+        y = buf("d_y_in", (B, Td, C))
+        hip.ln_fwd(enc_out[:, :P], W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), y[:, :P])
+        hip.ln_fwd(y0b, W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), y[:, P:])
+        segtab = W(d + "embed_seg_positions.weight")
+        old = segtab[ids(sb, sb, sb)].float()
+        spos = old if (h, w) == (sb, sb) else self._resize_hw(old.t(), (sb, sb), (h, w)).t()
+        tgt = torch.cat([spos, segtab[:1].float()], 0).to(BF).contiguous()                # internal order: bos last
+        tp = buf("d_tp", (Td, C))
+        hip.ln_fwd(tgt, W(d + "seg_pos_ln.weight"), W(d + "seg_pos_ln.bias"), tp)
+        spqk = buf("d_spqk", (Td, 2 * C))
+        hip.linear_fwd(tp, self._fused(self.p16, d + "self_pos_q_linear.weight", 2 * C, C),
+                       self._fused(self.p16, d + "self_pos_q_linear.bias", 2 * C), out=spqk, alpha=scaling, alpha_ncols=C)
+        cpq = buf("d_cpq", (Td, C))
+        hip.linear_fwd(tp, W(d + "cross_pos_q_linear.weight"), W(d + "cross_pos_q_linear.bias"), out=cpq, alpha=scaling)
+        cpk = buf("d_cpk", (T, C))
+        hip.linear_fwd(pos_all, W(d + "cross_pos_k_linear.weight"), W(d + "cross_pos_k_linear.bias"), out=cpk)
+        segb = self.model.decoder.seg_rp_bucket.to(dev)
+        perm = torch.cat([torch.arange(1, Td, device=dev), torch.zeros(1, dtype=torch.long, device=dev)])
+        mask = None
+        if not full_context_alignment:
+            mask = torch.triu(torch.full((Td, Td), float("-inf"), device=dev), 1)[perm][:, perm]
+        for l in range(cfg.dec_layers):
+            p = "%slayers.%d." % (d, l)
+            tg = "d%d" % l
+            rel = W("%sseg_rel_pos_table_list.%d.weight" % (d, l)).float()[segb].permute(2, 0, 1)        # [H,N0+1,N0+1]
+            if (h, w) != (sb, sb):
+                t = rel.transpose(1, 2)
+                t = torch.cat([t[..., :1], self._resize_hw(t[..., 1:], (sb, sb), (h, w))], -1)
+                t = t.transpose(1, 2)
+                rel = torch.cat([t[..., :1], self._resize_hw(t[..., 1:], (sb, sb), (h, w))], -1)
+            dense = rel[:, perm][:, :, perm]
+            if mask is not None:
+                dense = dense + mask
+            y = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", y, B, Td,
+                                     spqk[:, :C], spqk[:, C:], None, False, scaling, dense=dense.contiguous())
+            y = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling)
+            y = self._ffn_fwd(tg, p, y, B * Td)
+        featb = buf("d_feat", (B, Td, C))
+        hip.ln_fwd(y[:, :P], W(d + "layer_norm.weight"), W(d + "layer_norm.bias"), featb[:, 1:])
+        hip.ln_fwd(y[:, P:], W(d + "layer_norm.weight"), W(d + "layer_norm.bias"), featb[:, :1])
+        logits = buf("logits_pad", (B, Td, self.npad))
+        hip.linear_fwd(featb.view(B * Td, C), self.wseg_pad, out=logits.view(B * Td, self.npad))
+        self.ctx = ctx
+        return logits, ctx
+
+    def _self_block_fwd(self, tg, p, attn, ln1, ln2, x, B, T, pq, pk, rel, causal, scaling, dense=None):
         C, H = self.cfg.embed_dim, self.cfg.heads
         W, buf = self.W, self.buf
         a_ = p + attn
@@ -470,7 +595,7 @@ class HipEngine:
         lse = buf(tg + "_lse", (B, H, T), torch.float32)
         gain = self._gain32(tg + "_sa", a_ + ".c_attn")
         hip.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], pq, pk, o, lse, B, H, T, T, rel=rel,
-                     causal=causal, gain=gain)
+                     causal=causal, gain=gain, dense_bias=dense)
         a = buf(tg + "_a", (B * T, C))
         hip.linear_fwd(o.view(B * T, C), W(a_ + ".out_proj.weight"), W(a_ + ".out_proj.bias"), out=a)
         x1 = buf(tg + "_x1", (B, T, C))

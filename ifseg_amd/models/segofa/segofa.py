@@ -173,6 +173,7 @@ class SegOFAModel(nn.Module):
                 "image_embed_shape": [(ctx["h"], ctx["w"])],
                 "image_embed_before_proj": [ctx["feat"]],
                 "position_embeddings": [eng.ws["e_pos_all"]],
+                "resized_grid": bool(ctx.get("resized", False)),
                 "encoder_padding_mask": [torch.zeros(B, T, dtype=torch.bool, device=logits.device)],
             },
             "attn": [None],
@@ -184,7 +185,7 @@ class SegOFAModel(nn.Module):
 class _SegOFAFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, src_tokens, patch_images, prev, full, mode, anchor, *params):
-        logits_pad, _ = eng.forward(src_tokens, patch_images, prev, full)
+        logits_pad, _ = eng.forward(src_tokens, patch_images, prev, full, need_grad=bool(anchor.requires_grad))
         ctx.eng, ctx.mode, ctx.nparams = eng, mode, len(params)
         return logits_pad[:, :, : eng.cfg.num_seg_tokens]
 

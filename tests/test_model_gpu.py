@@ -165,3 +165,31 @@ def test_base_config1_vs_reference_golden(golden_dir):
     ai, al = logs["area_intersect"].cpu().numpy(), logs["area_label"].cpu().numpy()
     assert np.array_equal(al, g["area_label"])
     assert np.abs(ai - g["area_intersect"]).sum() <= 0.01 * al.sum()
+
+
+def test_resized_grid_eval_vs_reference_golden(golden_dir):
+    """eval on a 128x192 image with a model trained at 128x128 (P = 96 > 64): position-table and
+    rel-pos bias bilinear resizes (encoder_module.py:360-368,802-808; decoder_module.py:541-548,603-627)
+    through the dense-bias slow path of the HIP attention kernel, against the reference's logits."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "fixture_resize.npz"))
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    hw = tuple(int(v) for v in g["image_hw"])
+    batch = O.synthetic_batch(ocfg, 1, int(g["src_len"]), image_hw=hw, seed=int(g["seed"]))
+    m = _build(ocfg, sd, dev)
+    m.eval()
+    with torch.no_grad():
+        logits, extra = m(src_tokens=batch["src_tokens"].to(dev), patch_images=batch["patch_images"].to(dev),
+                          prev_output_tokens=batch["prev_output_tokens"].to(dev), patch_masks=batch["patch_masks"].to(dev))
+    assert extra["encoder_returns"]["image_embed_shape"][0] == (hw[0] // 16, hw[1] // 16)
+    ref = torch.from_numpy(g["logits_causal"])
+    e = _rel(logits, ref)
+    print("resized grid: logits rel-L2 %.4f" % e)
+    assert logits.shape == ref.shape and e <= 2e-2
+    # training on a resized grid is refused loudly
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(src_tokens=batch["src_tokens"].to(dev), patch_images=batch["patch_images"].to(dev))
