@@ -483,3 +483,58 @@ extern "C" int ifseg_rel_scatter_add(const float* d, const int* idx, float* acc,
   IFSEG_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- dropout + DropPath (training-time stochastic regularisers) -------------------------------
+// out = [resid +] dpscale[b] * keep(i) * x / (1 - p), keep(i) ~ Bernoulli(1 - p) from a counter-based
+// hash of (seed, element index): the backward re-generates the same mask (same call with x = dy,
+// resid = NULL), nothing is stored.  Reference: FairseqDropout (fairseq_dropout.py:23-27) after the
+// embedding LayerNorms, attn_ln / cross_attn_ln and fc2, and drop_path (unify_transformer_layer.py:19-35)
+// inside residual_connection (:196).  The RNG stream necessarily differs from torch's.
+namespace {
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void dropout_kernel(const bf16_t* x, const bf16_t* resid, bf16_t* out, long long nchunks, int C, float p,
+                               unsigned long long seed, const float* dpscale, int rows_per_batch, RowMap mx, RowMap mr,
+                               RowMap mo) {
+  const long long c8 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c8 >= nchunks) return;
+  const int nch = C >> 3;
+  const int row = (int)(c8 / nch), col = (int)(c8 % nch) * 8;
+  const float sc = (dpscale ? dpscale[row / rows_per_batch] : 1.f) * (p > 0.f ? 1.f / (1.f - p) : 1.f);
+  const unsigned thr = (unsigned)(p * 65536.f);
+  const unsigned long long r0 = splitmix64(seed + 2ull * (unsigned long long)c8), r1 = splitmix64(seed + 2ull * (unsigned long long)c8 + 1ull);
+  float f[8];
+  unpack8(*reinterpret_cast<const uint4*>(x + mx.off(row) + col), f);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const unsigned bits = (unsigned)(((e < 4 ? r0 : r1) >> (16 * (e & 3))) & 0xFFFFu);
+    f[e] = bits >= thr ? f[e] * sc : 0.f;
+  }
+  if (resid) {
+    float r[8];
+    unpack8(*reinterpret_cast<const uint4*>(resid + mr.off(row) + col), r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += r[e];
+  }
+  *reinterpret_cast<uint4*>(out + mo.off(row) + col) = pack8(f);
+}
+}  // namespace
+
+extern "C" int ifseg_dropout(const void* x, const void* resid, void* out, long long rows, int C, float p,
+                             unsigned long long seed, const float* drop_path_scale, int rows_per_batch, int rpb,
+                             long long x_bs, int ldx, long long r_bs, int ldr, long long o_bs, int ldo, void* stream) {
+  (void)hipGetLastError();
+  if (rows <= 0) return 0;
+  if ((C & 7) || p < 0.f || p >= 1.f || rows_per_batch <= 0) return IFSEG_ERR_BAD_ARG;
+  const long long nchunks = rows * (C / 8);
+  RowMap mx{rpb, x_bs, ldx}, mr{rpb, r_bs, ldr}, mo{rpb, o_bs, ldo};
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)resid, (bf16_t*)out, nchunks, C, p, seed, drop_path_scale, rows_per_batch,
+                     mx, mr, mo);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}

@@ -368,3 +368,19 @@ def seg_loss(logits_pad, target, hp, wp, H, W, nseg, seg_id_offset, tile_partial
                                        c_ll(dlogits_pad.stride(0)), c_int(B), c_int(hp), c_int(wp), c_int(nseg),
                                        _ptr(loss_out), _stream()), "seg_loss_gather")
     return loss_out
+
+
+def dropout(x, resid, out, p, seed, drop_path_scale=None, rows_per_batch=None):
+    """x / resid / out: [rows, C] or [B, rpb, C] bf16 views (last dim contiguous)"""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    rpb = x.shape[1] if x.dim() == 3 else 0
+    xb, xl = _map(x, rpb)
+    rb, rl = _map(resid, rpb)
+    ob, ol = _map(out, rpb)
+    rc = lib().ifseg_dropout(_ptr(x), _ptr(resid), _ptr(out), c_ll(rows), c_int(C), c_float(p),
+                             ctypes.c_ulonglong(seed & 0xFFFFFFFFFFFFFFFF), _ptr(drop_path_scale),
+                             c_int(rows_per_batch or (rpb if rpb else rows)), c_int(rpb), c_ll(xb), c_int(xl), c_ll(rb),
+                             c_int(rl), c_ll(ob), c_int(ol), _stream())
+    _check(rc, "dropout")
+    return out

@@ -34,6 +34,11 @@ class SegOFAConfig:
     max_source_positions: int = 1024
     max_target_positions: int = 1024
     code_image_size: int = 128
+    # stochastic regularisers (coco_unseen.sh:19-22: dropout 0.1, encoder/decoder drop-path 0.1,
+    # attention_dropout 0.0).  Parity is defined at 0 (the RNG stream cannot match torch's).
+    dropout: float = 0.0
+    encoder_drop_path_rate: float = 0.0
+    decoder_drop_path_rate: float = 0.0
     # freezes of the shipped recipe (coco_unseen.sh:31-33,76)
     freeze_resnet: bool = True
     freeze_embeddings: bool = True

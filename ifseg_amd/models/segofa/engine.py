@@ -47,7 +47,9 @@ class HipEngine:
         self.ws = {}
         self.geo = {}
         self.ctx = None
-        self.grad_ready_hook = None      # callable(lo, hi) on arena slices once their grads are final
+        self.grad_ready_hook = None      # callable(prefix) once every gradient under `prefix` is final
+        self.drop_on = False
+        self.step_seed = 0               # set by the trainer (seed + num_updates, trainer.py:1297)
 
     # ------------------------------------------------------------------ packing
     def _arena_order(self):
@@ -323,6 +325,35 @@ class HipEngine:
             out.append(o)
         return out
 
+    # ---- dropout / DropPath sites (a12) -------------------------------------------------------
+    def _drop_setup(self, B, train):
+        cfg = self.cfg
+        self.drop_on = bool(train and (cfg.dropout > 0 or cfg.encoder_drop_path_rate > 0 or cfg.decoder_drop_path_rate > 0))
+        if not self.drop_on:
+            return
+        # per-sample DropPath keep masks for every residual branch, one draw per forward
+        # (rates: torch.linspace(0, rate, n_layers), encoder_module.py:232 / decoder_module.py:219)
+        rates = []
+        for l in range(cfg.enc_layers):
+            r = cfg.encoder_drop_path_rate * l / max(1, cfg.enc_layers - 1)
+            rates += [r, r]
+        for l in range(cfg.dec_layers):
+            r = cfg.decoder_drop_path_rate * l / max(1, cfg.dec_layers - 1)
+            rates += [r, r, r]
+        keep = 1.0 - torch.tensor(rates, dtype=torch.float32, device=self.device)[:, None]
+        self.dp_scale = ((torch.rand(len(rates), B, device=self.device) < keep).float() / keep).contiguous()
+
+    def _dp(self, kind, layer, k):
+        i = 2 * layer + k if kind == "e" else 2 * self.cfg.enc_layers + 3 * layer + k
+        return self.dp_scale[i]
+
+    def _site_seed(self, site):
+        return (self.step_seed * 1000003 + site) * 0x100000001B3 + 0x9E3779B97F4A7C15
+
+    def _drop(self, x, resid, out, site, dp=None, rows_per_batch=None):
+        hip.dropout(x, resid, out, self.cfg.dropout, self._site_seed(site), dp, rows_per_batch)
+        return out
+
     def _ln_stats(self, tag, rows):
         return self.buf(tag + "_mu", (rows,), torch.float32), self.buf(tag + "_rs", (rows,), torch.float32)
 
@@ -362,6 +393,7 @@ class HipEngine:
             return self._forward_resized(src_tokens, feat, h, w, prev_output_tokens, full_context_alignment)
         g = self._geometry(h, w, L)
         T, Td = P + L, P + 1
+        self._drop_setup(B, need_grad)
         ctx = {"B": B, "L": L, "P": P, "T": T, "Td": Td, "h": h, "w": w, "full": bool(full_context_alignment),
                "src_tokens": src_tokens, "feat": feat}
         e = "encoder."
@@ -372,14 +404,20 @@ class HipEngine:
         hip.linear_fwd(feat.view(B * P, 1024), W(e + "image_proj.weight"), bias_img, out=img_pre)
         x = buf("e_x_in", (B, T, C))
         mu, rs = self._ln_stats("img_ln", B * P)
+        ydst = buf("img_ln_y", (B, P, C)) if self.drop_on else x[:, :P]
         hip.ln_fwd(img_pre.view(B, P, C), W(e + "patch_layernorm_embedding.weight"),
-                   W(e + "patch_layernorm_embedding.bias"), x[:, :P], mu, rs)
+                   W(e + "patch_layernorm_embedding.bias"), ydst, mu, rs)
+        if self.drop_on:
+            self._drop(ydst, None, x[:, :P], 1)
         tok_pre = buf("tok_pre", (B * L, C))
         hip.embed_rows(W(e + "embed_tokens.weight"), src_tokens.reshape(-1).contiguous(),
                        W(e + "type_embedding.weight")[0], tok_pre)
         mu, rs = self._ln_stats("tok_ln", B * L)
+        ydst = buf("tok_ln_y", (B, L, C)) if self.drop_on else x[:, P:]
         hip.ln_fwd(tok_pre.view(B, L, C), W(e + "layernorm_embedding.weight"), W(e + "layernorm_embedding.bias"),
-                   x[:, P:], mu, rs)
+                   ydst, mu, rs)
+        if self.drop_on:
+            self._drop(ydst, None, x[:, P:], 2)
         # ---- abs-pos operands (encoder_module.py:757-771): LN over the table rows in place
         bsz = cfg.image_bucket_size
         img_pos_view = W(e + "embed_image_positions.weight")[1:1 + bsz * h].view(h, bsz, C)[:, :w]
@@ -402,8 +440,8 @@ class HipEngine:
                 (None, g["enc_idxx"])])
             rel = hip.RelBias(P, g["gcode"], g["code_bias"], r2, r1, rx, grid_w=w)
             x = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", x, B, T,
-                                     ctx["e_pq"], ctx["e_pk"], rel, False, scaling)
-            x = self._ffn_fwd(tg, p, x, B * T)
+                                     ctx["e_pq"], ctx["e_pk"], rel, False, scaling, site=("e", l, 0))
+            x = self._ffn_fwd(tg, p, x, B * T, site=("e", l, 1), rpb=T)
         enc_out = buf("enc_out", (B, T, C))
         mu, rs = self._ln_stats("e_final_ln", B * T)
         hip.ln_fwd(x.view(B * T, C), W(e + "layer_norm.weight"), W(e + "layer_norm.bias"), enc_out.view(B * T, C), mu, rs)
@@ -418,9 +456,15 @@ class HipEngine:
         hip.embed_rows(W(e + "embed_tokens.weight"), bos.reshape(-1).contiguous(), None, y0b)
         y = buf("d_y_in", (B, Td, C))
         mu, rs = self._ln_stats("d_emb_ln_p", B * P)
-        hip.ln_fwd(enc_out[:, :P], W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), y[:, :P], mu, rs)
+        ydst = buf("d_emb_y", (B, P, C)) if self.drop_on else y[:, :P]
+        hip.ln_fwd(enc_out[:, :P], W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), ydst, mu, rs)
+        if self.drop_on:
+            self._drop(ydst, None, y[:, :P], 3)
         mu, rs = self._ln_stats("d_emb_ln_b", B)
-        hip.ln_fwd(y0b, W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), y[:, P:], mu, rs)
+        ydst = buf("d_emb_yb", (B, 1, C)) if self.drop_on else y[:, P:]
+        hip.ln_fwd(y0b, W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), ydst, mu, rs)
+        if self.drop_on:
+            self._drop(ydst, None, y[:, P:], 4)
         # positions: internal order [grid cells 1..P | slot 0]
         sb = cfg.seg_bucket_size
         segtab = W(d + "embed_seg_positions.weight")
@@ -445,9 +489,9 @@ class HipEngine:
             r2, r1, rx = self._rel_tables(tg, [(tab, g["dec_idx2d"]), (tab, g["dec_idx1d"]), (tab, g["dec_idxx"])])
             rel = hip.RelBias(P, g["gcode"], g["code_bias"], r2, r1, rx, grid_w=w)
             y = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", y, B, Td,
-                                     ctx["d_spq"], ctx["d_spk"], rel, causal, scaling)
-            y = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling)
-            y = self._ffn_fwd(tg, p, y, B * Td)
+                                     ctx["d_spq"], ctx["d_spk"], rel, causal, scaling, site=("d", l, 0))
+            y = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling, site=("d", l, 1))
+            y = self._ffn_fwd(tg, p, y, B * Td, site=("d", l, 2), rpb=Td)
         ctx["d_y_final"] = y
         # final LN written in reference order [bos, patches] (decoder_module.py:668-675)
         featb = buf("d_feat", (B, Td, C))
@@ -475,6 +519,7 @@ class HipEngine:
         (no activation is touched); every activation op is still a HIP kernel."""
         cfg, dev = self.cfg, self.device
         W, buf = self.W, self.buf
+        self.drop_on = False
         B, L = src_tokens.shape
         C, H = cfg.embed_dim, cfg.heads
         P, T, Td = h * w, h * w + L, h * w + 1
@@ -580,7 +625,11 @@ class HipEngine:
         self.ctx = ctx
         return logits, ctx
 
-    def _self_block_fwd(self, tg, p, attn, ln1, ln2, x, B, T, pq, pk, rel, causal, scaling, dense=None):
+    def _site_id(self, site):
+        kind, l, k = site
+        return 16 + (l * 4 + k) * 2 + (0 if kind == "e" else 1)
+
+    def _self_block_fwd(self, tg, p, attn, ln1, ln2, x, B, T, pq, pk, rel, causal, scaling, dense=None, site=None):
         C, H = self.cfg.embed_dim, self.cfg.heads
         W, buf = self.W, self.buf
         a_ = p + attn
@@ -600,12 +649,16 @@ class HipEngine:
         hip.linear_fwd(o.view(B * T, C), W(a_ + ".out_proj.weight"), W(a_ + ".out_proj.bias"), out=a)
         x1 = buf(tg + "_x1", (B, T, C))
         mu, rs = self._ln_stats(tg + "_ln2", B * T)
-        hip.ln_fwd(a, W(p + ln2 + ".weight"), W(p + ln2 + ".bias"), x1.view(B * T, C), mu, rs, resid=x.view(B * T, C))
-        self.ctx_tmp = None
-        self._save(tg + "_sa", x=x, xn=xn, qkv=qkv, o=o, lse=lse, a=a, rel=rel, gain=gain, causal=causal)
+        if self.drop_on and site is not None:
+            t = buf("drop_tmp_%d" % (B * T), (B * T, C))
+            hip.ln_fwd(a, W(p + ln2 + ".weight"), W(p + ln2 + ".bias"), t, mu, rs)
+            self._drop(t, x.view(B * T, C), x1.view(B * T, C), self._site_id(site), self._dp(*site), T)
+        else:
+            hip.ln_fwd(a, W(p + ln2 + ".weight"), W(p + ln2 + ".bias"), x1.view(B * T, C), mu, rs, resid=x.view(B * T, C))
+        self._save(tg + "_sa", x=x, xn=xn, qkv=qkv, o=o, lse=lse, a=a, rel=rel, gain=gain, causal=causal, site=site)
         return x1
 
-    def _cross_block_fwd(self, tg, p, y1, enc_out, B, Td, Te, cpq, cpk, scaling):
+    def _cross_block_fwd(self, tg, p, y1, enc_out, B, Td, Te, cpq, cpk, scaling, site=None):
         C, H = self.cfg.embed_dim, self.cfg.heads
         W, buf = self.W, self.buf
         a_ = p + "encoder_attn"
@@ -625,12 +678,17 @@ class HipEngine:
         hip.linear_fwd(o.view(B * Td, C), W(a_ + ".out_proj.weight"), W(a_ + ".out_proj.bias"), out=a)
         y2 = buf(tg + "_y2", (B, Td, C))
         mu, rs = self._ln_stats(tg + "_cln2", B * Td)
-        hip.ln_fwd(a, W(p + "cross_attn_ln.weight"), W(p + "cross_attn_ln.bias"), y2.view(B * Td, C), mu, rs,
-                   resid=y1.view(B * Td, C))
-        self._save(tg + "_ca", x=y1, xn=yn, q=q, kv=kv, o=o, lse=lse, a=a, gain=gain)
+        if self.drop_on and site is not None:
+            t = buf("drop_tmp_%d" % (B * Td), (B * Td, C))
+            hip.ln_fwd(a, W(p + "cross_attn_ln.weight"), W(p + "cross_attn_ln.bias"), t, mu, rs)
+            self._drop(t, y1.view(B * Td, C), y2.view(B * Td, C), self._site_id(site), self._dp(*site), Td)
+        else:
+            hip.ln_fwd(a, W(p + "cross_attn_ln.weight"), W(p + "cross_attn_ln.bias"), y2.view(B * Td, C), mu, rs,
+                       resid=y1.view(B * Td, C))
+        self._save(tg + "_ca", x=y1, xn=yn, q=q, kv=kv, o=o, lse=lse, a=a, gain=gain, site=site)
         return y2
 
-    def _ffn_fwd(self, tg, p, x1, rows):
+    def _ffn_fwd(self, tg, p, x1, rows, site=None, rpb=None):
         C, Fd = self.cfg.embed_dim, self.cfg.ffn_dim
         W, buf = self.W, self.buf
         xn = buf(tg + "_fxn", (rows, C))
@@ -642,8 +700,13 @@ class HipEngine:
         mu, rs = self._ln_stats(tg + "_fln2", rows)
         hip.ln_fwd(u, W(p + "ffn_layernorm.weight"), W(p + "ffn_layernorm.bias"), z, mu, rs, gelu=True)
         x2 = buf(tg + "_x2", x1.shape)
-        hip.linear_fwd(z, W(p + "fc2.weight"), W(p + "fc2.bias"), out=x2.view(rows, C), resid=x1.view(rows, C))
-        self._save(tg + "_ffn", x1=x1, xn=xn, u=u, z=z)
+        if self.drop_on and site is not None:
+            t = buf("drop_tmp_%d" % rows, (rows, C))
+            hip.linear_fwd(z, W(p + "fc2.weight"), W(p + "fc2.bias"), out=t)
+            self._drop(t, x1.view(rows, C), x2.view(rows, C), self._site_id(site), self._dp(*site), rpb)
+        else:
+            hip.linear_fwd(z, W(p + "fc2.weight"), W(p + "fc2.bias"), out=x2.view(rows, C), resid=x1.view(rows, C))
+        self._save(tg + "_ffn", x1=x1, xn=xn, u=u, z=z, site=site, rpb=rpb)
         return x2
 
     def _save(self, key, **kw):
@@ -691,7 +754,10 @@ class HipEngine:
         s = self.saved[tg + "_ffn"]
         W, G, buf = self.W, self.G, self.buf
         dz = buf("g_dz_%d" % rows, (rows, Fd))
-        self._linear_bwd(dx2, s["z"], W(p + "fc2.weight"), G(p + "fc2.weight"), G(p + "fc2.bias"), dx_out=dz)
+        dbr = dx2
+        if self.drop_on and s["site"] is not None:      # adjoint of dropout + DropPath on the branch
+            dbr = self._drop(dx2, None, buf("g_drop_%d" % rows, (rows, C)), self._site_id(s["site"]), self._dp(*s["site"]), s["rpb"])
+        self._linear_bwd(dbr, s["z"], W(p + "fc2.weight"), G(p + "fc2.weight"), G(p + "fc2.bias"), dx_out=dz)
         du = buf("g_du_%d" % rows, (rows, Fd))
         self._ln_bwd(dz, s["u"], p + "ffn_layernorm", tg + "_fln2", du, gelu=True)
         dxn = buf("g_dxn_%d" % rows, (rows, C))
@@ -746,7 +812,10 @@ class HipEngine:
         a_ = p + attn
         rows = B * T
         da = buf("g_da_%d" % rows, (rows, C))
-        self._ln_bwd(dx1, s["a"], p + ln2, tg + "_ln2", da)
+        dbr = dx1
+        if self.drop_on and s["site"] is not None:
+            dbr = self._drop(dx1, None, buf("g_drop_%d" % rows, (rows, C)), self._site_id(s["site"]), self._dp(*s["site"]), T)
+        self._ln_bwd(dbr, s["a"], p + ln2, tg + "_ln2", da)
         do = buf("g_do_%d" % rows, (B, T, C))
         self._linear_bwd(da, s["o"].view(rows, C), W(a_ + ".out_proj.weight"), G(a_ + ".out_proj.weight"),
                          G(a_ + ".out_proj.bias"), dx_out=do.view(rows, C))
@@ -770,7 +839,10 @@ class HipEngine:
         a_ = p + "encoder_attn"
         rows = B * Td
         da = buf("g_da_%d" % rows, (rows, C))
-        self._ln_bwd(dy2, s["a"], p + "cross_attn_ln", tg + "_cln2", da)
+        dbr = dy2
+        if self.drop_on and s["site"] is not None:
+            dbr = self._drop(dy2, None, buf("g_drop_%d" % rows, (rows, C)), self._site_id(s["site"]), self._dp(*s["site"]), Td)
+        self._ln_bwd(dbr, s["a"], p + "cross_attn_ln", tg + "_cln2", da)
         do = buf("g_do_%d" % rows, (B, Td, C))
         self._linear_bwd(da, s["o"].view(rows, C), W(a_ + ".out_proj.weight"), G(a_ + ".out_proj.weight"),
                          G(a_ + ".out_proj.bias"), dx_out=do.view(rows, C))
@@ -833,10 +905,14 @@ class HipEngine:
         # ---- decoder embedding LN (input = [enc_out[:, :P] | embed(bos)])
         dy3 = dy.view(B, Td, C)
         enc_out = ctx["enc_out"]
-        self._ln_bwd(dy3[:, :P], enc_out[:, :P], d + "layernorm_embedding", "d_emb_ln_p", d_enc_out[:, :P],
+        dyp, dyb = dy3[:, :P], dy3[:, P:]
+        if self.drop_on:
+            dyp = self._drop(dy3[:, :P], None, buf("g_drop_dp", (B, P, C)), 3)
+            dyb = self._drop(dy3[:, P:], None, buf("g_drop_db", (B, 1, C)), 4)
+        self._ln_bwd(dyp, enc_out[:, :P], d + "layernorm_embedding", "d_emb_ln_p", d_enc_out[:, :P],
                      dx_add=d_enc_out[:, :P])
         scratch = buf("g_bos_scratch", (B, 1, C))
-        self._ln_bwd(dy3[:, P:], self.ws["d_bos"], d + "layernorm_embedding", "d_emb_ln_b", scratch, accumulate=True)
+        self._ln_bwd(dyb, self.ws["d_bos"], d + "layernorm_embedding", "d_emb_ln_b", scratch, accumulate=True)
         # ---- decoder position operands
         dspqk = buf("g_dspqk", (Td, 2 * C))
         hip.cast_f32_bf16(dspq, buf("g_tmp_tc", (Td, C)))
@@ -895,10 +971,14 @@ class HipEngine:
                      G(e + "embed_positions.weight")[:L])
         # ---- encoder embeddings (embed_tokens / image_proj / ResNet frozen -> stop here)
         dx3 = dx.view(B, T, C)
+        dxi, dxt = dx3[:, :P], dx3[:, P:]
+        if self.drop_on:
+            dxi = self._drop(dx3[:, :P], None, buf("g_drop_ei", (B, P, C)), 1)
+            dxt = self._drop(dx3[:, P:], None, buf("g_drop_et", (B, L, C)), 2)
         dimg = buf("g_dimg_pre", (B, P, C))
-        self._ln_bwd(dx3[:, :P], self.ws["img_pre"].view(B, P, C), e + "patch_layernorm_embedding", "img_ln", dimg)
+        self._ln_bwd(dxi, self.ws["img_pre"].view(B, P, C), e + "patch_layernorm_embedding", "img_ln", dimg)
         dtok = buf("g_dtok_pre", (B, L, C))
-        self._ln_bwd(dx3[:, P:], self.ws["tok_pre"].view(B, L, C), e + "layernorm_embedding", "tok_ln", dtok)
+        self._ln_bwd(dxt, self.ws["tok_pre"].view(B, L, C), e + "layernorm_embedding", "tok_ln", dtok)
         gt = G(e + "type_embedding.weight")
         self._bias_grad(dtok.view(B * L, C), gt[0])
         self._bias_grad(dimg.view(B * P, C), gt[1])

@@ -105,6 +105,7 @@ class Trainer:
     # -- steps ------------------------------------------------------------------------------
     def train_step(self, samples):
         torch.manual_seed(self.seed + self.num_updates)
+        self.eng.step_seed = self.seed + self.num_updates
         self.model.train()
         logs, sample_sizes = [], []
         for sample in samples:            # update_freq > 1 would accumulate; the shipped recipe uses 1

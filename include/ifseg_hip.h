@@ -157,6 +157,14 @@ int ifseg_nchw_to_nhwc_bf16(const void* in, int in_is_f32, void* out, int B, int
 int ifseg_rel_gather(const void* table, const int* idx, float* out, int n, int H, void* stream);
 int ifseg_rel_scatter_add(const float* d, const int* idx, float* acc, int n, int H, void* stream);
 
+/* out = [resid +] drop_path_scale[row / rows_per_batch] * keep * x / (1 - p) on [rows, C] bf16 (row addressing as above);
+ * keep ~ Bernoulli(1-p) from a counter-based hash of (seed, element): calling it again with x = dy,
+ * resid = NULL is the backward.  FairseqDropout (fairseq_dropout.py:23-27) + drop_path
+ * (unify_transformer_layer.py:19-35, residual_connection :196). */
+int ifseg_dropout(const void* x, const void* resid, void* out, long long rows, int C, float p,
+                  unsigned long long seed, const float* drop_path_scale, int rows_per_batch, int rpb, long long x_bs,
+                  int ldx, long long r_bs, int ldr, long long o_bs, int ldo, void* stream);
+
 /* ------------------------------------------------------------ ResNet stem */
 /* conv1 7x7/2 (3->64) + folded FrozenBN + ReLU on an NHWC(4) bf16 image; w fp32
  * [7][7][3][64] with the BN scale folded, shift fp32 [64] (resnet.py:215-218). */

@@ -460,3 +460,31 @@ def test_fused_seg_loss(nseg, B, hp, wp):
     assert (stats[2 + n:2 + 2 * n] - ap).abs().sum().item() <= 1e-4 * H * W * B + 2
     assert torch.equal(stats[2 + 2 * n:2 + 3 * n], al)
     assert (stats[2:2 + n] - ai).abs().sum().item() <= 1e-4 * H * W * B + 2
+
+
+def test_dropout_kernel():
+    from ifseg_amd import hip
+    dev = _dev()
+    B, T, C, p = 4, 333, 768, 0.1
+    x = _rand((B * T, C), dev, 60)
+    ones = torch.ones(B * T, C, dtype=torch.bfloat16, device=dev)
+    m1 = torch.empty_like(ones); m2 = torch.empty_like(ones); m3 = torch.empty_like(ones)
+    hip.dropout(ones, None, m1, p, 1234)
+    hip.dropout(ones, None, m2, p, 1234)
+    hip.dropout(ones, None, m3, p, 1235)
+    assert torch.equal(m1, m2) and not torch.equal(m1, m3)               # counter-based: reproducible, seed-dependent
+    keep = (m1 != 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 3e-3, keep
+    assert (m1[m1 != 0].float() - 1 / (1 - p)).abs().max().item() < 5e-3
+    # forward with residual + per-sample DropPath scale; backward = same call on dy
+    dp = torch.tensor([1 / 0.9, 0.0, 1 / 0.9, 1 / 0.9], device=dev)
+    res = _rand((B * T, C), dev, 61)
+    out = torch.empty_like(x)
+    hip.dropout(x, res, out, p, 1234, dp, T)
+    ref = res.float() + x.float() * m1.float() * dp.repeat_interleave(T)[:, None]
+    assert _rel(out, ref) < 6e-3
+    # strided views
+    big = torch.zeros(B, T + 7, C, dtype=torch.bfloat16, device=dev)
+    hip.dropout(x.view(B, T, C), None, big[:, 3:3 + T], p, 1234)
+    assert _rel(big[:, 3:3 + T], x.view(B, T, C).float() * m1.view(B, T, C).float()) < 6e-3
+    assert big[:, :3].abs().sum() == 0

@@ -193,3 +193,43 @@ def test_resized_grid_eval_vs_reference_golden(golden_dir):
     m.train()
     with pytest.raises(NotImplementedError):
         m(src_tokens=batch["src_tokens"].to(dev), patch_images=batch["patch_images"].to(dev))
+
+
+def test_dropout_path_wiring_and_training_mode(golden_dir):
+    """a12: (i) with keep-probability ~1 the dropout/DropPath code path (unfused LN -> dropout kernel ->
+    residual, and its adjoint) must reproduce the fused p=0 path; (ii) with the shipped rates (0.1 / 0.1)
+    the step is finite, stochastic across steps and reproducible for a fixed seed."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ifseg_amd.criterions import SegCriterion
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    batch = O.synthetic_batch(ocfg, 2, 12)
+    sample = {"net_input": {k: batch[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks", "prev_output_tokens")},
+              "target": batch["target"].to(dev), "ntokens": 1, "nsentences": 2}
+    crit = SegCriterion(num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+
+    def run(dropout, dpr, seed):
+        m = _build(ocfg, sd, dev)
+        m.cfg.dropout, m.cfg.encoder_drop_path_rate, m.cfg.decoder_drop_path_rate = dropout, dpr, dpr
+        m.autograd_mode = "arena"
+        m.train()
+        m.engine.step_seed = seed
+        torch.manual_seed(seed)
+        loss, _, _ = crit(m, sample)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), m.engine.g16.float().clone(), m.engine.drop_on
+
+    l0, g0, on0 = run(0.0, 0.0, 1)
+    l1, g1, on1 = run(1e-9, 1e-9, 1)
+    assert not on0 and on1
+    assert abs(l0 - l1) < 2e-3, (l0, l1)
+    assert _rel(g1, g0) < 2e-2, _rel(g1, g0)
+    la, ga, _ = run(0.1, 0.1, 7)
+    lb, gb, _ = run(0.1, 0.1, 7)
+    lc, gc, _ = run(0.1, 0.1, 8)
+    assert la == lb and torch.equal(ga, gb)          # same seed -> same masks
+    assert la != lc and abs(la - l0) > 1e-4          # different seed / vs no dropout
+    assert torch.isfinite(ga).all() and ga.norm() > 0
