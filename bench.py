@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--nseg", type=int, default=15)
+    ap.add_argument("--dropout", type=float, default=0.1, help="dropout (coco_unseen.sh:22)")
+    ap.add_argument("--drop-path", type=float, default=0.1, help="encoder/decoder drop-path rate (coco_unseen.sh:20-21)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -82,6 +84,7 @@ def main():
     torch.manual_seed(0)
     task = SegmentationTask(num_seg_tokens=a.nseg, patch_image_size=512, arch="segofa_base")
     model = task.build_model()
+    model.cfg.dropout, model.cfg.encoder_drop_path_rate, model.cfg.decoder_drop_path_rate = a.dropout, a.drop_path, a.drop_path
     crit = SegCriterion(task)
     trainer = Trainer(model, crit, task, device=dev)
     sample = task.synthetic_sample(a.batch, dev, seed=1234 + rank)
@@ -122,8 +125,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: SegOFA-Base bf16, batch %d/GPU, 512x512, %d classes (L=%d), "
-                                   "frozen ResNet-101 trunk; step = fwd + upsample/CE loss + bwd + clip + Adam"
-                                   % (a.batch, a.nseg, task.src_len),
+                                   "frozen ResNet-101 trunk, dropout %.2f / drop-path %.2f; step = fwd + upsample/CE loss + bwd + clip + Adam"
+                                   % (a.batch, a.nseg, task.src_len, a.dropout, a.drop_path),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "loss": round(loss, 4)},
             "roofline": {"bound": "mfma", "kernel": dom["kind"], "achieved": round(ach, 2), "peak": MFMA_PEAK_TF,
                          "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": None,
