@@ -21,7 +21,18 @@ struct RowMap {  // logical row r -> element offset  (r / rpb) * bs + (r % rpb) 
   }
 };
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// erf(x/sqrt2) by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution); e = exp(-x^2/2) is the
+// same exponential the Gaussian pdf of the GELU derivative needs, so backward costs one exp per element.
+__device__ __forceinline__ float erf_as(float x, float e) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.f - poly * e;
+  return x < 0.f ? -r : r;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  return 0.5f * x * (1.f + erf_as(x, __expf(-0.5f * x * x)));
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
 }
@@ -125,9 +136,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
         for (int e = 0; e < 8; ++e) {
           float a = xr[i][e];
           if (GELU) {
-            const float xv = xr[i][e], er = erff(xv * 0.70710678118654752f);
+            const float xv = xr[i][e], ex = __expf(-0.5f * xv * xv), er = erf_as(xv, ex);
             a = 0.5f * xv * (1.f + er);
-            da[i][e] = 0.5f * (1.f + er) + xv * 0.39894228040143268f * __expf(-0.5f * xv * xv);
+            da[i][e] = 0.5f * (1.f + er) + xv * 0.39894228040143268f * ex;
           }
           const float xh = (a - mu) * rs;
           const float g = d[e] * gam[i][e];

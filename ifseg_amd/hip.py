@@ -148,7 +148,7 @@ class _AttnBwdArgs(ctypes.Structure):
                 + [(n, c_ll) for n in ("q_bs", "k_bs", "v_bs", "out_bs", "do_bs", "dq_bs", "dk_bs", "dv_bs")]
                 + [(n, c_int) for n in ("rel_mode", "P", "code_bias", "n2d", "causal", "nparts")]
                 + [(n, c_void_p) for n in ("gcode", "rel2d", "rel1d", "relx", "gain", "drel2d_part", "drel1d_part",
-                                           "drelx_part")]
+                                           "drelx_part")]   # field order == ifseg_attn_bwd_args
                 + [("dq_scale", c_float), ("dpq_scale", c_float), ("grid_w", c_int)])
 
 

@@ -358,9 +358,7 @@ class HipEngine:
         return self.buf(tag + "_mu", (rows,), torch.float32), self.buf(tag + "_rs", (rows,), torch.float32)
 
     def _gain32(self, tag, name):
-        g = self.buf(tag + "_gain", (self.cfg.heads,), torch.float32)
-        g.copy_(self.W(name))
-        return g
+        return self.W(name)        # the kernels read the bf16 parameter directly
 
     # ----------------------------------------------------------------- forward
     def forward(self, src_tokens, patch_images, prev_output_tokens=None, full_context_alignment=False,
@@ -716,14 +714,18 @@ class HipEngine:
 
     # ---------------------------------------------------------------- backward
     def _ln_param_grads(self, pname, C, accumulate=False):
-        hip.reduce_parts(self._dgp(C), self.G(pname + ".weight"), 1, hip.LN_BWD_BLOCKS, C, accumulate=accumulate)
-        hip.reduce_parts(self._dbp(C), self.G(pname + ".bias"), 1, hip.LN_BWD_BLOCKS, C, accumulate=accumulate)
+        # weight and bias of a LayerNorm are adjacent in the arena: one [2, C] reduction
+        gw = self._fused(self.g16, pname + ".weight", 2, C)
+        hip.reduce_parts(self._dgbp(C), gw, 2, hip.LN_BWD_BLOCKS, C, accumulate=accumulate)
+
+    def _dgbp(self, C):
+        return self.buf("ln_dgbp_%d" % C, (2, hip.LN_BWD_BLOCKS, C), torch.float32)
 
     def _dgp(self, C):
-        return self.buf("ln_dgp_%d" % C, (hip.LN_BWD_BLOCKS, C), torch.float32)
+        return self._dgbp(C)[0]
 
     def _dbp(self, C):
-        return self.buf("ln_dbp_%d" % C, (hip.LN_BWD_BLOCKS, C), torch.float32)
+        return self._dgbp(C)[1]
 
     def _ln_bwd(self, dy, x, pname, stats_tag, dx, dx_add=None, gelu=False, accumulate=False):
         C = x.shape[-1]
@@ -786,7 +788,7 @@ class HipEngine:
         hip.reduce_parts(dpk_part, dpk_acc, 1, B, S * C, accumulate=not first_pos)
         # d c_attn[h] = sum_{b,t} delta / c_attn[h]   (H scalars)
         hip.reduce_parts(delta.view(B, H * T), buf("g_dsum_bt", (H * T,), torch.float32), 1, B, H * T)
-        self.G(gain_name).copy_((self.ws["g_dsum_bt"].view(H, T).sum(1) / gain))
+        self.G(gain_name).copy_((self.ws["g_dsum_bt"].view(H, T).sum(1) / gain.float()))
         if rel is not None:
             for (tabname, idx), part in zip(rel_grads, parts):
                 if tabname is None:

@@ -82,12 +82,12 @@ int ifseg_attn_fwd(const void* q, const void* k, const void* v, const void* pos_
                    int ldpq, int ldpk, long long q_bs, long long k_bs, long long v_bs, long long o_bs,
                    int rel_mode, int P, const int* gcode, int code_bias, int n2d, const float* rel2d,
                    const float* rel1d, const float* relx, int causal, const float* dense_bias,
-                   const float* gain, void* stream);
+                   const void* gain /* bf16 [H] or NULL */, void* stream);
 
 /* Backward of ifseg_attn_fwd (autograd of the same reference lines).  Launches
  *   delta[b,h,t] = sum_d dout*out;  a key-stationary dK/dV kernel that also
  *   histograms d(rel2d/rel1d/relx) in LDS;  a query-stationary dQ kernel.
- * `gain` [H] fp32 is the per-head c_attn applied to `out` by the forward
+ * `gain` [H] (bf16) is the per-head c_attn applied to `out` by the forward
  * (unify_multihead_attention.py:509-512); d(gain)[h] = sum_{b,t} delta / gain[h].
  * dq is scaled by dq_scale (the reference's q scaling), the abs-pos halves of
  * dQ_ext / dK_ext are written as fp32 per-batch partials dpos_q_part [B,T,H*64]
@@ -105,7 +105,8 @@ typedef struct ifseg_attn_bwd_args {
   long long q_bs, k_bs, v_bs, out_bs, do_bs, dq_bs, dk_bs, dv_bs;
   int rel_mode, P, code_bias, n2d, causal, nparts;
   const int* gcode;
-  const float *rel2d, *rel1d, *relx, *gain;
+  const float *rel2d, *rel1d, *relx;
+  const void* gain; /* bf16 [H] or NULL */
   float *drel2d_part, *drel1d_part, *drelx_part;
   float dq_scale, dpq_scale;
   int grid_w; /* width of the token grid (0 if unknown); 32 enables the row-aligned bias-gradient reduction */

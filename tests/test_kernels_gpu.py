@@ -220,7 +220,7 @@ def test_attn_bwd(case):
     q, k, v = _rand((B, T, C), dev, 20, 0.35), _rand((B, S, C), dev, 21), _rand((B, S, C), dev, 22)
     pq, pk = _rand((T, C), dev, 23, 0.35), _rand((S, C), dev, 24)
     dout = _rand((B, T, C), dev, 25)
-    gain = (1.0 + 0.2 * torch.randn(H, generator=torch.Generator().manual_seed(5))).to(dev)
+    gain = (1.0 + 0.2 * torch.randn(H, generator=torch.Generator().manual_seed(5))).to(dev).to(torch.bfloat16)
     tabs = None
     if P is not None:
         gcode, code_bias, n2d = _grid_codes(gh, gw)
@@ -229,7 +229,7 @@ def test_attn_bwd(case):
         rel = hip.RelBias(P, gcode.to(dev), code_bias, tabs[0].to(dev), tabs[1].to(dev), tabs[2].to(dev), grid_w=gw)
     # ---- fp32 autograd reference
     qf, kf, vf, pqf, pkf = [t.float().clone().requires_grad_(True) for t in (q, k, v, pq, pk)]
-    gf = gain.clone().requires_grad_(True)
+    gf = gain.float().clone().requires_grad_(True)
     bias = None
     tl = None
     if tabs is not None:
@@ -258,7 +258,7 @@ def test_attn_bwd(case):
     torch.cuda.synchronize()
     errs = {"dq": _rel(dq, qf.grad * 0.5), "dk": _rel(dk, kf.grad), "dv": _rel(dv, vf.grad),
             "dpq": _rel(dpq.sum(0), pqf.grad * 0.25), "dpk": _rel(dpk.sum(0), pkf.grad)}
-    dgain = (delta.sum((0, 2)) / gain)
+    dgain = (delta.sum((0, 2)) / gain.float())
     errs["dgain"] = _rel(dgain, gf.grad)
     info = {}
     if rel is not None:
@@ -273,7 +273,7 @@ def test_attn_bwd(case):
             if mask is not None:
                 sc = sc.masked_fill(mask, float("-inf"))
             pr = torch.softmax(sc, -1)
-            doh = dout.float().view(B, T, H, 64).transpose(1, 2) * gain.view(1, H, 1, 1)
+            doh = dout.float().view(B, T, H, 64).transpose(1, 2) * gain.float().view(1, H, 1, 1)
             dS = pr * (doh @ vh.transpose(2, 3) - delta.unsqueeze(-1))
             dSb = dS.sum(0).cpu()                                        # [H,T,S]
             g2 = torch.zeros(H, n2d); g1 = torch.zeros(H, 2 * Lt - 1)

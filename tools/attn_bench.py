@@ -21,7 +21,7 @@ def main(kind="enc", iters=5):
                       torch.randn(H, 2 * Lt - 1, generator=g).to(dev), torch.randn(H, 2, generator=g).to(dev), grid_w=gw)
     if kind == "cross":
         rel = None
-    gain = torch.ones(H, device=dev)
+    gain = torch.ones(H, device=dev, dtype=torch.bfloat16)
     out = torch.zeros(B, T, C, dtype=torch.bfloat16, device=dev); lse = torch.zeros(B, H, T, device=dev)
     dqkv = torch.zeros_like(qkv); delta = torch.zeros(B, H, T, device=dev)
     dpq = torch.zeros(B, T, C, device=dev); dpk = torch.zeros(B, S, C, device=dev)
