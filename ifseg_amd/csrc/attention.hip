@@ -334,14 +334,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 //       dK^T[c,key]   += Q_ext^T dS        (A = Q tile tr-reads,   B = dS regs)
 //     so the key stays in the lane for S, P, dS and both accumulators.
 template <bool HAS_POS>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // single staging buffer: Q_ext tile [64][128], dO tile [64][64], lse[64], delta[64]
   unsigned char* sQ = smem;
   unsigned char* sO = smem + KT_BYTES;
   float* sL = reinterpret_cast<float*>(smem + KT_BYTES + VT_BYTES);
   const int n2dp = (a.n2d + 3) & ~3, n1d = a.rel_mode ? 2 * a.Lt - 1 : 0, n1dp = (n1d + 3) & ~3;
-  float* sTbl = reinterpret_cast<float*>(smem + KT_BYTES + VT_BYTES + 512);   // rel2d[h]
+  unsigned char* sVk = smem + KT_BYTES + VT_BYTES + 512;                       // V rows of this WG's 128 keys
+  float* sTbl = reinterpret_cast<float*>(sVk + 2 * VT_BYTES);                  // rel2d[h]
   float* sHist = sTbl + n2dp;                                                  // d rel2d[h]
   float* sHist1 = sHist + n2dp;
   float* sX = sHist1 + n1dp;          // relx0 / relx1 gradient accumulators
@@ -359,14 +360,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int NKS = HAS_POS ? 8 : 4;
   const float gain = a.gain ? bf2f(a.gain[h]) : 1.f;
 
-  bf16x8 kf[NKS], vf[4];
+  bf16x8 kf[NKS];
   {
     const bf16_t* kp = a.k + (long long)b * a.k_bs + (long long)krow * a.ldk + h * 64 + half * 8;
-    const bf16_t* vp = a.v + (long long)b * a.v_bs + (long long)krow * a.ldv + h * 64 + half * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      U128 u; u.v = *reinterpret_cast<const uint4*>(kp + ks * 16); kf[ks] = u.b;
-      U128 w; w.v = *reinterpret_cast<const uint4*>(vp + ks * 16); vf[ks] = w.b;
+    for (int ks = 0; ks < 4; ++ks) { U128 u; u.v = *reinterpret_cast<const uint4*>(kp + ks * 16); kf[ks] = u.b; }
+    // V rows of the workgroup's keys live in LDS (frees 16 VGPRs/lane so two workgroups fit a CU)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (tid >> 3) + 32 * i, c = tid & 7, j = k0 + r;
+      uint4 v4 = make_uint4(0, 0, 0, 0);
+      if (j < a.S) v4 = *reinterpret_cast<const uint4*>(a.v + (long long)b * a.v_bs + (long long)j * a.ldv + h * 64 + c * 8);
+      *reinterpret_cast<uint4*>(sVk + vx_off(r, c * 16)) = v4;
     }
     if constexpr (HAS_POS) {
       const bf16_t* pp = a.pk + (long long)krow * a.ldpk + h * 64 + half * 8;
@@ -440,14 +445,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     for (int c = 0; c < NKS / 2; ++c) dk[c][e] = 0.f;
   }
   const int i16 = lane & 15, g16 = (lane >> 4) & 1;
-  if (nsched > 0) DKV_LOAD(qs * 64);
-
   for (int it = 0; it < nsched; ++it) {
     const int i0 = (qs + it) * 64;
+    DKV_LOAD(i0);                 // latency hidden by the co-resident workgroup (2 per CU)
     __syncthreads();              // everyone is done reading the previous tile (and the table init)
     DKV_STORE();
     __syncthreads();
-    if (it + 1 < nsched) DKV_LOAD(i0 + 64);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       const int ib = i0 + qb * 32;
@@ -465,7 +468,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         bf16x8 of = lds_read_b128(sO + vx_off(qb * 32 + (lane & 31), (ks * 2 + half) * 16));
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vf[ks], dp, 0, 0, 0);
+        bf16x8 vfr = lds_read_b128(sVk + vx_off(wave * 32 + (lane & 31), (ks * 2 + half) * 16));
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vfr, dp, 0, 0, 0);
       }
       // element r <-> query ib + (r&3) + 8*(r>>2) + 4*half ; key = kj (lane)
       const int fast = (a.rel_mode && qb_grid && wave_kgrid) ? 1 : ((!a.rel_mode && !a.causal) ? 2 : 0);
@@ -950,7 +954,7 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   }
   const size_t n2dp = ((size_t)a.n2d + 3) & ~(size_t)3;
   const size_t n1dp = a.rel_mode ? (((size_t)(2 * a.Lt - 1) + 3) & ~(size_t)3) : 0;
-  const size_t lds_kv = (KT_BYTES + VT_BYTES + 512) + (a.rel_mode ? (2 * n2dp + n1dp + 4) * 4 + (size_t)a.P * 4 : 0);
+  const size_t lds_kv = (KT_BYTES + VT_BYTES + 512) + 2 * VT_BYTES + (a.rel_mode ? (2 * n2dp + n1dp + 4) * 4 + (size_t)a.P * 4 : 0);
   const size_t lds_q = 2 * (KT_BYTES + VT_BYTES) + (a.rel_mode ? n2dp * 4 + (size_t)a.P * 4 : 0);
   if (lds_kv > 160 * 1024 || lds_q > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
   if (x->pos_q) {
