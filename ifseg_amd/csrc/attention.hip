@@ -398,7 +398,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   // ---- q-tile schedule
   const int nqt = (a.T + 63) >> 6;
   int qs = 0, qe = nqt;
-  if (a.causal && k0 < a.P) { qs = k0 >> 6; qe = (k0 + 127 < a.P) ? (a.P >> 6) : nqt; }
+  // causal: a pure-grid key tile is visible only to grid queries at or after it; a tile holding tail
+  // keys (visible to every grid query) keeps the full range and relies on the per-wave skip below
+  if (a.causal && k0 + 127 < a.P) { qs = k0 >> 6; qe = a.P >> 6; }
   const int nsched = qe - qs;
 
   uint4 rq0, rq1, rq2, rq3, ro0, ro1;

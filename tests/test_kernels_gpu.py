@@ -195,7 +195,7 @@ def test_attn_fwd(case):
 
 
 # ----------------------------------------------------------------------------- attention backward
-@pytest.mark.parametrize("case", ["cross", "enc_rel", "dec_causal", "dec_full", "big_enc"])
+@pytest.mark.parametrize("case", ["cross", "enc_rel", "dec_causal", "dec_full", "big_enc", "dec_wide"])
 def test_attn_bwd(case):
     from ifseg_amd import hip
     dev = _dev()
@@ -216,6 +216,10 @@ def test_attn_bwd(case):
         gh, gw, P, Lt = 32, 32, 1024, 36
         T = S = P + Lt
         H, B = 3, 2
+    elif case == "dec_wide":          # 40-wide grid (SegOFA-Large at 640^2): P = 320 is not a multiple of 128,
+        gh, gw, P, Lt = 8, 40, 320, 1  # so the bos key shares a 128-key tile with grid keys
+        T = S = P + Lt
+        causal = True
     C = H * 64
     q, k, v = _rand((B, T, C), dev, 20, 0.35), _rand((B, S, C), dev, 21), _rand((B, S, C), dev, 22)
     pq, pk = _rand((T, C), dev, 23, 0.35), _rand((S, C), dev, 24)

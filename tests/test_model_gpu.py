@@ -233,3 +233,56 @@ def test_dropout_path_wiring_and_training_mode(golden_dir):
     assert la == lb and torch.equal(ga, gb)          # same seed -> same masks
     assert la != lc and abs(la - l0) > 1e-4          # different seed / vs no dropout
     assert torch.isfinite(ga).all() and ga.norm() > 0
+
+
+def _parity_case(ocfg, batch_size, src_len, image_hw, tol_logits=2e-2, check_grads=True):
+    """HIP vs CPU oracle (run here, fp32) on a derived configuration."""
+    from ifseg_amd.criterions import SegCriterion
+    dev = torch.device("cuda:0")
+    sd = O.procedural_state_dict(ocfg)
+    batch = O.synthetic_batch(ocfg, batch_size, src_len, image_hw=image_hw)
+    o_logits, o_loss, o_grads, _ = _oracle_all_grads(ocfg, sd, batch, image_hw)
+    m = _build(ocfg, sd, dev)
+    m.train()
+    crit = SegCriterion(num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+    sample = {"net_input": {k: batch[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks", "prev_output_tokens")},
+              "target": batch["target"].to(dev), "ntokens": 1, "nsentences": batch_size}
+    loss, _, _ = crit(m, sample)
+    loss.backward()
+    torch.cuda.synchronize()
+    logits = m.engine.ws["logits_pad"][:, :, : ocfg.num_seg_tokens].float().cpu()
+    e = _rel(logits, o_logits)
+    print("  logits rel-L2 %.4f  loss %.5f vs %.5f" % (e, loss.item(), o_loss.item()))
+    assert e <= tol_logits and abs(loss.item() - o_loss.item()) <= 1e-2
+    if check_grads:
+        named = dict(m.named_parameters())
+        bad = []
+        for k, og in o_grads.items():
+            if k not in named or not named[k].requires_grad or og.norm() == 0:
+                continue
+            if k.endswith(("k_proj.bias", "pos_k_linear.bias", "c_attn")):
+                continue
+            r = _rel(named[k].grad, og)
+            if r > 8e-2:
+                bad.append((round(r, 4), k))
+        assert not bad, bad[:8]
+
+
+def test_many_classes_long_prompt_vs_oracle():
+    """BASELINE config-3 flavour at fixture width: 150 classes, L = 215 text tokens -> the log-spaced
+    token buckets (|i-j| > 128, unify_transformer.py:55-68) and the 150-wide seg projection / loss."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ocfg = O.fixture_config(num_seg_tokens=150, vocab_size=400)
+    _parity_case(ocfg, 2, 215, (128, 128))
+
+
+def test_large_geometry_vs_oracle():
+    """BASELINE config-4 geometry (SegOFA-Large widths: C=1024, 16 heads, FFN 4096, 640x640 -> 40x40 grid,
+    P=1600, 171 classes, L=239) at depth 1+1 with a shallow trunk so the CPU oracle stays in seconds:
+    exercises the non-32-wide grid (LDS-histogram bias gradient), NCH=8 LayerNorm, H=16."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ocfg = O.SegOFAConfig(embed_dim=1024, ffn_dim=4096, heads=16, enc_layers=1, dec_layers=1, resnet_layers=(1, 1, 1),
+                          num_seg_tokens=171, vocab_size=600, patch_image_size=640, orig_patch_image_size=640)
+    _parity_case(ocfg, 1, 239, (640, 640))
