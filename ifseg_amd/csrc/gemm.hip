@@ -19,8 +19,14 @@
 
 namespace {
 
-constexpr int BM = 128, BK = 64;   // BN is a template parameter (128, or 64 for narrow / few-tile outputs)
+constexpr int GBK = 64;
+// LDS stages: 2 (64 KiB, two workgroups per CU, loads overlap the MFMAs inside the workgroup) when the
+// grid is at most ~2 rounds of that occupancy; 1 (32 KiB, four workgroups per CU overlap each other) for
+// the many-tile shapes.  Measured on the SegOFA-Base shapes, tools/gemm_bench.py.
+constexpr int TWO_STAGE_MAX_WGS = 1024;
+constexpr int BM = 128;   // BN, BK and the LDS stage count are template parameters
 enum { A_KC = 0, A_KS = 1, A_CONV = 2 };
+constexpr unsigned OOB = 0x80000000u;   // byte offset beyond every buffer (< 2 GiB each): the load returns zeros
 
 struct GemmArgs {
   const bf16_t* A; const bf16_t* B; void* C;
@@ -30,120 +36,168 @@ struct GemmArgs {
   int cH, cW, cC, cKW, cStride, cPad, cOH, cOW;
   long long sA, sB, sC, sR;
   int splitk, kchunk; long long sCsplit;
+  unsigned nrecA, nrecB;   // bytes addressable through the A / B buffer descriptors (per batch)
 };
 
-template <int AMODE, bool B_KS, int BN>
+// ---- LDS tile images -------------------------------------------------------
+// Tiles are filled by LDS-DMA (buffer_load_dwordx4 ... lds): one wave instruction
+// writes 1 KiB, lane l at byte 16 l, so the image is lane-linear and the XOR
+// swizzle is applied on the SOURCE address (x_src below) and again on the read
+// (x_off); both are the same involution inside a 256-byte line.
+//   KC tile: [rows][BK k], k contiguous in global.   BK = 64: kc_off (common.h).
+//            BK = 32: 64-byte rows, chunk ^= (row >> 2) & 3.
+//   KS tile: [BK k][128 cols], cols contiguous in global: ks_off (common.h).
+template <int BK>
+__device__ __forceinline__ int kct_off(int r, int c) {
+  if constexpr (BK == 64) return kc_off(r, c);
+  else return r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
+}
+template <int BK>
+__device__ __forceinline__ void kct_src(int seg, int l, int& row, int& c) {
+  if constexpr (BK == 64) {
+    const int line = seg * 4 + (l >> 4), s = (l & 15) ^ (line & 15);
+    row = line * 2 + (s >> 3);
+    c = s & 7;
+  } else {
+    row = seg * 16 + (l >> 2);
+    c = (l & 3) ^ ((row >> 2) & 3);
+  }
+}
+__device__ __forceinline__ void ks_src(int seg, int l, int& kr, int& col) {
+  kr = seg * 4 + (l >> 4);
+  const int slot = l & 15;
+  col = ((((slot >> 2) ^ (kr & 3)) << 2) | (slot & 3)) * 8;
+}
+template <int BK>
+__device__ __forceinline__ bf16x8 frag_kct(const unsigned char* tile, int rb, int ks, int lane) {
+  return lds_read_b128(tile + kct_off<BK>(rb + (lane & 31), ks * 2 + (lane >> 5)));
+}
+
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+// buffer descriptor (raw, stride 0) over `bytes` bytes at p; every field is made wave-uniform
+__device__ __forceinline__ v4i32 make_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  v4i32 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+// One LDS-DMA piece: 64 lanes x 16 bytes from rs[voff] to LDS bytes [lds_base, lds_base + 1024).
+// Issued from inline asm so the compiler does not serialise the following ds_reads behind it;
+// completion is counted by hand (s_waitcnt vmcnt(0) before the barrier that publishes the tile).
+__device__ __forceinline__ void lds_dma16(v4i32 rs, unsigned lds_base, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(lds_base), "v"(voff), "s"(rs) : "memory");
+}
+
+template <int AMODE, bool B_KS, int BN, int BK, int STAGES>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   static_assert(BN == 128 || (BN == 64 && !B_KS), "64-wide tiles only for k-contiguous B");
-  constexpr int NJ = BN / 64;        // 32-column MFMA tiles per wave along N
-  constexpr int NBI = BN / 32;       // B staging chunks per thread
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];
-  unsigned char* sA = smem;
-  unsigned char* sB = smem + 16384;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NJ = BN / 64;                 // 32-column MFMA tiles per wave along N
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int LA = A_BYTES / 4096, LB = B_BYTES / 4096;   // 1-KiB DMA pieces per wave
+  constexpr int KS_STEPS = BK / 16;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
   const int tiles_n = (g.N + BN - 1) / BN;
   const int tiles_m = (g.M + BM - 1) / BM;
   const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
-  const bf16_t* Ab = g.A + (long long)blockIdx.y * g.sA;
-  const bf16_t* Bb = g.B + (long long)blockIdx.y * g.sB;
+  const v4i32 rsA = make_rsrc(g.A + (long long)blockIdx.y * g.sA, g.nrecA);
+  const v4i32 rsB = make_rsrc(g.B + (long long)blockIdx.y * g.sB, g.nrecB);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-  // ---- per-thread staging geometry -------------------------------------
-  // KC tile: chunk (row = tid/8 + 32 i, c = tid%8); KS tile: (krow = tid/16 + 16 i, c = tid%16)
-  uint4 ra[4], rb[4];
-  long long a_rowbase[4];  // element offset of the row start (KC / CONV), or -1
-  int cv_b[4], cv_oy[4], cv_ox[4];
-  if (AMODE == A_KC) {
+  // split-K: slice blockIdx.z reduces k in [kbeg, kend) into its own fp32 slab of C
+  const int kbeg = g.splitk > 1 ? blockIdx.z * g.kchunk : 0;
+  const int kend = g.splitk > 1 ? min(g.K, kbeg + g.kchunk) : g.K;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  const bool ktail = (kend - kbeg) & (BK - 1);
+
+  // ---- per-lane source offsets (bytes, at k = kbeg); rows outside the matrix -> OOB (zeros)
+  unsigned offA[LA], offB[LB];
+  int c8A[LA], c8B[LB];                 // k offset of the lane's chunk inside a KC tile (k-tail test)
+  int cv_b[LA], cv_oy[LA], cv_ox[LA];   // conv: output pixel of the lane's row
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int m = m0 + (tid >> 3) + 32 * i;
-      a_rowbase[i] = (m < g.M) ? (long long)m * g.lda : -1;
-    }
-  } else if (AMODE == A_CONV) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int m = m0 + (tid >> 3) + 32 * i;
-      if (m < g.M) {
-        cv_ox[i] = m % g.cOW;
-        int q = m / g.cOW;
-        cv_oy[i] = q % g.cOH;
-        cv_b[i] = q / g.cOH;
+  for (int i = 0; i < LA; ++i) {
+    if (AMODE == A_KS) {
+      int kr, col;
+      ks_src(wave * LA + i, lane, kr, col);
+      offA[i] = (m0 + col < g.M) ? (unsigned)(((long long)(kbeg + kr) * g.lda + m0 + col) * 2) : OOB;
+      c8A[i] = 0;
+    } else {
+      int row, c;
+      kct_src<BK>(wave * LA + i, lane, row, c);
+      const int m = m0 + row;
+      c8A[i] = c * 8;
+      if (AMODE == A_KC) {
+        offA[i] = (m < g.M) ? (unsigned)(((long long)m * g.lda + kbeg + c * 8) * 2) : OOB;
       } else {
-        cv_b[i] = -1; cv_oy[i] = 0; cv_ox[i] = 0;
+        offA[i] = 0;
+        if (m < g.M) {
+          cv_ox[i] = m % g.cOW;
+          const int q = m / g.cOW;
+          cv_oy[i] = q % g.cOH;
+          cv_b[i] = q / g.cOH;
+        } else {
+          cv_b[i] = -1; cv_oy[i] = 0; cv_ox[i] = 0;
+        }
       }
     }
   }
-  long long b_rowbase[4];
-  if (!B_KS) {
 #pragma unroll
-    for (int i = 0; i < NBI; ++i) {
-      int n = n0 + (tid >> 3) + 32 * i;
-      b_rowbase[i] = (n < g.N) ? (long long)n * g.ldb : -1;
+  for (int i = 0; i < LB; ++i) {
+    if (B_KS) {
+      int kr, col;
+      ks_src(wave * LB + i, lane, kr, col);
+      offB[i] = (n0 + col < g.N) ? (unsigned)(((long long)(kbeg + kr) * g.ldb + n0 + col) * 2) : OOB;
+      c8B[i] = 0;
+    } else {
+      int row, c;
+      kct_src<BK>(wave * LB + i, lane, row, c);
+      const int n = n0 + row;
+      c8B[i] = c * 8;
+      offB[i] = (n < g.N) ? (unsigned)(((long long)n * g.ldb + kbeg + c * 8) * 2) : OOB;
     }
   }
+  const unsigned kadvA = (AMODE == A_KS) ? (unsigned)BK * g.lda * 2 : BK * 2;
+  const unsigned kadvB = B_KS ? (unsigned)BK * g.ldb * 2 : BK * 2;
 
-  auto load_tiles = [&](int k0) {
-    // ---- A ----
-    if (AMODE == A_KC) {
-      const int kc = k0 + (tid & 7) * 8;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = make_uint4(0, 0, 0, 0);
-        if (a_rowbase[i] >= 0 && kc < g.K)
-          ra[i] = *reinterpret_cast<const uint4*>(Ab + a_rowbase[i] + kc);
-      }
-    } else if (AMODE == A_CONV) {
-      const int tap = k0 / g.cC, c0 = k0 - tap * g.cC + (tid & 7) * 8;
+  auto issue = [&](int kt, int st) {
+    const unsigned dA = lds0 + st * STAGE_BYTES + wave * (LA * 1024);
+    const unsigned dB = lds0 + st * STAGE_BYTES + A_BYTES + wave * (LB * 1024);
+    const int krem = (kend - kbeg) - kt * BK;           // valid k in this tile (>= BK except on a tail)
+    const bool tail = ktail && kt == nk - 1;
+    if (AMODE == A_CONV) {
+      const int k0 = kbeg + kt * BK;
+      const int tap = k0 / g.cC, c0 = k0 - tap * g.cC;
       const int ky = tap / g.cKW, kx = tap - ky * g.cKW;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = make_uint4(0, 0, 0, 0);
-        int iy = cv_oy[i] * g.cStride + ky - g.cPad, ix = cv_ox[i] * g.cStride + kx - g.cPad;
-        if (cv_b[i] >= 0 && k0 < g.K && iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW)
-          ra[i] = *reinterpret_cast<const uint4*>(
-              Ab + (((long long)cv_b[i] * g.cH + iy) * g.cW + ix) * g.cC + c0);
-      }
-    } else {  // A_KS: global [K][M], tile [64 k][128 m]
-      const int mc = m0 + (tid & 15) * 8;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int k = k0 + (tid >> 4) + 16 * i;
-        ra[i] = make_uint4(0, 0, 0, 0);
-        if (k < g.K && mc < g.M) ra[i] = *reinterpret_cast<const uint4*>(Ab + (long long)k * g.lda + mc);
-      }
-    }
-    // ---- B ----
-    if (!B_KS) {
-      const int kc = k0 + (tid & 7) * 8;
-#pragma unroll
-      for (int i = 0; i < NBI; ++i) {
-        rb[i] = make_uint4(0, 0, 0, 0);
-        if (b_rowbase[i] >= 0 && kc < g.K)
-          rb[i] = *reinterpret_cast<const uint4*>(Bb + b_rowbase[i] + kc);
+      for (int i = 0; i < LA; ++i) {
+        const int iy = cv_oy[i] * g.cStride + ky - g.cPad, ix = cv_ox[i] * g.cStride + kx - g.cPad;
+        const bool ok = cv_b[i] >= 0 && iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW;
+        const unsigned v = ok ? (unsigned)(((((long long)cv_b[i] * g.cH + iy) * g.cW + ix) * g.cC + c0 + c8A[i]) * 2) : OOB;
+        lds_dma16(rsA, dA + i * 1024, v);
       }
     } else {
-      const int nc = n0 + (tid & 15) * 8;
+      const unsigned ka = (unsigned)kt * kadvA;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int k = k0 + (tid >> 4) + 16 * i;
-        rb[i] = make_uint4(0, 0, 0, 0);
-        if (k < g.K && nc < g.N) rb[i] = *reinterpret_cast<const uint4*>(Bb + (long long)k * g.ldb + nc);
+      for (int i = 0; i < LA; ++i) {
+        unsigned v = offA[i] + ka;
+        if (AMODE == A_KC && tail && c8A[i] >= krem) v = OOB;
+        lds_dma16(rsA, dA + i * 1024, v);
       }
     }
-  };
-  auto store_tiles = [&]() {
+    const unsigned kb = (unsigned)kt * kadvB;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (AMODE == A_KS)
-        *reinterpret_cast<uint4*>(sA + ks_off((tid >> 4) + 16 * i, (tid & 15) * 8)) = ra[i];
-      else
-        *reinterpret_cast<uint4*>(sA + kc_off((tid >> 3) + 32 * i, tid & 7)) = ra[i];
-      if (B_KS)
-        *reinterpret_cast<uint4*>(sB + ks_off((tid >> 4) + 16 * i, (tid & 15) * 8)) = rb[i];
-      else if (i < NBI)
-        *reinterpret_cast<uint4*>(sB + kc_off((tid >> 3) + 32 * i, tid & 7)) = rb[i];
+    for (int i = 0; i < LB; ++i) {
+      unsigned v = offB[i] + kb;
+      if (!B_KS && tail && c8B[i] >= krem) v = OOB;
+      lds_dma16(rsB, dB + i * 1024, v);
     }
   };
 
@@ -155,35 +209,42 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // split-K: slice blockIdx.z reduces k in [kbeg, kend) into its own fp32 slab of C
-  const int kbeg = g.splitk > 1 ? blockIdx.z * g.kchunk : 0;
-  const int kend = g.splitk > 1 ? min(g.K, kbeg + g.kchunk) : g.K;
-  const int nk = (kend - kbeg + BK - 1) / BK;
-  if (g.splitk > 1) g.K = kend;       // loaders zero-fill beyond the slice
-  load_tiles(kbeg);
-  store_tiles();
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);  // in flight under the MFMAs below
+  auto compute = [&](int st) {
+    const unsigned char* sA = smem + st * STAGE_BYTES;
+    const unsigned char* sB = sA + A_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS_STEPS; ++ks) {
       bf16x8 fa[2], fb[NJ];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        fa[i] = (AMODE == A_KS) ? frag_ks(sA, wm * 64 + i * 32, ks, lane) : frag_kc(sA, wm * 64 + i * 32, ks, lane);
+        fa[i] = (AMODE == A_KS) ? frag_ks(sA, wm * 64 + i * 32, ks, lane) : frag_kct<BK>(sA, wm * 64 + i * 32, ks, lane);
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
-        fb[j] = B_KS ? frag_ks(sB, wn * (BN / 2) + j * 32, ks, lane) : frag_kc(sB, wn * (BN / 2) + j * 32, ks, lane);
+        fb[j] = B_KS ? frag_ks(sB, wn * (BN / 2) + j * 32, ks, lane) : frag_kct<BK>(sB, wn * (BN / 2) + j * 32, ks, lane);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      store_tiles();
+  };
+
+  if constexpr (STAGES == 1) {
+    for (int kt = 0; kt < nk; ++kt) {
+      issue(kt, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      compute(0);
+      __syncthreads();
+    }
+  } else {
+    // tile kt+1 streams into the other stage while tile kt feeds the MFMAs: one barrier per k-step
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+      compute(kt & 1);
     }
   }
 
@@ -269,10 +330,15 @@ extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C
     // C must be an fp32 workspace [splitk][M][ldc]; epilogue extras are not applied to partial sums
     if (!(flags & IFSEG_GEMM_OUT_F32) || (flags & IFSEG_GEMM_ACCUMULATE) || bias || resid || alpha != 1.0f)
       return IFSEG_ERR_BAD_ARG;
-    g.kchunk = (((K + splitk - 1) / splitk) + BK - 1) / BK * BK;
+    g.kchunk = (((K + splitk - 1) / splitk) + 63) / 64 * 64;
     g.splitk = (K + g.kchunk - 1) / g.kchunk;
     g.sCsplit = (long long)M * ldc;
   }
+  // bytes each buffer descriptor may address (loads beyond it return zeros: that is the k / row padding)
+  const long long nrA = layout == IFSEG_GEMM_TN ? ((long long)(K - 1) * lda + M) * 2 : ((long long)(M - 1) * lda + K) * 2;
+  const long long nrB = layout == IFSEG_GEMM_NT ? ((long long)(N - 1) * ldb + K) * 2 : ((long long)(K - 1) * ldb + N) * 2;
+  if (nrA >= (1ll << 31) || nrB >= (1ll << 31)) return IFSEG_ERR_BAD_SHAPE;
+  g.nrecA = (unsigned)nrA; g.nrecB = (unsigned)nrB;
   const int tiles128 = ((M + BM - 1) / BM) * ((N + 127) / 128);
   // narrow tiles when the output is narrow or there are too few 128-wide tiles to fill 256 CUs
   const bool narrow = layout == IFSEG_GEMM_NT && g.splitk == 1 && (N <= 64 || tiles128 < 384);
@@ -282,13 +348,19 @@ extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C
   if (layout < 0 || layout > 2) return IFSEG_ERR_BAD_ARG;
   const double nb = batch > 0 ? batch : 1;
   ifseg_prof_begin(IFSEG_K_GEMM_NT + layout, s, 2.0 * M * N * K * nb, 2.0 * nb * ((double)M * K + (double)N * K + (double)M * N));
+  const bool two_stage = (long long)tiles * g.splitk * (batch > 0 ? batch : 1) <= TWO_STAGE_MAX_WGS;
+#define LAUNCH2(AM, BKS, BNV)                                                                        \
+  do {                                                                                               \
+    if (two_stage) hipLaunchKernelGGL((gemm_kernel<AM, BKS, BNV, GBK, 2>), grid, block, 0, s, g);    \
+    else hipLaunchKernelGGL((gemm_kernel<AM, BKS, BNV, GBK, 1>), grid, block, 0, s, g);              \
+  } while (0)
   switch (layout) {
     case IFSEG_GEMM_NT:
-      if (narrow) hipLaunchKernelGGL((gemm_kernel<A_KC, false, 64>), grid, block, 0, s, g);
-      else hipLaunchKernelGGL((gemm_kernel<A_KC, false, 128>), grid, block, 0, s, g);
+      if (narrow) LAUNCH2(A_KC, false, 64);
+      else LAUNCH2(A_KC, false, 128);
       break;
-    case IFSEG_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<A_KC, true, 128>), grid, block, 0, s, g); break;
-    case IFSEG_GEMM_TN: hipLaunchKernelGGL((gemm_kernel<A_KS, true, 128>), grid, block, 0, s, g); break;
+    case IFSEG_GEMM_NN: LAUNCH2(A_KC, true, 128); break;
+    case IFSEG_GEMM_TN: LAUNCH2(A_KS, true, 128); break;
   }
   ifseg_prof_end(IFSEG_K_GEMM_NT + layout, s);
   IFSEG_CHECK_LAUNCH();
@@ -312,12 +384,18 @@ extern "C" int ifseg_conv2d_nhwc_bf16(const void* in, const void* w, const void*
   g.bias = (const bf16_t*)shift; g.resid = (const bf16_t*)resid; g.ldr = Cout;
   g.alpha = 1.f; g.alpha_ncols = 0; g.flags = relu ? IFSEG_GEMM_RELU : 0;
   g.cH = H; g.cW = W; g.cC = Cin; g.cKW = KW; g.cStride = stride; g.cPad = pad; g.cOH = OH; g.cOW = OW;
+  const long long nrA = (long long)B * H * W * Cin * 2, nrB = (long long)g.N * g.K * 2;
+  if (nrA >= (1ll << 31) || nrB >= (1ll << 31)) return IFSEG_ERR_BAD_SHAPE;
+  g.nrecA = (unsigned)nrA; g.nrecB = (unsigned)nrB;
   const int tiles128 = ((g.M + BM - 1) / BM) * ((g.N + 127) / 128);
   const bool narrow = g.N <= 64 || tiles128 < 384;
   const int tiles = narrow ? ((g.M + BM - 1) / BM) * ((g.N + 63) / 64) : tiles128;
   ifseg_prof_begin(IFSEG_K_CONV, (hipStream_t)stream, 2.0 * g.M * g.N * g.K, 2.0 * ((double)B * H * W * Cin + (double)g.N * g.K + (double)g.M * g.N));
-  if (narrow) hipLaunchKernelGGL((gemm_kernel<A_CONV, false, 64>), dim3(tiles, 1), dim3(256), 0, (hipStream_t)stream, g);
-  else hipLaunchKernelGGL((gemm_kernel<A_CONV, false, 128>), dim3(tiles, 1), dim3(256), 0, (hipStream_t)stream, g);
+  const bool two_stage = tiles <= TWO_STAGE_MAX_WGS;
+  const dim3 grid(tiles, 1), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (narrow) LAUNCH2(A_CONV, false, 64);
+  else LAUNCH2(A_CONV, false, 128);
   ifseg_prof_end(IFSEG_K_CONV, (hipStream_t)stream);
   IFSEG_CHECK_LAUNCH();
   return 0;
