@@ -51,6 +51,8 @@ struct AttnArgs {
 
 constexpr int KT_BYTES = 64 * 256;  // K_ext tile  [64 keys][128] bf16
 constexpr int VT_BYTES = 64 * 128;  // V tile      [64 keys][64]  bf16
+constexpr int DKV_STAGE_BYTES = 32 * 256 + 32 * 128 + 256;  // dK/dV kernel: Q_ext, dO, lse|delta of 32 queries
+static_assert(2 * DKV_STAGE_BYTES == KT_BYTES + VT_BYTES + 512, "host-side LDS size formula");
 constexpr float NEG_INF = -INFINITY;
 
 // LDS images that are read BOTH row-wise (ds_read_b128: 16 rows x one 16-byte chunk per lane
@@ -336,10 +338,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 template <bool HAS_POS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // single staging buffer: Q_ext tile [64][128], dO tile [64][64], lse[64], delta[64]
-  unsigned char* sQ = smem;
-  unsigned char* sO = smem + KT_BYTES;
-  float* sL = reinterpret_cast<float*>(smem + KT_BYTES + VT_BYTES);
+  // two staging buffers of DKV_STAGE_BYTES (one 32-query block each) open the LDS image
   const int n2dp = (a.n2d + 3) & ~3, n1d = a.rel_mode ? 2 * a.Lt - 1 : 0, n1dp = (n1d + 3) & ~3;
   unsigned char* sVk = smem + KT_BYTES + VT_BYTES + 512;                       // V rows of this WG's 128 keys
   float* sTbl = reinterpret_cast<float*>(sVk + 2 * VT_BYTES);                  // rel2d[h]
@@ -403,41 +402,43 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   if (a.causal && k0 + 127 < a.P) { qs = k0 >> 6; qe = a.P >> 6; }
   const int nsched = qe - qs;
 
-  uint4 rq0, rq1, rq2, rq3, ro0, ro1;
-  float rl = 0.f;
   const bf16_t* qb_ = a.q + (long long)b * a.q_bs + h * 64;
   const bf16_t* pqb_ = HAS_POS ? a.pq + h * 64 : nullptr;
   const bf16_t* dob_ = a.dO + (long long)b * a.do_bs + h * 64;
   const float* lseb = a.lse + ((long long)b * a.H + h) * a.T;
   const float* delb = a.delta + ((long long)b * a.H + h) * a.T;
-  const int sr = tid >> 3, sc = tid & 7;
-#define DKV_LOAD(i0_)                                                                                   \
-  {                                                                                                     \
-    const int qa_ = (i0_) + sr, qb2_ = (i0_) + sr + 32;                                                 \
-    const uint4 z_ = make_uint4(0, 0, 0, 0);                                                            \
-    rq0 = qa_ < a.T ? *reinterpret_cast<const uint4*>(qb_ + (long long)qa_ * a.ldq + sc * 8) : z_;      \
-    rq1 = qb2_ < a.T ? *reinterpret_cast<const uint4*>(qb_ + (long long)qb2_ * a.ldq + sc * 8) : z_;    \
-    if (HAS_POS) {                                                                                      \
-      rq2 = qa_ < a.T ? *reinterpret_cast<const uint4*>(pqb_ + (long long)qa_ * a.ldpq + sc * 8) : z_;  \
-      rq3 = qb2_ < a.T ? *reinterpret_cast<const uint4*>(pqb_ + (long long)qb2_ * a.ldpq + sc * 8) : z_;\
-    }                                                                                                   \
-    ro0 = qa_ < a.T ? *reinterpret_cast<const uint4*>(dob_ + (long long)qa_ * a.lddo + sc * 8) : z_;    \
-    ro1 = qb2_ < a.T ? *reinterpret_cast<const uint4*>(dob_ + (long long)qb2_ * a.lddo + sc * 8) : z_;  \
-    if (tid < 64) { const int qi_ = (i0_) + tid; rl = qi_ < a.T ? lseb[qi_] : INFINITY; }               \
-    else if (tid < 128) { const int qi_ = (i0_) + tid - 64; rl = qi_ < a.T ? delb[qi_] : 0.f; }         \
+  // ---- staging by LDS-DMA, two stages of one 32-query block each:
+  //   [Q_ext 32 x 256 B | dO 32 x 128 B | lse 32 f32 | delta 32 f32]
+  // wave w moves Q rows 8w..8w+7 (two 1-KiB pieces), dO rows 8w..8w+7 (one piece); wave 0 also the
+  // statistics.  Rows past T are clamped to T-1 (their P is masked to zero below).
+  constexpr int STG = DKV_STAGE_BYTES;
+  const unsigned lds0 = lds_addr(smem);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  int q_row[2], q_c[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    q_row[i] = (wv * 2 + i) * 4 + (lane >> 4);
+    q_c[i] = (lane & 15) ^ (((q_row[i] & 3) << 2) | ((q_row[i] >> 2) & 3));
   }
-#define DKV_STORE()                                                                   \
-  {                                                                                   \
-    *reinterpret_cast<uint4*>(sQ + kx_off(sr, sc)) = rq0;                             \
-    *reinterpret_cast<uint4*>(sQ + kx_off(sr + 32, sc)) = rq1;                        \
-    if (HAS_POS) {                                                                    \
-      *reinterpret_cast<uint4*>(sQ + kx_off(sr, 8 + sc)) = rq2;                       \
-      *reinterpret_cast<uint4*>(sQ + kx_off(sr + 32, 8 + sc)) = rq3;                  \
-    }                                                                                 \
-    *reinterpret_cast<uint4*>(sO + vx_off(sr, sc * 16)) = ro0;                        \
-    *reinterpret_cast<uint4*>(sO + vx_off(sr + 32, sc * 16)) = ro1;                   \
-    if (tid < 128) sL[tid] = rl; /* lse at [0..63], delta at [64..127] */             \
-  }
+  const int o_row = wv * 8 + (lane >> 3);
+  const int o_c = ((lane & 7) ^ ((((o_row >> 1) & 1) << 2) | ((o_row >> 2) & 3))) & 7;
+  auto issue = [&](int ib, int st) {
+    const unsigned base = lds0 + st * STG;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int qr = min(ib + q_row[i], a.T - 1);
+      if (q_c[i] < 8) lds_dma16_g(qb_ + (long long)qr * a.ldq + q_c[i] * 8, base + (wv * 2 + i) * 1024);
+      else if (HAS_POS) lds_dma16_g(pqb_ + (long long)qr * a.ldpq + (q_c[i] - 8) * 8, base + (wv * 2 + i) * 1024);
+    }
+    {
+      const int qr = min(ib + o_row, a.T - 1);
+      lds_dma16_g(dob_ + (long long)qr * a.lddo + o_c * 8, base + 8192 + wv * 1024);
+    }
+    if (wv == 0) {
+      const int qr = min(ib + (lane & 31), a.T - 1);
+      lds_dma4_g((lane < 32 ? lseb : delb) + qr, base + 8192 + 4096);
+    }
+  };
 
   f32x16 dv[2], dk[NKS / 2];
 #pragma unroll
@@ -447,16 +448,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     for (int c = 0; c < NKS / 2; ++c) dk[c][e] = 0.f;
   }
   const int i16 = lane & 15, g16 = (lane >> 4) & 1;
-  for (int it = 0; it < nsched; ++it) {
-    const int i0 = (qs + it) * 64;
-    DKV_LOAD(i0);                 // latency hidden by the co-resident workgroup (2 per CU)
-    __syncthreads();              // everyone is done reading the previous tile (and the table init)
-    DKV_STORE();
-    __syncthreads();
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const int ib = i0 + qb * 32;
-      const bool skip = (ib >= a.T) || (a.causal && wave_kgrid && ((ib + 31 < kw) || (ib >= a.P)));
+  const int nblk = min(qe * 2, (a.T + 31) >> 5) - qs * 2;
+  if (nblk > 0) issue(qs * 64, 0);
+  for (int n = 0; n < nblk; ++n) {
+    const int ib = (qs * 2 + n) * 32;
+    const unsigned char* sQ = smem + (n & 1) * STG;
+    const unsigned char* sO = sQ + 8192;
+    const float* sL = reinterpret_cast<const float*>(sQ + 8192 + 4096);
+    lds_dma_wait();
+    __syncthreads();              // block n has landed; everyone is done with block n-1 (and the table init)
+    if (n + 1 < nblk) issue(ib + 32, (n + 1) & 1);
+    {
+      const bool skip = a.causal && wave_kgrid && ((ib + 31 < kw) || (ib >= a.P));
       if (skip) continue;
       const bool qb_grid = ib + 31 < a.P;
       f32x16 s, dp;
@@ -464,17 +467,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        bf16x8 qf = lds_read_b128(sQ + kx_off(qb * 32 + (lane & 31), ks * 2 + half));
+        bf16x8 qf = lds_read_b128(sQ + kx_off(lane & 31, ks * 2 + half));
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 of = lds_read_b128(sO + vx_off(qb * 32 + (lane & 31), (ks * 2 + half) * 16));
+        bf16x8 of = lds_read_b128(sO + vx_off(lane & 31, (ks * 2 + half) * 16));
         bf16x8 vfr = lds_read_b128(sVk + vx_off(wave * 32 + (lane & 31), (ks * 2 + half) * 16));
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vfr, dp, 0, 0, 0);
       }
       // element r <-> query ib + (r&3) + 8*(r>>2) + 4*half ; key = kj (lane)
-      const int fast = (a.rel_mode && qb_grid && wave_kgrid) ? 1 : ((!a.rel_mode && !a.causal) ? 2 : 0);
+      const int fast = (a.rel_mode && qb_grid && wave_kgrid) ? 1 : ((!a.rel_mode && !a.causal && ib + 32 <= a.T) ? 2 : 0);
       float accA = 0.f, accB = 0.f;
       bf16x8 pfr[2], dsf[2];
 #pragma unroll
@@ -483,9 +486,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
         for (int rg2 = 0; rg2 < 2; ++rg2) {
           const int rg = s2 * 2 + rg2;
-          const int iq = ib + 8 * rg + 4 * half, il = qb * 32 + 8 * rg + 4 * half;
+          const int iq = ib + 8 * rg + 4 * half, il = 8 * rg + 4 * half;
           const float4 l4 = *reinterpret_cast<const float4*>(sL + il);
-          const float4 d4 = *reinterpret_cast<const float4*>(sL + 64 + il);
+          const float4 d4 = *reinterpret_cast<const float4*>(sL + 32 + il);
           const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
           float pv[4], dsv[4];
           if (fast == 1) {
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
                 }
                 sv += bias;
               }
-              bool masked = !kvalid;
+              bool masked = !kvalid || i >= a.T;
               if (a.causal) {
                 if (k_grid) masked |= (i >= a.P) || (kj > i);
                 else masked |= (i >= a.P) && (kj > i);
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       // dV^T += dO^T P ; dK^T += Q^T dS ; slot (kh,e) <-> query ib + 16*s2 + 4*kh + (e&3) + 8*(e>>2)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const int r0 = qb * 32 + 16 * s2 + 4 * half + (i16 >> 2);
+        const int r0 = 16 * s2 + 4 * half + (i16 >> 2);
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const int colb = (db * 32 + g16 * 16 + (i16 & 3) * 4) * 2;
@@ -595,8 +598,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       }
     }
   }
-#undef DKV_LOAD
-#undef DKV_STORE
 
   // ---- write dV, dK, dpos_k partial: lane = key, reg r <-> column (r&3) + 8*(r>>2) + 4*half
   if (kvalid) {

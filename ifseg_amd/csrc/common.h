@@ -103,6 +103,22 @@ __device__ __forceinline__ bf16x8 frag_ks(const unsigned char* tile, int cb, int
   return u.b;
 }
 
+// ---- LDS-DMA (global -> LDS without staging registers) -----------------------
+// One wave instruction moves 64 x 16 (or 64 x 4) bytes: lane l's source is its own
+// address, its destination is lds_base + 16 l (4 l); lds_base must be wave-uniform.
+// Issued from inline asm, so the compiler neither counts it nor orders ds_reads behind
+// it: the issuing wave waits (lds_dma_wait) and then a barrier publishes the data.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+__device__ __forceinline__ void lds_dma16_g(const void* gsrc, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void lds_dma4_g(const void* gsrc, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(gsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ float warp_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
