@@ -53,7 +53,14 @@ constexpr int KT_BYTES = 64 * 256;  // K_ext tile  [64 keys][128] bf16
 constexpr int VT_BYTES = 64 * 128;  // V tile      [64 keys][64]  bf16
 constexpr int DKV_STAGE_BYTES = 32 * 256 + 32 * 128 + 256;  // dK/dV kernel: Q_ext, dO, lse|delta of 32 queries
 static_assert(2 * DKV_STAGE_BYTES == KT_BYTES + VT_BYTES + 512, "host-side LDS size formula");
+#ifndef IFSEG_SEED32
+#define IFSEG_SEED32 1
+#endif
 constexpr float NEG_INF = -INFINITY;
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+// forward: the running reference maximum is only raised when a tile exceeds it by more than this
+// (log2 units), so the O / l rescale is a rare wave-uniform branch; P stays <= 2^8 in between
+constexpr float LAZY_MAX_SLACK = 8.f;
 
 // LDS images that are read BOTH row-wise (ds_read_b128: 16 rows x one 16-byte chunk per lane
 // group) and transposed (ds_read_b64_tr_b16: 4 consecutive rows x one 64-byte granule):
@@ -119,6 +126,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const int ti = qi - a.P;
   const float relx0 = a.rel_mode ? a.relx[h * 2 + 0] : 0.f, relx1 = a.rel_mode ? a.relx[h * 2 + 1] : 0.f;
   const float* rel1d = a.rel_mode ? a.rel1d + (long long)h * (2 * a.Lt - 1) + (a.Lt - 1) : nullptr;
+  const bool row32 = a.rel_mode && a.grid_w == 32;   // raster grid, 32 wide: a 32-key block is one grid row
 
   // ---- tile schedule (causal: skip grid tiles wholly above the diagonal)
   const int ntile = (a.S + 63) >> 6;
@@ -175,11 +183,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     // wave-level causal skip: every key of a grid tile is beyond every query of this wave
     const bool skip = a.causal && tile_grid && (j0 > qw + 31 || qw >= a.P);
     if (!skip) {
+      const bool wave_grid = __builtin_amdgcn_readfirstlane(qw) + 31 < a.P;
+      const bool gg = a.rel_mode && tile_grid && wave_grid && !a.dense;   // grid x grid: the bulk of self-attention
       f32x16 s[2];
+      if (gg && row32) {
+        // the block's keys are one grid row (codes cjb + x): the lane's 16 bias values sit at constant
+        // offsets from one table address and are loaded straight into the accumulator, so the MFMA adds them
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const int cjb = sGc[j0 + kb * 32];
+          const float* tp = sTbl + (ci - cjb - 4 * half - 27);
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[kb][rg * 4 + e] = tp[27 - (8 * rg + e)];
+        }
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+      }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
           bf16x8 kf = lds_read_b128(sKb(cur) + kx_off(kb * 32 + (lane & 31), ks * 2 + half));
@@ -187,20 +213,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         }
       }
       // ---- bias + mask ; lane element (kb, r) <-> key j0 + kb*32 + (r&3) + 8*(r>>2) + 4*half
+      // (scores stay in natural units; log2 e is folded into the exponent's fma)
       float mx = NEG_INF;
-      const bool wave_grid = __builtin_amdgcn_readfirstlane(qw) + 31 < a.P;
-      if (a.rel_mode && tile_grid && wave_grid && !a.dense) {
-        // grid x grid (the bulk of every self-attention): branch-free table lookup
+      if (gg) {
+        if (!row32) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+          for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            const int jb = j0 + kb * 32 + 8 * rg + 4 * half;
-            const int4 cj = *reinterpret_cast<const int4*>(sGc + jb);
-            s[kb][rg * 4 + 0] += sTbl[ci - cj.x];
-            s[kb][rg * 4 + 1] += sTbl[ci - cj.y];
-            s[kb][rg * 4 + 2] += sTbl[ci - cj.z];
-            s[kb][rg * 4 + 3] += sTbl[ci - cj.w];
+            for (int rg = 0; rg < 4; ++rg) {
+              const int jb = j0 + kb * 32 + 8 * rg + 4 * half;
+              const int4 cj = *reinterpret_cast<const int4*>(sGc + jb);
+              s[kb][rg * 4 + 0] += sTbl[ci - cj.x];
+              s[kb][rg * 4 + 1] += sTbl[ci - cj.y];
+              s[kb][rg * 4 + 2] += sTbl[ci - cj.z];
+              s[kb][rg * 4 + 3] += sTbl[ci - cj.w];
+            }
           }
         }
         if (a.causal) {
@@ -220,10 +247,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
           for (int e = 0; e < 16; ++e) m4[e & 3] = fmaxf(m4[e & 3], s[kb][e]);
         mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
       } else if (!a.rel_mode && !a.causal && !a.dense && j0 + 64 <= a.S) {
+        float m4[4] = {NEG_INF, NEG_INF, NEG_INF, NEG_INF};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kb][e]);
+          for (int e = 0; e < 16; ++e) m4[e & 3] = fmaxf(m4[e & 3], s[kb][e]);
+        mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
       } else {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -256,10 +285,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
           }
         }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run, mx);
-      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-      const float alpha = __expf(m_run - m_use);   // m_run = -inf -> 0
+      mx = fmaxf(mx, __shfl_xor(mx, 32)) * LOG2E;     // m_run / l_run live in the exp2 domain
+      if (__builtin_amdgcn_ballot_w64(mx > m_run + LAZY_MAX_SLACK)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == NEG_INF) ? 0.f : m_new));   // m_run = -inf -> 0
+        l_run *= alpha;
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
+      }
+      const float m_use = (m_run == NEG_INF) ? 0.f : m_run;
       float ps4[4] = {0.f, 0.f, 0.f, 0.f};
       bf16x8 pf[2][2];
 #pragma unroll
@@ -269,18 +304,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
           U128 u;
 #pragma unroll
           for (int e = 0; e < 8; e += 2) {
-            float p0 = __expf(s[kb][s2 * 8 + e] - m_use), p1 = __expf(s[kb][s2 * 8 + e + 1] - m_use);
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb][s2 * 8 + e], LOG2E, -m_use));
+            const float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb][s2 * 8 + e + 1], LOG2E, -m_use));
             ps4[(e >> 1) & 3] += p0 + p1;
             u.w[e >> 1] = pack2bf(p0, p1);
           }
           pf[kb][s2] = u.b;
         }
       }
-      const float psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
-      l_run = l_run * alpha + psum;
-      m_run = m_new;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
+      l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
       // ---- O^T += V^T P^T ; slot (kh, e) <-> key kb*32 + 16*s2 + 4*kh + (e&3) + 8*(e>>2)
       const int i16 = lane & 15, g16 = (lane >> 4) & 1;
 #pragma unroll
@@ -318,7 +350,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             make_uint2(pack2bf(oacc[db][rg * 4] * inv, oacc[db][rg * 4 + 1] * inv),
                        pack2bf(oacc[db][rg * 4 + 2] * inv, oacc[db][rg * 4 + 3] * inv));
       }
-    if (half == 0) a.lse[((long long)b * a.H + h) * a.T + qi] = m_run + __logf(l_tot);
+    // log2-domain log-sum-exp (natural lse x log2 e): what the backward's exp2 consumes directly
+    if (half == 0) a.lse[((long long)b * a.H + h) * a.T + qi] = m_run + __log2f(l_tot);
   }
 }
 
@@ -391,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   const float relx0 = a.rel_mode ? a.relx[h * 2 + 0] : 0.f, relx1 = a.rel_mode ? a.relx[h * 2 + 1] : 0.f;
   float gx0 = 0.f, gx1 = 0.f;
   const bool row32 = a.rel_mode && a.grid_w == 32;
+  const bool seed32 = row32 && IFSEG_SEED32;
   const int cj0 = __builtin_amdgcn_readfirstlane(cj);     // code of the wave's first key (x = 0 when row32)
   const int xl = (lane & 31) + 4 * half;
 
@@ -462,9 +496,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       const bool skip = a.causal && wave_kgrid && ((ib + 31 < kw) || (ib >= a.P));
       if (skip) continue;
       const bool qb_grid = ib + 31 < a.P;
+      const int fast = (a.rel_mode && qb_grid && wave_kgrid) ? 1 : ((!a.rel_mode && !a.causal && ib + 32 <= a.T) ? 2 : 0);
       f32x16 s, dp;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+      for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+      if (fast == 1 && seed32) {
+        // the block's queries are one grid row (codes cib + x): the lane's 16 bias values sit at constant
+        // offsets from one table address; they seed the accumulator so the MFMA adds them
+        const float* tq = sTbl + (sGc[ib] - cj + 4 * half);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[rg * 4 + e] = tq[8 * rg + e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+      }
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         bf16x8 qf = lds_read_b128(sQ + kx_off(lane & 31, ks * 2 + half));
@@ -477,7 +524,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vfr, dp, 0, 0, 0);
       }
       // element r <-> query ib + (r&3) + 8*(r>>2) + 4*half ; key = kj (lane)
-      const int fast = (a.rel_mode && qb_grid && wave_kgrid) ? 1 : ((!a.rel_mode && !a.causal && ib + 32 <= a.T) ? 2 : 0);
       float accA = 0.f, accB = 0.f;
       bf16x8 pfr[2], dsf[2];
 #pragma unroll
@@ -498,7 +544,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int hidx = cis[e] - cj;
-              float p = __expf(s[rg * 4 + e] + sTbl[hidx] - ls[e]);
+              const float sv = seed32 ? s[rg * 4 + e] : s[rg * 4 + e] + sTbl[hidx];
+              float p = __builtin_amdgcn_exp2f(fmaf(sv, LOG2E, -ls[e]));
               if (a.causal) p = (di > e) ? 0.f : p;
               const float ds = p * (gain * dp[rg * 4 + e] - dl[e]);
               pv[e] = p; dsv[e] = ds;
@@ -517,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
           } else if (fast == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float p = kvalid ? __expf(s[rg * 4 + e] - ls[e]) : 0.f;
+              const float p = kvalid ? __builtin_amdgcn_exp2f(fmaf(s[rg * 4 + e], LOG2E, -ls[e])) : 0.f;
               pv[e] = p; dsv[e] = p * (gain * dp[rg * 4 + e] - dl[e]);
             }
           } else {
@@ -550,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
                 if (k_grid) masked |= (i >= a.P) || (kj > i);
                 else masked |= (i >= a.P) && (kj > i);
               }
-              const float p = masked ? 0.f : __expf(sv - ls[e]);
+              const float p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sv, LOG2E, -ls[e]));
               const float ds = p * (gain * dp[rg * 4 + e] - dl[e]);
               pv[e] = p; dsv[e] = ds;
               if (a.rel_mode) {
@@ -676,7 +723,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       for (int ks = 0; ks < 4; ++ks) { U128 u; u.v = *reinterpret_cast<const uint4*>(pp + ks * 16); qf[4 + ks] = u.b; }
     }
   }
-  const float lse_q = qvalid ? a.lse[((long long)b * a.H + h) * a.T + qi] : INFINITY;
+  const float nlse_q = qvalid ? -a.lse[((long long)b * a.H + h) * a.T + qi] : -INFINITY;   // log2 units
+  const bool row32 = a.rel_mode && a.grid_w == 32 && IFSEG_SEED32;
   const float del_q = qvalid ? a.delta[((long long)b * a.H + h) * a.T + qi] : 0.f;
   if (a.rel_mode) {
     for (int i = tid; i < a.n2d; i += 256) sTbl[i] = a.rel2d[(long long)h * a.n2d + i];
@@ -744,9 +792,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     if (!skip) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
+        const bool wave_grid = __builtin_amdgcn_readfirstlane(qw) + 31 < a.P;
+        const int fast = (a.rel_mode && tile_grid && wave_grid) ? 1 : ((!a.rel_mode && !a.causal && j0 + 64 <= a.S) ? 2 : 0);
         f32x16 s, dp;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+        for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+        if (fast == 1 && row32) {
+          // bias values of the key row at constant offsets from one table address seed the accumulator
+          const float* tp = sTbl + (ci - sGc[j0 + kb * 32] - 4 * half - 27);
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[rg * 4 + e] = tp[27 - (8 * rg + e)];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
           bf16x8 kf = lds_read_b128(sKb(cur) + kx_off(kb * 32 + (lane & 31), ks * 2 + half));
@@ -758,8 +819,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, dof[ks], dp, 0, 0, 0);
         }
         bf16x8 dsf[2];
-        const bool wave_grid = __builtin_amdgcn_readfirstlane(qw) + 31 < a.P;
-        const int fast = (a.rel_mode && tile_grid && wave_grid) ? 1 : ((!a.rel_mode && !a.causal && j0 + 64 <= a.S) ? 2 : 0);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           U128 ud;
@@ -769,18 +828,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             const int jb = j0 + kb * 32 + 8 * rg + 4 * half;
             float dsv[4];
             if (fast == 1) {
-              const int4 cj = *reinterpret_cast<const int4*>(sGc + jb);
               const int dj = jb - qi;
-              const int cjs[4] = {cj.x, cj.y, cj.z, cj.w};
+              float sv[4];
+              if (row32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sv[e] = s[rg * 4 + e];
+              } else {
+                const int4 cj = *reinterpret_cast<const int4*>(sGc + jb);
+                const int cjs[4] = {cj.x, cj.y, cj.z, cj.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sv[e] = s[rg * 4 + e] + sTbl[ci - cjs[e]];
+              }
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                float p = __expf(s[rg * 4 + e] + sTbl[ci - cjs[e]] - lse_q);
+                float p = __builtin_amdgcn_exp2f(fmaf(sv[e], LOG2E, nlse_q));
                 if (a.causal) p = (dj + e > 0) ? 0.f : p;
                 dsv[e] = p * (gain * dp[rg * 4 + e] - del_q);
               }
             } else if (fast == 2) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) dsv[e] = __expf(s[rg * 4 + e] - lse_q) * (gain * dp[rg * 4 + e] - del_q);
+              for (int e = 0; e < 4; ++e)
+                dsv[e] = __builtin_amdgcn_exp2f(fmaf(s[rg * 4 + e], LOG2E, nlse_q)) * (gain * dp[rg * 4 + e] - del_q);
             } else {
               int4 cj = make_int4(0, 0, 0, 0);
               if (a.rel_mode && tile_grid) cj = *reinterpret_cast<const int4*>(sGc + jb);
@@ -800,7 +868,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                   if (tile_grid) masked |= (qi >= a.P) || (j > qi);
                   else masked |= (qi >= a.P) && (j > qi);
                 }
-                const float p = masked ? 0.f : __expf(sv - lse_q);
+                const float p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sv, LOG2E, nlse_q));
                 dsv[e] = p * (gain * dp[rg * 4 + e] - del_q);
               }
             }
@@ -894,9 +962,10 @@ extern "C" int ifseg_attn_fwd(const void* q, const void* k, const void* v, const
                               int ldo, int ldpq, int ldpk, long long q_bs, long long k_bs, long long v_bs,
                               long long o_bs, int rel_mode, int P, const int* gcode, int code_bias, int n2d,
                               const float* rel2d, const float* rel1d, const float* relx, int causal,
-                              const float* dense_bias, const void* gain, void* stream) {
+                              const float* dense_bias, const void* gain, int grid_w, void* stream) {
   (void)hipGetLastError();
   AttnArgs a{};
+  a.grid_w = grid_w;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
   a.pq = (const bf16_t*)pos_q; a.pk = (const bf16_t*)pos_k; a.o = (bf16_t*)out; a.lse = lse;
   a.B = B; a.H = H; a.T = T; a.S = S; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;

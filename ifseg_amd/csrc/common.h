@@ -112,10 +112,10 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
 }
 __device__ __forceinline__ void lds_dma16_g(const void* gsrc, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_base) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
 }
 __device__ __forceinline__ void lds_dma4_g(const void* gsrc, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(gsrc), "s"(lds_base) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
 }
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

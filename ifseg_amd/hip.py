@@ -33,7 +33,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 1:
+        if _lib.ifseg_abi_version() != 2:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -172,7 +172,7 @@ def attn_fwd_gain(q, k, v, pos_q, pos_k, out, lse, B, H, T, S, rel=None, causal=
                           c_int(rel.rel2d.shape[1] if rel is not None else 0),
                           _ptr(rel.rel2d) if rel is not None else None, _ptr(rel.rel1d) if rel is not None else None,
                           _ptr(rel.relx) if rel is not None else None, c_int(1 if causal else 0), _ptr(dense_bias),
-                          _ptr(gain), _stream())
+                          _ptr(gain), c_int(rel.grid_w if rel is not None else 0), _stream())
     _check(rc, "attn_fwd")
     return out
 

@@ -23,7 +23,9 @@ and their autograd.  Internal token order of the decoder is [patches..., bos]
 (bos moved to the end so the seg grid is tile aligned); logits are produced in the
 reference order [bos, patches...].
 """
+import contextlib
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -50,6 +52,11 @@ class HipEngine:
         self.grad_ready_hook = None      # callable(prefix) once every gradient under `prefix` is final
         self.drop_on = False
         self.step_seed = 0               # set by the trainer (seed + num_updates, trainer.py:1297)
+        # backward: everything that only produces PARAMETER gradients (dW GEMMs, bias / LayerNorm / table
+        # reductions) is enqueued on a second HIP stream and overlaps the dX chain on the main stream
+        self.overlap = os.environ.get("IFSEG_NO_OVERLAP") is None
+        self._side = None
+        self._bt = ""                    # tag of the backward block being processed (unique gradient buffers)
 
     # ------------------------------------------------------------------ packing
     def _arena_order(self):
@@ -231,6 +238,40 @@ class HipEngine:
             t = torch.empty(shape, dtype=dtype, device=self.device)
             self.ws[name] = t
         return t
+
+    def gbuf(self, name, shape, dtype=BF):
+        """backward buffer that weight-gradient work on the side stream may still be reading while the main
+        stream has moved on: one instance per block so it is never overwritten within a step"""
+        return self.buf(name + "@" + self._bt if self.overlap else name, shape, dtype)
+
+    # ---- second stream for weight-gradient work ------------------------------------------------
+    def _ev(self):
+        e = self._evs[self._evi]
+        self._evi = (self._evi + 1) % len(self._evs)
+        return e
+
+    @contextlib.contextmanager
+    def _wgrad(self):
+        """Everything enqueued so far on the current stream happens-before the body; the body runs on the
+        side stream (in order with earlier bodies).  `_join_side` makes the main stream wait for it."""
+        if not self.overlap:
+            yield
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._evs = [torch.cuda.Event() for _ in range(64)]
+            self._evi = 0
+        e = self._ev()
+        e.record(torch.cuda.current_stream())
+        self._side.wait_event(e)
+        with torch.cuda.stream(self._side):
+            yield
+
+    def _join_side(self):
+        if self.overlap and self._side is not None:
+            e = self._ev()
+            e.record(self._side)
+            torch.cuda.current_stream().wait_event(e)
 
     def _geometry(self, h, w, L):
         """index tables for a (h, w) feature grid and L text tokens (device tensors, cached)."""
@@ -713,26 +754,19 @@ class HipEngine:
         self.saved[key] = kw
 
     # ---------------------------------------------------------------- backward
-    def _ln_param_grads(self, pname, C, accumulate=False):
-        # weight and bias of a LayerNorm are adjacent in the arena: one [2, C] reduction
-        gw = self._fused(self.g16, pname + ".weight", 2, C)
-        hip.reduce_parts(self._dgbp(C), gw, 2, hip.LN_BWD_BLOCKS, C, accumulate=accumulate)
-
-    def _dgbp(self, C):
-        return self.buf("ln_dgbp_%d" % C, (2, hip.LN_BWD_BLOCKS, C), torch.float32)
-
-    def _dgp(self, C):
-        return self._dgbp(C)[0]
-
-    def _dbp(self, C):
-        return self._dgbp(C)[1]
-
     def _ln_bwd(self, dy, x, pname, stats_tag, dx, dx_add=None, gelu=False, accumulate=False):
         C = x.shape[-1]
         rows = x.numel() // C
         mu, rs = self._ln_stats(stats_tag, rows)
-        hip.ln_bwd(dy, x, self.W(pname + ".weight"), mu, rs, dx, self._dgp(C), self._dbp(C), dx_add=dx_add, gelu=gelu)
-        self._ln_param_grads(pname, C, accumulate)
+        # per-block partial sums of d(gamma), d(beta); one buffer per LayerNorm site (the reduction below
+        # runs on the side stream)
+        part = self.buf("ln_dgbp_%d@%s" % (C, stats_tag) if self.overlap else "ln_dgbp_%d" % C,
+                        (2, hip.LN_BWD_BLOCKS, C), torch.float32)
+        hip.ln_bwd(dy, x, self.W(pname + ".weight"), mu, rs, dx, part[0], part[1], dx_add=dx_add, gelu=gelu)
+        with self._wgrad():
+            # weight and bias of a LayerNorm are adjacent in the arena: one [2, C] reduction
+            hip.reduce_parts(part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C,
+                             accumulate=accumulate)
         return dx
 
     def _bias_grad(self, dy2d, gout, accumulate=False):
@@ -743,9 +777,10 @@ class HipEngine:
 
     def _linear_bwd(self, dy, x, wname_or_view, gw, gb, dx_out=None, dx_resid=None, dx_accumulate=False, need_dx=True):
         """dy [M,N], x [M,K]: writes dW -> gw, db -> gb, returns dx [M,K]"""
-        hip.linear_dw(dy, x, gw)
-        if gb is not None:
-            self._bias_grad(dy, gb)
+        with self._wgrad():
+            hip.linear_dw(dy, x, gw)
+            if gb is not None:
+                self._bias_grad(dy, gb)
         if need_dx:
             return hip.linear_dx(dy, wname_or_view, out=dx_out, resid=dx_resid, accumulate=dx_accumulate)
         return None
@@ -755,16 +790,18 @@ class HipEngine:
         C, Fd = self.cfg.embed_dim, self.cfg.ffn_dim
         s = self.saved[tg + "_ffn"]
         W, G, buf = self.W, self.G, self.buf
+        self._bt = tg + "f"
+        gbuf = self.gbuf
         dz = buf("g_dz_%d" % rows, (rows, Fd))
         dbr = dx2
         if self.drop_on and s["site"] is not None:      # adjoint of dropout + DropPath on the branch
-            dbr = self._drop(dx2, None, buf("g_drop_%d" % rows, (rows, C)), self._site_id(s["site"]), self._dp(*s["site"]), s["rpb"])
+            dbr = self._drop(dx2, None, gbuf("g_drop_%d" % rows, (rows, C)), self._site_id(s["site"]), self._dp(*s["site"]), s["rpb"])
         self._linear_bwd(dbr, s["z"], W(p + "fc2.weight"), G(p + "fc2.weight"), G(p + "fc2.bias"), dx_out=dz)
-        du = buf("g_du_%d" % rows, (rows, Fd))
+        du = gbuf("g_du_%d" % rows, (rows, Fd))
         self._ln_bwd(dz, s["u"], p + "ffn_layernorm", tg + "_fln2", du, gelu=True)
         dxn = buf("g_dxn_%d" % rows, (rows, C))
         self._linear_bwd(du, s["xn"], W(p + "fc1.weight"), G(p + "fc1.weight"), G(p + "fc1.bias"), dx_out=dxn)
-        dx1 = buf("g_dx1_%d" % rows, (rows, C))
+        dx1 = gbuf("g_dx1_%d" % rows, (rows, C))
         self._ln_bwd(dxn, s["x1"].view(rows, C), p + "final_layer_norm", tg + "_fln1", dx1, dx_add=dx2)
         return dx1
 
@@ -773,31 +810,33 @@ class HipEngine:
         cfg = self.cfg
         C, H = cfg.embed_dim, cfg.heads
         buf = self.buf
-        delta = buf("g_delta_%d" % T, (B, H, T), torch.float32)
-        dpq_part = buf("g_dpq_part_%d" % T, (B, T, C), torch.float32)
-        dpk_part = buf("g_dpk_part_%d" % S, (B, S, C), torch.float32)
+        gbuf = self.gbuf
+        delta = gbuf("g_delta_%d" % T, (B, H, T), torch.float32)
+        dpq_part = gbuf("g_dpq_part_%d" % T, (B, T, C), torch.float32)
+        dpk_part = gbuf("g_dpk_part_%d" % S, (B, S, C), torch.float32)
         nparts = B * ((S + 127) // 128)
         parts = [None, None, None]
         if rel is not None:
-            parts = [buf("g_relp%d_%d" % (i, t.shape[1]), (H, nparts, t.shape[1]), torch.float32)
+            parts = [gbuf("g_relp%d_%d" % (i, t.shape[1]), (H, nparts, t.shape[1]), torch.float32)
                      for i, t in enumerate((rel.rel2d, rel.rel1d, rel.relx))]
         hip.attn_bwd(q, k, v, pq, pk, o, do, lse, delta, dq, dk, dv, dpq_part, dpk_part, B, H, T, S, rel=rel,
                      causal=causal, gain=gain, dq_scale=scaling, dpq_scale=scaling, drel2d_part=parts[0],
                      drel1d_part=parts[1], drelx_part=parts[2], nparts=nparts)
-        hip.reduce_parts(dpq_part, dpq_acc, 1, B, T * C, accumulate=not first_pos)
-        hip.reduce_parts(dpk_part, dpk_acc, 1, B, S * C, accumulate=not first_pos)
-        # d c_attn[h] = sum_{b,t} delta / c_attn[h]   (H scalars)
-        hip.reduce_parts(delta.view(B, H * T), buf("g_dsum_bt", (H * T,), torch.float32), 1, B, H * T)
-        self.G(gain_name).copy_((self.ws["g_dsum_bt"].view(H, T).sum(1) / gain.float()))
-        if rel is not None:
-            for (tabname, idx), part in zip(rel_grads, parts):
-                if tabname is None:
-                    continue
-                n = part.shape[2]
-                red = buf("g_relred_%d" % n, (H, n), torch.float32)
-                hip.reduce_parts(part, red, H, nparts, n)
-                acc = self._table_acc(tabname)
-                hip.rel_scatter_add(red, idx, acc)
+        with self._wgrad():
+            hip.reduce_parts(dpq_part, dpq_acc, 1, B, T * C, accumulate=not first_pos)
+            hip.reduce_parts(dpk_part, dpk_acc, 1, B, S * C, accumulate=not first_pos)
+            # d c_attn[h] = sum_{b,t} delta / c_attn[h]   (H scalars)
+            hip.reduce_parts(delta.view(B, H * T), buf("g_dsum_bt", (H * T,), torch.float32), 1, B, H * T)
+            self.G(gain_name).copy_((self.ws["g_dsum_bt"].view(H, T).sum(1) / gain.float()))
+            if rel is not None:
+                for (tabname, idx), part in zip(rel_grads, parts):
+                    if tabname is None:
+                        continue
+                    n = part.shape[2]
+                    red = buf("g_relred_%d" % n, (H, n), torch.float32)
+                    hip.reduce_parts(part, red, H, nparts, n)
+                    acc = self._table_acc(tabname)
+                    hip.rel_scatter_add(red, idx, acc)
 
     def _table_acc(self, tabname):
         key = "g_tabacc_" + tabname
@@ -813,7 +852,9 @@ class HipEngine:
         W, G, buf = self.W, self.G, self.buf
         a_ = p + attn
         rows = B * T
-        da = buf("g_da_%d" % rows, (rows, C))
+        self._bt = tg + "s"
+        gbuf = self.gbuf
+        da = gbuf("g_da_%d" % rows, (rows, C))
         dbr = dx1
         if self.drop_on and s["site"] is not None:
             dbr = self._drop(dx1, None, buf("g_drop_%d" % rows, (rows, C)), self._site_id(s["site"]), self._dp(*s["site"]), T)
@@ -821,7 +862,7 @@ class HipEngine:
         do = buf("g_do_%d" % rows, (B, T, C))
         self._linear_bwd(da, s["o"].view(rows, C), W(a_ + ".out_proj.weight"), G(a_ + ".out_proj.weight"),
                          G(a_ + ".out_proj.bias"), dx_out=do.view(rows, C))
-        dqkv = buf("g_dqkv_%d" % rows, (B, T, 3 * C))
+        dqkv = gbuf("g_dqkv_%d" % rows, (B, T, 3 * C))
         qkv = s["qkv"]
         self._attn_core_bwd(tg, qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], pq, pk, s["o"], s["lse"], do,
                             dqkv[:, :, :C], dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:], B, T, T, s["rel"], s["causal"],
@@ -830,7 +871,7 @@ class HipEngine:
         self._linear_bwd(dqkv.view(rows, 3 * C), s["xn"], self._fused(self.p16, a_ + ".q_proj.weight", 3 * C, C),
                          self._fused(self.g16, a_ + ".q_proj.weight", 3 * C, C),
                          self._fused(self.g16, a_ + ".q_proj.bias", 3 * C), dx_out=dxn)
-        dx = buf("g_dx0_%d" % rows, (rows, C))
+        dx = gbuf("g_dx0_%d" % rows, (rows, C))
         self._ln_bwd(dxn, s["x"].view(rows, C), p + ln1, tg + "_ln1", dx, dx_add=dx1)
         return dx
 
@@ -840,7 +881,9 @@ class HipEngine:
         W, G, buf = self.W, self.G, self.buf
         a_ = p + "encoder_attn"
         rows = B * Td
-        da = buf("g_da_%d" % rows, (rows, C))
+        self._bt = tg + "c"
+        gbuf = self.gbuf
+        da = gbuf("g_da_%d" % rows, (rows, C))
         dbr = dy2
         if self.drop_on and s["site"] is not None:
             dbr = self._drop(dy2, None, buf("g_drop_%d" % rows, (rows, C)), self._site_id(s["site"]), self._dp(*s["site"]), Td)
@@ -848,8 +891,8 @@ class HipEngine:
         do = buf("g_do_%d" % rows, (B, Td, C))
         self._linear_bwd(da, s["o"].view(rows, C), W(a_ + ".out_proj.weight"), G(a_ + ".out_proj.weight"),
                          G(a_ + ".out_proj.bias"), dx_out=do.view(rows, C))
-        dq = buf("g_cdq", (B, Td, C))
-        dkv = buf("g_cdkv", (B, Te, 2 * C))
+        dq = gbuf("g_cdq", (B, Td, C))
+        dkv = gbuf("g_cdkv", (B, Te, 2 * C))
         kv = s["kv"]
         self._attn_core_bwd(tg + "c", s["q"], kv[:, :, :C], kv[:, :, C:], cpq, cpk, s["o"], s["lse"], do, dq,
                             dkv[:, :, :C], dkv[:, :, C:], B, Td, Te, None, False, s["gain"], a_ + ".c_attn", scaling,
@@ -863,7 +906,7 @@ class HipEngine:
                          self._fused(self.g16, a_ + ".k_proj.weight", 2 * C, C),
                          self._fused(self.g16, a_ + ".k_proj.bias", 2 * C), dx_out=d_enc_out.view(B * Te, C),
                          dx_accumulate=not first_cross)
-        dy1 = buf("g_dy1c_%d" % rows, (rows, C))
+        dy1 = gbuf("g_dy1c_%d" % rows, (rows, C))
         self._ln_bwd(dyn, s["x"].view(rows, C), p + "encoder_attn_layer_norm", tg + "_cln1", dy1, dx_add=dy2)
         return dy1
 
@@ -877,6 +920,7 @@ class HipEngine:
         g = self._geometry(h, w, L)
         self.g16.zero_()
         self._tab_touched = {}
+        self._bt = "top"
         e, d = "encoder.", "decoder."
         # ---- seg projection (frozen, tied to seg_embed_tokens: no weight grad)
         dl = buf("g_dlogits", (B * Td, self.npad))
@@ -902,9 +946,12 @@ class HipEngine:
             dy = self._self_block_bwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", dy, B, Td,
                                       ctx["d_spq"], ctx["d_spk"], scaling, dspq, dspk, first,
                                       [(tabn, g["dec_idx2d"]), (tabn, g["dec_idx1d"]), (tabn, g["dec_idxx"])])
-            self._flush_tables()
-            self._notify(p)
+            with self._wgrad():      # the layer's gradients become final in side-stream order
+                self._flush_tables()
+                self._notify(p)
         # ---- decoder embedding LN (input = [enc_out[:, :P] | embed(bos)])
+        self._bt = "dtop"
+        self._join_side()            # the position-operand accumulators below were filled on the side stream
         dy3 = dy.view(B, Td, C)
         enc_out = ctx["enc_out"]
         dyp, dyb = dy3[:, :P], dy3[:, P:]
@@ -940,7 +987,8 @@ class HipEngine:
         dpos_all = buf("g_dpos_all", (T, C))
         self._linear_bwd(dcpk16, pos_all, W(d + "cross_pos_k_linear.weight"), G(d + "cross_pos_k_linear.weight"),
                          G(d + "cross_pos_k_linear.bias"), dx_out=dpos_all)
-        self._notify(d)
+        with self._wgrad():
+            self._notify(d)
         # ---- encoder
         dx = buf("g_dx_enc", (B * T, C))
         self._ln_bwd(d_enc_out.view(B * T, C), ctx["e_x_final"].view(B * T, C), e + "layer_norm", "e_final_ln", dx)
@@ -955,9 +1003,12 @@ class HipEngine:
                                       [("%simage_rel_pos_table_list.%d.weight" % (e, l), g["enc_idx2d"]),
                                        ("%stoken_rel_pos_table_list.%d.weight" % (e, l), g["enc_idx1d"]),
                                        (None, None)])
-            self._flush_tables()
-            self._notify(p)
+            with self._wgrad():
+                self._flush_tables()
+                self._notify(p)
         # ---- encoder abs-pos operands
+        self._bt = "etop"
+        self._join_side()
         depqk = buf("g_depqk", (T, 2 * C))
         tmp = buf("g_tmp_ec", (T, C))
         hip.cast_f32_bf16(depq, tmp); depqk[:, :C].copy_(tmp)
@@ -982,9 +1033,11 @@ class HipEngine:
         dtok = buf("g_dtok_pre", (B, L, C))
         self._ln_bwd(dxt, self.ws["tok_pre"].view(B, L, C), e + "layernorm_embedding", "tok_ln", dtok)
         gt = G(e + "type_embedding.weight")
-        self._bias_grad(dtok.view(B * L, C), gt[0])
-        self._bias_grad(dimg.view(B * P, C), gt[1])
-        self._notify(e)
+        with self._wgrad():
+            self._bias_grad(dtok.view(B * L, C), gt[0])
+            self._bias_grad(dimg.view(B * P, C), gt[1])
+            self._notify(e)
+        self._join_side()            # the optimizer (main stream) reads the whole gradient arena next
         return self.g16
 
     def _flush_tables(self):

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 1
+#define IFSEG_ABI_VERSION 2
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -69,7 +69,8 @@ int ifseg_conv2d_nhwc_bf16(const void* in, const void* w, const void* shift, con
  * encoder_module.py:757-771,790-809 / decoder_module.py:335-366,553-558,601-631.
  * q,k,v,out: bf16, row stride ld*, batch stride *_bs (elements), head h at columns
  * [h*64, h*64+64).  pos_q [T,ldpq], pos_k [S,ldpk] batch-invariant (may be NULL).
- * lse: fp32 [B,H,T].  Token order: grid tokens [0,P) then tail tokens [P,T)
+ * lse: fp32 [B,H,T], the log-sum-exp of the scores in log2 units (natural lse x log2 e; the backward
+ * consumes it with exp2).  Token order: grid tokens [0,P) then tail tokens [P,T)
  * (decoder: bos is moved to the end by the caller).  rel_mode=1:
  *   i,j <  P : rel2d[h][gcode[i]-gcode[j]+code_bias]     (image / seg grid)
  *   i,j >= P : rel1d[h][(i-j)+Lt-1], Lt=T-P               (text; decoder bos corner)
@@ -82,7 +83,10 @@ int ifseg_attn_fwd(const void* q, const void* k, const void* v, const void* pos_
                    int ldpq, int ldpk, long long q_bs, long long k_bs, long long v_bs, long long o_bs,
                    int rel_mode, int P, const int* gcode, int code_bias, int n2d, const float* rel2d,
                    const float* rel1d, const float* relx, int causal, const float* dense_bias,
-                   const void* gain /* bf16 [H] or NULL */, void* stream);
+                   const void* gain /* bf16 [H] or NULL */,
+                   int grid_w /* token-grid width if gcode is the raster code y*(2w-1)+x, else 0; 32 enables
+                                 the row-aligned bias lookup */,
+                   void* stream);
 
 /* Backward of ifseg_attn_fwd (autograd of the same reference lines).  Launches
  *   delta[b,h,t] = sum_d dout*out;  a key-stationary dK/dV kernel that also
