@@ -53,9 +53,6 @@ constexpr int KT_BYTES = 64 * 256;  // K_ext tile  [64 keys][128] bf16
 constexpr int VT_BYTES = 64 * 128;  // V tile      [64 keys][64]  bf16
 constexpr int DKV_STAGE_BYTES = 32 * 256 + 32 * 128 + 256;  // dK/dV kernel: Q_ext, dO, lse|delta of 32 queries
 static_assert(2 * DKV_STAGE_BYTES == KT_BYTES + VT_BYTES + 512, "host-side LDS size formula");
-#ifndef IFSEG_SEED32
-#define IFSEG_SEED32 1
-#endif
 constexpr float NEG_INF = -INFINITY;
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 // forward: the running reference maximum is only raised when a tile exceeds it by more than this
@@ -424,7 +421,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   const float relx0 = a.rel_mode ? a.relx[h * 2 + 0] : 0.f, relx1 = a.rel_mode ? a.relx[h * 2 + 1] : 0.f;
   float gx0 = 0.f, gx1 = 0.f;
   const bool row32 = a.rel_mode && a.grid_w == 32;
-  const bool seed32 = row32 && IFSEG_SEED32;
   const int cj0 = __builtin_amdgcn_readfirstlane(cj);     // code of the wave's first key (x = 0 when row32)
   const int xl = (lane & 31) + 4 * half;
 
@@ -500,18 +496,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       f32x16 s, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) dp[e] = 0.f;
-      if (fast == 1 && seed32) {
-        // the block's queries are one grid row (codes cib + x): the lane's 16 bias values sit at constant
-        // offsets from one table address; they seed the accumulator so the MFMA adds them
-        const float* tq = sTbl + (sGc[ib] - cj + 4 * half);
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) s[rg * 4 + e] = tq[8 * rg + e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.f;
-      }
+      for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         bf16x8 qf = lds_read_b128(sQ + kx_off(lane & 31, ks * 2 + half));
@@ -544,8 +530,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int hidx = cis[e] - cj;
-              const float sv = seed32 ? s[rg * 4 + e] : s[rg * 4 + e] + sTbl[hidx];
-              float p = __builtin_amdgcn_exp2f(fmaf(sv, LOG2E, -ls[e]));
+              float p = __builtin_amdgcn_exp2f(fmaf(s[rg * 4 + e] + sTbl[hidx], LOG2E, -ls[e]));
               if (a.causal) p = (di > e) ? 0.f : p;
               const float ds = p * (gain * dp[rg * 4 + e] - dl[e]);
               pv[e] = p; dsv[e] = ds;
@@ -724,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     }
   }
   const float nlse_q = qvalid ? -a.lse[((long long)b * a.H + h) * a.T + qi] : -INFINITY;   // log2 units
-  const bool row32 = a.rel_mode && a.grid_w == 32 && IFSEG_SEED32;
+  const bool row32 = a.rel_mode && a.grid_w == 32;
   const float del_q = qvalid ? a.delta[((long long)b * a.H + h) * a.T + qi] : 0.f;
   if (a.rel_mode) {
     for (int i = tid; i < a.n2d; i += 256) sTbl[i] = a.rel2d[(long long)h * a.n2d + i];

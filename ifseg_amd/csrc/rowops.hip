@@ -103,35 +103,55 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const bf16
 
 // backward: dx = [dx_add +] act'(x) * rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma
 // dgamma/dbeta: per-block partial sums over the rows the block visited -> [nblk][C]
-template <int NCH, bool GELU>
+// WPR = waves per row: 1 (narrow rows: a wave owns a row, four rows per block in flight) or 4 (wide rows: the
+// block owns a row, a thread keeps NCH <= 2 chunks so the three per-column accumulators stay in registers).
+// The next row's x / dy are fetched (as packed bf16) while the current row is reduced.
+template <int NCH, bool GELU, int WPR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
                                                      const float* mean, const float* rstd, const bf16_t* dx_add,
                                                      bf16_t* dx, float* dgamma_part, float* dbeta_part, int rows, int C,
                                                      RowMap mdy, RowMap mx, RowMap mdx, RowMap madd) {
-  __shared__ float red[4][64 * 8 + 8];
+  __shared__ float red[(WPR == 1) ? 4 * (64 * 8 + 8) : 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C >> 3;
+  const int tl = (WPR == 1) ? lane : threadIdx.x;      // chunk lane of this thread inside its row
+  constexpr int TS = 64 * WPR;                          // chunk stride
   float gam[NCH][8], dg[NCH][8], db[NCH][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = lane + i * 64;
+    const int c = tl + i * TS;
     if (c < nch) unpack8(*reinterpret_cast<const uint4*>(gamma + c * 8), gam[i]);
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; if (c >= nch) gam[i][e] = 0.f; }
   }
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+  const int row0 = (WPR == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
+  const int rstep = (WPR == 1) ? gridDim.x * 4 : gridDim.x;
+  uint4 rx[NCH], rd[NCH];
+  auto fetch = [&](int row) {
     const bf16_t* xp = x + mx.off(row);
     const bf16_t* dyp = dy + mdy.off(row);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tl + i * TS;
+      if (c < nch) {
+        rx[i] = *reinterpret_cast<const uint4*>(xp + c * 8);
+        rd[i] = *reinterpret_cast<const uint4*>(dyp + c * 8);
+      }
+    }
+  };
+  if (row0 < rows) fetch(row0);
+  int it = 0;
+  for (int row = row0; row < rows; row += rstep, ++it) {
     const float mu = mean[row], rs = rstd[row];
     float xr[NCH][8], gv[NCH][8], da[GELU ? NCH : 1][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + i * 64;
+      const int c = tl + i * TS;
       if (c < nch) {
         float d[8];
-        unpack8(*reinterpret_cast<const uint4*>(xp + c * 8), xr[i]);
-        unpack8(*reinterpret_cast<const uint4*>(dyp + c * 8), d);
+        unpack8(rx[i], xr[i]);
+        unpack8(rd[i], d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float a = xr[i][e];
@@ -149,12 +169,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
         }
       }
     }
-    s1 = warp_sum(s1) / C; s2 = warp_sum(s2) / C;
+    if (row + rstep < rows) fetch(row + rstep);      // in flight under the reduction and the store below
+    s1 = warp_sum(s1); s2 = warp_sum(s2);
+    if (WPR > 1) {
+      float* slot = red + (it & 1) * 8;               // double-buffered: one barrier per row
+      if (lane == 0) { slot[wave * 2] = s1; slot[wave * 2 + 1] = s2; }
+      __syncthreads();
+      s1 = (slot[0] + slot[2]) + (slot[4] + slot[6]);
+      s2 = (slot[1] + slot[3]) + (slot[5] + slot[7]);
+    }
+    s1 /= C; s2 /= C;
     bf16_t* dxp = dx + mdx.off(row);
     const bf16_t* ap = dx_add ? dx_add + madd.off(row) : nullptr;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + i * 64;
+      const int c = tl + i * TS;
       if (c < nch) {
         float o[8];
 #pragma unroll
@@ -172,20 +201,36 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
       }
     }
   }
-  // cross-wave reduction of dgamma / dbeta partials (chunk by chunk through LDS)
-  if (dgamma_part) {
+  if (!dgamma_part) return;
+  if (WPR > 1) {
+    // every thread owns its columns: the block's partial sums go straight out
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tl + i * TS;
+      if (c < nch) {
+        float* gp = dgamma_part + (long long)blockIdx.x * C + c * 8;
+        float* bp = dbeta_part + (long long)blockIdx.x * C + c * 8;
+        *reinterpret_cast<float4*>(gp) = make_float4(dg[i][0], dg[i][1], dg[i][2], dg[i][3]);
+        *reinterpret_cast<float4*>(gp + 4) = make_float4(dg[i][4], dg[i][5], dg[i][6], dg[i][7]);
+        *reinterpret_cast<float4*>(bp) = make_float4(db[i][0], db[i][1], db[i][2], db[i][3]);
+        *reinterpret_cast<float4*>(bp + 4) = make_float4(db[i][4], db[i][5], db[i][6], db[i][7]);
+      }
+    }
+  } else {
+    // cross-wave reduction of the four rows' partials (chunk by chunk through LDS)
+    float (*r4)[64 * 8 + 8] = reinterpret_cast<float (*)[64 * 8 + 8]>(red);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = pass ? db[i][e] : dg[i][e];
+        for (int e = 0; e < 8; ++e) r4[wave][lane * 8 + e] = pass ? db[i][e] : dg[i][e];
         __syncthreads();
         for (int t = threadIdx.x; t < 512; t += 256) {
           const int c = (t >> 3) + i * 64;
           if (c < nch) {
-            const float sum = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+            const float sum = r4[0][t] + r4[1][t] + r4[2][t] + r4[3][t];
             (pass ? dbeta_part : dgamma_part)[(long long)blockIdx.x * C + c * 8 + (t & 7)] = sum;
           }
         }
@@ -335,12 +380,12 @@ int launch_ln_fwd(bool gelu, dim3 g, hipStream_t s, const bf16_t* x, const bf16_
   else hipLaunchKernelGGL((ln_fwd_kernel<NCH, false>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr);
   return 0;
 }
-template <int NCH>
+template <int NCH, int WPR>
 int launch_ln_bwd(bool gelu, dim3 g, hipStream_t s, const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
                   const float* mean, const float* rstd, const bf16_t* add, bf16_t* dx, float* dgp, float* dbp, int rows,
                   int C, RowMap mdy, RowMap mx, RowMap mdx, RowMap madd) {
-  if (gelu) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true>), g, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgp, dbp, rows, C, mdy, mx, mdx, madd);
-  else hipLaunchKernelGGL((ln_bwd_kernel<NCH, false>), g, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgp, dbp, rows, C, mdy, mx, mdx, madd);
+  if (gelu) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, WPR>), g, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgp, dbp, rows, C, mdy, mx, mdx, madd);
+  else hipLaunchKernelGGL((ln_bwd_kernel<NCH, false, WPR>), g, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgp, dbp, rows, C, mdy, mx, mdx, madd);
   return 0;
 }
 
@@ -377,9 +422,8 @@ extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, co
   hipStream_t s = (hipStream_t)stream;
   const bf16_t *DY = (const bf16_t*)dy, *X = (const bf16_t*)x, *G = (const bf16_t*)gamma, *A = (const bf16_t*)dx_add;
   ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 8.0 : 6.0));
-  if (C <= 1024) launch_ln_bwd<2>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd);
-  else if (C <= 3072) launch_ln_bwd<6>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd);
-  else launch_ln_bwd<8>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd);
+  if (C <= 1024) launch_ln_bwd<2, 1>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd);
+  else launch_ln_bwd<2, 4>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd);
   ifseg_prof_end(IFSEG_K_LN_BWD, s);
   IFSEG_CHECK_LAUNCH();
   return 0;

@@ -233,7 +233,7 @@ def ln_fwd(x, gamma, beta, y, mean=None, rstd=None, resid=None, gelu=False, eps=
     return y
 
 
-LN_BWD_BLOCKS = 512
+LN_BWD_BLOCKS = 768   # three resident blocks per CU (146-162 VGPRs): best of a 256..2048 sweep on MI355X
 
 
 def ln_bwd(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx_add=None, gelu=False):
