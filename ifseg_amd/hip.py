@@ -50,7 +50,21 @@ def _ptr(t):
     return c_void_p(t.data_ptr())
 
 
+_stream_handle = None     # set by the engine for the duration of a forward / backward (saves a torch lookup per launch)
+
+
+def set_stream(handle):
+    """Pin the HIP stream every following launch goes to (raw hipStream_t as int), or None to follow
+    torch.cuda.current_stream() again.  Returns the previous setting."""
+    global _stream_handle
+    prev = _stream_handle
+    _stream_handle = handle
+    return prev
+
+
 def _stream():
+    if _stream_handle is not None:
+        return c_void_p(_stream_handle)
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -47,6 +47,7 @@ class HipEngine:
         self.packed = False
         self.device = None
         self.ws = {}
+        self._views = {}
         self.geo = {}
         self.ctx = None
         self.grad_ready_hook = None      # callable(prefix) once every gradient under `prefix` is final
@@ -134,6 +135,7 @@ class HipEngine:
             off += _pad8(names[n].numel())
         total = off
         n_train = offs[order[n_train_names]] if n_train_names < len(order) else total
+        self._views = {}
         p16 = torch.zeros(total, dtype=BF, device=device)
         g16 = torch.zeros(n_train, dtype=BF, device=device)
         master = torch.zeros(n_train, dtype=torch.float32, device=device)
@@ -169,22 +171,31 @@ class HipEngine:
     def trainable_params(self):
         return tuple(self.names[n] for n in self.trainable_names())
 
+    # views into the arenas are cached: the arenas are allocated once per pack()
     def W(self, n):
-        o = self.offs[n]
-        sh = self.shapes[n]
-        return self.p16[o:o + math.prod(sh)].view(sh)
+        v = self._views.get(n)
+        if v is None:
+            o, sh = self.offs[n], self.shapes[n]
+            v = self._views[n] = self.p16[o:o + math.prod(sh)].view(sh)
+        return v
 
     def G(self, n):
-        o = self.offs[n]
-        sh = self.shapes[n]
-        return self.g16[o:o + math.prod(sh)].view(sh)
+        v = self._views.get(("g", n))
+        if v is None:
+            o, sh = self.offs[n], self.shapes[n]
+            v = self._views[("g", n)] = self.g16[o:o + math.prod(sh)].view(sh)
+        return v
 
     def _fused(self, arena, first, rows, cols=None):
         """view of `rows` x cols starting at parameter `first` (parameters laid out contiguously)"""
-        o = self.offs[first]
-        n = rows * (cols or 1)
-        v = arena[o:o + n]
-        return v.view(rows, cols) if cols else v
+        key = (arena is self.g16, first, rows, cols)
+        v = self._views.get(key)
+        if v is None:
+            o = self.offs[first]
+            n = rows * (cols or 1)
+            v = arena[o:o + n]
+            v = self._views[key] = v.view(rows, cols) if cols else v
+        return v
 
     def _pack_resnet(self):
         """Fold FrozenBN into the conv weights (frozen_bn.py:39-40: scale = w*rsqrt(var+eps),
@@ -233,6 +244,8 @@ class HipEngine:
     # --------------------------------------------------------------- workspace
     def buf(self, name, shape, dtype=BF):
         t = self.ws.get(name)
+        if t is not None and t.shape == shape and t.dtype == dtype:
+            return t
         shape = tuple(int(s) for s in shape)
         if t is None or tuple(t.shape) != shape or t.dtype != dtype:
             t = torch.empty(shape, dtype=dtype, device=self.device)
@@ -265,7 +278,11 @@ class HipEngine:
         e.record(torch.cuda.current_stream())
         self._side.wait_event(e)
         with torch.cuda.stream(self._side):
-            yield
+            prev = hip.set_stream(self._side.cuda_stream)
+            try:
+                yield
+            finally:
+                hip.set_stream(prev)
 
     def _join_side(self):
         if self.overlap and self._side is not None:
@@ -374,19 +391,28 @@ class HipEngine:
             return
         # per-sample DropPath keep masks for every residual branch, one draw per forward
         # (rates: torch.linspace(0, rate, n_layers), encoder_module.py:232 / decoder_module.py:219)
-        rates = []
-        for l in range(cfg.enc_layers):
-            r = cfg.encoder_drop_path_rate * l / max(1, cfg.enc_layers - 1)
-            rates += [r, r]
-        for l in range(cfg.dec_layers):
-            r = cfg.decoder_drop_path_rate * l / max(1, cfg.dec_layers - 1)
-            rates += [r, r, r]
-        keep = 1.0 - torch.tensor(rates, dtype=torch.float32, device=self.device)[:, None]
-        self.dp_scale = ((torch.rand(len(rates), B, device=self.device) < keep).float() / keep).contiguous()
+        key = (cfg.encoder_drop_path_rate, cfg.decoder_drop_path_rate, cfg.enc_layers, cfg.dec_layers, self.device)
+        if getattr(self, "_dp_key", None) != key:
+            rates = []
+            for l in range(cfg.enc_layers):
+                r = cfg.encoder_drop_path_rate * l / max(1, cfg.enc_layers - 1)
+                rates += [r, r]
+            for l in range(cfg.dec_layers):
+                r = cfg.decoder_drop_path_rate * l / max(1, cfg.dec_layers - 1)
+                rates += [r, r, r]
+            self._dp_keep = 1.0 - torch.tensor(rates, dtype=torch.float32, device=self.device)[:, None]
+            self._dp_key = key
+        keep = self._dp_keep
+        self.dp_scale = self.buf("dp_scale", (keep.shape[0], B), torch.float32)
+        torch.div((torch.rand(keep.shape[0], B, device=self.device) < keep).float(), keep, out=self.dp_scale)
+        self._dp_rows = {}
 
     def _dp(self, kind, layer, k):
         i = 2 * layer + k if kind == "e" else 2 * self.cfg.enc_layers + 3 * layer + k
-        return self.dp_scale[i]
+        v = self._dp_rows.get(i)
+        if v is None:
+            v = self._dp_rows[i] = self.dp_scale[i]
+        return v
 
     def _site_seed(self, site):
         return (self.step_seed * 1000003 + site) * 0x100000001B3 + 0x9E3779B97F4A7C15
@@ -402,8 +428,22 @@ class HipEngine:
         return self.W(name)        # the kernels read the bf16 parameter directly
 
     # ----------------------------------------------------------------- forward
-    def forward(self, src_tokens, patch_images, prev_output_tokens=None, full_context_alignment=False,
-                need_grad=True):
+    def forward(self, *args, **kw):
+        prev = hip.set_stream(torch.cuda.current_stream().cuda_stream)    # one stream lookup per pass, not per launch
+        try:
+            return self._forward(*args, **kw)
+        finally:
+            hip.set_stream(prev)
+
+    def backward(self, dlogits):
+        prev = hip.set_stream(torch.cuda.current_stream().cuda_stream)
+        try:
+            return self._backward(dlogits)
+        finally:
+            hip.set_stream(prev)
+
+    def _forward(self, src_tokens, patch_images, prev_output_tokens=None, full_context_alignment=False,
+                 need_grad=True):
         cfg = self.cfg
         dev = patch_images.device
         if not self.packed or self.device != dev:
@@ -910,7 +950,7 @@ class HipEngine:
         self._ln_bwd(dyn, s["x"].view(rows, C), p + "encoder_attn_layer_norm", tg + "_cln1", dy1, dx_add=dy2)
         return dy1
 
-    def backward(self, dlogits):
+    def _backward(self, dlogits):
         """dlogits: [B, P+1, nseg] (any float dtype) in reference order.  Fills the gradient arena."""
         cfg, ctx = self.cfg, self.ctx
         B, L, P, T, Td, h, w = (ctx[k] for k in ("B", "L", "P", "T", "Td", "h", "w"))

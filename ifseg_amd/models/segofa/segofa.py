@@ -154,8 +154,13 @@ class SegOFAModel(nn.Module):
         if patch_images is None or not patch_images.is_cuda:
             raise RuntimeError("ifseg_amd.SegOFAModel runs only on an MI355X: patch_images must be a device tensor "
                                "(there is no CPU / PyTorch fallback)")
-        if patch_masks is not None and not bool(patch_masks.all()):
-            raise NotImplementedError("masked-out patch images are not supported")
+        if patch_masks is not None:
+            # the check reads the mask back (a device sync): once per mask tensor, not once per step
+            key = (patch_masks.data_ptr(), patch_masks._version, tuple(patch_masks.shape))
+            if getattr(self, "_checked_masks", None) != key:
+                if not bool(patch_masks.all()):
+                    raise NotImplementedError("masked-out patch images are not supported")
+                self._checked_masks = key
         eng = self.engine
         if not eng.packed or eng.device != patch_images.device:
             eng.pack(patch_images.device)

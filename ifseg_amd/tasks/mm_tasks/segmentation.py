@@ -95,7 +95,8 @@ class SegmentationTask:
 
     def train_step(self, sample, model, criterion, optimizer, update_num, ignore_grad=False):
         """tasks/mm_tasks/segmentation.py:190-222."""
-        model.train()
+        if not model.training:      # nn.Module.train() walks every sub-module: only when the mode changes
+            model.train()
         loss, sample_size, logging_output = criterion(model, sample, update_num=update_num)
         if ignore_grad:
             loss = loss * 0
@@ -107,7 +108,8 @@ class SegmentationTask:
 
     def valid_step(self, sample, model, criterion):
         """tasks/mm_tasks/segmentation.py:225-229."""
-        model.eval()
+        if model.training:
+            model.eval()
         with torch.no_grad():
             loss, sample_size, logging_output = criterion(model, sample)
         return loss, sample_size, logging_output

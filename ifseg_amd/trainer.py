@@ -106,7 +106,8 @@ class Trainer:
     def train_step(self, samples):
         torch.manual_seed(self.seed + self.num_updates)
         self.eng.step_seed = self.seed + self.num_updates
-        self.model.train()
+        if not self.model.training:
+            self.model.train()
         logs, sample_sizes = [], []
         for sample in samples:            # update_freq > 1 would accumulate; the shipped recipe uses 1
             loss, ss, lg = self.task.train_step(sample, self.model, self.criterion, None, self.num_updates)
