@@ -121,7 +121,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   // ---- per-lane source offsets (bytes, at k = kbeg); rows outside the matrix -> OOB (zeros)
   unsigned offA[LA], offB[LB];
   int c8A[LA], c8B[LB];                 // k offset of the lane's chunk inside a KC tile (k-tail test)
-  int cv_b[LA], cv_oy[LA], cv_ox[LA];   // conv: output pixel of the lane's row
+  // conv: per-lane byte offset of tap (0,0) of the lane's output pixel (may lie in the padding: the
+  // sum with the tap offset is only used when the tap is in bounds) and the pixel's top-left input coords
+  int cv_base[LA], cv_iy0[LA], cv_ix0[LA];
 #pragma unroll
   for (int i = 0; i < LA; ++i) {
     if (AMODE == A_KS) {
@@ -139,12 +141,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       } else {
         offA[i] = 0;
         if (m < g.M) {
-          cv_ox[i] = m % g.cOW;
-          const int q = m / g.cOW;
-          cv_oy[i] = q % g.cOH;
-          cv_b[i] = q / g.cOH;
+          const int ox = m % g.cOW, q = m / g.cOW, oy = q % g.cOH, b = q / g.cOH;
+          cv_iy0[i] = oy * g.cStride - g.cPad;
+          cv_ix0[i] = ox * g.cStride - g.cPad;
+          cv_base[i] = (((b * g.cH + cv_iy0[i]) * g.cW + cv_ix0[i]) * g.cC + c * 8) * 2;
         } else {
-          cv_b[i] = -1; cv_oy[i] = 0; cv_ox[i] = 0;
+          cv_iy0[i] = -0x40000000; cv_ix0[i] = -0x40000000; cv_base[i] = 0;   // never in bounds
         }
       }
     }
@@ -164,6 +166,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       offB[i] = (n < g.N) ? (unsigned)(((long long)n * g.ldb + kbeg + c * 8) * 2) : OOB;
     }
   }
+  // conv: (ky, kx, c0) of the next k-tile, advanced incrementally (tiles are issued in k order)
+  int cky = 0, ckx = 0, cc0 = 0;
+  if (AMODE == A_CONV) {
+    const int tap = kbeg / g.cC;
+    cc0 = kbeg - tap * g.cC;
+    cky = tap / g.cKW;
+    ckx = tap - cky * g.cKW;
+  }
   const unsigned kadvA = (AMODE == A_KS) ? (unsigned)BK * g.lda * 2 : BK * 2;
   const unsigned kadvB = B_KS ? (unsigned)BK * g.ldb * 2 : BK * 2;
 
@@ -173,16 +183,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     const int krem = (kend - kbeg) - kt * BK;           // valid k in this tile (>= BK except on a tail)
     const bool tail = ktail && kt == nk - 1;
     if (AMODE == A_CONV) {
-      const int k0 = kbeg + kt * BK;
-      const int tap = k0 / g.cC, c0 = k0 - tap * g.cC;
-      const int ky = tap / g.cKW, kx = tap - ky * g.cKW;
+      const int delta = ((cky * g.cW + ckx) * g.cC + cc0) * 2;       // wave-uniform byte offset of this tap / channel block
+      const bool interior = g.cPad == 0 && g.cKW == 1;               // 1x1 convolutions never leave the image
 #pragma unroll
       for (int i = 0; i < LA; ++i) {
-        const int iy = cv_oy[i] * g.cStride + ky - g.cPad, ix = cv_ox[i] * g.cStride + kx - g.cPad;
-        const bool ok = cv_b[i] >= 0 && iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW;
-        const unsigned v = ok ? (unsigned)(((((long long)cv_b[i] * g.cH + iy) * g.cW + ix) * g.cC + c0 + c8A[i]) * 2) : OOB;
-        lds_dma16(rsA, dA + i * 1024, v);
+        unsigned v = (unsigned)(cv_base[i] + delta);
+        const bool ok = interior ? cv_iy0[i] >= 0
+                                 : ((unsigned)(cv_iy0[i] + cky) < (unsigned)g.cH && (unsigned)(cv_ix0[i] + ckx) < (unsigned)g.cW);
+        lds_dma16(rsA, dA + i * 1024, ok ? v : OOB);
       }
+      cc0 += BK;
+      if (cc0 >= g.cC) { cc0 = 0; if (++ckx == g.cKW) { ckx = 0; ++cky; } }
     } else {
       const unsigned ka = (unsigned)kt * kadvA;
 #pragma unroll

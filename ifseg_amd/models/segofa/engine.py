@@ -57,6 +57,8 @@ class HipEngine:
         # reductions) is enqueued on a second HIP stream and overlaps the dX chain on the main stream
         self.overlap = os.environ.get("IFSEG_NO_OVERLAP") is None
         self._side = None
+        self._trunk_stream, self._pf, self._pf_slot = None, None, 0
+        self._pf_request = None          # images of the next batch (set by the trainer; consumed by the next forward)
         self._bt = ""                    # tag of the backward block being processed (unique gradient buffers)
 
     # ------------------------------------------------------------------ packing
@@ -322,16 +324,55 @@ class HipEngine:
         return g
 
     # ------------------------------------------------------------------ ResNet
-    def _resnet(self, images):
+    def prefetch_trunk(self, patch_images):
+        """Start the frozen ResNet-101 trunk of a FUTURE batch on its own stream.
+
+        The trunk has no trainable parameter (resnet.py + frozen_bn.py, `freeze_resnet`), so its output for
+        batch n+1 does not depend on the update of step n: its ~90 small convolutions (each too small to fill
+        256 CUs) run underneath step n instead of in front of step n+1.  `forward` picks the features up when
+        it is handed the same tensor; anything else falls back to running the trunk in line."""
+        if not self.packed or self.device != patch_images.device:
+            return
+        if self._trunk_stream is None:
+            self._trunk_stream = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)                                   # the images were produced on the caller's stream
+        self._trunk_stream.wait_event(ready)
+        slot = self._pf_slot = self._pf_slot ^ 1            # two feature buffers: the running step keeps its own
+        with torch.cuda.stream(self._trunk_stream):
+            prev = hip.set_stream(self._trunk_stream.cuda_stream)
+            try:
+                feat, h, w = self._resnet(patch_images, "@pf%d" % slot)
+            finally:
+                hip.set_stream(prev)
+            done = torch.cuda.Event()
+            done.record(self._trunk_stream)
+        self._pf = {"key": self._tkey(patch_images), "images": patch_images, "feat": feat, "h": h, "w": w, "done": done}
+
+    @staticmethod
+    def _tkey(t):
+        return (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+
+    def _trunk(self, patch_images):
+        pf, self._pf = self._pf, None
+        if pf is not None and pf["key"] == self._tkey(patch_images):
+            torch.cuda.current_stream().wait_event(pf["done"])
+            return pf["feat"], pf["h"], pf["w"]
+        return self._resnet(patch_images)
+
+    def _resnet(self, images, tag=""):
         B, _, Hh, Ww = images.shape
-        x4 = self.buf("rn_x4", (B, Hh, Ww, 4))
+        _buf = self.buf
+        buf = lambda name, shape: _buf(name + tag, shape)
+        x4 = buf("rn_x4", (B, Hh, Ww, 4))
         hip.nchw_to_nhwc(images.contiguous(), x4, 4)
         H1, W1 = (Hh + 6 - 7) // 2 + 1, (Ww + 6 - 7) // 2 + 1
-        s = self.buf("rn_stem", (B, H1, W1, 64))
+        s = buf("rn_stem", (B, H1, W1, 64))
         hip.stem_conv(x4, self.stem_w, self.stem_shift, s, B, Hh, Ww)
         H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
         maxel = B * H2 * W2 * 256
-        pool = [self.buf("rn_p%d" % i, (maxel,)) for i in range(4)]
+        pool = [buf("rn_p%d" % i, (maxel,)) for i in range(4)]
         cur = pool[0][: B * H2 * W2 * 64].view(B, H2, W2, 64)
         hip.maxpool(s, cur, B, H1, W1, 64)
         curi, Hc, Wc, Cc = 0, H2, W2, 64
@@ -365,7 +406,7 @@ class HipEngine:
             out = pool[io][: B * Ho * Wo * cout].view(B, Ho, Wo, cout)
             hip.conv2d_nhwc(o2, w3, s3, idt, out, B, Ho, Wo, mid, cout, 1, 1, 1, 0, True)
             cur, curi, Hc, Wc, Cc = out, io, Ho, Wo, cout
-        feat = self.buf("rn_feat", (B, Hc * Wc, Cc))
+        feat = buf("rn_feat", (B, Hc * Wc, Cc))
         feat.copy_(cur.view(B, Hc * Wc, Cc))
         return feat, Hc, Wc
 
@@ -458,7 +499,10 @@ class HipEngine:
         C, Fd, H = cfg.embed_dim, cfg.ffn_dim, cfg.heads
         scaling = float(cfg.head_dim * cfg.attn_scale_factor) ** -0.5
         W, buf = self.W, self.buf
-        feat, h, w = self._resnet(patch_images)
+        feat, h, w = self._trunk(patch_images)
+        if self._pf_request is not None:      # the next batch's trunk starts once this batch's features are taken
+            req, self._pf_request = self._pf_request, None
+            self.prefetch_trunk(req)
         P = h * w
         oh = cfg.orig_patch_image_size // 16
         slow = (h, w) != (oh, oh) or (h, w) != (cfg.seg_bucket_size,) * 2 or P % 64 != 0

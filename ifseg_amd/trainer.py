@@ -103,7 +103,12 @@ class Trainer:
         return self.min_lr + 0.5 * (self.lr0 - self.min_lr) * (1 + math.cos(math.pi * t / self.max_update))
 
     # -- steps ------------------------------------------------------------------------------
-    def train_step(self, samples):
+    def train_step(self, samples, prefetch=None):
+        """One update.  `prefetch`: the samples of the NEXT call, if the data iterator already holds them:
+        their frozen-trunk features are computed on a second stream underneath this step
+        (HipEngine.prefetch_trunk)."""
+        if prefetch:
+            self.eng._pf_request = prefetch[0]["net_input"]["patch_images"]
         torch.manual_seed(self.seed + self.num_updates)
         self.eng.step_seed = self.seed + self.num_updates
         if not self.model.training:

@@ -286,3 +286,30 @@ def test_large_geometry_vs_oracle():
     ocfg = O.SegOFAConfig(embed_dim=1024, ffn_dim=4096, heads=16, enc_layers=1, dec_layers=1, resnet_layers=(1, 1, 1),
                           num_seg_tokens=171, vocab_size=600, patch_image_size=640, orig_patch_image_size=640)
     _parity_case(ocfg, 1, 239, (640, 640))
+
+
+def test_trunk_prefetch_matches_inline():
+    """HipEngine.prefetch_trunk: features computed one batch ahead on the trunk stream give the same logits
+    as the in-line trunk, and a different tensor falls back to the in-line path."""
+    import torch
+    from ifseg_amd.tasks.mm_tasks.segmentation import SegmentationTask
+    dev = torch.device("cuda:0")
+    task = SegmentationTask(num_seg_tokens=5, patch_image_size=128, arch="segofa_tiny")
+    model = task.build_model().to(dev).eval()
+    s1 = task.synthetic_sample(2, dev, seed=11)
+    s2 = task.synthetic_sample(2, dev, seed=12)
+    with torch.no_grad():
+        ref1 = model(**s1["net_input"])[0].float().clone()
+        ref2 = model(**s2["net_input"])[0].float().clone()
+        eng = model.engine
+        eng.prefetch_trunk(s2["net_input"]["patch_images"])
+        assert eng._pf is not None
+        out1 = model(**s1["net_input"])[0].float().clone()      # other tensor: in-line trunk, prefetch dropped
+        assert eng._pf is None
+        eng.prefetch_trunk(s2["net_input"]["patch_images"])
+        out2 = model(**s2["net_input"])[0].float().clone()      # same tensor: prefetched features
+        assert eng._pf is None
+    torch.cuda.synchronize()
+    assert torch.equal(out1, ref1)
+    assert torch.equal(out2, ref2)
+    assert not torch.equal(ref1, ref2)
