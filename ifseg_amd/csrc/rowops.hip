@@ -45,11 +45,40 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
 }
 
-// y = [resid +] LN(act(x)) * gamma + beta ; one wave per row, NCH 8-element chunks per lane
+// ---- dropout + DropPath (training-time stochastic regularisers) -------------------------------
+// keep(i) ~ Bernoulli(1 - p) from a counter-based hash of (seed, 8-element chunk index): the backward
+// re-generates the same mask, nothing is stored.  Reference: FairseqDropout (fairseq_dropout.py:23-27)
+// after the embedding LayerNorms, attn_ln / cross_attn_ln and fc2, and drop_path
+// (unify_transformer_layer.py:19-35) inside residual_connection (:196).  The RNG stream necessarily
+// differs from torch's.  The same mask is applied by the stand-alone kernel (ifseg_dropout) and by the
+// fused epilogue of ln_fwd / prologue of ln_bwd.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+struct DropArgs {   // on == 0: identity
+  int on; float p; unsigned long long seed; const float* dpscale; int rows_per_batch;
+};
+// f[0..8) *= keep * scale for chunk c8 (= row * C/8 + chunk) of logical row `row`
+__device__ __forceinline__ void drop8(float* f, const DropArgs& d, long long c8, int row) {
+  const float sc = (d.dpscale ? d.dpscale[row / d.rows_per_batch] : 1.f) * (d.p > 0.f ? 1.f / (1.f - d.p) : 1.f);
+  const unsigned thr = (unsigned)(d.p * 65536.f);
+  const unsigned long long r0 = splitmix64(d.seed + 2ull * (unsigned long long)c8), r1 = splitmix64(d.seed + 2ull * (unsigned long long)c8 + 1ull);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const unsigned bits = (unsigned)(((e < 4 ? r0 : r1) >> (16 * (e & 3))) & 0xFFFFu);
+    f[e] = bits >= thr ? f[e] * sc : 0.f;
+  }
+}
+
+// y = [resid +] drop(LN(act(x)) * gamma + beta) ; one wave per row, NCH 8-element chunks per lane
 template <int NCH, bool GELU>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const bf16_t* gamma, const bf16_t* beta,
                                                      const bf16_t* resid, bf16_t* y, float* mean, float* rstd,
-                                                     int rows, int C, float eps, RowMap mx, RowMap my, RowMap mr) {
+                                                     int rows, int C, float eps, RowMap mx, RowMap my, RowMap mr,
+                                                     DropArgs drop) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nch = C >> 3;
@@ -90,6 +119,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const bf16
       unpack8(*reinterpret_cast<const uint4*>(beta + c * 8), b);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+      if (drop.on) drop8(o, drop, (long long)row * nch + c, row);
       if (rp) {
         float r[8];
         unpack8(*reinterpret_cast<const uint4*>(rp + c * 8), r);
@@ -110,7 +140,7 @@ template <int NCH, bool GELU, int WPR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
                                                      const float* mean, const float* rstd, const bf16_t* dx_add,
                                                      bf16_t* dx, float* dgamma_part, float* dbeta_part, int rows, int C,
-                                                     RowMap mdy, RowMap mx, RowMap mdx, RowMap madd) {
+                                                     RowMap mdy, RowMap mx, RowMap mdx, RowMap madd, DropArgs drop) {
   __shared__ float red[(WPR == 1) ? 4 * (64 * 8 + 8) : 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C >> 3;
@@ -152,6 +182,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
         float d[8];
         unpack8(rx[i], xr[i]);
         unpack8(rd[i], d);
+        if (drop.on) drop8(d, drop, (long long)row * nch + c, row);     // adjoint of the forward's fused dropout
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float a = xr[i][e];
@@ -375,17 +406,17 @@ __global__ void nchw_to_nhwc_kernel(const TIN* in, bf16_t* out, int B, int Cc, i
 template <int NCH>
 int launch_ln_fwd(bool gelu, dim3 g, hipStream_t s, const bf16_t* x, const bf16_t* gamma, const bf16_t* beta,
                   const bf16_t* resid, bf16_t* y, float* mean, float* rstd, int rows, int C, float eps, RowMap mx,
-                  RowMap my, RowMap mr) {
-  if (gelu) hipLaunchKernelGGL((ln_fwd_kernel<NCH, true>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr);
-  else hipLaunchKernelGGL((ln_fwd_kernel<NCH, false>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr);
+                  RowMap my, RowMap mr, DropArgs dr) {
+  if (gelu) hipLaunchKernelGGL((ln_fwd_kernel<NCH, true>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr, dr);
+  else hipLaunchKernelGGL((ln_fwd_kernel<NCH, false>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr, dr);
   return 0;
 }
 template <int NCH, int WPR>
 int launch_ln_bwd(bool gelu, dim3 g, hipStream_t s, const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
                   const float* mean, const float* rstd, const bf16_t* add, bf16_t* dx, float* dgp, float* dbp, int rows,
-                  int C, RowMap mdy, RowMap mx, RowMap mdx, RowMap madd) {
-  if (gelu) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, WPR>), g, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgp, dbp, rows, C, mdy, mx, mdx, madd);
-  else hipLaunchKernelGGL((ln_bwd_kernel<NCH, false, WPR>), g, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgp, dbp, rows, C, mdy, mx, mdx, madd);
+                  int C, RowMap mdy, RowMap mx, RowMap mdx, RowMap madd, DropArgs dr) {
+  if (gelu) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, WPR>), g, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgp, dbp, rows, C, mdy, mx, mdx, madd, dr);
+  else hipLaunchKernelGGL((ln_bwd_kernel<NCH, false, WPR>), g, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgp, dbp, rows, C, mdy, mx, mdx, madd, dr);
   return 0;
 }
 
@@ -393,18 +424,24 @@ int launch_ln_bwd(bool gelu, dim3 g, hipStream_t s, const bf16_t* dy, const bf16
 
 extern "C" int ifseg_ln_fwd(const void* x, const void* gamma, const void* beta, const void* resid, void* y,
                             float* mean, float* rstd, int rows, int C, float eps, int act_gelu, int rpb,
-                            long long x_bs, int ldx, long long y_bs, int ldy, long long r_bs, int ldr, void* stream) {
+                            long long x_bs, int ldx, long long y_bs, int ldy, long long r_bs, int ldr,
+                            const ifseg_drop_args* drop, void* stream) {
   (void)hipGetLastError();
   if (rows <= 0) return 0;
   if ((C & 7) || C > 4096 || (ldx & 7) || (ldy & 7) || (resid && (ldr & 7))) return IFSEG_ERR_BAD_SHAPE;
+  DropArgs dr{};
+  if (drop) {
+    if (drop->p < 0.f || drop->p >= 1.f || drop->rows_per_batch <= 0) return IFSEG_ERR_BAD_ARG;
+    dr = DropArgs{1, drop->p, drop->seed, drop->drop_path_scale, drop->rows_per_batch};
+  }
   RowMap mx{rpb, x_bs, ldx}, my{rpb, y_bs, ldy}, mr{rpb, r_bs, ldr};
   dim3 g((rows + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
   const bf16_t *X = (const bf16_t*)x, *G = (const bf16_t*)gamma, *Bt = (const bf16_t*)beta, *R = (const bf16_t*)resid;
   ifseg_prof_begin(IFSEG_K_LN_FWD, s, 0, (double)rows * C * (resid ? 6.0 : 4.0));
-  if (C <= 1024) launch_ln_fwd<2>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr);
-  else if (C <= 3072) launch_ln_fwd<6>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr);
-  else launch_ln_fwd<8>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr);
+  if (C <= 1024) launch_ln_fwd<2>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr, dr);
+  else if (C <= 3072) launch_ln_fwd<6>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr, dr);
+  else launch_ln_fwd<8>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr, dr);
   ifseg_prof_end(IFSEG_K_LN_FWD, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
@@ -413,17 +450,23 @@ extern "C" int ifseg_ln_fwd(const void* x, const void* gamma, const void* beta, 
 extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
                             const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, int nblocks,
                             int rows, int C, int act_gelu, int rpb, long long dy_bs, int lddy, long long x_bs,
-                            int ldx, long long dx_bs, int lddx, long long add_bs, int ldadd, void* stream) {
+                            int ldx, long long dx_bs, int lddx, long long add_bs, int ldadd,
+                            const ifseg_drop_args* drop, void* stream) {
   (void)hipGetLastError();
   if (rows <= 0) return 0;
   if ((C & 7) || C > 4096 || nblocks <= 0) return IFSEG_ERR_BAD_SHAPE;
+  DropArgs dr{};
+  if (drop) {
+    if (drop->p < 0.f || drop->p >= 1.f || drop->rows_per_batch <= 0) return IFSEG_ERR_BAD_ARG;
+    dr = DropArgs{1, drop->p, drop->seed, drop->drop_path_scale, drop->rows_per_batch};
+  }
   RowMap mdy{rpb, dy_bs, lddy}, mx{rpb, x_bs, ldx}, mdx{rpb, dx_bs, lddx}, madd{rpb, add_bs, ldadd};
   dim3 g(nblocks);
   hipStream_t s = (hipStream_t)stream;
   const bf16_t *DY = (const bf16_t*)dy, *X = (const bf16_t*)x, *G = (const bf16_t*)gamma, *A = (const bf16_t*)dx_add;
   ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 8.0 : 6.0));
-  if (C <= 1024) launch_ln_bwd<2, 1>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd);
-  else launch_ln_bwd<2, 4>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd);
+  if (C <= 1024) launch_ln_bwd<2, 1>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd, dr);
+  else launch_ln_bwd<2, 4>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd, dr);
   ifseg_prof_end(IFSEG_K_LN_BWD, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
@@ -539,19 +582,9 @@ extern "C" int ifseg_rel_scatter_add(const float* d, const int* idx, float* acc,
   return 0;
 }
 
-// ---- dropout + DropPath (training-time stochastic regularisers) -------------------------------
-// out = [resid +] dpscale[b] * keep(i) * x / (1 - p), keep(i) ~ Bernoulli(1 - p) from a counter-based
-// hash of (seed, element index): the backward re-generates the same mask (same call with x = dy,
-// resid = NULL), nothing is stored.  Reference: FairseqDropout (fairseq_dropout.py:23-27) after the
-// embedding LayerNorms, attn_ln / cross_attn_ln and fc2, and drop_path (unify_transformer_layer.py:19-35)
-// inside residual_connection (:196).  The RNG stream necessarily differs from torch's.
+// stand-alone dropout + DropPath: out = [resid +] dpscale[b] * keep(i) * x / (1 - p)  (mask: drop8 above;
+// the backward is the same call with x = dy, resid = NULL)
 namespace {
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
 __global__ void dropout_kernel(const bf16_t* x, const bf16_t* resid, bf16_t* out, long long nchunks, int C, float p,
                                unsigned long long seed, const float* dpscale, int rows_per_batch, RowMap mx, RowMap mr,
                                RowMap mo) {
@@ -559,16 +592,9 @@ __global__ void dropout_kernel(const bf16_t* x, const bf16_t* resid, bf16_t* out
   if (c8 >= nchunks) return;
   const int nch = C >> 3;
   const int row = (int)(c8 / nch), col = (int)(c8 % nch) * 8;
-  const float sc = (dpscale ? dpscale[row / rows_per_batch] : 1.f) * (p > 0.f ? 1.f / (1.f - p) : 1.f);
-  const unsigned thr = (unsigned)(p * 65536.f);
-  const unsigned long long r0 = splitmix64(seed + 2ull * (unsigned long long)c8), r1 = splitmix64(seed + 2ull * (unsigned long long)c8 + 1ull);
   float f[8];
   unpack8(*reinterpret_cast<const uint4*>(x + mx.off(row) + col), f);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const unsigned bits = (unsigned)(((e < 4 ? r0 : r1) >> (16 * (e & 3))) & 0xFFFFu);
-    f[e] = bits >= thr ? f[e] * sc : 0.f;
-  }
+  drop8(f, DropArgs{1, p, seed, dpscale, rows_per_batch}, c8, row);
   if (resid) {
     float r[8];
     unpack8(*reinterpret_cast<const uint4*>(resid + mr.off(row) + col), r);

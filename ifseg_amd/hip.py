@@ -33,7 +33,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 2:
+        if _lib.ifseg_abi_version() != 3:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -232,8 +232,21 @@ def _map(t, rpb):
     return 0, t.stride(0)
 
 
-def ln_fwd(x, gamma, beta, y, mean=None, rstd=None, resid=None, gelu=False, eps=1e-5):
-    """x, y, resid: [rows, C] or [B, rpb, C] (strided views allowed, last dim contiguous)."""
+class _DropArgs(ctypes.Structure):
+    _fields_ = [("p", c_float), ("seed", ctypes.c_ulonglong), ("drop_path_scale", c_void_p), ("rows_per_batch", c_int)]
+
+
+def _drop_ref(drop, rows):
+    """drop = (p, seed, drop_path_scale tensor or None, rows_per_batch or None) -> byref(ifseg_drop_args) / None"""
+    if drop is None:
+        return None
+    p, seed, dps, rpb = drop
+    return ctypes.byref(_DropArgs(p, seed & 0xFFFFFFFFFFFFFFFF, dps.data_ptr() if dps is not None else None, rpb or rows))
+
+
+def ln_fwd(x, gamma, beta, y, mean=None, rstd=None, resid=None, gelu=False, eps=1e-5, drop=None):
+    """x, y, resid: [rows, C] or [B, rpb, C] (strided views allowed, last dim contiguous).
+    drop: fused dropout/DropPath of the normalised output before the residual add (see _drop_ref)."""
     C = x.shape[-1]
     rows = x.numel() // C
     rpb = x.shape[1] if x.dim() == 3 else 0
@@ -242,7 +255,7 @@ def ln_fwd(x, gamma, beta, y, mean=None, rstd=None, resid=None, gelu=False, eps=
     rb, rl = _map(resid, rpb)
     rc = lib().ifseg_ln_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(resid), _ptr(y), _ptr(mean), _ptr(rstd),
                             c_int(rows), c_int(C), c_float(eps), c_int(1 if gelu else 0), c_int(rpb), c_ll(xb),
-                            c_int(xl), c_ll(yb), c_int(yl), c_ll(rb), c_int(rl), _stream())
+                            c_int(xl), c_ll(yb), c_int(yl), c_ll(rb), c_int(rl), _drop_ref(drop, rpb or rows), _stream())
     _check(rc, "ln_fwd")
     return y
 
@@ -250,7 +263,7 @@ def ln_fwd(x, gamma, beta, y, mean=None, rstd=None, resid=None, gelu=False, eps=
 LN_BWD_BLOCKS = 768   # three resident blocks per CU (146-162 VGPRs): best of a 256..2048 sweep on MI355X
 
 
-def ln_bwd(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx_add=None, gelu=False):
+def ln_bwd(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx_add=None, gelu=False, drop=None):
     C = x.shape[-1]
     rows = x.numel() // C
     rpb = x.shape[1] if x.dim() == 3 else 0
@@ -261,7 +274,7 @@ def ln_bwd(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx_add=None, g
     rc = lib().ifseg_ln_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx_add), _ptr(dx),
                             _ptr(dgamma_part), _ptr(dbeta_part), c_int(LN_BWD_BLOCKS), c_int(rows), c_int(C),
                             c_int(1 if gelu else 0), c_int(rpb), c_ll(db_), c_int(dl), c_ll(xb), c_int(xl), c_ll(ob),
-                            c_int(ol), c_ll(ab), c_int(al), _stream())
+                            c_int(ol), c_ll(ab), c_int(al), _drop_ref(drop, rpb or rows), _stream())
     _check(rc, "ln_bwd")
     return dx
 

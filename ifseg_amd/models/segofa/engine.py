@@ -462,6 +462,12 @@ class HipEngine:
         hip.dropout(x, resid, out, self.cfg.dropout, self._site_seed(site), dp, rows_per_batch)
         return out
 
+    def _dropargs(self, site, dp=None, rows_per_batch=None):
+        """operand of the dropout fused into ln_fwd / ln_bwd (same mask as `_drop` at that site), or None"""
+        if not self.drop_on:
+            return None
+        return (self.cfg.dropout, self._site_seed(site), dp, rows_per_batch)
+
     def _ln_stats(self, tag, rows):
         return self.buf(tag + "_mu", (rows,), torch.float32), self.buf(tag + "_rs", (rows,), torch.float32)
 
@@ -527,20 +533,14 @@ class HipEngine:
         hip.linear_fwd(feat.view(B * P, 1024), W(e + "image_proj.weight"), bias_img, out=img_pre)
         x = buf("e_x_in", (B, T, C))
         mu, rs = self._ln_stats("img_ln", B * P)
-        ydst = buf("img_ln_y", (B, P, C)) if self.drop_on else x[:, :P]
         hip.ln_fwd(img_pre.view(B, P, C), W(e + "patch_layernorm_embedding.weight"),
-                   W(e + "patch_layernorm_embedding.bias"), ydst, mu, rs)
-        if self.drop_on:
-            self._drop(ydst, None, x[:, :P], 1)
+                   W(e + "patch_layernorm_embedding.bias"), x[:, :P], mu, rs, drop=self._dropargs(1))
         tok_pre = buf("tok_pre", (B * L, C))
         hip.embed_rows(W(e + "embed_tokens.weight"), src_tokens.reshape(-1).contiguous(),
                        W(e + "type_embedding.weight")[0], tok_pre)
         mu, rs = self._ln_stats("tok_ln", B * L)
-        ydst = buf("tok_ln_y", (B, L, C)) if self.drop_on else x[:, P:]
         hip.ln_fwd(tok_pre.view(B, L, C), W(e + "layernorm_embedding.weight"), W(e + "layernorm_embedding.bias"),
-                   ydst, mu, rs)
-        if self.drop_on:
-            self._drop(ydst, None, x[:, P:], 2)
+                   x[:, P:], mu, rs, drop=self._dropargs(2))
         # ---- abs-pos operands (encoder_module.py:757-771): LN over the table rows in place
         bsz = cfg.image_bucket_size
         img_pos_view = W(e + "embed_image_positions.weight")[1:1 + bsz * h].view(h, bsz, C)[:, :w]
@@ -579,15 +579,11 @@ class HipEngine:
         hip.embed_rows(W(e + "embed_tokens.weight"), bos.reshape(-1).contiguous(), None, y0b)
         y = buf("d_y_in", (B, Td, C))
         mu, rs = self._ln_stats("d_emb_ln_p", B * P)
-        ydst = buf("d_emb_y", (B, P, C)) if self.drop_on else y[:, :P]
-        hip.ln_fwd(enc_out[:, :P], W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), ydst, mu, rs)
-        if self.drop_on:
-            self._drop(ydst, None, y[:, :P], 3)
+        hip.ln_fwd(enc_out[:, :P], W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), y[:, :P],
+                   mu, rs, drop=self._dropargs(3))
         mu, rs = self._ln_stats("d_emb_ln_b", B)
-        ydst = buf("d_emb_yb", (B, 1, C)) if self.drop_on else y[:, P:]
-        hip.ln_fwd(y0b, W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), ydst, mu, rs)
-        if self.drop_on:
-            self._drop(ydst, None, y[:, P:], 4)
+        hip.ln_fwd(y0b, W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), y[:, P:], mu, rs,
+                   drop=self._dropargs(4))
         # positions: internal order [grid cells 1..P | slot 0]
         sb = cfg.seg_bucket_size
         segtab = W(d + "embed_seg_positions.weight")
@@ -772,12 +768,9 @@ class HipEngine:
         hip.linear_fwd(o.view(B * T, C), W(a_ + ".out_proj.weight"), W(a_ + ".out_proj.bias"), out=a)
         x1 = buf(tg + "_x1", (B, T, C))
         mu, rs = self._ln_stats(tg + "_ln2", B * T)
-        if self.drop_on and site is not None:
-            t = buf("drop_tmp_%d" % (B * T), (B * T, C))
-            hip.ln_fwd(a, W(p + ln2 + ".weight"), W(p + ln2 + ".bias"), t, mu, rs)
-            self._drop(t, x.view(B * T, C), x1.view(B * T, C), self._site_id(site), self._dp(*site), T)
-        else:
-            hip.ln_fwd(a, W(p + ln2 + ".weight"), W(p + ln2 + ".bias"), x1.view(B * T, C), mu, rs, resid=x.view(B * T, C))
+        drop = self._dropargs(self._site_id(site), self._dp(*site), T) if (self.drop_on and site is not None) else None
+        hip.ln_fwd(a, W(p + ln2 + ".weight"), W(p + ln2 + ".bias"), x1.view(B * T, C), mu, rs, resid=x.view(B * T, C),
+                   drop=drop)
         self._save(tg + "_sa", x=x, xn=xn, qkv=qkv, o=o, lse=lse, a=a, rel=rel, gain=gain, causal=causal, site=site)
         return x1
 
@@ -801,13 +794,9 @@ class HipEngine:
         hip.linear_fwd(o.view(B * Td, C), W(a_ + ".out_proj.weight"), W(a_ + ".out_proj.bias"), out=a)
         y2 = buf(tg + "_y2", (B, Td, C))
         mu, rs = self._ln_stats(tg + "_cln2", B * Td)
-        if self.drop_on and site is not None:
-            t = buf("drop_tmp_%d" % (B * Td), (B * Td, C))
-            hip.ln_fwd(a, W(p + "cross_attn_ln.weight"), W(p + "cross_attn_ln.bias"), t, mu, rs)
-            self._drop(t, y1.view(B * Td, C), y2.view(B * Td, C), self._site_id(site), self._dp(*site), Td)
-        else:
-            hip.ln_fwd(a, W(p + "cross_attn_ln.weight"), W(p + "cross_attn_ln.bias"), y2.view(B * Td, C), mu, rs,
-                       resid=y1.view(B * Td, C))
+        drop = self._dropargs(self._site_id(site), self._dp(*site), Td) if (self.drop_on and site is not None) else None
+        hip.ln_fwd(a, W(p + "cross_attn_ln.weight"), W(p + "cross_attn_ln.bias"), y2.view(B * Td, C), mu, rs,
+                   resid=y1.view(B * Td, C), drop=drop)
         self._save(tg + "_ca", x=y1, xn=yn, q=q, kv=kv, o=o, lse=lse, a=a, gain=gain, site=site)
         return y2
 
@@ -838,7 +827,7 @@ class HipEngine:
         self.saved[key] = kw
 
     # ---------------------------------------------------------------- backward
-    def _ln_bwd(self, dy, x, pname, stats_tag, dx, dx_add=None, gelu=False, accumulate=False):
+    def _ln_bwd(self, dy, x, pname, stats_tag, dx, dx_add=None, gelu=False, accumulate=False, drop=None):
         C = x.shape[-1]
         rows = x.numel() // C
         mu, rs = self._ln_stats(stats_tag, rows)
@@ -846,7 +835,7 @@ class HipEngine:
         # runs on the side stream)
         part = self.buf("ln_dgbp_%d@%s" % (C, stats_tag) if self.overlap else "ln_dgbp_%d" % C,
                         (2, hip.LN_BWD_BLOCKS, C), torch.float32)
-        hip.ln_bwd(dy, x, self.W(pname + ".weight"), mu, rs, dx, part[0], part[1], dx_add=dx_add, gelu=gelu)
+        hip.ln_bwd(dy, x, self.W(pname + ".weight"), mu, rs, dx, part[0], part[1], dx_add=dx_add, gelu=gelu, drop=drop)
         with self._wgrad():
             # weight and bias of a LayerNorm are adjacent in the arena: one [2, C] reduction
             hip.reduce_parts(part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C,
@@ -939,10 +928,10 @@ class HipEngine:
         self._bt = tg + "s"
         gbuf = self.gbuf
         da = gbuf("g_da_%d" % rows, (rows, C))
-        dbr = dx1
-        if self.drop_on and s["site"] is not None:
-            dbr = self._drop(dx1, None, buf("g_drop_%d" % rows, (rows, C)), self._site_id(s["site"]), self._dp(*s["site"]), T)
-        self._ln_bwd(dbr, s["a"], p + ln2, tg + "_ln2", da)
+        drop = None
+        if self.drop_on and s["site"] is not None:       # adjoint of the dropout fused into the forward LN
+            drop = self._dropargs(self._site_id(s["site"]), self._dp(*s["site"]), T)
+        self._ln_bwd(dx1, s["a"], p + ln2, tg + "_ln2", da, drop=drop)
         do = buf("g_do_%d" % rows, (B, T, C))
         self._linear_bwd(da, s["o"].view(rows, C), W(a_ + ".out_proj.weight"), G(a_ + ".out_proj.weight"),
                          G(a_ + ".out_proj.bias"), dx_out=do.view(rows, C))
@@ -968,10 +957,10 @@ class HipEngine:
         self._bt = tg + "c"
         gbuf = self.gbuf
         da = gbuf("g_da_%d" % rows, (rows, C))
-        dbr = dy2
+        drop = None
         if self.drop_on and s["site"] is not None:
-            dbr = self._drop(dy2, None, buf("g_drop_%d" % rows, (rows, C)), self._site_id(s["site"]), self._dp(*s["site"]), Td)
-        self._ln_bwd(dbr, s["a"], p + "cross_attn_ln", tg + "_cln2", da)
+            drop = self._dropargs(self._site_id(s["site"]), self._dp(*s["site"]), Td)
+        self._ln_bwd(dy2, s["a"], p + "cross_attn_ln", tg + "_cln2", da, drop=drop)
         do = buf("g_do_%d" % rows, (B, Td, C))
         self._linear_bwd(da, s["o"].view(rows, C), W(a_ + ".out_proj.weight"), G(a_ + ".out_proj.weight"),
                          G(a_ + ".out_proj.bias"), dx_out=do.view(rows, C))
@@ -1039,13 +1028,11 @@ class HipEngine:
         dy3 = dy.view(B, Td, C)
         enc_out = ctx["enc_out"]
         dyp, dyb = dy3[:, :P], dy3[:, P:]
-        if self.drop_on:
-            dyp = self._drop(dy3[:, :P], None, buf("g_drop_dp", (B, P, C)), 3)
-            dyb = self._drop(dy3[:, P:], None, buf("g_drop_db", (B, 1, C)), 4)
         self._ln_bwd(dyp, enc_out[:, :P], d + "layernorm_embedding", "d_emb_ln_p", d_enc_out[:, :P],
-                     dx_add=d_enc_out[:, :P])
+                     dx_add=d_enc_out[:, :P], drop=self._dropargs(3))
         scratch = buf("g_bos_scratch", (B, 1, C))
-        self._ln_bwd(dyb, self.ws["d_bos"], d + "layernorm_embedding", "d_emb_ln_b", scratch, accumulate=True)
+        self._ln_bwd(dyb, self.ws["d_bos"], d + "layernorm_embedding", "d_emb_ln_b", scratch, accumulate=True,
+                     drop=self._dropargs(4))
         # ---- decoder position operands
         dspqk = buf("g_dspqk", (Td, 2 * C))
         hip.cast_f32_bf16(dspq, buf("g_tmp_tc", (Td, C)))
@@ -1109,13 +1096,12 @@ class HipEngine:
         # ---- encoder embeddings (embed_tokens / image_proj / ResNet frozen -> stop here)
         dx3 = dx.view(B, T, C)
         dxi, dxt = dx3[:, :P], dx3[:, P:]
-        if self.drop_on:
-            dxi = self._drop(dx3[:, :P], None, buf("g_drop_ei", (B, P, C)), 1)
-            dxt = self._drop(dx3[:, P:], None, buf("g_drop_et", (B, L, C)), 2)
         dimg = buf("g_dimg_pre", (B, P, C))
-        self._ln_bwd(dxi, self.ws["img_pre"].view(B, P, C), e + "patch_layernorm_embedding", "img_ln", dimg)
+        self._ln_bwd(dxi, self.ws["img_pre"].view(B, P, C), e + "patch_layernorm_embedding", "img_ln", dimg,
+                     drop=self._dropargs(1))
         dtok = buf("g_dtok_pre", (B, L, C))
-        self._ln_bwd(dxt, self.ws["tok_pre"].view(B, L, C), e + "layernorm_embedding", "tok_ln", dtok)
+        self._ln_bwd(dxt, self.ws["tok_pre"].view(B, L, C), e + "layernorm_embedding", "tok_ln", dtok,
+                     drop=self._dropargs(2))
         gt = G(e + "type_embedding.weight")
         with self._wgrad():
             self._bias_grad(dtok.view(B * L, C), gt[0])

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 2
+#define IFSEG_ABI_VERSION 3
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -130,15 +130,26 @@ int ifseg_attn_bwd(const ifseg_attn_bwd_args* args, void* stream);
  * unify_transformer_layer.py:258,270,278,282,465,513,522,546,554,559 and
  * encoder_module.py:408,423,757-759,829 / decoder_module.py:344,576,668, fused with
  * activation_fn GELU (modules/gelu.py:24-25) and residual_connection (:196). */
+/* Optional fused dropout + DropPath of the LayerNorm output (forward) / of dy (backward): the mask is the one
+ * ifseg_dropout generates for the same (seed, logical row, column), so stand-alone and fused calls can be mixed
+ * (FairseqDropout after attn_ln / cross_attn_ln / the embedding LayerNorms, drop_path in residual_connection:
+ * unify_transformer_layer.py:19-35,196).  NULL = no dropout. */
+typedef struct ifseg_drop_args {
+  float p;                       /* drop probability in [0, 1) */
+  unsigned long long seed;
+  const float* drop_path_scale;  /* [batch] fp32 keep/(1-rate) per sample, or NULL */
+  int rows_per_batch;            /* logical rows per sample (indexes drop_path_scale) */
+} ifseg_drop_args;
 int ifseg_ln_fwd(const void* x, const void* gamma, const void* beta, const void* resid, void* y, float* mean,
                  float* rstd, int rows, int C, float eps, int act_gelu, int rpb, long long x_bs, int ldx,
-                 long long y_bs, int ldy, long long r_bs, int ldr, void* stream);
-/* dx = [dx_add +] d/dx of the above; per-block partials of dgamma / dbeta are
- * written to dgamma_part / dbeta_part [nblocks][C] (sum with ifseg_reduce_parts). */
+                 long long y_bs, int ldy, long long r_bs, int ldr, const ifseg_drop_args* drop, void* stream);
+/* dx = [dx_add +] d/dx of the above (dy is first masked like the forward output when `drop` is given);
+ * per-block partials of dgamma / dbeta are written to dgamma_part / dbeta_part [nblocks][C]
+ * (sum with ifseg_reduce_parts). */
 int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
                  const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, int nblocks, int rows,
                  int C, int act_gelu, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx,
-                 long long dx_bs, int lddx, long long add_bs, int ldadd, void* stream);
+                 long long dx_bs, int lddx, long long add_bs, int ldadd, const ifseg_drop_args* drop, void* stream);
 /* out[o][i] (+)= scale * sum_p in[o][p][i]   (fp32 in; fp32 or bf16 out) */
 int ifseg_reduce_parts(const float* in, void* out, int outer, int parts, long long n, int accumulate,
                        int out_bf16, float scale, void* stream);

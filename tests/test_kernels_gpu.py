@@ -492,3 +492,37 @@ def test_dropout_kernel():
     hip.dropout(x.view(B, T, C), None, big[:, 3:3 + T], p, 1234)
     assert _rel(big[:, 3:3 + T], x.view(B, T, C).float() * m1.view(B, T, C).float()) < 6e-3
     assert big[:, :3].abs().sum() == 0
+
+
+@pytest.mark.parametrize("C,gelu", [(768, False), (3072, True)])
+def test_ln_fused_dropout_matches_standalone_mask(C, gelu):
+    """ifseg_ln_fwd / ifseg_ln_bwd with ifseg_drop_args: same mask as ifseg_dropout at the same (seed, row, col);
+    forward = resid + drop(LN(x)), backward = LN'(drop(dy))."""
+    from ifseg_amd import hip
+    dev = _dev()
+    B, T, p, seed = 3, 257, 0.1, 987654321
+    rows = B * T
+    x, res, dy = _rand((rows, C), dev, 70), _rand((rows, C), dev, 71), _rand((rows, C), dev, 72)
+    g, b = _rand((C,), dev, 73, 0.2) + 1, _rand((C,), dev, 74, 0.2)
+    dp = torch.tensor([1 / 0.8, 0.0, 1 / 0.8], device=dev)
+    mu, rs = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    # un-fused chain
+    t = torch.empty_like(x); ref = torch.empty_like(x)
+    hip.ln_fwd(x, g, b, t, mu, rs, gelu=gelu)
+    hip.dropout(t, res, ref, p, seed, dp, T)
+    out = torch.empty_like(x)
+    hip.ln_fwd(x, g, b, out, mu, rs, resid=res, gelu=gelu, drop=(p, seed, dp, T))
+    assert _rel(out, ref) < 6e-3
+    dropped_ref = (ref.float() - res.float()) == 0
+    dropped = (out.float() - res.float()) == 0
+    assert (dropped_ref != dropped).float().mean().item() < 2e-3      # identical mask (up to exact-zero LN outputs)
+    assert 0.35 < dropped.float().mean().item() < 0.45                 # p = 0.1 and one of three samples path-dropped
+    # backward
+    nb = hip.LN_BWD_BLOCKS
+    part = torch.empty(2, nb, C, device=dev); part2 = torch.empty(2, nb, C, device=dev)
+    dym = torch.empty_like(dy); dx_ref = torch.empty_like(x); dx = torch.empty_like(x)
+    hip.dropout(dy, None, dym, p, seed, dp, T)
+    hip.ln_bwd(dym, x, g, mu, rs, dx_ref, part[0], part[1], gelu=gelu)
+    hip.ln_bwd(dy, x, g, mu, rs, dx, part2[0], part2[1], gelu=gelu, drop=(p, seed, dp, T))
+    assert _rel(dx, dx_ref) < 8e-3
+    assert _rel(part2.sum(1), part.sum(1)) < 8e-3
