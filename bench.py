@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--drop-path", type=float, default=0.1, help="encoder/decoder drop-path rate (coco_unseen.sh:20-21)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="run the frozen trunk in line instead of one batch ahead")
+    ap.add_argument("--image-free", action="store_true",
+                    help="the recipe's image-free step (SURVEY 8f row 1, coco_unseen.sh:51): loss on an artificial image "
+                         "(EmbeddingBag patches, no trunk) + a no-grad pass over the real images for the metrics")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,7 +89,7 @@ def main():
     task = SegmentationTask(num_seg_tokens=a.nseg, patch_image_size=512, arch="segofa_base")
     model = task.build_model()
     model.cfg.dropout, model.cfg.encoder_drop_path_rate, model.cfg.decoder_drop_path_rate = a.dropout, a.drop_path, a.drop_path
-    crit = SegCriterion(task)
+    crit = SegCriterion(task, unsupervised_segmentation=a.image_free)
     trainer = Trainer(model, crit, task, device=dev)
     # two different synthetic batches, alternated: batch i+1 is handed to the trainer as `prefetch` (what a data
     # iterator holds one step ahead), so its frozen-trunk pass runs underneath step i on a second stream
@@ -94,6 +97,8 @@ def main():
     for j in range(2):
         sm = task.synthetic_sample(a.batch, dev, seed=1234 + rank + 7919 * j)
         sm["net_input"]["patch_images"] = sm["net_input"]["patch_images"].to(torch.bfloat16)
+        if a.image_free:
+            sm.update(task.synthetic_aux_sample(a.batch, dev, seed=4321 + rank + 7919 * j))
         ring.append(sm)
     sample = ring[0]
     step_no = [0]
@@ -137,7 +142,7 @@ def main():
             "metric": "images/sec (512x512, SegOFA-Base fwd+bwd)", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: SegOFA-Base bf16, batch %d/GPU, 512x512, %d classes (L=%d), "
+            "config": {"workload": ("IMAGE-FREE step (not the headline config) -- " if a.image_free else "") + "BASELINE configs[1]: SegOFA-Base bf16, batch %d/GPU, 512x512, %d classes (L=%d), "
                                    "frozen ResNet-101 trunk%s, dropout %.2f / drop-path %.2f; step = fwd + upsample/CE loss + bwd + clip + Adam"
                                    % (a.batch, a.nseg, task.src_len,
                                       "" if a.no_prefetch else " (run one batch ahead on a second stream; two alternating batches)",

@@ -74,11 +74,21 @@ class SegCriterion:
         """seg_criterion.py:165-235 (supervised train branch / eval branch)."""
         self.iter += 1
         if self.unsupervised_segmentation and model.training:
-            raise NotImplementedError("image-free training branch (seg_criterion.py:179-186): SURVEY 8f row 1")
-        net_output = model(**sample["net_input"], full_context_alignment=self.full_context_alignment)
-        loss, metrics, ntokens = self.compute_loss(model, net_output, sample, update_num, reduce=reduce)
+            # image-free training (seg_criterion.py:179-186): the loss comes from the artificial image; the real
+            # images are only evaluated (no grad) for the logged metrics
+            net_output = model(full_context_alignment=self.full_context_alignment, aux_input=sample["aux_input"])
+            imfree_loss = self.compute_imfree_loss(model, net_output[1]["aux_output"], sample, update_num, reduce=reduce)
+            loss = imfree_loss
+            with torch.no_grad():
+                seg_output = model(**sample["net_input"], full_context_alignment=self.full_context_alignment)
+                seg_loss, metrics, ntokens = self.compute_loss(model, seg_output, sample, update_num, reduce=reduce,
+                                                               bufs_name="_bufs_metrics")
+        else:
+            net_output = model(**sample["net_input"], full_context_alignment=self.full_context_alignment)
+            seg_loss, metrics, ntokens = self.compute_loss(model, net_output, sample, update_num, reduce=reduce)
+            loss, imfree_loss = seg_loss, seg_loss.data.new_zeros(1)
         sample_size = ntokens
-        logging_output = {"loss": loss.data, "imfree_loss": loss.data.new_zeros(1), "seg_loss": loss.data,
+        logging_output = {"loss": loss.data, "imfree_loss": imfree_loss.data, "seg_loss": seg_loss.data,
                           "ntokens": sample["ntokens"], "nsentences": sample["nsentences"],
                           "sample_size": sample_size}
         logging_output.update({k: (v.data if isinstance(v, torch.Tensor) else v) for k, v in metrics.items()})
@@ -94,7 +104,28 @@ class SegCriterion:
         lo = lo.reshape(B, n, h * w).transpose(1, 2)
         return torch.cat([lo, logits[:, -1:]], dim=1)
 
-    def compute_loss(self, model, net_output, sample, update_num, reduce=True):
+    def compute_imfree_loss(self, model, net_output, sample, update_num, reduce=True):
+        """seg_criterion.py:246-267: CE of the bilinear-upsampled (32x32 -> 512x512 in the reference; here the
+        model's grid x16) logits of the artificial image against ``text2seg_target``; eos / pad / ignore dropped."""
+        scores_low, extra = net_output
+        target = sample["text2seg_target"]
+        hp, wp = extra["encoder_returns"]["image_embed_shape"][0]
+        h, w = 16 * hp, 16 * wp
+        pad = extra.get("logits_padded")
+        if (pad is not None and self.eps == 0.0 and self.num_seg <= 192 and target.shape[1] == h * w + 1):
+            if not hasattr(self, "_bufs_imfree"):
+                self._bufs_imfree = {}
+            loss, _ = _FusedSegLossFn.apply(scores_low, pad, target.contiguous(), hp, wp, h, w, self.num_seg,
+                                            self.seg_id_offset, self._bufs_imfree)
+            return loss
+        scores = self.upsample_logits(scores_low.float(), hp, wp, h, w)[:, :-1]
+        tgt = target[:, :-1]
+        scores = scores.reshape(-1, scores.shape[-1])
+        tgt = tgt.reshape(-1)
+        mask = (tgt != self.padding_idx) & (tgt != self.seg_id_offset + self.num_seg)
+        return F.cross_entropy(scores[mask], tgt[mask] - self.seg_id_offset, label_smoothing=self.eps)
+
+    def compute_loss(self, model, net_output, sample, update_num, reduce=True, bufs_name="_bufs"):
         scores_low, extra = net_output
         target = sample["target"]
         hp, wp = extra["encoder_returns"]["image_embed_shape"][0]
@@ -102,10 +133,10 @@ class SegCriterion:
         pad = extra.get("logits_padded")
         if (pad is not None and self.eps == 0.0 and self.upscale_lprobs and h == 16 * hp and w == 16 * wp
                 and self.num_seg <= 192 and target.shape[1] == h * w + 1):
-            if not hasattr(self, "_bufs"):
-                self._bufs = {}
+            if not hasattr(self, bufs_name):
+                setattr(self, bufs_name, {})
             loss, stats = _FusedSegLossFn.apply(scores_low, pad, target.contiguous(), hp, wp, h, w, self.num_seg,
-                                                self.seg_id_offset, self._bufs)
+                                                self.seg_id_offset, getattr(self, bufs_name))
             n = self.num_seg
             ai, ap, al = stats[2:2 + n], stats[2 + n:2 + 2 * n], stats[2 + 2 * n:2 + 3 * n]
             metrics = {"area_intersect": ai, "area_pred_label": ap, "area_label": al, "area_union": ap + al - ai,

@@ -517,6 +517,50 @@ extern "C" int ifseg_embed_rows(const void* table, const long long* ids, const v
   return 0;
 }
 
+// Image-free patch embeddings: out[b, p, :] = mean_{t in bag(b,p)} table[ids[b, t], :] + add[:]
+// (nn.EmbeddingBag(mode='mean') over the token table, encoder_module.py:147-148,529-538, followed by the
+// type embedding of the image segment :589-591).  Bags are described the way the collater ships them:
+// ids [B, maxlen] (padded at the end of each row), ends [B, P] = per-sample cumulative bag ends, so bag
+// (b, p) = ids[b, ends[b,p-1] : ends[b,p]] -- no pad stripping, no host sync.  Empty bag -> add only.
+namespace {
+__global__ void embed_bag_mean_kernel(const bf16_t* table, const long long* ids, const long long* ends, const bf16_t* add,
+                                      bf16_t* out, int B, int P, int C, int maxlen, RowMap mo) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nch = C >> 3;
+  if (gid >= (long long)B * P * nch) return;
+  const int c = (int)(gid % nch) * 8;
+  const int bag = (int)(gid / nch), b = bag / P, p = bag - b * P;
+  const long long lo = p ? ends[(long long)b * P + p - 1] : 0, hi = ends[(long long)b * P + p];
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long long t = lo; t < hi && t < maxlen; ++t) {
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(table + ids[(long long)b * maxlen + t] * C + c), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += f[e];
+  }
+  const float inv = hi > lo ? 1.f / (float)(hi - lo) : 0.f;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (add) unpack8(*reinterpret_cast<const uint4*>(add + c), a);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = acc[e] * inv + a[e];
+  *reinterpret_cast<uint4*>(out + mo.off(bag) + c) = pack8(acc);
+}
+}  // namespace
+
+extern "C" int ifseg_embed_bag_mean(const void* table, const long long* ids, const long long* ends, const void* add,
+                                    void* out, int B, int P, int C, int maxlen, int rpb, long long o_bs, int ldo,
+                                    void* stream) {
+  (void)hipGetLastError();
+  if (B <= 0 || P <= 0) return 0;
+  if ((C & 7) || maxlen <= 0) return IFSEG_ERR_BAD_SHAPE;
+  RowMap mo{rpb, o_bs, ldo};
+  const long long total = (long long)B * P * (C / 8);
+  hipLaunchKernelGGL(embed_bag_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)table, ids, ends, (const bf16_t*)add, (bf16_t*)out, B, P, C, maxlen, mo);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int ifseg_cast_f32_bf16(const float* in, void* out, long long n, float scale, void* stream) {
   (void)hipGetLastError();
   if (n <= 0) return 0;

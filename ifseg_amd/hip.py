@@ -302,6 +302,21 @@ def colsum(x, part):
     return part
 
 
+def embed_bag_mean(table, ids, ends, add, out):
+    """table [V,C] bf16; ids int64 [B,maxlen]; ends int64 [B,P] (per-sample cumulative bag ends); add [C] bf16 or None;
+    out [B*P, C] or [B, P, C] bf16 view"""
+    B, maxlen = ids.shape
+    P = ends.numel() // B
+    C = table.shape[1]
+    rpb = out.shape[1] if out.dim() == 3 else 0
+    ob, ol = _map(out, rpb)
+    assert ids.dtype == torch.int64 and ends.dtype == torch.int64 and ids.is_contiguous() and ends.is_contiguous()
+    rc = lib().ifseg_embed_bag_mean(_ptr(table), _ptr(ids), _ptr(ends), _ptr(add), _ptr(out), c_int(B), c_int(P), c_int(C),
+                                    c_int(maxlen), c_int(rpb), c_ll(ob), c_int(ol), _stream())
+    _check(rc, "embed_bag_mean")
+    return out
+
+
 def embed_rows(table, ids, add, out):
     C = table.shape[1]
     n = ids.numel()

@@ -46,7 +46,14 @@ class HipEngine:
         self.cfg = model.cfg
         self.packed = False
         self.device = None
-        self.ws = {}
+        # activation workspaces: `_ws_grad` belongs to the forward a backward will differentiate; a no-grad
+        # forward issued while that backward is still pending (the image-free criterion evaluates the real
+        # images for its metrics between the two, seg_criterion.py:179-186) runs in `_ws_aux` so that it does
+        # not overwrite the saved activations.  `ws` / `saved` / `ctx` always name the current one.
+        self._ws_grad, self._ws_aux = {}, {}
+        self._saved_grad, self._saved_aux = {}, {}
+        self.ws, self.saved = self._ws_grad, self._saved_grad
+        self._gctx = None                 # ctx of the forward awaiting its backward
         self._views = {}
         self.geo = {}
         self.ctx = None
@@ -164,7 +171,9 @@ class HipEngine:
         self._pack_resnet()
         self._pack_misc()
         self.packed = True
-        self.ws.clear()
+        self._ws_grad.clear(); self._ws_aux.clear()
+        self._saved_grad.clear(); self._saved_aux.clear()
+        self._gctx = None
         self.geo.clear()
 
     def trainable_names(self):
@@ -477,22 +486,37 @@ class HipEngine:
     # ----------------------------------------------------------------- forward
     def forward(self, *args, **kw):
         prev = hip.set_stream(torch.cuda.current_stream().cuda_stream)    # one stream lookup per pass, not per launch
+        need_grad = kw.get("need_grad", True)
+        aux = (not need_grad) and self._gctx is not None
+        self.ws, self.saved = (self._ws_aux, self._saved_aux) if aux else (self._ws_grad, self._saved_grad)
         try:
-            return self._forward(*args, **kw)
+            out = self._forward(*args, **kw)
+            if need_grad:
+                self._gctx = self.ctx
+                self.ctx["drop_state"] = (self.drop_on, getattr(self, "dp_scale", None), getattr(self, "_dp_rows", None))
+            return out
         finally:
             hip.set_stream(prev)
 
     def backward(self, dlogits):
+        if self._gctx is None:
+            raise RuntimeError("ifseg_amd HIP engine: backward without a pending training forward")
         prev = hip.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.ws, self.saved, self.ctx = self._ws_grad, self._saved_grad, self._gctx
+        self.drop_on, self.dp_scale, self._dp_rows = self.ctx["drop_state"]
         try:
             return self._backward(dlogits)
         finally:
+            self._gctx = None
             hip.set_stream(prev)
 
     def _forward(self, src_tokens, patch_images, prev_output_tokens=None, full_context_alignment=False,
-                 need_grad=True):
+                 need_grad=True, bag=None):
+        """bag = (ids int64 [B, maxlen], ends int64 [B*P]): the image-free entry (encode_with_artificial_image,
+        encoder_module.py:499-675) -- patch embeddings are EmbeddingBag means of class-name tokens, the ResNet
+        trunk and image_proj are not run; `patch_images` is ignored."""
         cfg = self.cfg
-        dev = patch_images.device
+        dev = src_tokens.device if bag is not None else patch_images.device
         if not self.packed or self.device != dev:
             self.pack(dev)
         key = (src_tokens.data_ptr(), src_tokens._version, tuple(src_tokens.shape))
@@ -505,10 +529,15 @@ class HipEngine:
         C, Fd, H = cfg.embed_dim, cfg.ffn_dim, cfg.heads
         scaling = float(cfg.head_dim * cfg.attn_scale_factor) ** -0.5
         W, buf = self.W, self.buf
-        feat, h, w = self._trunk(patch_images)
-        if self._pf_request is not None:      # the next batch's trunk starts once this batch's features are taken
-            req, self._pf_request = self._pf_request, None
-            self.prefetch_trunk(req)
+        if bag is not None:
+            feat, h, w = None, cfg.patch_image_size // 16, cfg.patch_image_size // 16     # encoder_module.py:540
+            if bag[1].numel() != B * h * w:
+                raise RuntimeError("aux_input: %d bags for a batch of %d x %dx%d patches" % (bag[1].numel(), B, h, w))
+        else:
+            feat, h, w = self._trunk(patch_images)
+            if self._pf_request is not None:  # the next batch's trunk starts once this batch's features are taken
+                req, self._pf_request = self._pf_request, None
+                self.prefetch_trunk(req)
         P = h * w
         oh = cfg.orig_patch_image_size // 16
         slow = (h, w) != (oh, oh) or (h, w) != (cfg.seg_bucket_size,) * 2 or P % 64 != 0
@@ -527,10 +556,14 @@ class HipEngine:
                "src_tokens": src_tokens, "feat": feat}
         e = "encoder."
         # ---- embeddings (forward_embedding, encoder_module.py:388-446)
-        bias_img = buf("bias_img", (C,))
-        hip.add_bf16(W(e + "image_proj.bias"), W(e + "type_embedding.weight")[1], bias_img)
         img_pre = buf("img_pre", (B * P, C))
-        hip.linear_fwd(feat.view(B * P, 1024), W(e + "image_proj.weight"), bias_img, out=img_pre)
+        if bag is not None:
+            hip.embed_bag_mean(W(e + "embed_tokens.weight"), bag[0].contiguous(), bag[1].contiguous(),
+                               W(e + "type_embedding.weight")[1], img_pre)
+        else:
+            bias_img = buf("bias_img", (C,))
+            hip.add_bf16(W(e + "image_proj.bias"), W(e + "type_embedding.weight")[1], bias_img)
+            hip.linear_fwd(feat.view(B * P, 1024), W(e + "image_proj.weight"), bias_img, out=img_pre)
         x = buf("e_x_in", (B, T, C))
         mu, rs = self._ln_stats("img_ln", B * P)
         hip.ln_fwd(img_pre.view(B, P, C), W(e + "patch_layernorm_embedding.weight"),
@@ -822,8 +855,6 @@ class HipEngine:
         return x2
 
     def _save(self, key, **kw):
-        if not hasattr(self, "saved"):
-            self.saved = {}
         self.saved[key] = kw
 
     # ---------------------------------------------------------------- backward

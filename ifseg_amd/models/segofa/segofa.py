@@ -149,27 +149,45 @@ class SegOFAModel(nn.Module):
                 full_context_alignment=False, classification_head_name=None, token_embeddings=None,
                 return_all_hiddens=False, alignment_layer=None, alignment_heads=None, encoder_only=False,
                 aux_input=None):
-        if aux_input is not None:
-            raise NotImplementedError("image-free (aux_input) branch: SURVEY 8f row 1, not built in this round")
-        if patch_images is None or not patch_images.is_cuda:
-            raise RuntimeError("ifseg_amd.SegOFAModel runs only on an MI355X: patch_images must be a device tensor "
-                               "(there is no CPU / PyTorch fallback)")
-        if patch_masks is not None:
-            # the check reads the mask back (a device sync): once per mask tensor, not once per step
-            key = (patch_masks.data_ptr(), patch_masks._version, tuple(patch_masks.shape))
-            if getattr(self, "_checked_masks", None) != key:
-                if not bool(patch_masks.all()):
-                    raise NotImplementedError("masked-out patch images are not supported")
-                self._checked_masks = key
         eng = self.engine
-        if not eng.packed or eng.device != patch_images.device:
-            eng.pack(patch_images.device)
+        x, extra = None, {}
+        if src_tokens is not None:
+            if patch_images is None or not patch_images.is_cuda:
+                raise RuntimeError("ifseg_amd.SegOFAModel runs only on an MI355X: patch_images must be a device tensor "
+                                   "(there is no CPU / PyTorch fallback)")
+            if patch_masks is not None:
+                # the check reads the mask back (a device sync): once per mask tensor, not once per step
+                key = (patch_masks.data_ptr(), patch_masks._version, tuple(patch_masks.shape))
+                if getattr(self, "_checked_masks", None) != key:
+                    if not bool(patch_masks.all()):
+                        raise NotImplementedError("masked-out patch images are not supported")
+                    self._checked_masks = key
+            x, extra = self._run(src_tokens, patch_images, prev_output_tokens, bool(full_context_alignment), None)
+        if aux_input is not None:
+            # image-free branch (segofa.py:136-151): encoder on the artificial image, decoder with its defaults
+            # (causal).  The engine keeps the activations of ONE forward: when both branches are requested the
+            # second forward (this one) is the one a following backward differentiates.
+            a_src = aux_input.get("src_tokens")
+            if a_src is None or not a_src.is_cuda:
+                raise RuntimeError("ifseg_amd.SegOFAModel runs only on an MI355X: aux_input tensors must be on the device")
+            if x is not None and torch.is_grad_enabled() and self.training:
+                raise NotImplementedError("gradients through both the image and the image-free branch of one call "
+                                          "(the reference's criterion never asks for it: seg_criterion.py:179-186)")
+            bag = (aux_input.get("patch_images"), aux_input.get("patch_masks"))
+            extra["aux_output"] = self._run(a_src, None, aux_input.get("prev_output_tokens"), False, bag)
+        return x, extra
+
+    def _run(self, src_tokens, patch_images, prev_output_tokens, full, bag):
+        eng = self.engine
+        dev = src_tokens.device
+        if not eng.packed or eng.device != dev:
+            eng.pack(dev)
         eng.refresh_frozen()
         need_grad = torch.is_grad_enabled() and self.training
         params = eng.trainable_params() if (need_grad and self.autograd_mode == "inputs") else ()
-        anchor = torch.zeros(1, device=patch_images.device, requires_grad=need_grad)
-        logits = _SegOFAFn.apply(eng, src_tokens, patch_images, prev_output_tokens, bool(full_context_alignment),
-                                 self.autograd_mode, anchor, *params)
+        anchor = torch.zeros(1, device=dev, requires_grad=need_grad)
+        logits = _SegOFAFn.apply(eng, src_tokens, patch_images, prev_output_tokens, full, self.autograd_mode, anchor,
+                                 bag, *params)
         ctx = eng.ctx
         B, T, Cc = ctx["enc_out"].shape
         extra = {
@@ -189,8 +207,8 @@ class SegOFAModel(nn.Module):
 
 class _SegOFAFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, src_tokens, patch_images, prev, full, mode, anchor, *params):
-        logits_pad, _ = eng.forward(src_tokens, patch_images, prev, full, need_grad=bool(anchor.requires_grad))
+    def forward(ctx, eng, src_tokens, patch_images, prev, full, mode, anchor, bag, *params):
+        logits_pad, _ = eng.forward(src_tokens, patch_images, prev, full, need_grad=bool(anchor.requires_grad), bag=bag)
         ctx.eng, ctx.mode, ctx.nparams = eng, mode, len(params)
         return logits_pad[:, :, : eng.cfg.num_seg_tokens]
 
@@ -201,7 +219,7 @@ class _SegOFAFn(torch.autograd.Function):
         grads = ()
         if ctx.mode == "inputs":
             grads = tuple(eng.G(n) for n in eng.trainable_names())
-        return (None,) * 6 + (None,) + grads
+        return (None,) * 8 + grads
 
 
 def _make_arch(arch_name):

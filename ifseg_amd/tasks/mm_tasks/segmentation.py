@@ -93,6 +93,39 @@ class SegmentationTask:
             "target": tgt.to(device),
         }
 
+    def synthetic_aux_sample(self, batch, device, seed=4321):
+        """Image-free half of a batch in the collater's layout (segmentation_dataset.py:303-345, :85-107):
+        a random low-res class map (``rand_k-1-33``) nearest-resized to the patch grid (EmbeddingBag ids of the
+        class names; every "name" here is 1-3 random BPE ids) and to the image (targets).
+        -> {"aux_input": {...}, "text2seg_target": [B, S*S+1]}"""
+        import torch.nn.functional as F
+        nseg, S = self.cfg.num_seg_tokens, self.cfg.patch_image_size
+        hp = S // 16
+        g = torch.Generator().manual_seed(seed)
+        L = self.src_len
+        name_len = torch.randint(1, 4, (nseg,), generator=g)
+        names = [torch.randint(4, min(50000, self.seg_id_offset - 1), (int(k),), generator=g) for k in name_len]
+        body = list(PROMPT_IDS)[: max(0, L - 2)]
+        body += torch.randint(4, min(50000, self.seg_id_offset - 1), (max(0, L - 2 - len(body)),), generator=g).tolist()
+        src = torch.tensor([BOS] + body + [EOS]).repeat(batch, 1)
+        ids, ends, tgts = [], [], []
+        for _ in range(batch):
+            sh, sw = (int(v) for v in torch.randint(1, 33, (2,), generator=g))
+            coarse = torch.randint(0, nseg, (1, 1, sh, sw), generator=g).float()
+            low = F.interpolate(coarse, size=(hp, hp), mode="nearest").long().reshape(-1)
+            high = F.interpolate(coarse, size=(S, S), mode="nearest").long().reshape(-1)
+            ids.append(torch.cat([names[int(c)] for c in low]))
+            ends.append(name_len[low].cumsum(0))
+            tgts.append(torch.cat([high + self.seg_id_offset, torch.tensor([EOS])]))
+        maxlen = max(t.numel() for t in ids)
+        padded = torch.full((batch, maxlen), PAD, dtype=torch.long)
+        for b, t in enumerate(ids):
+            padded[b, : t.numel()] = t
+        return {"aux_input": {"src_tokens": src.to(device), "src_lengths": torch.full((batch,), L).to(device),
+                              "patch_images": padded.to(device), "patch_masks": torch.cat(ends).to(device),
+                              "prev_output_tokens": torch.zeros(batch, 1, dtype=torch.long, device=device)},
+                "text2seg_target": torch.stack(tgts).to(device)}
+
     def train_step(self, sample, model, criterion, optimizer, update_num, ignore_grad=False):
         """tasks/mm_tasks/segmentation.py:190-222."""
         if not model.training:      # nn.Module.train() walks every sub-module: only when the mode changes

@@ -160,6 +160,13 @@ int ifseg_colsum_bf16(const void* x, float* part, int nblk_rows, int M, int N, i
 /* out[r] = table[ids[r]] + add  (embed_tokens + type_embedding, encoder_module.py:400-406) */
 int ifseg_embed_rows(const void* table, const long long* ids, const void* add, void* out, int n, int C, int rpb,
                      long long o_bs, int ldo, void* stream);
+/* Image-free patch embeddings: out[b,p,:] = mean of table rows ids[b, ends[b,p-1]:ends[b,p]] + add
+ * (nn.EmbeddingBag(mode='mean') sharing embed_tokens.weight, encoder_module.py:147-148,529-538, + the image
+ * type embedding :589-591).  ids int64 [B,maxlen] (row-padded), ends int64 [B,P] per-sample cumulative bag ends
+ * exactly as the collater produces them (segmentation_dataset.py:327-328,99-100); out bf16 rows addressed like
+ * ifseg_embed_rows. */
+int ifseg_embed_bag_mean(const void* table, const long long* ids, const long long* ends, const void* add, void* out,
+                         int B, int P, int C, int maxlen, int rpb, long long o_bs, int ldo, void* stream);
 int ifseg_cast_f32_bf16(const float* in, void* out, long long n, float scale, void* stream);
 int ifseg_add_bf16(const void* a, const void* b, void* out, long long n, void* stream);
 /* NCHW (fp32 / bf16) image -> NHWC bf16 with channels zero-padded to Cpad */

@@ -16,6 +16,9 @@ and then stores the REFERENCE's outputs as the golden vectors:
                                    area histograms, selected parameter grads
   tests/golden/fixture_resize.npz  small config, 128x192 image (P=96 > orig 64):
                                    the double-bilinear rel-pos resize path, eval
+  tests/golden/fixture_imfree.npz  small widths on the full 32x32 patch grid: the image-free branch
+                                   (aux_input, EmbeddingBag patches, causal decoder) + the
+                                   reference's compute_imfree_loss, selected grads
   tests/golden/base_c1.npz         SegOFA-Base, B=1, 512x512, nseg 15, L=36
                                    (BASELINE config 1 shapes): logits, loss,
                                    grad norms
@@ -185,15 +188,65 @@ def case_resize(cfg, arch, overrides, out_name):
                         seed=4321, src_len=12)
 
 
+def case_imfree(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys):
+    """Image-free branch: SegOFAModel.forward(aux_input=...) + SegCriterion.compute_imfree_loss
+    of the reference vs the restatement.  The reference's loss hard-codes a 32x32 -> 512x512 upsample
+    (seg_criterion.py:236,249), so this case runs the small-width fixture on the full 32x32 patch grid."""
+    t0 = time.time()
+    model, sd = build_reference(cfg, arch, overrides)
+    crit = build_criterion(cfg)
+    batch = O.synthetic_aux_batch(cfg, batch_size, src_len)
+    model.train()
+    params = dict(model.named_parameters())
+    for k in grad_keys:
+        params[k].requires_grad_(True)
+    x, extra = model(aux_input=batch["aux_input"])
+    assert x is None
+    aux_out = extra["aux_output"]
+    loss = crit.compute_imfree_loss(model, aux_out, {"text2seg_target": batch["text2seg_target"]}, 0)
+    loss.backward()
+    ref_logits = aux_out[0].detach()
+    print("[%s] reference done %.1fs loss=%.9f" % (out_name, time.time() - t0, loss.item()))
+    sdg = {k: v.clone() for k, v in sd.items()}
+    for name, (_, kind) in O.state_dict_spec(cfg).items():
+        if kind.startswith("alias:"):
+            sdg[name] = sdg[kind[6:]]
+    for k in grad_keys:
+        sdg[k].requires_grad_(True)
+    o_logits, _ = O.segofa_forward_imfree(sdg, cfg, batch["aux_input"])
+    o_loss = O.imfree_loss(cfg, o_logits, batch["text2seg_target"])
+    o_loss.backward()
+    err = (o_logits.detach() - ref_logits).abs().max().item()
+    print("  oracle vs reference: logits max-abs %.3e  loss diff %.3e" % (err, abs(o_loss.item() - loss.item())))
+    assert err <= 2e-5 and abs(o_loss.item() - loss.item()) <= 2e-6
+    save = {"logits": ref_logits.numpy(), "loss": np.float64(loss.item()), "batch_size": batch_size, "src_len": src_len}
+    for k in grad_keys:
+        g_ref, g_o = params[k].grad, sdg[k].grad
+        rel = ((g_o - g_ref).norm() / (g_ref.norm() + 1e-30)).item()
+        print("  grad %-52s rel-L2 %.2e  |g|=%.4e" % (k, rel, g_ref.norm().item()))
+        assert rel <= 2e-5, k
+        save["gradnorm:" + k] = np.float64(g_ref.norm().item())
+        if g_ref.numel() <= 65536:
+            save["grad:" + k] = g_ref.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, out_name), **save)
+    print("  wrote", out_name, "%.1fs" % (time.time() - t0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-base", action="store_true")
+    ap.add_argument("--only-imfree", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
     fx = O.fixture_config()
     ov = dict(encoder_embed_dim=fx.embed_dim, encoder_ffn_embed_dim=fx.ffn_dim, encoder_layers=fx.enc_layers,
               decoder_layers=fx.dec_layers, encoder_attention_heads=fx.heads, decoder_attention_heads=fx.heads)
+    fx512 = O.fixture_config(patch_image_size=512, orig_patch_image_size=512)
+    imfree_keys = [k for k in GRAD_KEYS if "token_rel_pos" not in k] + ["encoder.patch_layernorm_embedding.weight"]
+    case_imfree(fx512, "tiny", ov, 2, 12, "fixture_imfree.npz", imfree_keys)
+    if a.only_imfree:
+        return
     case_train(fx, "tiny", ov, 2, 12, "fixture_train.npz", GRAD_KEYS)
     case_resize(fx, "tiny", ov, "fixture_resize.npz")
     if not a.skip_base:

@@ -436,19 +436,51 @@ def encoder_rel_bias(sd, cfg, idx, L, hw, image_rp_bucket, token_rp_bucket):
     return tok, img
 
 
-def encode(sd, cfg, src_tokens, patch_images, patch_masks=None, image_feat=None):
-    """TransformerEncoder.encode (encoder_module.py:677-851), real-image path.
+def embed_bag_offsets(offsets_cat, B):
+    """encode_with_artificial_image (encoder_module.py:531-536): the collated per-sample cumulative bag
+    ends ``offsets_cat`` [B*P] (segmentation_dataset.py:327-328,100) -> EmbeddingBag start offsets [B*P]
+    into the pad-stripped, concatenated id stream."""
+    o = offsets_cat.view(B, -1)
+    o = torch.cat([o.new_zeros(B, 1), o], dim=1)
+    base = torch.cat([o.new_zeros(1), o[:-1, -1]]).cumsum(0)
+    return (o + base[:, None])[:, :-1].reshape(-1)
+
+
+def embed_bag_mean(weight, ids, starts):
+    """nn.EmbeddingBag(mode='mean') over ``weight`` (encoder_module.py:147-148,538): bag i averages rows
+    ids[starts[i]:starts[i+1]] (last bag runs to the end); an empty bag is zero."""
+    n = starts.numel()
+    ends = torch.cat([starts[1:], torch.tensor([ids.numel()])])
+    seg = torch.repeat_interleave(torch.arange(n), ends - starts)
+    out = torch.zeros(n, weight.shape[1], dtype=weight.dtype)
+    out = out.index_add(0, seg, weight[ids])
+    cnt = (ends - starts).clamp(min=1).to(weight.dtype)
+    return out / cnt[:, None]
+
+
+def encode(sd, cfg, src_tokens, patch_images, patch_masks=None, image_feat=None, bag=None):
+    """TransformerEncoder.encode (encoder_module.py:677-851), real-image path; with ``bag`` =
+    (padded ids [B, maxlen], collated bag ends [B*P]) the image-free entry
+    encode_with_artificial_image (encoder_module.py:499-675): the patch embeddings are the mean
+    token embedding of a class name per patch -- no ResNet, no image_proj.
 
     Returns dict with batch-first tensors: encoder_out [B,T,C],
     position_embeddings [T,C] (LN'd, batch-invariant), image_embed_shape,
     image_embed_before_proj [B,P,1024], encoder_padding_mask [B,T] | None."""
     B, L = src_tokens.shape
     H = cfg.heads
-    if image_feat is None:
-        image_feat = resnet_trunk(sd, "encoder.embed_images.", patch_images, cfg.resnet_layers)
-    h, w = image_feat.shape[-2:]
-    P = h * w
-    image_embed = image_feat.flatten(2).transpose(1, 2)                   # [B,P,1024]
+    if bag is not None:
+        ids, ends = bag
+        h = w = cfg.patch_image_size // 16                                # :540
+        P = h * w
+        flat = ids[ids != PAD]                                            # :529
+        image_embed = embed_bag_mean(sd["encoder.embed_tokens.weight"], flat, embed_bag_offsets(ends, B)).view(B, P, -1)
+    else:
+        if image_feat is None:
+            image_feat = resnet_trunk(sd, "encoder.embed_images.", patch_images, cfg.resnet_layers)
+        h, w = image_feat.shape[-2:]
+        P = h * w
+        image_embed = image_feat.flatten(2).transpose(1, 2)               # [B,P,1024]
     # ---- get_patch_images_info :333-372 ----
     ids = image_grid_ids(h, w, cfg.image_bucket_size)
     oh = cfg.orig_patch_image_size // 16
@@ -461,13 +493,16 @@ def encode(sd, cfg, src_tokens, patch_images, patch_masks=None, image_feat=None)
     # ---- forward_embedding :388-446 (embed_scale 1.0, type embedding, LN) ----
     tok = sd["encoder.embed_tokens.weight"][src_tokens] + sd["encoder.type_embedding.weight"][0]
     tok = _ln(sd, "encoder.layernorm_embedding", tok)
-    img = _lin(sd, "encoder.image_proj", image_embed) + sd["encoder.type_embedding.weight"][1]
+    if bag is not None:
+        img = image_embed + sd["encoder.type_embedding.weight"][1]        # :589-593 (embed_scale 1.0)
+    else:
+        img = _lin(sd, "encoder.image_proj", image_embed) + sd["encoder.type_embedding.weight"][1]
     img = _ln(sd, "encoder.patch_layernorm_embedding", img)
     x = torch.cat([img, tok], dim=1)                                      # [B,T,C]
     # ---- padding :730-752 ----
     pad_mask = src_tokens.eq(PAD)
     img_pad = torch.zeros(B, P, dtype=torch.bool)
-    if patch_masks is not None:
+    if patch_masks is not None and bag is None:
         img_pad[~patch_masks] = True
     pad_mask = torch.cat([img_pad, pad_mask], dim=1)
     has_pads = bool(pad_mask.any())
@@ -493,7 +528,7 @@ def encode(sd, cfg, src_tokens, patch_images, patch_masks=None, image_feat=None)
         "encoder_out": x,
         "position_embeddings": pos_all,
         "image_embed_shape": (h, w),
-        "image_embed_before_proj": image_embed,
+        "image_embed_before_proj": image_embed if bag is None else None,
         "encoder_padding_mask": pad_mask if has_pads else None,
     }
 
@@ -560,6 +595,30 @@ def segofa_forward(sd, cfg, src_tokens, patch_images, prev_output_tokens=None, p
     return logits, {"encoder_returns": enc, "penultimate": feat}
 
 
+def segofa_forward_imfree(sd, cfg, aux_input):
+    """SegOFAModel.forward, ``aux_input`` branch (segofa.py:136-151): encoder on the artificial image,
+    decoder with its defaults (causal).  aux_input: src_tokens [B,L], patch_images = padded bag ids
+    [B,maxlen], patch_masks = collated bag ends [B*P], prev_output_tokens [B,>=1] (only bos is read)."""
+    enc = encode(sd, cfg, aux_input["src_tokens"], None, None,
+                 bag=(aux_input["patch_images"], aux_input["patch_masks"]))
+    logits, feat = decode(sd, cfg, enc, aux_input["prev_output_tokens"], False)
+    return logits, {"encoder_returns": enc, "penultimate": feat}
+
+
+def imfree_loss(cfg, logits, text2seg_target, label_smoothing=0.0):
+    """compute_imfree_loss (seg_criterion.py:246-267): upsample_logits with its defaults (32x32 -> 512x512),
+    drop eos / pad / ignore, mean CE."""
+    P = logits.shape[1] - 1
+    hp = wp = int(round(P ** 0.5))
+    h = w = int(round((text2seg_target.shape[1] - 1) ** 0.5))
+    scores = upsample_logits(logits.float(), hp, wp, h, w)[:, :-1]
+    tgt = text2seg_target[:, :-1]
+    scores = scores.reshape(-1, scores.shape[-1])
+    tgt = tgt.reshape(-1)
+    mask = (tgt != PAD) & (tgt != cfg.seg_id_offset + cfg.num_seg_tokens)
+    return F.cross_entropy(scores[mask], tgt[mask] - cfg.seg_id_offset, label_smoothing=label_smoothing)
+
+
 # --------------------------------------------------------------------------- #
 # criterion math (criterions/seg_criterion.py)                                #
 # --------------------------------------------------------------------------- #
@@ -617,3 +676,35 @@ def synthetic_batch(cfg, batch, src_len, image_size=None, seed=1234, image_hw=No
     return {"src_tokens": src, "patch_images": img, "target": tgt,
             "prev_output_tokens": torch.zeros(batch, 1, dtype=torch.long),
             "patch_masks": torch.ones(batch, dtype=torch.bool)}
+
+
+def synthetic_aux_batch(cfg, batch, src_len, seed=4321, image_size=None):
+    """Image-free sample in the layout of segmentation_dataset.py:303-345 + collate :85-107:
+    every class "name" is 1-3 random BPE ids; a random low-res class map (``rand_k``) is nearest-resized
+    to the patch grid (bag ids) and to the image (targets)."""
+    g = torch.Generator().manual_seed(seed)
+    S = image_size or cfg.patch_image_size
+    hp = S // 16
+    n = cfg.num_seg_tokens
+    name_len = torch.randint(1, 4, (n,), generator=g)
+    names = [torch.randint(4, min(50000, cfg.vocab_size - 1), (int(k),), generator=g) for k in name_len]
+    src = torch.randint(4, min(50000, cfg.vocab_size - 1), (1, src_len), generator=g).repeat(batch, 1)
+    src[:, 0] = BOS
+    src[:, -1] = EOS
+    ids, ends, tgts = [], [], []
+    for _ in range(batch):
+        sh, sw = (int(v) for v in torch.randint(1, hp + 1, (2,), generator=g))
+        coarse = torch.randint(0, n, (1, 1, sh, sw), generator=g).float()
+        low = F.interpolate(coarse, size=(hp, hp), mode="nearest").long().reshape(-1)
+        high = F.interpolate(coarse, size=(S, S), mode="nearest").long().reshape(-1)
+        ids.append(torch.cat([names[int(c)] for c in low]))
+        ends.append(torch.tensor([int(name_len[int(c)]) for c in low]).cumsum(0))
+        tgts.append(torch.cat([high + cfg.seg_id_offset, torch.tensor([EOS])]))
+    maxlen = max(t.numel() for t in ids)
+    padded = torch.full((batch, maxlen), PAD, dtype=torch.long)
+    for b, t in enumerate(ids):
+        padded[b, : t.numel()] = t
+    return {"aux_input": {"src_tokens": src, "src_lengths": torch.full((batch,), src_len),
+                          "patch_images": padded, "patch_masks": torch.cat(ends),
+                          "prev_output_tokens": torch.zeros(batch, 1, dtype=torch.long)},
+            "text2seg_target": torch.stack(tgts)}

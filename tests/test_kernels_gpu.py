@@ -526,3 +526,31 @@ def test_ln_fused_dropout_matches_standalone_mask(C, gelu):
     hip.ln_bwd(dy, x, g, mu, rs, dx, part2[0], part2[1], gelu=gelu, drop=(p, seed, dp, T))
     assert _rel(dx, dx_ref) < 8e-3
     assert _rel(part2.sum(1), part.sum(1)) < 8e-3
+
+
+def test_embed_bag_mean_vs_torch():
+    """ifseg_embed_bag_mean against F.embedding_bag(mode='mean') on the pad-stripped stream
+    (encoder_module.py:529-538), ragged bags incl. an empty one, strided output."""
+    from ifseg_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    V, C, B, P = 997, 256, 3, 64
+    table = _rand((V, C), dev, 80)
+    add = _rand((C,), dev, 81)
+    lens = torch.randint(1, 4, (B, P), generator=g)
+    lens[1, 7] = 0                                            # an empty bag
+    ends = lens.cumsum(1)
+    maxlen = int(ends[:, -1].max())
+    ids = torch.full((B, maxlen), 1, dtype=torch.long)
+    for b in range(B):
+        n = int(ends[b, -1])
+        ids[b, :n] = torch.randint(4, V, (n,), generator=g)
+    out = torch.zeros(B, P + 5, C, dtype=torch.bfloat16, device=dev)
+    hip.embed_bag_mean(table, ids.to(dev), ends.reshape(-1).to(dev), add, out[:, 2:2 + P])
+    flat = torch.cat([ids[b, : int(ends[b, -1])] for b in range(B)])
+    base = torch.cat([torch.zeros(1, dtype=torch.long), ends[:-1, -1]]).cumsum(0)
+    starts = (torch.cat([torch.zeros(B, 1, dtype=torch.long), ends], 1) + base[:, None])[:, :-1].reshape(-1)
+    ref = torch.nn.functional.embedding_bag(flat, table.float().cpu(), starts, mode="mean") + add.float().cpu()
+    assert _rel(out[:, 2:2 + P].reshape(B * P, C).cpu(), ref) < 4e-3
+    assert out[:, :2].abs().sum() == 0 and out[:, 2 + P:].abs().sum() == 0
+    assert torch.equal(out[1, 2 + 7].float().cpu(), add.float().cpu().to(torch.bfloat16).float())

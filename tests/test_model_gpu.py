@@ -313,3 +313,81 @@ def test_trunk_prefetch_matches_inline():
     assert torch.equal(out1, ref1)
     assert torch.equal(out2, ref2)
     assert not torch.equal(ref1, ref2)
+
+
+def test_image_free_branch_vs_reference_golden(golden_dir):
+    """model(aux_input=...) (EmbeddingBag patches, no trunk, causal decoder) + the criterion's
+    image-free branch (loss on the artificial image, no-grad evaluation of the real images in between) against
+    the reference golden and the oracle's gradients."""
+    from ifseg_amd.criterions import SegCriterion
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config(patch_image_size=512, orig_patch_image_size=512)
+    sd = O.procedural_state_dict(ocfg)
+    g = np.load(os.path.join(golden_dir, "fixture_imfree.npz"))
+    aux = O.synthetic_aux_batch(ocfg, 2, 12)
+    real = O.synthetic_batch(ocfg, 2, 12)
+    # oracle gradients of every parameter
+    sdg = {}
+    spec = O.state_dict_spec(ocfg)
+    for k, v in sd.items():
+        if not spec[k][1].startswith("alias:"):
+            sdg[k] = v.clone().requires_grad_(v.dtype.is_floating_point and "embed_images" not in k)
+    for k, (_, kind) in spec.items():
+        if kind.startswith("alias:"):
+            sdg[k] = sdg[kind[6:]]
+    o_logits, _ = O.segofa_forward_imfree(sdg, ocfg, aux["aux_input"])
+    o_loss = O.imfree_loss(ocfg, o_logits, aux["text2seg_target"])
+    o_loss.backward()
+    assert np.abs(o_logits.detach().numpy() - g["logits"]).max() <= 1e-5
+
+    m = _build(ocfg, sd, dev)
+    m.train()
+    crit = SegCriterion(num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset, unsupervised_segmentation=True)
+    to = lambda d: {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+    sample = {"net_input": to({"src_tokens": real["src_tokens"], "src_lengths": torch.full((2,), 12),
+                               "patch_images": real["patch_images"], "patch_masks": real["patch_masks"],
+                               "prev_output_tokens": real["prev_output_tokens"]}),
+              "target": real["target"].to(dev), "aux_input": to(aux["aux_input"]),
+              "text2seg_target": aux["text2seg_target"].to(dev), "ntokens": 1, "nsentences": 2}
+    loss, sample_size, logs = crit(m, sample)          # aux forward (grad) -> real-image forward (no grad) -> ...
+    assert float(logs["imfree_loss"]) == loss.item() and float(logs["seg_loss"]) != loss.item()
+    e_loss = abs(loss.item() - float(g["loss"]))
+    loss.backward()                                   # ... -> backward of the aux forward
+    torch.cuda.synchronize()
+    logits = m.engine._ws_grad["logits_pad"][:, :, : ocfg.num_seg_tokens].float().cpu()
+    e_logits = _rel(logits, torch.from_numpy(g["logits"]))
+    print("image-free: logits rel-L2 %.4f  loss %.5f vs %.5f" % (e_logits, loss.item(), float(g["loss"])))
+    assert e_logits <= 2e-2 and e_loss <= 1e-2
+    named = dict(m.named_parameters())
+    worst = []
+    gain_scale = max(v.grad.abs().max().item() for k, v in sdg.items() if k.endswith("c_attn") and v.grad is not None)
+    for k, v in sorted(sdg.items()):
+        og = v.grad
+        if og is None or k not in named or not named[k].requires_grad or og.norm() == 0:
+            continue
+        if k.endswith(("k_proj.bias", "pos_k_linear.bias")):
+            assert named[k].grad.float().norm().item() < 2e-2, k
+            continue
+        hg = named[k].grad
+        assert hg is not None, k
+        if k.endswith("c_attn"):
+            assert (hg.float().cpu() - og).abs().max().item() <= 5e-2 * gain_scale, k
+            continue
+        worst.append((_rel(hg, og), k))
+    worst.sort(reverse=True)
+    print("worst grads:", [(round(e, 4), k) for e, k in worst[:6]], "checked", len(worst))
+    assert len(worst) > 100
+    # the 12 text tokens are ~1 % of this 1036-token sequence: the text rel-pos tables collect a tiny, heavily
+    # cancelling gradient (|g| ~ 1e-4) and sit at the bf16 noise floor -- 8e-2 for them, 6e-2 for everything else
+    bad = [(e, k) for e, k in worst if e > (8e-2 if "token_rel_pos_table" in k else 6e-2)]
+    assert not bad, bad[:10]
+    for k in [f[9:] for f in g.files if f.startswith("gradnorm:")]:
+        if k.endswith("c_attn"):
+            continue
+        assert abs(named[k].grad.float().norm().item() / float(g["gradnorm:" + k]) - 1) <= 5e-2, k
+    # the no-grad forward on the real images in between must equal a stand-alone evaluation
+    m.eval()
+    with torch.no_grad():
+        alone = m(**sample["net_input"])[0].float().cpu()
+    o_real = O.segofa_forward(sd, ocfg, real["src_tokens"], real["patch_images"])[0]
+    assert _rel(alone, o_real) <= 2e-2

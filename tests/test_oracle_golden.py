@@ -105,3 +105,30 @@ def test_base_config1_against_reference(golden_dir):
         loss, _, _ = O.seg_loss(cfg, logits, batch["target"], 32, 32, 512, 512)
     assert np.abs(logits.numpy() - g["logits_causal"]).max() <= 1e-4
     assert abs(loss.item() - float(g["loss"])) <= 1e-5
+
+
+def test_fixture_imfree_branch(golden_dir):
+    """Image-free branch (aux_input -> encode_with_artificial_image -> causal decoder, compute_imfree_loss):
+    the restatement against the reference's logits / loss / gradients."""
+    g = _load(golden_dir, "fixture_imfree.npz")
+    cfg = O.fixture_config(patch_image_size=512, orig_patch_image_size=512)
+    sd = dict(O.procedural_state_dict(cfg))
+    batch = O.synthetic_aux_batch(cfg, int(g["batch_size"]), int(g["src_len"]))
+    keys = [k[5:] for k in g.files if k.startswith("grad:")]
+    for k in keys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    logits, _ = O.segofa_forward_imfree(sd, cfg, batch["aux_input"])
+    loss = O.imfree_loss(cfg, logits, batch["text2seg_target"])
+    loss.backward()
+    assert np.abs(logits.detach().numpy() - g["logits"]).max() <= 1e-5
+    assert abs(loss.item() - float(g["loss"])) <= 1e-6
+    for k in keys:
+        ref = torch.from_numpy(g["grad:" + k])
+        rel = (sd[k].grad - ref).norm() / ref.norm()
+        assert rel <= 1e-5, (k, rel)
+    # EmbeddingBag plumbing: ragged bags, per-sample offsets rebased onto the pad-stripped stream
+    ids, ends = batch["aux_input"]["patch_images"], batch["aux_input"]["patch_masks"]
+    starts = O.embed_bag_offsets(ends, ids.shape[0])
+    flat = ids[ids != O.PAD]
+    ref = torch.nn.functional.embedding_bag(flat, sd["encoder.embed_tokens.weight"].detach(), starts, mode="mean")
+    assert torch.allclose(O.embed_bag_mean(sd["encoder.embed_tokens.weight"].detach(), flat, starts), ref, atol=1e-6)
