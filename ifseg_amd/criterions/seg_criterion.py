@@ -55,8 +55,11 @@ PAD, EOS = 1, 2
 @register_criterion("seg_criterion")
 class SegCriterion:
     def __init__(self, task=None, label_smoothing=0.0, upscale_lprobs=True, unsupervised_segmentation=False,
-                 full_context_alignment=False, num_seg_tokens=None, seg_id_offset=None):
+                 full_context_alignment=False, num_seg_tokens=None, seg_id_offset=None, resnet_topk=3,
+                 resnet_prob_temperature=1.0, resnet_iters=0):
         self.task = task
+        # eval-time top-k neighbour smoothing on the trunk features (seg_criterion.py:93-101,197-213)
+        self.resnet_topk, self.resnet_prob_temperature, self.resnet_iters = resnet_topk, resnet_prob_temperature, resnet_iters
         self.eps = label_smoothing
         self.upscale_lprobs = upscale_lprobs
         self.unsupervised_segmentation = unsupervised_segmentation
@@ -83,6 +86,13 @@ class SegCriterion:
                 seg_output = model(**sample["net_input"], full_context_alignment=self.full_context_alignment)
                 seg_loss, metrics, ntokens = self.compute_loss(model, seg_output, sample, update_num, reduce=reduce,
                                                                bufs_name="_bufs_metrics")
+        elif not model.training and sample.get("ori_semantic_seg") is not None:
+            # evaluation at the original image resolution (seg_criterion.py:194-217,289-347); batch 1 like the
+            # reference (`ori_semantic_seg[0]`)
+            with torch.no_grad():
+                net_output = model(**sample["net_input"], full_context_alignment=self.full_context_alignment)
+                seg_loss, metrics, ntokens = self.compute_loss_eval(model, net_output, sample)
+            loss, imfree_loss = seg_loss, seg_loss.data.new_zeros(1)
         else:
             net_output = model(**sample["net_input"], full_context_alignment=self.full_context_alignment)
             seg_loss, metrics, ntokens = self.compute_loss(model, net_output, sample, update_num, reduce=reduce)
@@ -124,6 +134,34 @@ class SegCriterion:
         tgt = tgt.reshape(-1)
         mask = (tgt != self.padding_idx) & (tgt != self.seg_id_offset + self.num_seg)
         return F.cross_entropy(scores[mask], tgt[mask] - self.seg_id_offset, label_smoothing=self.eps)
+
+    def compute_loss_eval(self, model, net_output, sample):
+        """compute_loss, ``not model.training`` (seg_criterion.py:289-347) + the top-k neighbour smoothing of
+        :197-213: per-patch scores resized bilinearly to the ORIGINAL image shape, argmax, area histograms, display
+        CE -- all on the device (csrc/evalops.hip), the [h*w, n] score tensor is never built."""
+        scores_low, extra = net_output
+        pad = extra["logits_padded"]
+        hp, wp = extra["encoder_returns"]["image_embed_shape"][0]
+        P, n, dev = hp * wp, self.num_seg, pad.device
+        ori = sample["ori_semantic_seg"][0]
+        ori = torch.as_tensor(ori)
+        h, w = ori.shape[:2]
+        target = ori.reshape(-1).long().to(dev) + self.seg_id_offset
+        scores = hip.rows_to_f32(pad[:1], n, P)[0]
+        loss, hist = hip.seg_eval(scores, hp, wp, target, h, w, self.seg_id_offset)
+        f = lambda t: t.float()
+        metrics = {"area_intersect": f(hist[0]), "area_pred_label": f(hist[1]), "area_label": f(hist[2]),
+                   "area_union": f(hist[1] + hist[2] - hist[0]), "nll_loss": loss}
+        if self.resnet_iters > 0:
+            feat = extra["encoder_returns"]["image_embed_before_proj"][0]
+            prob = hip.neighbour_smoothing(pad[:1], n, feat[:1], self.resnet_iters, self.resnet_topk,
+                                           self.resnet_prob_temperature)
+            extra["resnet_postprocess_probability"] = torch.cat([prob, prob.new_zeros(1, 1, n)], dim=1)
+            _, hpp = hip.seg_eval(prob[0], hp, wp, target, h, w, self.seg_id_offset)
+            metrics.update({"area_intersect_resnet_postprocess": f(hpp[0]), "area_pred_label_resnet_postprocess": f(hpp[1]),
+                            "area_label_resnet_postprocess": f(hpp[2]),
+                            "area_union_resnet_postprocess": f(hpp[1] + hpp[2] - hpp[0])})
+        return loss, metrics, 1
 
     def compute_loss(self, model, net_output, sample, update_num, reduce=True, bufs_name="_bufs"):
         scores_low, extra = net_output

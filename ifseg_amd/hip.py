@@ -412,6 +412,52 @@ def seg_loss(logits_pad, target, hp, wp, H, W, nseg, seg_id_offset, tile_partial
     return loss_out
 
 
+# ---------------------------------------------------------------------- eval post-processing
+def rows_to_f32(logits_pad, nseg, rows_per_batch, softmax=False, temperature=1.0):
+    """logits_pad bf16 [B, T, ld] -> fp32 [B, rows_per_batch, nseg] (first rows of every sample), optionally softmaxed"""
+    B = logits_pad.shape[0]
+    out = torch.empty(B, rows_per_batch, nseg, dtype=torch.float32, device=logits_pad.device)
+    _check(lib().ifseg_softmax_rows(_ptr(logits_pad), c_ll(logits_pad.stride(0)), c_int(rows_per_batch),
+                                    c_int(logits_pad.stride(1)), _ptr(out), c_int(B * rows_per_batch), c_int(nseg),
+                                    c_float(1.0 / temperature), c_int(1 if softmax else 0), _stream()), "softmax_rows")
+    return out
+
+
+def neighbour_smoothing(logits_pad, nseg, feat, iters, topk, temperature=1.0):
+    """seg_criterion.py:197-213 on the device: logits_pad bf16 [B, P+1, ld], feat bf16 [B, P, D] (trunk features)
+    -> smoothed class probabilities fp32 [B, P, nseg]"""
+    B, P, D = feat.shape
+    dev = feat.device
+    fn = torch.empty(B * P, D, dtype=torch.bfloat16, device=dev)
+    _check(lib().ifseg_l2norm_rows_bf16(_ptr(feat.contiguous()), _ptr(fn), c_int(B * P), c_int(D), _stream()), "l2norm_rows")
+    sim = torch.empty(B, P, P, dtype=torch.float32, device=dev)
+    gemm(GEMM_NT, fn, fn, sim, P, P, D, D, D, P, flags=GEMM_OUT_F32, batch=B, sA=P * D, sB=P * D, sC=P * P)
+    idx = torch.empty(B * P, topk, dtype=torch.int32, device=dev)
+    _check(lib().ifseg_topk_rows_f32(_ptr(sim), _ptr(idx), c_int(B * P), c_int(P), c_int(topk), _stream()), "topk_rows")
+    prob = rows_to_f32(logits_pad, nseg, P, softmax=True, temperature=temperature)
+    tmp = torch.empty_like(prob)
+    for _ in range(iters):
+        _check(lib().ifseg_gather_mean(_ptr(prob), _ptr(idx), _ptr(tmp), c_int(B), c_int(P), c_int(nseg), c_int(topk),
+                                       _stream()), "gather_mean")
+        prob, tmp = tmp, prob
+    return prob
+
+
+def seg_eval(scores, hp, wp, target, h, w, seg_id_offset):
+    """scores fp32 [hp*wp, n] (one image), target int64 [h*w] -> (display CE loss tensor, int64 hist [3, n] =
+    intersect / predicted / label pixel counts) at the original h x w resolution (seg_criterion.py:289-347)"""
+    n = scores.shape[-1]
+    dev = scores.device
+    nblk = (h * w + 255) // 256
+    hist = torch.zeros(3, n, dtype=torch.int64, device=dev)
+    part = torch.empty(nblk, 2, dtype=torch.float32, device=dev)
+    _check(lib().ifseg_seg_eval(_ptr(scores.contiguous()), c_int(hp), c_int(wp), c_int(n), _ptr(target.contiguous()), c_int(h),
+                                c_int(w), c_ll(seg_id_offset), _ptr(hist), _ptr(part), c_int(nblk), _stream()), "seg_eval")
+    tot = torch.empty(2, dtype=torch.float32, device=dev)
+    reduce_parts(part, tot, 1, nblk, 2)
+    return tot[0] / tot[1], hist
+
+
 def dropout(x, resid, out, p, seed, drop_path_scale=None, rows_per_batch=None):
     """x / resid / out: [rows, C] or [B, rpb, C] bf16 views (last dim contiguous)"""
     C = x.shape[-1]

@@ -216,6 +216,24 @@ int ifseg_seg_loss_gather(const float* tile_partial, const float* stats, void* d
                           long long dlogits_bs, int B, int hp, int wp, int nseg, float* loss_out, void* stream);
 
 /* -------------------------------------------------------------- optimizer */
+/* ---- eval-time post-processing of the criterion (BASELINE config 5) ----------------------
+ * top-k neighbour smoothing (criterions/seg_criterion.py:197-213):
+ *   f = ifseg_l2norm_rows_bf16(trunk features [B*P, D]);  sim = f f^T (ifseg_gemm_bf16 NT, fp32 out, per batch);
+ *   idx = ifseg_topk_rows_f32(sim, k);  prob = ifseg_softmax_rows(logits / temperature);
+ *   iters x: prob = ifseg_gather_mean(prob, idx)
+ * metrics at the original image resolution (:289-347): ifseg_seg_eval resizes the [hp, wp, n] fp32 score grid
+ * bilinearly (align_corners=False, any ratio) to [h, w], takes the argmax and accumulates hist[3][n] =
+ * {intersect, predicted, label} pixel counts (uint64, caller zeroes them) and per-block {CE sum, pixel count}
+ * partials loss_part[nblocks][2], nblocks = ceil(h*w / 256).  target: int64 [h*w] dictionary ids
+ * (seg_id_offset + class; anything outside [0, n) after the offset is ignored). */
+int ifseg_l2norm_rows_bf16(const void* x, void* out, int rows, int D, void* stream);
+int ifseg_topk_rows_f32(const float* sim, int* idx, int rows, int N, int k /* <= 8 */, void* stream);
+int ifseg_softmax_rows(const void* logits /* bf16 */, long long batch_stride, int rows_per_batch, int ld, float* prob,
+                       int rows, int n, float inv_temperature, int do_softmax /* 0: fp32 copy only */, void* stream);
+int ifseg_gather_mean(const float* in, const int* idx, float* out, int B, int P, int n, int k, void* stream);
+int ifseg_seg_eval(const float* scores, int hp, int wp, int n, const long long* target, int h, int w,
+                   long long seg_id_offset, unsigned long long* hist, float* loss_part, int nblocks, void* stream);
+
 /* sum of squares of a bf16 gradient arena -> out_sumsq[0] (device). */
 int ifseg_grad_sumsq_bf16(const void* g, long long n, float* workspace, float* out_sumsq, void* stream);
 /* Fused grad scaling + clip-by-global-norm + Adam with decoupled weight decay over a

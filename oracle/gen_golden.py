@@ -232,16 +232,69 @@ def case_imfree(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys):
     print("  wrote", out_name, "%.1fs" % (time.time() - t0))
 
 
+def case_eval(cfg, arch, overrides, out_name, ori_hw=(150, 200), iters=25, topk=3):
+    """Eval branch of the criterion (BASELINE config 5 / SURVEY 8f row 4): top-k neighbour smoothing of the class
+    probabilities on the trunk features (seg_criterion.py:197-213) and metrics at the ORIGINAL image resolution
+    (:289-347), reference vs restatement."""
+    model, sd = build_reference(cfg, arch, overrides)
+    model.eval()
+    crit = build_criterion(cfg)
+    crit.resnet_iters, crit.resnet_topk, crit.resnet_prob_temperature = iters, topk, 1.0
+    batch = O.synthetic_batch(cfg, 1, 12, seed=777)
+    sd = O.diversify_seg_projection(sd, cfg, batch)          # predictions that differ from patch to patch
+    missing, unexpected = torch.nn.Module.load_state_dict(model, sd, strict=False)
+    assert not unexpected
+    g = torch.Generator().manual_seed(778)
+    ori = torch.randint(0, cfg.num_seg_tokens + 1, ori_hw, generator=g)      # num_seg = ignore label
+    sample = {"net_input": {"src_tokens": batch["src_tokens"], "src_lengths": torch.full((1,), 12),
+                            "patch_images": batch["patch_images"], "patch_masks": batch["patch_masks"],
+                            "prev_output_tokens": batch["prev_output_tokens"]},
+              "target": batch["target"], "ori_semantic_seg": [ori.numpy()], "ori_shape": [(ori_hw[0], ori_hw[1], 3)],
+              "ntokens": 1, "nsentences": 1}
+    import unittest.mock as mock
+    with torch.no_grad(), mock.patch("torch.zeros", wraps=torch.zeros) as z:
+        # the reference builds `imfree_loss = torch.zeros(..., device='cuda')` in eval (:215): run it on the CPU
+        z.side_effect = lambda *a, **k: torch.ones(()).new_zeros(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+        loss, ss, logs = crit(model, sample)
+        out = ref_forward(model, batch, False)
+    logits, extra = out
+    feat = extra["encoder_returns"]["image_embed_before_proj"][0]
+    hp, wp = extra["encoder_returns"]["image_embed_shape"][0]
+    with torch.no_grad():
+        o_logits, o_extra = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"])
+        o_prob = O.neighbour_smoothing(o_logits, o_extra["encoder_returns"]["image_embed_before_proj"], iters, topk)
+        o_loss, o_hist = O.seg_eval(cfg, o_logits, ori, hp, wp)
+        _, o_hist_pp = O.seg_eval(cfg, o_prob, ori, hp, wp)
+    assert (o_logits - logits).abs().max().item() <= 2e-5
+    assert abs(o_loss.item() - loss.item()) <= 2e-6, (o_loss.item(), loss.item())
+    names = ("area_intersect", "area_pred_label", "area_label", "area_union")
+    save = {"loss": np.float64(loss.item()), "ori": ori.numpy(), "logits": logits.numpy(), "prob_smooth": o_prob.numpy(),
+            "iters": iters, "topk": topk}
+    for nme, a in zip(names, o_hist):
+        assert torch.equal(a, logs[nme]), nme
+        save[nme] = logs[nme].numpy()
+    for nme, a in zip(names, o_hist_pp):
+        assert torch.equal(a, logs[nme + "_resnet_postprocess"]), nme
+        save[nme + "_pp"] = logs[nme + "_resnet_postprocess"].numpy()
+    print("[%s] eval loss %.6f; hist and smoothed-hist equal to the reference" % (out_name, loss.item()))
+    np.savez_compressed(os.path.join(GOLDEN, out_name), **save)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-base", action="store_true")
     ap.add_argument("--only-imfree", action="store_true")
+    ap.add_argument("--only-eval", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
     fx = O.fixture_config()
     ov = dict(encoder_embed_dim=fx.embed_dim, encoder_ffn_embed_dim=fx.ffn_dim, encoder_layers=fx.enc_layers,
               decoder_layers=fx.dec_layers, encoder_attention_heads=fx.heads, decoder_attention_heads=fx.heads)
+    if a.only_eval:
+        case_eval(fx, "tiny", ov, "fixture_eval.npz")
+        return
+    case_eval(fx, "tiny", ov, "fixture_eval.npz")
     fx512 = O.fixture_config(patch_image_size=512, orig_patch_image_size=512)
     imfree_keys = [k for k in GRAD_KEYS if "token_rel_pos" not in k] + ["encoder.patch_layernorm_embedding.weight"]
     case_imfree(fx512, "tiny", ov, 2, 12, "fixture_imfree.npz", imfree_keys)

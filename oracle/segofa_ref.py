@@ -644,6 +644,52 @@ def seg_loss(cfg, logits, target, hp, wp, h, w, label_smoothing=0.0):
     return loss, s, t
 
 
+def neighbour_smoothing(logits, resnet_feature, iters=25, topk=3, temperature=1.0):
+    """Eval-time post-processing of seg_criterion.py:197-213: every patch's class probabilities are replaced,
+    ``iters`` times, by the mean over its ``topk`` nearest patches in cosine similarity of the trunk features
+    (the patch itself is its own nearest neighbour).  logits [B,P+1,n], resnet_feature [B,P,D]
+    -> probabilities [B,P+1,n] with a zero row in the eos slot."""
+    f = F.normalize(resnet_feature, dim=-1)
+    sim = f @ f.transpose(-1, -2)
+    _, ind = torch.topk(sim, k=topk, dim=-1)                       # [B,P,k]
+    B, P = ind.shape[:2]
+    bi = torch.arange(B).view(B, 1, 1).expand(B, P, topk)
+    prob = (logits / temperature).softmax(-1)
+    for _ in range(iters):
+        prob = prob[bi, ind].mean(dim=-2)
+    return torch.cat([prob, prob.new_zeros(B, 1, prob.size(-1))], dim=1)
+
+
+def diversify_seg_projection(sd, cfg, batch, gain=6.0):
+    """Test helper for the eval fixtures: with the procedural weights every patch predicts the same class (the
+    class offsets W x_mean dominate the logits), which would make argmax / histogram checks vacuous.  Project the
+    mean penultimate feature out of the (tied) seg projection rows and scale them, so predictions vary across
+    patches.  Deterministic given (sd, batch); returns a new state dict."""
+    with torch.no_grad():
+        _, extra = segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"])
+        xm = extra["penultimate"].reshape(-1, cfg.embed_dim).mean(0)
+        w = sd["encoder.seg_embed_tokens.weight"]
+        w = (w - torch.outer(w @ xm / xm.dot(xm), xm)) * gain
+    out = dict(sd)
+    for k in ("encoder.seg_embed_tokens.weight", "decoder.seg_embed_tokens.weight", "decoder.seg_projection.weight"):
+        out[k] = w
+    return out
+
+
+def seg_eval(cfg, scores_low, ori_seg, hp, wp):
+    """compute_loss, eval branch (seg_criterion.py:289-347): per-patch scores (logits, or the smoothed
+    probabilities) are bilinearly resized to the ORIGINAL image shape, the eos slot dropped, and compared with
+    the original label map.  scores_low [1,P+1,n]; ori_seg int [h,w] class ids (num_seg = ignore).
+    -> (display CE loss, (intersect, pred, label, union) histograms)."""
+    h, w = ori_seg.shape
+    target = ori_seg.reshape(1, -1).long() + cfg.seg_id_offset
+    scores = upsample_logits(scores_low.float(), hp, wp, h, w)[:, :-1]
+    mask = (target == PAD) | (target == cfg.seg_id_offset + cfg.num_seg_tokens) | (target == EOS)
+    t = target[~mask] - cfg.seg_id_offset
+    s = scores[~mask]
+    return F.cross_entropy(s, t), seg_metric(s, t, cfg.num_seg_tokens)
+
+
 def seg_metric(scores, target, num_classes):
     """compute_metric (seg_criterion.py:349-362): per-class area histograms."""
     pred = scores.argmax(-1)

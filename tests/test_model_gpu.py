@@ -391,3 +391,54 @@ def test_image_free_branch_vs_reference_golden(golden_dir):
         alone = m(**sample["net_input"])[0].float().cpu()
     o_real = O.segofa_forward(sd, ocfg, real["src_tokens"], real["patch_images"])[0]
     assert _rel(alone, o_real) <= 2e-2
+
+
+def test_eval_branch_vs_reference_golden(golden_dir):
+    """BASELINE config 5 / SURVEY 8f row 4: SegCriterion eval branch on the device -- logits, metrics at the original
+    150x200 resolution and the top-k neighbour smoothing (25 iterations, k=3) against the reference golden."""
+    from ifseg_amd.criterions import SegCriterion
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    g = np.load(os.path.join(golden_dir, "fixture_eval.npz"))
+    batch = O.synthetic_batch(ocfg, 1, 12, seed=777)
+    sd = O.diversify_seg_projection(sd, ocfg, batch)
+    m = _build(ocfg, sd, dev)
+    m.eval()
+    crit = SegCriterion(num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset, resnet_iters=int(g["iters"]),
+                        resnet_topk=int(g["topk"]))
+    sample = {"net_input": {"src_tokens": batch["src_tokens"].to(dev), "src_lengths": torch.full((1,), 12).to(dev),
+                            "patch_images": batch["patch_images"].to(dev), "patch_masks": batch["patch_masks"].to(dev),
+                            "prev_output_tokens": batch["prev_output_tokens"].to(dev)},
+              "target": batch["target"].to(dev), "ori_semantic_seg": [g["ori"]], "ori_shape": [g["ori"].shape + (3,)],
+              "ntokens": 1, "nsentences": 1}
+    loss, ss, logs = crit(m, sample)
+    n = ocfg.num_seg_tokens
+    valid = int((g["ori"] < n).sum())
+    print("eval loss %.5f vs %.5f" % (loss.item(), float(g["loss"])))
+    assert abs(loss.item() - float(g["loss"])) <= 1e-2
+    assert np.array_equal(logs["area_label"].cpu().numpy(), g["area_label"])                 # label counts are exact
+    assert logs["area_pred_label"].sum().item() == valid
+    for k in ("area_intersect", "area_pred_label"):
+        d = np.abs(logs[k].cpu().numpy() - g[k]).sum()
+        dpp = np.abs(logs[k + "_resnet_postprocess"].cpu().numpy() - g[k + "_pp"]).sum()
+        print(k, "L1 diff", d, "smoothed", dpp, "of", valid)
+        # 5 near-tied synthetic classes: ~3 % of the pixels flip their argmax between bf16 and fp32 logits
+        # (each flip moves two histogram bins)
+        assert d <= 0.08 * valid and dpp <= 0.05 * valid
+    # the resize / argmax / histogram kernel itself, fed the HIP logits, against the restatement on the same logits
+    hl = m.engine.ws["logits_pad"][:, :, :n].float().cpu()
+    o_loss, o_hist = O.seg_eval(ocfg, hl, torch.from_numpy(g["ori"]), 8, 8)
+    assert abs(o_loss.item() - loss.item()) <= 1e-4
+    for k, a in zip(("area_intersect", "area_pred_label", "area_label", "area_union"), o_hist):
+        assert np.abs(logs[k].cpu().numpy() - a.numpy()).sum() <= 0.002 * valid, k
+    # the smoothing itself, on identical inputs (the oracle's logits / features), is exact up to fp32 round-off
+    from ifseg_amd import hip
+    with torch.no_grad():
+        ol, oe = O.segofa_forward(sd, ocfg, batch["src_tokens"], batch["patch_images"])
+    feat = oe["encoder_returns"]["image_embed_before_proj"].to(torch.bfloat16)
+    lp = torch.zeros(1, ol.shape[1], 8, dtype=torch.bfloat16, device=dev)
+    lp[:, :, :n] = ol.to(torch.bfloat16).to(dev)
+    prob = hip.neighbour_smoothing(lp, n, feat.to(dev), int(g["iters"]), int(g["topk"]))
+    ref = O.neighbour_smoothing(ol.to(torch.bfloat16).float(), feat.float(), int(g["iters"]), int(g["topk"]))[:, :-1]
+    assert _rel(prob, ref) <= 2e-2

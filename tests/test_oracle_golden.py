@@ -132,3 +132,26 @@ def test_fixture_imfree_branch(golden_dir):
     flat = ids[ids != O.PAD]
     ref = torch.nn.functional.embedding_bag(flat, sd["encoder.embed_tokens.weight"].detach(), starts, mode="mean")
     assert torch.allclose(O.embed_bag_mean(sd["encoder.embed_tokens.weight"].detach(), flat, starts), ref, atol=1e-6)
+
+
+def test_fixture_eval_branch(golden_dir):
+    """Eval branch of the criterion: top-k neighbour smoothing + metrics at the original image resolution
+    (seg_criterion.py:197-213,289-347), restatement vs the reference's histograms and loss."""
+    g = _load(golden_dir, "fixture_eval.npz")
+    cfg = O.fixture_config()
+    sd = O.procedural_state_dict(cfg)
+    batch = O.synthetic_batch(cfg, 1, 12, seed=777)
+    sd = O.diversify_seg_projection(sd, cfg, batch)
+    ori = torch.from_numpy(g["ori"])
+    with torch.no_grad():
+        logits, extra = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"])
+        hp, wp = extra["encoder_returns"]["image_embed_shape"]
+        prob = O.neighbour_smoothing(logits, extra["encoder_returns"]["image_embed_before_proj"], int(g["iters"]), int(g["topk"]))
+        loss, hist = O.seg_eval(cfg, logits, ori, hp, wp)
+        _, hist_pp = O.seg_eval(cfg, prob, ori, hp, wp)
+    assert np.abs(logits.numpy() - g["logits"]).max() <= 1e-5
+    assert abs(loss.item() - float(g["loss"])) <= 1e-6
+    for name, a, b in zip(("area_intersect", "area_pred_label", "area_label", "area_union"), hist, hist_pp):
+        assert np.array_equal(a.numpy(), g[name]), name
+        assert np.array_equal(b.numpy(), g[name + "_pp"]), name
+    assert not np.array_equal(g["area_pred_label"], g["area_pred_label_pp"])     # the smoothing changes predictions
