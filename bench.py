@@ -48,6 +48,16 @@ def cpu_baseline(nseg, src_len):
             "sample": "1 image of the 8-image batch: 1 fwd+bwd step of oracle/segofa_ref.py (fp32, %.1f s)" % dt}
 
 
+def _pmc_traffic(kind):
+    """HBM bytes per launch of a kernel family from the committed PMC collection (profiles/round1_hbm_traffic.json:
+    separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE); None if not collected"""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_hbm_traffic.json")) as f:
+            return json.load(f)[kind]["bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,7 +159,7 @@ def main():
                                       a.dropout, a.drop_path),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "loss": round(loss, 4)},
             "roofline": {"bound": "mfma", "kernel": dom["kind"], "achieved": round(ach, 2), "peak": MFMA_PEAK_TF,
-                         "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": _pmc_traffic(dom["kind"]),
                          "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(1, dom["launches"]), 2),
                          "whole_step_frac": round(value / world * GF_PER_IMG.get(a.nseg, 912.0) / 1e3 / MFMA_PEAK_TF, 4)},
             "kernel_families_ms_per_step": {f["kind"]: round(f["ms"], 3) for f in fam},
