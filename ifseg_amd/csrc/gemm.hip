@@ -92,7 +92,7 @@ __device__ __forceinline__ void lds_dma16(v4i32 rs, unsigned lds_base, unsigned 
                :: "s"(lds_base), "v"(voff), "s"(rs) : "memory");
 }
 
-template <int AMODE, bool B_KS, int BN, int BK, int STAGES>
+template <int AMODE, bool B_KS, int BN, int BK, int STAGES, bool COLSUM = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   static_assert(BN == 128 || (BN == 64 && !B_KS), "64-wide tiles only for k-contiguous B");
   constexpr int NJ = BN / 64;                 // 32-column MFMA tiles per wave along N
@@ -219,6 +219,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // COLSUM (weight-gradient GEMMs): the column sums of A (= the bias gradient) come out of the same A fragments
+  // through one more MFMA against an all-ones B fragment, in the workgroups of the first column tile only
+  f32x16 accb[COLSUM ? 2 : 1];
+  const bool do_colsum = COLSUM && n0 == 0 && wn == 0;
+  if (COLSUM) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) accb[i][e] = 0.f;
+  }
 
   auto compute = [&](int st) {
     const unsigned char* sA = smem + st * STAGE_BYTES;
@@ -237,6 +247,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      if constexpr (COLSUM) {
+        if (do_colsum) {
+          U128 one;
+          one.w[0] = one.w[1] = one.w[2] = one.w[3] = 0x3F803F80u;      // eight bf16 1.0
+#pragma unroll
+          for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one.b, fa[i], accb[i], 0, 0, 0);
+        }
+      }
     }
   };
 
@@ -259,6 +277,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
   }
 
+  if constexpr (COLSUM) {
+    // every row of accb holds sum_k A[k][m]; lanes 0..31 carry row 0 in register 0.  Slab layout per k-slice:
+    // [M x ldc | M] floats, so one reduction pass over M*ldc + M elements yields dW followed by db.
+    if (do_colsum && lane < 32) {
+      float* cb = reinterpret_cast<float*>(g.C) + (long long)blockIdx.z * g.sCsplit + (long long)g.M * g.ldc;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + lane;
+        if (m < g.M) cb[m] = accb[i][0];
+      }
+    }
+  }
   // ---- epilogue: lane owns row m = ..+(lane&31), 4 consecutive columns per reg group
   const bool relu = g.flags & IFSEG_GEMM_RELU, out_f32 = g.flags & IFSEG_GEMM_OUT_F32,
              accum = g.flags & IFSEG_GEMM_ACCUMULATE;
@@ -343,7 +373,7 @@ extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C
       return IFSEG_ERR_BAD_ARG;
     g.kchunk = (((K + splitk - 1) / splitk) + 63) / 64 * 64;
     g.splitk = (K + g.kchunk - 1) / g.kchunk;
-    g.sCsplit = (long long)M * ldc;
+    g.sCsplit = (long long)M * ldc + ((flags & IFSEG_GEMM_COLSUM) ? ((M + 3) & ~3) : 0);
   }
   // bytes each buffer descriptor may address (loads beyond it return zeros: that is the k / row padding)
   const long long nrA = layout == IFSEG_GEMM_TN ? ((long long)(K - 1) * lda + M) * 2 : ((long long)(M - 1) * lda + K) * 2;
@@ -357,6 +387,7 @@ extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C
   dim3 grid(tiles, batch > 0 ? batch : 1, g.splitk), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (layout < 0 || layout > 2) return IFSEG_ERR_BAD_ARG;
+  if ((flags & IFSEG_GEMM_COLSUM) && layout != IFSEG_GEMM_TN) return IFSEG_ERR_BAD_ARG;
   const double nb = batch > 0 ? batch : 1;
   ifseg_prof_begin(IFSEG_K_GEMM_NT + layout, s, 2.0 * M * N * K * nb, 2.0 * nb * ((double)M * K + (double)N * K + (double)M * N));
   const bool two_stage = (long long)tiles * g.splitk * (batch > 0 ? batch : 1) <= TWO_STAGE_MAX_WGS;
@@ -371,7 +402,15 @@ extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C
       else LAUNCH2(A_KC, false, 128);
       break;
     case IFSEG_GEMM_NN: LAUNCH2(A_KC, true, 128); break;
-    case IFSEG_GEMM_TN: LAUNCH2(A_KS, true, 128); break;
+    case IFSEG_GEMM_TN:
+      if (flags & IFSEG_GEMM_COLSUM) {
+        if (splitk <= 1 || ldc != N) return IFSEG_ERR_BAD_ARG;
+        if (two_stage) hipLaunchKernelGGL((gemm_kernel<A_KS, true, 128, GBK, 2, true>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_kernel<A_KS, true, 128, GBK, 1, true>), grid, block, 0, s, g);
+      } else {
+        LAUNCH2(A_KS, true, 128);
+      }
+      break;
   }
   ifseg_prof_end(IFSEG_K_GEMM_NT + layout, s);
   IFSEG_CHECK_LAUNCH();

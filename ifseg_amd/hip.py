@@ -108,10 +108,16 @@ def linear_dx(dy, w, out=None, resid=None, accumulate=False):
 _splitk_ws = {}
 
 
-def linear_dw(dy, x, out, accumulate=False):
-    """dw[N,K] = dy[M,N]^T @ x[M,K]   (out bf16 or fp32 decided by out.dtype).
-    The reduction runs over the M tokens; with few output tiles it is split over
-    workgroups (split-K into an fp32 workspace, then one reduction pass)."""
+GEMM_COLSUM = 8
+
+
+def linear_dw(dy, x, out, accumulate=False, bias_out=None):
+    """dw[N,K] = dy[M,N]^T @ x[M,K]   (out bf16 or fp32 decided by out.dtype); with ``bias_out`` also
+    db[N] = colsum(dy).  The reduction runs over the M tokens; with few output tiles it is split over
+    workgroups (split-K into an fp32 workspace, then one reduction pass).  When ``bias_out`` sits right behind
+    ``out`` in memory (a Linear's weight and bias in the gradient arena) the column sums ride on the same
+    GEMM (one extra MFMA against an all-ones fragment) and the same reduction pass.
+    Returns True if db was produced, False if the caller still has to compute it."""
     M, N = dy.shape
     K = x.shape[1]
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
@@ -119,16 +125,21 @@ def linear_dw(dy, x, out, accumulate=False):
     if splitk > 1 and out.is_contiguous():
         kchunk = (((M + splitk - 1) // splitk) + 63) // 64 * 64
         nsl = (M + kchunk - 1) // kchunk
+        fuse_b = (bias_out is not None and N % 4 == 0 and bias_out.dtype == out.dtype and bias_out.is_contiguous()
+                  and bias_out.data_ptr() == out.data_ptr() + out.numel() * out.element_size())
+        slab = N * K + (N if fuse_b else 0)
         ws = _splitk_ws.get(dy.device)
-        if ws is None or ws.numel() < nsl * N * K:
-            ws = torch.empty(max(nsl * N * K, 16 * 3072 * 768), dtype=torch.float32, device=dy.device)
+        if ws is None or ws.numel() < nsl * slab:
+            ws = torch.empty(max(nsl * slab, 16 * (3072 * 768 + 3072)), dtype=torch.float32, device=dy.device)
             _splitk_ws[dy.device] = ws
-        gemm(GEMM_TN, _bf(dy), _bf(x), ws, N, K, M, dy.stride(0), x.stride(0), K, flags=GEMM_OUT_F32, splitk=splitk)
-        reduce_parts(ws, out, 1, nsl, N * K, accumulate=accumulate)
-        return out
+        gemm(GEMM_TN, _bf(dy), _bf(x), ws, N, K, M, dy.stride(0), x.stride(0), K,
+             flags=GEMM_OUT_F32 | (GEMM_COLSUM if fuse_b else 0), splitk=splitk)
+        dst = out.as_strided((slab,), (1,)) if fuse_b else out       # dW followed by db, contiguous in the arena
+        reduce_parts(ws, dst, 1, nsl, slab, accumulate=accumulate)
+        return fuse_b
     flags = (GEMM_OUT_F32 if out.dtype == torch.float32 else 0) | (GEMM_ACCUMULATE if accumulate else 0)
     gemm(GEMM_TN, _bf(dy), _bf(x), out, N, K, M, dy.stride(0), x.stride(0), out.stride(0), flags=flags)
-    return out
+    return False
 
 
 def conv2d_nhwc(x, w, shift, resid, out, B, H, W, Cin, Cout, KH, KW, stride, pad, relu):

@@ -78,11 +78,18 @@ class HipEngine:
             if n in names and n not in order:
                 order.append(n)
 
-        def mha(p):
+        def mha(p, cross=False):
+            # every (fused) Linear is laid out weight-then-bias so that dW and db are one contiguous range
             add(p + ".c_attn")
-            for suf in (".weight", ".bias"):
-                for pr in ("q_proj", "k_proj", "v_proj"):
-                    add("%s.%s%s" % (p, pr, suf))
+            if cross:       # q projects the decoder stream, k|v (one GEMM) the encoder output
+                add(p + ".q_proj.weight"); add(p + ".q_proj.bias")
+                for suf in (".weight", ".bias"):
+                    for pr in ("k_proj", "v_proj"):
+                        add("%s.%s%s" % (p, pr, suf))
+            else:
+                for suf in (".weight", ".bias"):
+                    for pr in ("q_proj", "k_proj", "v_proj"):
+                        add("%s.%s%s" % (p, pr, suf))
             add(p + ".out_proj.weight"); add(p + ".out_proj.bias")
 
         def lnp(p):
@@ -112,7 +119,7 @@ class HipEngine:
             add(d + n + ".weight"); add(d + n + ".bias")
         for i in range(cfg.dec_layers):
             p = "%slayers.%d." % (d, i)
-            mha(p + "self_attn"); mha(p + "encoder_attn")
+            mha(p + "self_attn"); mha(p + "encoder_attn", cross=True)
             for q in ("self_attn_layer_norm", "self_attn_ln", "encoder_attn_layer_norm", "cross_attn_ln",
                       "final_layer_norm", "ffn_layernorm"):
                 lnp(p + q)
@@ -882,8 +889,7 @@ class HipEngine:
     def _linear_bwd(self, dy, x, wname_or_view, gw, gb, dx_out=None, dx_resid=None, dx_accumulate=False, need_dx=True):
         """dy [M,N], x [M,K]: writes dW -> gw, db -> gb, returns dx [M,K]"""
         with self._wgrad():
-            hip.linear_dw(dy, x, gw)
-            if gb is not None:
+            if not hip.linear_dw(dy, x, gw, bias_out=gb) and gb is not None:
                 self._bias_grad(dy, gb)
         if need_dx:
             return hip.linear_dx(dy, wname_or_view, out=dx_out, resid=dx_resid, accumulate=dx_accumulate)

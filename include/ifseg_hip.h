@@ -32,6 +32,9 @@ int ifseg_abi_version(void);
 #define IFSEG_GEMM_RELU 1
 #define IFSEG_GEMM_OUT_F32 2
 #define IFSEG_GEMM_ACCUMULATE 4 /* C += result */
+#define IFSEG_GEMM_COLSUM 8     /* TN + splitk > 1 only: every k-slice slab is [M x N | round4(M)] floats, the extra
+                                   M floats being sum_k A[k][m] -- the bias gradient of a Linear whose weight gradient is
+                                   this GEMM (dW = dY^T X, db = colsum dY); summed by the same ifseg_reduce_parts pass */
 
 /* bf16 MFMA GEMM, fp32 accumulate, epilogue
  *   C = ((A.B + bias[n]) * alpha[for n < alpha_ncols]) + resid[m,n]  (+relu)
