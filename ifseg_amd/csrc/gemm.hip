@@ -7,12 +7,14 @@
 //   TN : C[M,N] = A[K,M]^T . B[K,N]         dW = dY^T . X   (reduction over tokens)
 //   CONV: A rows gathered from an NHWC image (resnet.py:117-137 convs, BN folded)
 //
-// 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 2x2 tiles of
-// v_mfma_f32_32x32x16_bf16.  Operands are staged global -> registers -> LDS in
-// their natural (coalesced) orientation; k-contiguous tiles are read with
-// ds_read_b128, k-strided tiles with ds_read_b64_tr_b16 (hardware transpose), so
-// no operand is ever transposed in HBM.  The MFMA is issued "swapped"
-// (D[n][m]) so each lane owns 4 consecutive output columns -> 8/16-byte stores.
+// 128x128x64 block tile (128x64 for narrow outputs), 4 waves (2x2), each wave 64x64 = 2x2 tiles of
+// v_mfma_f32_32x32x16_bf16.  Operand tiles go HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no staging
+// registers, zero padding from the buffer descriptor) in their natural (coalesced) orientation, one or two
+// LDS stages; k-contiguous tiles are read with ds_read_b128, k-strided tiles with ds_read_b64_tr_b16
+// (hardware transpose), so no operand is ever transposed in HBM.  The MFMA is issued "swapped" (D[n][m]) so
+// each lane owns 4 consecutive output columns -> 8/16-byte stores.  Split-K (weight gradients) writes fp32
+// slabs that a second launch sums: a fused "last workgroup reduces" was measured 2-3x slower on MI355X -- the
+// agent-scope release/acquire it needs writes back / invalidates the per-XCD L2s.
 #include "common.h"
 #include "prof.h"
 #include "../../include/ifseg_hip.h"
