@@ -58,6 +58,18 @@ def _pmc_traffic(kind):
         return None
 
 
+def _group_roofline(rs, steps):
+    ms = sum(r["ms"] for r in rs)
+    nl = sum(r["launches"] for r in rs)
+    ach = sum(r["flops"] for r in rs) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    tr = [_pmc_traffic(r["kind"]) for r in rs]
+    return {"bound": "mfma", "kernel": "gemm_kernel", "instantiations": [r["kind"] for r in rs], "achieved": round(ach, 2),
+            "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TF, 4),
+            "traffic": round(sum(t * r["launches"] for t, r in zip(tr, rs)) / max(1, nl)) if all(t is not None for t in tr) else None,
+            "launches": nl, "avg_launch_us": round(ms * 1e3 / max(1, nl), 2), "ms_per_step": round(ms / max(1, steps), 3),
+            "measured": "separate pass of %d steps after the timed region (per-launch events on every GEMM slow the step)" % steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +155,17 @@ def main():
     dt = tt.item()
     dom = hip.prof_read(dominant)
     hip.prof_enable(0)
+    # second view, outside the timed region (timing ~300 launches per step with events costs ~8 % of the step): the four
+    # GEMM-shaped families are instantiations of ONE kernel, gemm_kernel (csrc/gemm.hip); together they are the largest
+    # time consumer, so their aggregate MFMA rate is reported next to the dominant single family
+    gk = [k for k, n in enumerate(hip.PROF_KINDS) if n.startswith("gemm_") or n == "conv"]
+    hip.prof_reset(); hip.prof_enable(sum(1 << k for k in gk))
+    extra = min(3, a.steps)
+    for _ in range(extra):
+        one_step()
+    torch.cuda.synchronize()
+    grs = [hip.prof_read(k) for k in gk]
+    hip.prof_enable(0)
     loss = float(logs[-1]["loss"])
     if rank == 0:
         imgs = a.batch * world * a.steps
@@ -162,6 +185,7 @@ def main():
                          "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": _pmc_traffic(dom["kind"]),
                          "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(1, dom["launches"]), 2),
                          "whole_step_frac": round(value / world * GF_PER_IMG.get(a.nseg, 912.0) / 1e3 / MFMA_PEAK_TF, 4)},
+            "roofline_gemm_kernel": _group_roofline(grs, extra),
             "kernel_families_ms_per_step": {f["kind"]: round(f["ms"], 3) for f in fam},
         }
         if not a.no_cpu_baseline and world == 1:
