@@ -606,17 +606,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         }
       }
       // dV^T += dO^T P ; dK^T += Q^T dS ; slot (kh,e) <-> query ib + 16*s2 + 4*kh + (e&3) + 8*(e>>2)
+      // all transposed operand reads of one s2 half are issued before its MFMAs (the scheduling barrier keeps
+      // the compiler from sinking each read next to its MFMA, which serialises LDS latency 6 times per half;
+      // batching both halves at once spills)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const int r0 = 16 * s2 + 4 * half + (i16 >> 2);
+        U128 fo[2], fq[NKS / 2];
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const int colb = (db * 32 + g16 * 16 + (i16 & 3) * 4) * 2;
           U64 x, y;
           x.s = lds_read_tr(sO + vx_off(r0, colb));
           y.s = lds_read_tr(sO + vx_off(r0 + 8, colb));
-          U128 f; f.w[0] = x.w[0]; f.w[1] = x.w[1]; f.w[2] = y.w[0]; f.w[3] = y.w[1];
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, pfr[s2], dv[db], 0, 0, 0);
+          fo[db].w[0] = x.w[0]; fo[db].w[1] = x.w[1]; fo[db].w[2] = y.w[0]; fo[db].w[3] = y.w[1];
         }
 #pragma unroll
         for (int cb = 0; cb < NKS / 2; ++cb) {
@@ -624,9 +627,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
           U64 x, y;
           x.s = lds_read_tr(sQ + kx_off(r0, col >> 3) + (col & 7) * 2);
           y.s = lds_read_tr(sQ + kx_off(r0 + 8, col >> 3) + (col & 7) * 2);
-          U128 f; f.w[0] = x.w[0]; f.w[1] = x.w[1]; f.w[2] = y.w[0]; f.w[3] = y.w[1];
-          dk[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, dsf[s2], dk[cb], 0, 0, 0);
+          fq[cb].w[0] = x.w[0]; fq[cb].w[1] = x.w[1]; fq[cb].w[2] = y.w[0]; fq[cb].w[3] = y.w[1];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[db].b, pfr[s2], dv[db], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < NKS / 2; ++cb) dk[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[cb].b, dsf[s2], dk[cb], 0, 0, 0);
       }
     }
   }
