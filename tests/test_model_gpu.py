@@ -442,3 +442,37 @@ def test_eval_branch_vs_reference_golden(golden_dir):
     prob = hip.neighbour_smoothing(lp, n, feat.to(dev), int(g["iters"]), int(g["topk"]))
     ref = O.neighbour_smoothing(ol.to(torch.bfloat16).float(), feat.float(), int(g["iters"]), int(g["topk"]))[:, :-1]
     assert _rel(prob, ref) <= 2e-2
+
+
+def test_training_step_is_deterministic_across_streams():
+    """Two trainers stepped on the same batches (Base, B=2, dropout on, weight-gradient stream + trunk prefetch stream
+    active) produce bit-identical losses, gradients and updated parameters: no race between the streams, no
+    order-dependent reduction anywhere in the step."""
+    from ifseg_amd.criterions import SegCriterion
+    from ifseg_amd.tasks.mm_tasks import SegmentationTask
+    from ifseg_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+
+    def run():
+        torch.manual_seed(0)
+        task = SegmentationTask(num_seg_tokens=15, patch_image_size=512, arch="segofa_base")
+        model = task.build_model()
+        model.cfg.dropout, model.cfg.encoder_drop_path_rate, model.cfg.decoder_drop_path_rate = 0.1, 0.1, 0.1
+        tr = Trainer(model, SegCriterion(task), task, device=dev)
+        ring = []
+        for j in range(2):
+            sm = task.synthetic_sample(2, dev, seed=100 + j)
+            sm["net_input"]["patch_images"] = sm["net_input"]["patch_images"].to(torch.bfloat16)
+            ring.append(sm)
+        losses = []
+        for i in range(3):
+            logs = tr.train_step([ring[i % 2]], prefetch=[ring[(i + 1) % 2]])
+            losses.append(float(logs[-1]["loss"]))
+        torch.cuda.synchronize()
+        return losses, tr.eng.g16.clone(), tr.eng.p16.clone()
+
+    l1, g1, p1 = run()
+    l2, g2, p2 = run()
+    assert l1 == l2, (l1, l2)
+    assert torch.equal(g1, g2) and torch.equal(p1, p2)
+    assert g1.float().abs().sum().item() > 0 and all(x == x for x in l1)
