@@ -75,3 +75,39 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     lib.ifseg_abi_version.restype = ctypes.c_int
     assert lib.ifseg_abi_version() == 3
+
+
+def test_arena_lays_every_linear_out_weight_then_bias():
+    """The gradient arena keeps each (fused) Linear's bias right behind its weight(s): dW and db are then one
+    contiguous range, which lets the weight-gradient GEMM's split-K reduction write both (IFSEG_GEMM_COLSUM), and
+    q|k|v (self-attention) / k|v (cross-attention) weights are adjacent so one GEMM serves them."""
+    from ifseg_amd.models.segofa import SegOFAModel, make_config
+    m = SegOFAModel(make_config("segofa_tiny", embed_dim=128, ffn_dim=256, heads=2, enc_layers=2, dec_layers=2,
+                                resnet_layers=(3, 4, 6), num_seg_tokens=5, vocab_size=101, patch_image_size=128,
+                                orig_patch_image_size=128))
+    eng = m.engine
+    eng.pack(torch.device("cpu"))
+    off, shp = eng.offs, eng.shapes
+    numel = lambda n: int(torch.tensor(shp[n]).prod())
+
+    def adjacent(*names):
+        for a, b in zip(names[:-1], names[1:]):
+            assert off[b] == off[a] + numel(a), (a, b, off[a], numel(a), off[b])
+
+    for l in range(2):
+        e, d = "encoder.layers.%d." % l, "decoder.layers.%d." % l
+        for p in (e + "self_attn", d + "self_attn"):
+            adjacent(p + ".q_proj.weight", p + ".k_proj.weight", p + ".v_proj.weight", p + ".q_proj.bias", p + ".k_proj.bias",
+                     p + ".v_proj.bias")
+            adjacent(p + ".out_proj.weight", p + ".out_proj.bias")
+        c = d + "encoder_attn"
+        adjacent(c + ".q_proj.weight", c + ".q_proj.bias")
+        adjacent(c + ".k_proj.weight", c + ".v_proj.weight", c + ".k_proj.bias", c + ".v_proj.bias")
+        adjacent(c + ".out_proj.weight", c + ".out_proj.bias")
+        for p in (e, d):
+            adjacent(p + "fc1.weight", p + "fc1.bias")
+            adjacent(p + "fc2.weight", p + "fc2.bias")
+    adjacent("encoder.pos_q_linear.weight", "encoder.pos_k_linear.weight", "encoder.pos_q_linear.bias", "encoder.pos_k_linear.bias")
+    # the nn.Parameters are views into the arena (state_dict contract is unchanged by the layout)
+    w = dict(m.named_parameters())["decoder.layers.1.encoder_attn.q_proj.bias"]
+    assert w.data_ptr() == eng.p16.data_ptr() + 2 * off["decoder.layers.1.encoder_attn.q_proj.bias"]
