@@ -476,3 +476,31 @@ def test_training_step_is_deterministic_across_streams():
     assert l1 == l2, (l1, l2)
     assert torch.equal(g1, g2) and torch.equal(p1, p2)
     assert g1.float().abs().sum().item() > 0 and all(x == x for x in l1)
+
+
+def test_inference_forward_is_graph_capturable():
+    """The eval forward touches only its static workspace, launches every kernel on the current stream and never
+    syncs after the first call on a given input tensor, so it can be captured into a HIP graph and replayed on new
+    data copied into the static inputs (serving path; tools/infer_time.py measures it on Base)."""
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    m = _build(ocfg, sd, dev)
+    m.eval()
+    b1, b2 = O.synthetic_batch(ocfg, 2, 12, seed=5), O.synthetic_batch(ocfg, 2, 12, seed=6)
+    inp = lambda b: {"src_tokens": b["src_tokens"].to(dev), "src_lengths": torch.full((2,), 12).to(dev),
+                     "patch_images": b["patch_images"].to(dev), "patch_masks": b["patch_masks"].to(dev),
+                     "prev_output_tokens": b["prev_output_tokens"].to(dev)}
+    static, other = inp(b1), inp(b2)
+    with torch.no_grad():
+        ref_other = m(**other)[0].clone()
+        m(**static)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = m(**static)[0]
+        for k in ("src_tokens", "patch_images"):
+            static[k].copy_(other[k])
+        g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, ref_other)
