@@ -1011,7 +1011,8 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   const int nkt = (a.S + 127) / 128, nq = (a.T + 127) / 128;
   if (a.rel_mode && a.nparts != a.B * nkt) return IFSEG_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  {  // delta = rowsum(dO * O)
+  const int ph = x->phases ? x->phases : (IFSEG_ATTN_BWD_DELTA | IFSEG_ATTN_BWD_DKV | IFSEG_ATTN_BWD_DQ);
+  if (ph & IFSEG_ATTN_BWD_DELTA) {  // delta = rowsum(dO * O)
     const long long threads = (long long)a.B * a.T * a.H * 8;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
                        (const bf16_t*)x->out, a.dO, x->delta, a.B, a.H, a.T, x->out_bs, x->ldout, a.do_bs, a.lddo);
@@ -1021,20 +1022,25 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   const size_t lds_kv = (KT_BYTES + VT_BYTES + 512) + 2 * VT_BYTES + (a.rel_mode ? (2 * n2dp + n1dp + 4) * 4 + (size_t)a.P * 4 : 0);
   const size_t lds_q = 2 * (KT_BYTES + VT_BYTES) + (a.rel_mode ? n2dp * 4 + (size_t)a.P * 4 : 0);
   if (lds_kv > 160 * 1024 || lds_q > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
+  const bool do_kv = ph & IFSEG_ATTN_BWD_DKV, do_q = ph & IFSEG_ATTN_BWD_DQ;
   if (x->pos_q) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-    ifseg_prof_begin(IFSEG_K_ATTN_DKV, s, 6.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);   // dV, dP, dK of the reference
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(nkt * a.H * a.B), dim3(256), lds_kv, s, a);
-    ifseg_prof_end(IFSEG_K_ATTN_DKV, s);
-    ifseg_prof_begin(IFSEG_K_ATTN_DQ, s, 2.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);    // dQ of the reference
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(nq * a.H * a.B), dim3(256), lds_q, s, a);
-    ifseg_prof_end(IFSEG_K_ATTN_DQ, s);
+    if (do_kv) {
+      ifseg_prof_begin(IFSEG_K_ATTN_DKV, s, 6.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);   // dV, dP, dK of the reference
+      hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(nkt * a.H * a.B), dim3(256), lds_kv, s, a);
+      ifseg_prof_end(IFSEG_K_ATTN_DKV, s);
+    }
+    if (do_q) {
+      ifseg_prof_begin(IFSEG_K_ATTN_DQ, s, 2.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);    // dQ of the reference
+      hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(nq * a.H * a.B), dim3(256), lds_q, s, a);
+      ifseg_prof_end(IFSEG_K_ATTN_DQ, s);
+    }
   } else {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(nkt * a.H * a.B), dim3(256), lds_kv, s, a);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(nq * a.H * a.B), dim3(256), lds_q, s, a);
+    if (do_kv) hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(nkt * a.H * a.B), dim3(256), lds_kv, s, a);
+    if (do_q) hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(nq * a.H * a.B), dim3(256), lds_q, s, a);
   }
   IFSEG_CHECK_LAUNCH();
   return 0;

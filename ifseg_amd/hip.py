@@ -33,7 +33,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 3:
+        if _lib.ifseg_abi_version() != 4:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -174,7 +174,7 @@ class _AttnBwdArgs(ctypes.Structure):
                 + [(n, c_int) for n in ("rel_mode", "P", "code_bias", "n2d", "causal", "nparts")]
                 + [(n, c_void_p) for n in ("gcode", "rel2d", "rel1d", "relx", "gain", "drel2d_part", "drel1d_part",
                                            "drelx_part")]   # field order == ifseg_attn_bwd_args
-                + [("dq_scale", c_float), ("dpq_scale", c_float), ("grid_w", c_int)])
+                + [("dq_scale", c_float), ("dpq_scale", c_float), ("grid_w", c_int), ("phases", c_int)])
 
 
 def _p(t):
@@ -202,9 +202,12 @@ def attn_fwd_gain(q, k, v, pos_q, pos_k, out, lse, B, H, T, S, rel=None, causal=
     return out
 
 
+ATTN_BWD_DELTA, ATTN_BWD_DKV, ATTN_BWD_DQ = 1, 2, 4
+
+
 def attn_bwd(q, k, v, pos_q, pos_k, out, dout, lse, delta, dq, dk, dv, dpq_part, dpk_part, B, H, T, S, rel=None,
              causal=False, P=None, gain=None, dq_scale=1.0, dpq_scale=1.0, drel2d_part=None, drel1d_part=None,
-             drelx_part=None, nparts=0):
+             drelx_part=None, nparts=0, phases=0):
     a = _AttnBwdArgs()
     if rel is not None:
         P = rel.P
@@ -229,6 +232,7 @@ def attn_bwd(q, k, v, pos_q, pos_k, out, dout, lse, delta, dq, dk, dv, dpq_part,
         a.gcode, a.rel2d, a.rel1d, a.relx = _p(rel.gcode), _p(rel.rel2d), _p(rel.rel1d), _p(rel.relx)
         a.grid_w = rel.grid_w
     a.dq_scale, a.dpq_scale = dq_scale, dpq_scale
+    a.phases = phases
     rc = lib().ifseg_attn_bwd(ctypes.byref(a), _stream())
     _check(rc, "attn_bwd")
 

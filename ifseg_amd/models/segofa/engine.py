@@ -281,6 +281,12 @@ class HipEngine:
         self._evi = (self._evi + 1) % len(self._evs)
         return e
 
+    def _wgrad_init(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._evs = [torch.cuda.Event() for _ in range(128)]
+            self._evi = 0
+
     @contextlib.contextmanager
     def _wgrad(self):
         """Everything enqueued so far on the current stream happens-before the body; the body runs on the
@@ -288,15 +294,31 @@ class HipEngine:
         if not self.overlap:
             yield
             return
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._evs = [torch.cuda.Event() for _ in range(64)]
-            self._evi = 0
+        self._wgrad_init()
         e = self._ev()
         e.record(torch.cuda.current_stream())
         self._side.wait_event(e)
         with torch.cuda.stream(self._side):
             prev = hip.set_stream(self._side.cuda_stream)
+            try:
+                yield
+            finally:
+                hip.set_stream(prev)
+
+    def _dq_stream_get(self):
+        if getattr(self, "_dqs", None) is None:
+            self._wgrad_init()
+            self._dqs = torch.cuda.Stream(device=self.device)
+        return self._dqs
+
+    @contextlib.contextmanager
+    def _fork(self, stream):
+        """body runs on `stream`, after everything enqueued so far on the current stream"""
+        e = self._ev()
+        e.record(torch.cuda.current_stream())
+        stream.wait_event(e)
+        with torch.cuda.stream(stream):
+            prev = hip.set_stream(stream.cuda_stream)
             try:
                 yield
             finally:
@@ -929,9 +951,21 @@ class HipEngine:
         if rel is not None:
             parts = [gbuf("g_relp%d_%d" % (i, t.shape[1]), (H, nparts, t.shape[1]), torch.float32)
                      for i, t in enumerate((rel.rel2d, rel.rel1d, rel.relx))]
-        hip.attn_bwd(q, k, v, pq, pk, o, do, lse, delta, dq, dk, dv, dpq_part, dpk_part, B, H, T, S, rel=rel,
-                     causal=causal, gain=gain, dq_scale=scaling, dpq_scale=scaling, drel2d_part=parts[0],
-                     drel1d_part=parts[1], drelx_part=parts[2], nparts=nparts)
+        kw = dict(rel=rel, causal=causal, gain=gain, dq_scale=scaling, dpq_scale=scaling, drel2d_part=parts[0],
+                  drel1d_part=parts[1], drelx_part=parts[2], nparts=nparts)
+        args = (q, k, v, pq, pk, o, do, lse, delta, dq, dk, dv, dpq_part, dpk_part, B, H, T, S)
+        if self.overlap:
+            # dK/dV and dQ are independent once delta exists; each leaves its last round of workgroups partly
+            # empty (864 workgroups on 512 slots), so they run on two streams and fill each other's holes
+            hip.attn_bwd(*args, phases=hip.ATTN_BWD_DELTA, **kw)
+            with self._fork(self._dq_stream_get()):
+                hip.attn_bwd(*args, phases=hip.ATTN_BWD_DQ, **kw)
+                dq_done = self._ev()
+                dq_done.record(self._dqs)
+            hip.attn_bwd(*args, phases=hip.ATTN_BWD_DKV, **kw)
+            torch.cuda.current_stream().wait_event(dq_done)
+        else:
+            hip.attn_bwd(*args, **kw)
         with self._wgrad():
             hip.reduce_parts(dpq_part, dpq_acc, 1, B, T * C, accumulate=not first_pos)
             hip.reduce_parts(dpk_part, dpk_acc, 1, B, S * C, accumulate=not first_pos)

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 3
+#define IFSEG_ABI_VERSION 4
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -117,7 +117,13 @@ typedef struct ifseg_attn_bwd_args {
   float *drel2d_part, *drel1d_part, *drelx_part;
   float dq_scale, dpq_scale;
   int grid_w; /* width of the token grid (0 if unknown); 32 enables the row-aligned bias-gradient reduction */
+  int phases; /* 0 = everything; else a mask: 1 = delta, 2 = dK/dV kernel, 4 = dQ kernel.  The dQ kernel only needs
+                 delta, so a caller may launch {1|2} and {4} on two streams (ordered by an event after delta): the two
+                 kernels then fill each other's partially occupied last round of workgroups. */
 } ifseg_attn_bwd_args;
+#define IFSEG_ATTN_BWD_DELTA 1
+#define IFSEG_ATTN_BWD_DKV 2
+#define IFSEG_ATTN_BWD_DQ 4
 int ifseg_attn_bwd(const ifseg_attn_bwd_args* args, void* stream);
 
 /* -------------------------------------------------------------- row ops */

@@ -445,20 +445,21 @@ def test_eval_branch_vs_reference_golden(golden_dir):
 
 
 def test_training_step_is_deterministic_across_streams():
-    """Two trainers stepped on the same batches (Base, B=2, dropout on, weight-gradient stream + trunk prefetch stream
-    active) produce bit-identical losses, gradients and updated parameters: no race between the streams, no
-    order-dependent reduction anywhere in the step."""
+    """Two trainers stepped on the same batches (Base, B=2, dropout on; weight-gradient, dQ and trunk-prefetch streams
+    active) produce bit-identical losses, gradients and updated parameters, and so does the single-stream execution:
+    no race between the streams, no order-dependent reduction anywhere in the step."""
     from ifseg_amd.criterions import SegCriterion
     from ifseg_amd.tasks.mm_tasks import SegmentationTask
     from ifseg_amd.trainer import Trainer
     dev = torch.device("cuda:0")
 
-    def run():
+    def run(overlap=True):
         torch.manual_seed(0)
         task = SegmentationTask(num_seg_tokens=15, patch_image_size=512, arch="segofa_base")
         model = task.build_model()
         model.cfg.dropout, model.cfg.encoder_drop_path_rate, model.cfg.decoder_drop_path_rate = 0.1, 0.1, 0.1
         tr = Trainer(model, SegCriterion(task), task, device=dev)
+        tr.eng.overlap = overlap
         ring = []
         for j in range(2):
             sm = task.synthetic_sample(2, dev, seed=100 + j)
@@ -466,7 +467,7 @@ def test_training_step_is_deterministic_across_streams():
             ring.append(sm)
         losses = []
         for i in range(3):
-            logs = tr.train_step([ring[i % 2]], prefetch=[ring[(i + 1) % 2]])
+            logs = tr.train_step([ring[i % 2]], prefetch=[ring[(i + 1) % 2]] if overlap else None)
             losses.append(float(logs[-1]["loss"]))
         torch.cuda.synchronize()
         return losses, tr.eng.g16.clone(), tr.eng.p16.clone()
@@ -475,6 +476,9 @@ def test_training_step_is_deterministic_across_streams():
     l2, g2, p2 = run()
     assert l1 == l2, (l1, l2)
     assert torch.equal(g1, g2) and torch.equal(p1, p2)
+    # ... and identical to the single-stream execution of the same step (wgrad / dQ / trunk streams off)
+    l3, g3, p3 = run(overlap=False)
+    assert l1 == l3 and torch.equal(g1, g3) and torch.equal(p1, p3)
     assert g1.float().abs().sum().item() > 0 and all(x == x for x in l1)
 
 
