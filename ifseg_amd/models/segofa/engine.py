@@ -54,6 +54,7 @@ class HipEngine:
         self._saved_grad, self._saved_aux = {}, {}
         self.ws, self.saved = self._ws_grad, self._saved_grad
         self._gctx = None                 # ctx of the forward awaiting its backward
+        self.ctx_building = None          # ctx of the forward being enqueued
         self._views = {}
         self.geo = {}
         self.ctx = None
@@ -545,6 +546,7 @@ class HipEngine:
         encoder_module.py:499-675) -- patch embeddings are EmbeddingBag means of class-name tokens, the ResNet
         trunk and image_proj are not run; `patch_images` is ignored."""
         cfg = self.cfg
+        self.ctx_building = None
         dev = src_tokens.device if bag is not None else patch_images.device
         if not self.packed or self.device != dev:
             self.pack(dev)
@@ -583,6 +585,7 @@ class HipEngine:
         self._drop_setup(B, need_grad)
         ctx = {"B": B, "L": L, "P": P, "T": T, "Td": Td, "h": h, "w": w, "full": bool(full_context_alignment),
                "src_tokens": src_tokens, "feat": feat}
+        self.ctx_building = ctx
         e = "encoder."
         # ---- embeddings (forward_embedding, encoder_module.py:388-446)
         img_pre = buf("img_pre", (B * P, C))
@@ -635,6 +638,18 @@ class HipEngine:
 
         # ---- decoder (extract_features_scriptable_surrogate, decoder_module.py:486-677)
         d = "decoder."
+        # the K|V projections of every decoder layer's cross-attention only read the encoder output: they run on
+        # the side stream underneath the first decoder blocks instead of inside each layer's dependent chain
+        ctx["ckv_ready"] = None
+        if self.overlap and need_grad:
+            with self._wgrad():
+                for l in range(cfg.dec_layers):
+                    a_ = "%slayers.%d.encoder_attn" % (d, l)
+                    kv = buf("d%d_ckv" % l, (B, T, 2 * C))
+                    hip.linear_fwd(enc_out.view(B * T, C), self._fused(self.p16, a_ + ".k_proj.weight", 2 * C, C),
+                                   self._fused(self.p16, a_ + ".k_proj.bias", 2 * C), out=kv.view(B * T, 2 * C))
+                ctx["ckv_ready"] = self._ev()
+                ctx["ckv_ready"].record(self._side)
         y0b = buf("d_bos", (B, 1, C))
         bos = (prev_output_tokens[:, :1] if prev_output_tokens is not None
                else torch.zeros(B, 1, dtype=torch.long, device=dev))
@@ -846,8 +861,13 @@ class HipEngine:
         q = buf(tg + "_cq", (B, Td, C))
         hip.linear_fwd(yn, W(a_ + ".q_proj.weight"), W(a_ + ".q_proj.bias"), out=q.view(B * Td, C), alpha=scaling)
         kv = buf(tg + "_ckv", (B, Te, 2 * C))
-        hip.linear_fwd(enc_out.view(B * Te, C), self._fused(self.p16, a_ + ".k_proj.weight", 2 * C, C),
-                       self._fused(self.p16, a_ + ".k_proj.bias", 2 * C), out=kv.view(B * Te, 2 * C))
+        ready = self.ctx_building.get("ckv_ready") if self.ctx_building is not None else None
+        if ready is not None:
+            if tg == "d0":
+                torch.cuda.current_stream().wait_event(ready)      # all layers' K|V were projected on the side stream
+        else:
+            hip.linear_fwd(enc_out.view(B * Te, C), self._fused(self.p16, a_ + ".k_proj.weight", 2 * C, C),
+                           self._fused(self.p16, a_ + ".k_proj.bias", 2 * C), out=kv.view(B * Te, 2 * C))
         o = buf(tg + "_co", (B, Td, C))
         lse = buf(tg + "_clse", (B, H, Td), torch.float32)
         gain = self._gain32(tg + "_ca", a_ + ".c_attn")
@@ -1046,10 +1066,13 @@ class HipEngine:
                          G(a_ + ".q_proj.bias"), dx_out=dyn)
         # K/V projections read the encoder output: accumulate into d_enc_out
         enc2d = self.ctx["enc_out"].view(B * Te, C)
-        self._linear_bwd(dkv.view(B * Te, 2 * C), enc2d, self._fused(self.p16, a_ + ".k_proj.weight", 2 * C, C),
-                         self._fused(self.g16, a_ + ".k_proj.weight", 2 * C, C),
-                         self._fused(self.g16, a_ + ".k_proj.bias", 2 * C), dx_out=d_enc_out.view(B * Te, C),
-                         dx_accumulate=not first_cross)
+        # the K|V projections read the encoder output: their dX accumulates into d_enc_out, which nothing needs before
+        # the encoder backward starts -- the whole linear backward (dW, db, dX) goes to the side stream, in layer order
+        with self._wgrad():
+            self._linear_bwd(dkv.view(B * Te, 2 * C), enc2d, self._fused(self.p16, a_ + ".k_proj.weight", 2 * C, C),
+                             self._fused(self.g16, a_ + ".k_proj.weight", 2 * C, C),
+                             self._fused(self.g16, a_ + ".k_proj.bias", 2 * C), dx_out=d_enc_out.view(B * Te, C),
+                             dx_accumulate=not first_cross)
         dy1 = gbuf("g_dy1c_%d" % rows, (rows, C))
         self._ln_bwd(dyn, s["x"].view(rows, C), p + "encoder_attn_layer_norm", tg + "_cln1", dy1, dx_add=dy2)
         return dy1
