@@ -114,16 +114,32 @@ class Trainer:
         if not self.model.training:
             self.model.train()
         logs, sample_sizes = [], []
-        for sample in samples:            # update_freq > 1 would accumulate; the shipped recipe uses 1
-            loss, ss, lg = self.task.train_step(sample, self.model, self.criterion, None, self.num_updates)
-            logs.append(lg)
-            sample_sizes.append(ss)
+        eng = self.eng
+        accumulate = len(samples) > 1       # update_freq > 1 (trainer.py:745-830; the shipped recipe uses 1)
+        hook = eng.grad_ready_hook
+        if accumulate:
+            # every backward rewrites the bf16 gradient arena: the micro-batch gradients are summed in fp32 and the
+            # ranks are reduced once, on the sum (fairseq's no_sync on all but the last micro-batch)
+            eng.grad_ready_hook = None
+            if getattr(self, "_gacc", None) is None:
+                self._gacc = torch.empty(eng.n_train, dtype=torch.float32, device=self.device)
+            self._gacc.zero_()
+        try:
+            for sample in samples:
+                loss, ss, lg = self.task.train_step(sample, self.model, self.criterion, None, self.num_updates)
+                logs.append(lg)
+                sample_sizes.append(ss)
+                if accumulate:
+                    self._gacc.add_(eng.g16)
+        finally:
+            eng.grad_ready_hook = hook
+        if accumulate:
+            eng.g16.copy_(self._gacc)
         total_ss = float(sum(sample_sizes))
         if self.world > 1:
             self.reducer.finish()
             total_ss *= self.world          # every rank reports sample_size 1 (seg_criterion.py:345)
         gscale = 1.0 / total_ss             # sum over ranks * (world / total) / world
-        eng = self.eng
         hip.grad_sumsq(eng.g16, self.ws, self.sumsq)
         self.num_updates += 1
         hip.adam_step(self.p32, eng.g16, self.m, self.v, eng.p16[: eng.n_train], self.get_lr(), self.betas[0],

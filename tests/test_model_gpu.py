@@ -508,3 +508,31 @@ def test_inference_forward_is_graph_capturable():
         g.replay()
         torch.cuda.synchronize()
     assert torch.equal(out, ref_other)
+
+
+def test_update_freq_accumulates_micro_batches():
+    """train_step([s1, s2]) (update_freq 2): the gradient handed to Adam is the fp32 sum of the two micro-batch
+    gradients, scaled by 1 / (number of micro-batches) inside the fused optimizer step."""
+    from ifseg_amd.criterions import SegCriterion
+    from ifseg_amd.tasks.mm_tasks import SegmentationTask
+    from ifseg_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    task = SegmentationTask(num_seg_tokens=5, patch_image_size=128, arch="segofa_tiny")
+
+    def make():
+        torch.manual_seed(0)
+        return Trainer(task.build_model(), SegCriterion(task), task, device=dev)
+
+    s1, s2 = task.synthetic_sample(2, dev, seed=1), task.synthetic_sample(2, dev, seed=2)
+    ta = make()
+    grads = []
+    for s in (s1, s2):                       # the two micro-batch gradients, each from the same initial weights
+        t = make()
+        t.task.train_step(s, t.model, t.criterion, None, 0)
+        torch.cuda.synchronize()
+        grads.append(t.eng.g16.float().clone())
+    ta.train_step([s1, s2])
+    torch.cuda.synchronize()
+    want = (grads[0] + grads[1]).to(torch.bfloat16).float()
+    assert torch.equal(ta.eng.g16.float(), want)
+    assert ta.num_updates == 1
