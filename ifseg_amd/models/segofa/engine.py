@@ -67,6 +67,7 @@ class HipEngine:
         self._side = None
         self._trunk_stream, self._pf, self._pf_slot = None, None, 0
         self._pf_request = None          # images of the next batch (set by the trainer; consumed by the next forward)
+        self._pending, self._in_flush = [], False
         self._bt = ""                    # tag of the backward block being processed (unique gradient buffers)
 
     # ------------------------------------------------------------------ packing
@@ -306,6 +307,27 @@ class HipEngine:
             finally:
                 hip.set_stream(prev)
 
+    def _side_do(self, fn):
+        """Queue parameter-gradient work for the side stream.  The queue is flushed once per backward block
+        (`_side_flush`): one event on the main stream per block instead of one per call site.  Everything a queued
+        body reads lives in per-block buffers (`gbuf`), so running it later is safe."""
+        if not self.overlap or self._in_flush:
+            fn()
+        else:
+            self._pending.append(fn)
+
+    def _side_flush(self):
+        if not self._pending:
+            return
+        todo, self._pending = self._pending, []
+        with self._wgrad():
+            self._in_flush = True
+            try:
+                for fn in todo:
+                    fn()
+            finally:
+                self._in_flush = False
+
     def _dq_stream_get(self):
         if getattr(self, "_dqs", None) is None:
             self._wgrad_init()
@@ -326,6 +348,7 @@ class HipEngine:
                 hip.set_stream(prev)
 
     def _join_side(self):
+        self._side_flush()
         if self.overlap and self._side is not None:
             e = self._ev()
             e.record(self._side)
@@ -916,10 +939,9 @@ class HipEngine:
         part = self.buf("ln_dgbp_%d@%s" % (C, stats_tag) if self.overlap else "ln_dgbp_%d" % C,
                         (2, hip.LN_BWD_BLOCKS, C), torch.float32)
         hip.ln_bwd(dy, x, self.W(pname + ".weight"), mu, rs, dx, part[0], part[1], dx_add=dx_add, gelu=gelu, drop=drop)
-        with self._wgrad():
-            # weight and bias of a LayerNorm are adjacent in the arena: one [2, C] reduction
-            hip.reduce_parts(part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C,
-                             accumulate=accumulate)
+        # weight and bias of a LayerNorm are adjacent in the arena: one [2, C] reduction
+        self._side_do(lambda: hip.reduce_parts(part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C,
+                                               accumulate=accumulate))
         return dx
 
     def _bias_grad(self, dy2d, gout, accumulate=False):
@@ -930,9 +952,10 @@ class HipEngine:
 
     def _linear_bwd(self, dy, x, wname_or_view, gw, gb, dx_out=None, dx_resid=None, dx_accumulate=False, need_dx=True):
         """dy [M,N], x [M,K]: writes dW -> gw, db -> gb, returns dx [M,K]"""
-        with self._wgrad():
+        def wgrad():
             if not hip.linear_dw(dy, x, gw, bias_out=gb) and gb is not None:
                 self._bias_grad(dy, gb)
+        self._side_do(wgrad)
         if need_dx:
             return hip.linear_dx(dy, wname_or_view, out=dx_out, resid=dx_resid, accumulate=dx_accumulate)
         return None
@@ -955,6 +978,7 @@ class HipEngine:
         self._linear_bwd(du, s["xn"], W(p + "fc1.weight"), G(p + "fc1.weight"), G(p + "fc1.bias"), dx_out=dxn)
         dx1 = gbuf("g_dx1_%d" % rows, (rows, C))
         self._ln_bwd(dxn, s["x1"].view(rows, C), p + "final_layer_norm", tg + "_fln1", dx1, dx_add=dx2)
+        self._side_flush()
         return dx1
 
     def _attn_core_bwd(self, tag, q, k, v, pq, pk, o, lse, do, dq, dk, dv, B, T, S, rel, causal, gain, gain_name,
@@ -986,7 +1010,7 @@ class HipEngine:
             torch.cuda.current_stream().wait_event(dq_done)
         else:
             hip.attn_bwd(*args, **kw)
-        with self._wgrad():
+        def reductions():
             hip.reduce_parts(dpq_part, dpq_acc, 1, B, T * C, accumulate=not first_pos)
             hip.reduce_parts(dpk_part, dpk_acc, 1, B, S * C, accumulate=not first_pos)
             # d c_attn[h] = sum_{b,t} delta / c_attn[h]   (H scalars)
@@ -1001,6 +1025,7 @@ class HipEngine:
                     hip.reduce_parts(part, red, H, nparts, n)
                     acc = self._table_acc(tabname)
                     hip.rel_scatter_add(red, idx, acc)
+        self._side_do(reductions)
 
     def _table_acc(self, tabname):
         key = "g_tabacc_" + tabname
@@ -1037,6 +1062,7 @@ class HipEngine:
                          self._fused(self.g16, a_ + ".q_proj.bias", 3 * C), dx_out=dxn)
         dx = gbuf("g_dx0_%d" % rows, (rows, C))
         self._ln_bwd(dxn, s["x"].view(rows, C), p + ln1, tg + "_ln1", dx, dx_add=dx1)
+        self._side_flush()
         return dx
 
     def _cross_block_bwd(self, tg, p, dy2, B, Td, Te, cpq, cpk, scaling, d_enc_out, first_cross, dcpq_acc, dcpk_acc):
@@ -1068,13 +1094,13 @@ class HipEngine:
         enc2d = self.ctx["enc_out"].view(B * Te, C)
         # the K|V projections read the encoder output: their dX accumulates into d_enc_out, which nothing needs before
         # the encoder backward starts -- the whole linear backward (dW, db, dX) goes to the side stream, in layer order
-        with self._wgrad():
-            self._linear_bwd(dkv.view(B * Te, 2 * C), enc2d, self._fused(self.p16, a_ + ".k_proj.weight", 2 * C, C),
-                             self._fused(self.g16, a_ + ".k_proj.weight", 2 * C, C),
-                             self._fused(self.g16, a_ + ".k_proj.bias", 2 * C), dx_out=d_enc_out.view(B * Te, C),
-                             dx_accumulate=not first_cross)
+        self._side_do(lambda: self._linear_bwd(
+            dkv.view(B * Te, 2 * C), enc2d, self._fused(self.p16, a_ + ".k_proj.weight", 2 * C, C),
+            self._fused(self.g16, a_ + ".k_proj.weight", 2 * C, C), self._fused(self.g16, a_ + ".k_proj.bias", 2 * C),
+            dx_out=d_enc_out.view(B * Te, C), dx_accumulate=not first_cross))
         dy1 = gbuf("g_dy1c_%d" % rows, (rows, C))
         self._ln_bwd(dyn, s["x"].view(rows, C), p + "encoder_attn_layer_norm", tg + "_cln1", dy1, dx_add=dy2)
+        self._side_flush()
         return dy1
 
     def _backward(self, dlogits):
@@ -1113,9 +1139,8 @@ class HipEngine:
             dy = self._self_block_bwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", dy, B, Td,
                                       ctx["d_spq"], ctx["d_spk"], scaling, dspq, dspk, first,
                                       [(tabn, g["dec_idx2d"]), (tabn, g["dec_idx1d"]), (tabn, g["dec_idxx"])])
-            with self._wgrad():      # the layer's gradients become final in side-stream order
-                self._flush_tables()
-                self._notify(p)
+            self._side_do(lambda p=p: (self._flush_tables(), self._notify(p)))   # final in side-stream order
+            self._side_flush()
         # ---- decoder embedding LN (input = [enc_out[:, :P] | embed(bos)])
         self._bt = "dtop"
         self._join_side()            # the position-operand accumulators below were filled on the side stream
@@ -1152,8 +1177,8 @@ class HipEngine:
         dpos_all = buf("g_dpos_all", (T, C))
         self._linear_bwd(dcpk16, pos_all, W(d + "cross_pos_k_linear.weight"), G(d + "cross_pos_k_linear.weight"),
                          G(d + "cross_pos_k_linear.bias"), dx_out=dpos_all)
-        with self._wgrad():
-            self._notify(d)
+        self._side_do(lambda: self._notify(d))
+        self._side_flush()
         # ---- encoder
         dx = buf("g_dx_enc", (B * T, C))
         self._ln_bwd(d_enc_out.view(B * T, C), ctx["e_x_final"].view(B * T, C), e + "layer_norm", "e_final_ln", dx)
@@ -1168,9 +1193,8 @@ class HipEngine:
                                       [("%simage_rel_pos_table_list.%d.weight" % (e, l), g["enc_idx2d"]),
                                        ("%stoken_rel_pos_table_list.%d.weight" % (e, l), g["enc_idx1d"]),
                                        (None, None)])
-            with self._wgrad():
-                self._flush_tables()
-                self._notify(p)
+            self._side_do(lambda p=p: (self._flush_tables(), self._notify(p)))
+            self._side_flush()
         # ---- encoder abs-pos operands
         self._bt = "etop"
         self._join_side()
@@ -1197,11 +1221,9 @@ class HipEngine:
         self._ln_bwd(dxt, self.ws["tok_pre"].view(B, L, C), e + "layernorm_embedding", "tok_ln", dtok,
                      drop=self._dropargs(2))
         gt = G(e + "type_embedding.weight")
-        with self._wgrad():
-            self._bias_grad(dtok.view(B * L, C), gt[0])
-            self._bias_grad(dimg.view(B * P, C), gt[1])
-            self._notify(e)
-        self._join_side()            # the optimizer (main stream) reads the whole gradient arena next
+        self._side_do(lambda: (self._bias_grad(dtok.view(B * L, C), gt[0]), self._bias_grad(dimg.view(B * P, C), gt[1]),
+                               self._notify(e)))
+        self._join_side()            # (flushes) the optimizer (main stream) reads the whole gradient arena next
         return self.g16
 
     def _flush_tables(self):
