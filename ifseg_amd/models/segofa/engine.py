@@ -1062,8 +1062,7 @@ class HipEngine:
                          self._fused(self.g16, a_ + ".q_proj.bias", 3 * C), dx_out=dxn)
         dx = gbuf("g_dx0_%d" % rows, (rows, C))
         self._ln_bwd(dxn, s["x"].view(rows, C), p + ln1, tg + "_ln1", dx, dx_add=dx1)
-        self._side_flush()
-        return dx
+        return dx                # the caller flushes the side queue together with the layer's hook
 
     def _cross_block_bwd(self, tg, p, dy2, B, Td, Te, cpq, cpk, scaling, d_enc_out, first_cross, dcpq_acc, dcpk_acc):
         C = self.cfg.embed_dim
