@@ -600,6 +600,15 @@ __global__ void rel_gather_kernel(const bf16_t* table, const int* idx, float* ou
   const int r = idx[i];
   out[gid] = r >= 0 ? bf2f(table[(long long)r * H + h]) : 0.f;
 }
+// the same gather for up to 16 tables of one shape at once (the per-layer rel-pos tables): out[l][h][i]
+struct TablePtrs { const bf16_t* t[16]; };
+__global__ void rel_gather_multi_kernel(TablePtrs tabs, const int* idx, float* out, int n, int H, int L) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long long)L * n * H) return;
+  const int i = (int)(gid % n), h = (int)((gid / n) % H), l = (int)(gid / ((long long)n * H));
+  const int r = idx[i];
+  out[gid] = r >= 0 ? bf2f(tabs.t[l][(long long)r * H + h]) : 0.f;
+}
 // acc[idx[i]][h] += d[h][i]   (fp32 accumulation buffer, tiny; duplicates allowed)
 __global__ void rel_scatter_kernel(const float* d, const int* idx, float* acc, int n, int H) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -615,6 +624,19 @@ extern "C" int ifseg_rel_gather(const void* table, const int* idx, float* out, i
   if (n <= 0) return 0;
   hipLaunchKernelGGL(rel_gather_kernel, dim3((n * H + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)table, idx, out, n, H);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int ifseg_rel_gather_multi(const void* const* tables, int L, const int* idx, float* out, int n, int H,
+                                      void* stream) {
+  (void)hipGetLastError();
+  if (n <= 0 || L <= 0) return 0;
+  if (L > 16) return IFSEG_ERR_BAD_ARG;
+  TablePtrs tp{};
+  for (int l = 0; l < L; ++l) tp.t[l] = (const bf16_t*)tables[l];
+  const long long total = (long long)L * n * H;
+  hipLaunchKernelGGL(rel_gather_multi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tp, idx,
+                     out, n, H, L);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

@@ -388,6 +388,14 @@ def rel_gather(table, idx, out):
     return out
 
 
+def rel_gather_multi(tables, idx, out):
+    """tables: list of L <= 16 bf16 [N, H] tensors of one shape; out fp32 [L, H, n]"""
+    L, n, H = len(tables), idx.numel(), tables[0].shape[1]
+    arr = (c_void_p * L)(*[t.data_ptr() for t in tables])
+    _check(lib().ifseg_rel_gather_multi(arr, c_int(L), _ptr(idx), _ptr(out), c_int(n), c_int(H), _stream()), "rel_gather_multi")
+    return out
+
+
 def rel_scatter_add(d, idx, acc):
     n, H = idx.numel(), acc.shape[1]
     _check(lib().ifseg_rel_scatter_add(_ptr(d), _ptr(idx), _ptr(acc), c_int(n), c_int(H), _stream()), "rel_scatter")

@@ -252,12 +252,17 @@ class HipEngine:
         npad = _pad8(cfg.num_seg_tokens)
         self.npad = npad
         self.wseg_pad = torch.zeros(npad, C, dtype=BF, device=dev)
+        self._wseg_key = None
         self.refresh_frozen()
 
     def refresh_frozen(self):
         """Re-derive packed copies of frozen tensors (call after they are modified in place,
         e.g. seg_criterion._lazy_initialization writes seg_embed_tokens)."""
         w = self.model.decoder.seg_projection.weight.data
+        key = (w.data_ptr(), w._version, tuple(w.shape))
+        if getattr(self, "_wseg_key", None) == key:
+            return                      # unchanged since the last forward (the weight is frozen in the recipe)
+        self._wseg_key = key
         self.wseg_pad.zero_()
         self.wseg_pad[: w.shape[0]] = w.to(self.wseg_pad.device, BF)
 
@@ -486,6 +491,23 @@ class HipEngine:
             out.append(o)
         return out
 
+    def _rel_tables_all(self, tag, names, idxs):
+        """the delta tables of every layer in one launch per index set: names[l] = parameter of layer l (or None for
+        an all-zero table), idxs = index sets -> list over index sets of fp32 [L, H, n] (layer l = [l])"""
+        H, L = self.cfg.heads, len(names)
+        out = []
+        for k, (use, idx) in enumerate(idxs):
+            name = "%s_relall%d" % (tag, k)
+            fresh = name not in self.ws
+            o = self.buf(name, (L, H, idx.numel()), torch.float32)
+            if not use:
+                if fresh:
+                    o.zero_()             # constant: zeroed once per allocation
+            else:
+                hip.rel_gather_multi([self.W(n) for n in names], idx, o)
+            out.append(o)
+        return out
+
     # ---- dropout / DropPath sites (a12) -------------------------------------------------------
     def _drop_setup(self, B, train):
         cfg = self.cfg
@@ -641,15 +663,16 @@ class HipEngine:
         hip.linear_fwd(pos_all, self._fused(self.p16, e + "pos_q_linear.weight", 2 * C, C),
                        self._fused(self.p16, e + "pos_q_linear.bias", 2 * C), out=pqk, alpha=scaling, alpha_ncols=C)
         ctx["e_pq"], ctx["e_pk"] = pqk[:, :C], pqk[:, C:]
-        # ---- encoder layers
+        # ---- encoder layers (rel-pos delta tables of all layers: two launches)
+        (e_r2,) = self._rel_tables_all("e_img", ["%simage_rel_pos_table_list.%d.weight" % (e, l) for l in range(cfg.enc_layers)],
+                                       [(True, g["enc_idx2d"])])
+        (e_r1,) = self._rel_tables_all("e_tok", ["%stoken_rel_pos_table_list.%d.weight" % (e, l) for l in range(cfg.enc_layers)],
+                                       [(True, g["enc_idx1d"])])
+        (e_rx,) = self._rel_tables_all("e_x", [None] * cfg.enc_layers, [(False, g["enc_idxx"])])
         for l in range(cfg.enc_layers):
             p = "%slayers.%d." % (e, l)
             tg = "e%d" % l
-            r2, r1, rx = self._rel_tables(tg, [
-                (W("%simage_rel_pos_table_list.%d.weight" % (e, l)), g["enc_idx2d"]),
-                (W("%stoken_rel_pos_table_list.%d.weight" % (e, l)), g["enc_idx1d"]),
-                (None, g["enc_idxx"])])
-            rel = hip.RelBias(P, g["gcode"], g["code_bias"], r2, r1, rx, grid_w=w)
+            rel = hip.RelBias(P, g["gcode"], g["code_bias"], e_r2[l], e_r1[l], e_rx[l], grid_w=w)
             x = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", x, B, T,
                                      ctx["e_pq"], ctx["e_pk"], rel, False, scaling, site=("e", l, 0))
             x = self._ffn_fwd(tg, p, x, B * T, site=("e", l, 1), rpb=T)
@@ -701,12 +724,13 @@ class HipEngine:
         hip.linear_fwd(pos_all, W(d + "cross_pos_k_linear.weight"), W(d + "cross_pos_k_linear.bias"), out=cpk)
         ctx.update(d_spq=spqk[:, :C], d_spk=spqk[:, C:], d_cpq=cpq, d_cpk=cpk)
         causal = not full_context_alignment
+        d_r2, d_r1, d_rx = self._rel_tables_all(
+            "d_seg", ["%sseg_rel_pos_table_list.%d.weight" % (d, l) for l in range(cfg.dec_layers)],
+            [(True, g["dec_idx2d"]), (True, g["dec_idx1d"]), (True, g["dec_idxx"])])
         for l in range(cfg.dec_layers):
             p = "%slayers.%d." % (d, l)
             tg = "d%d" % l
-            tab = W("%sseg_rel_pos_table_list.%d.weight" % (d, l))
-            r2, r1, rx = self._rel_tables(tg, [(tab, g["dec_idx2d"]), (tab, g["dec_idx1d"]), (tab, g["dec_idxx"])])
-            rel = hip.RelBias(P, g["gcode"], g["code_bias"], r2, r1, rx, grid_w=w)
+            rel = hip.RelBias(P, g["gcode"], g["code_bias"], d_r2[l], d_r1[l], d_rx[l], grid_w=w)
             y = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", y, B, Td,
                                      ctx["d_spq"], ctx["d_spk"], rel, causal, scaling, site=("d", l, 0))
             y = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling, site=("d", l, 1))

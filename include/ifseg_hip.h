@@ -187,6 +187,9 @@ int ifseg_nchw_to_nhwc_bf16(const void* in, int in_is_f32, void* out, int B, int
  * (F.embedding(rp_bucket, table) of encoder_module.py:313-331, decoder_module.py:327-333).
  * ifseg_rel_scatter_add is its adjoint (embedding_dense_backward) into an fp32 buffer. */
 int ifseg_rel_gather(const void* table, const int* idx, float* out, int n, int H, void* stream);
+/* the same gather for L <= 16 tables of one shape in one launch (all layers' tables at the start of a forward):
+ * tables = host array of L device pointers, out fp32 [L][H][n] */
+int ifseg_rel_gather_multi(const void* const* tables, int L, const int* idx, float* out, int n, int H, void* stream);
 int ifseg_rel_scatter_add(const float* d, const int* idx, float* acc, int n, int H, void* stream);
 
 /* out = [resid +] drop_path_scale[row / rows_per_batch] * keep * x / (1 - p) on [rows, C] bf16 (row addressing as above);
