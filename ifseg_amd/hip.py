@@ -405,7 +405,8 @@ def rel_scatter_add(d, idx, acc):
 PROF_KINDS = ("gemm_nt", "gemm_nn", "gemm_tn", "conv", "attn_fwd", "attn_bwd_dkv", "attn_bwd_dq", "ln_fwd", "ln_bwd")
 
 
-def prof_enable(mask):
+def prof_enable(mask, stride=1):
+    lib().ifseg_prof_stride(c_int(stride))
     lib().ifseg_prof_enable(ctypes.c_uint(mask))
 
 

@@ -68,6 +68,7 @@ class HipEngine:
         self._trunk_stream, self._pf, self._pf_slot = None, None, 0
         self._pf_request = None          # images of the next batch (set by the trainer; consumed by the next forward)
         self._pending, self._in_flush = [], False
+        self.attn_bwd_timing = None      # {"stride": n, "seen": 0, "pairs": []} while bench.py times the attention backward
         self._bt = ""                    # tag of the backward block being processed (unique gradient buffers)
 
     # ------------------------------------------------------------------ packing
@@ -1022,6 +1023,14 @@ class HipEngine:
         kw = dict(rel=rel, causal=causal, gain=gain, dq_scale=scaling, dpq_scale=scaling, drel2d_part=parts[0],
                   drel1d_part=parts[1], drelx_part=parts[2], nparts=nparts)
         args = (q, k, v, pq, pk, o, do, lse, delta, dq, dk, dv, dpq_part, dpk_part, B, H, T, S)
+        timing = self.attn_bwd_timing
+        if timing is not None:
+            timing["seen"] += 1
+            if (timing["seen"] - 1) % timing["stride"]:
+                timing = None
+            else:       # one event pair on the main stream around delta + dK/dV + dQ (bench.py's roofline object)
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record()
         if self.overlap:
             # dK/dV and dQ are independent once delta exists; each leaves its last round of workgroups partly
             # empty (864 workgroups on 512 slots), so they run on two streams and fill each other's holes
@@ -1034,6 +1043,10 @@ class HipEngine:
             torch.cuda.current_stream().wait_event(dq_done)
         else:
             hip.attn_bwd(*args, **kw)
+        if timing is not None:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record()
+            timing["pairs"].append((t0, t1, 8.0 * 64 * T * S * B * H))   # dV, dP, dK, dQ of the reference at d = 64
         def reductions():
             hip.reduce_parts(dpq_part, dpq_acc, 1, B, T * C, accumulate=not first_pos)
             hip.reduce_parts(dpk_part, dpk_acc, 1, B, S * C, accumulate=not first_pos)

@@ -261,6 +261,7 @@ int ifseg_adam_step(float* p32, const void* g, float* m, float* v, void* p16, lo
  * 5 ATTN_BWD_DKV, 6 ATTN_BWD_DQ, 7 LN_FWD, 8 LN_BWD.  ifseg_prof_read returns the summed
  * kernel time and the summed ALGORITHMIC flops / bytes of the recorded launches. */
 int ifseg_prof_enable(unsigned mask);
+int ifseg_prof_stride(int stride); /* time only every stride-th launch of an enabled family (default 1) */
 int ifseg_prof_reset(void);
 int ifseg_prof_read(int kind, double* ms, double* flops, double* bytes, int* launches);
 
