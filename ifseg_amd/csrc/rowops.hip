@@ -78,7 +78,8 @@ template <int NCH, bool GELU>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const bf16_t* gamma, const bf16_t* beta,
                                                      const bf16_t* resid, bf16_t* y, float* mean, float* rstd,
                                                      int rows, int C, float eps, RowMap mx, RowMap my, RowMap mr,
-                                                     DropArgs drop) {
+                                                     DropArgs drop, const bf16_t* gamma2, const bf16_t* beta2, bf16_t* y2,
+                                                     float* mean2, float* rstd2, RowMap my2) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nch = C >> 3;
@@ -126,7 +127,43 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const bf16
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += r[e];
       }
-      *reinterpret_cast<uint4*>(yp + c * 8) = pack8(o);
+      const uint4 packed = pack8(o);
+      *reinterpret_cast<uint4*>(yp + c * 8) = packed;
+      if (y2) unpack8(packed, v[i]);        // the second LayerNorm sees y exactly as it is stored (bf16)
+    }
+  }
+  // ---- optional second LayerNorm of the row just produced: y2 = LN2(y)  (the pre-LN of the next block, fused so
+  // the residual stream is not read back: attn_ln -> +x -> final_layer_norm, unify_transformer_layer.py:256-292)
+  if (y2) {
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (lane + i * 64 < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s2 += v[i][e];
+      }
+    const float mu2 = warp_sum(s2) / C;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (lane + i * 64 < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu2; q2 += d * d; }
+      }
+    const float rs2 = rsqrtf(warp_sum(q2) / C + eps);
+    if (lane == 0 && mean2) { mean2[row] = mu2; rstd2[row] = rs2; }
+    bf16_t* y2p = y2 + my2.off(row);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        float g[8], b[8], o[8];
+        unpack8(*reinterpret_cast<const uint4*>(gamma2 + c * 8), g);
+        unpack8(*reinterpret_cast<const uint4*>(beta2 + c * 8), b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu2) * rs2 * g[e] + b[e];
+        *reinterpret_cast<uint4*>(y2p + c * 8) = pack8(o);
+      }
     }
   }
 }
@@ -406,9 +443,10 @@ __global__ void nchw_to_nhwc_kernel(const TIN* in, bf16_t* out, int B, int Cc, i
 template <int NCH>
 int launch_ln_fwd(bool gelu, dim3 g, hipStream_t s, const bf16_t* x, const bf16_t* gamma, const bf16_t* beta,
                   const bf16_t* resid, bf16_t* y, float* mean, float* rstd, int rows, int C, float eps, RowMap mx,
-                  RowMap my, RowMap mr, DropArgs dr) {
-  if (gelu) hipLaunchKernelGGL((ln_fwd_kernel<NCH, true>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr, dr);
-  else hipLaunchKernelGGL((ln_fwd_kernel<NCH, false>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr, dr);
+                  RowMap my, RowMap mr, DropArgs dr, const bf16_t* g2 = nullptr, const bf16_t* b2 = nullptr, bf16_t* y2 = nullptr,
+                  float* mean2 = nullptr, float* rstd2 = nullptr, RowMap my2 = RowMap{0, 0, 0}) {
+  if (gelu) hipLaunchKernelGGL((ln_fwd_kernel<NCH, true>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr, dr, g2, b2, y2, mean2, rstd2, my2);
+  else hipLaunchKernelGGL((ln_fwd_kernel<NCH, false>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr, dr, g2, b2, y2, mean2, rstd2, my2);
   return 0;
 }
 template <int NCH, int WPR>
@@ -422,29 +460,50 @@ int launch_ln_bwd(bool gelu, dim3 g, hipStream_t s, const bf16_t* dy, const bf16
 
 }  // namespace
 
-extern "C" int ifseg_ln_fwd(const void* x, const void* gamma, const void* beta, const void* resid, void* y,
-                            float* mean, float* rstd, int rows, int C, float eps, int act_gelu, int rpb,
-                            long long x_bs, int ldx, long long y_bs, int ldy, long long r_bs, int ldr,
-                            const ifseg_drop_args* drop, void* stream) {
+static int ln_fwd_impl(const void* x, const void* gamma, const void* beta, const void* resid, void* y,
+                       float* mean, float* rstd, int rows, int C, float eps, int act_gelu, int rpb,
+                       long long x_bs, int ldx, long long y_bs, int ldy, long long r_bs, int ldr,
+                       const ifseg_drop_args* drop, const void* gamma2, const void* beta2, void* y2, float* mean2,
+                       float* rstd2, long long y2_bs, int ldy2, void* stream) {
   (void)hipGetLastError();
   if (rows <= 0) return 0;
-  if ((C & 7) || C > 4096 || (ldx & 7) || (ldy & 7) || (resid && (ldr & 7))) return IFSEG_ERR_BAD_SHAPE;
+  if ((C & 7) || C > 4096 || (ldx & 7) || (ldy & 7) || (resid && (ldr & 7)) || (y2 && (ldy2 & 7))) return IFSEG_ERR_BAD_SHAPE;
+  if (y2 && (!gamma2 || !beta2)) return IFSEG_ERR_BAD_ARG;
   DropArgs dr{};
   if (drop) {
     if (drop->p < 0.f || drop->p >= 1.f || drop->rows_per_batch <= 0) return IFSEG_ERR_BAD_ARG;
     dr = DropArgs{1, drop->p, drop->seed, drop->drop_path_scale, drop->rows_per_batch};
   }
-  RowMap mx{rpb, x_bs, ldx}, my{rpb, y_bs, ldy}, mr{rpb, r_bs, ldr};
+  RowMap mx{rpb, x_bs, ldx}, my{rpb, y_bs, ldy}, mr{rpb, r_bs, ldr}, my2{rpb, y2_bs, ldy2};
   dim3 g((rows + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
   const bf16_t *X = (const bf16_t*)x, *G = (const bf16_t*)gamma, *Bt = (const bf16_t*)beta, *R = (const bf16_t*)resid;
-  ifseg_prof_begin(IFSEG_K_LN_FWD, s, 0, (double)rows * C * (resid ? 6.0 : 4.0));
-  if (C <= 1024) launch_ln_fwd<2>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr, dr);
-  else if (C <= 3072) launch_ln_fwd<6>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr, dr);
-  else launch_ln_fwd<8>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr, dr);
+  const bf16_t *G2 = (const bf16_t*)gamma2, *B2 = (const bf16_t*)beta2;
+  ifseg_prof_begin(IFSEG_K_LN_FWD, s, 0, (double)rows * C * ((resid ? 6.0 : 4.0) + (y2 ? 2.0 : 0.0)));
+  if (C <= 1024) launch_ln_fwd<2>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr, dr, G2, B2, (bf16_t*)y2, mean2, rstd2, my2);
+  else if (C <= 3072) launch_ln_fwd<6>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr, dr, G2, B2, (bf16_t*)y2, mean2, rstd2, my2);
+  else launch_ln_fwd<8>(act_gelu, g, s, X, G, Bt, R, (bf16_t*)y, mean, rstd, rows, C, eps, mx, my, mr, dr, G2, B2, (bf16_t*)y2, mean2, rstd2, my2);
   ifseg_prof_end(IFSEG_K_LN_FWD, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int ifseg_ln_fwd(const void* x, const void* gamma, const void* beta, const void* resid, void* y,
+                            float* mean, float* rstd, int rows, int C, float eps, int act_gelu, int rpb,
+                            long long x_bs, int ldx, long long y_bs, int ldy, long long r_bs, int ldr,
+                            const ifseg_drop_args* drop, void* stream) {
+  return ln_fwd_impl(x, gamma, beta, resid, y, mean, rstd, rows, C, eps, act_gelu, rpb, x_bs, ldx, y_bs, ldy, r_bs, ldr, drop,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int ifseg_ln_fwd_pair(const void* x, const void* gamma, const void* beta, const void* resid, void* y,
+                                 float* mean, float* rstd, const void* gamma2, const void* beta2, void* y2, float* mean2,
+                                 float* rstd2, int rows, int C, float eps, int rpb, long long x_bs, int ldx, long long y_bs,
+                                 int ldy, long long r_bs, int ldr, long long y2_bs, int ldy2, const ifseg_drop_args* drop,
+                                 void* stream) {
+  if (!y2) return IFSEG_ERR_BAD_ARG;
+  return ln_fwd_impl(x, gamma, beta, resid, y, mean, rstd, rows, C, eps, 0, rpb, x_bs, ldx, y_bs, ldy, r_bs, ldr, drop, gamma2,
+                     beta2, y2, mean2, rstd2, y2_bs, ldy2, stream);
 }
 
 extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,

@@ -275,6 +275,23 @@ def ln_fwd(x, gamma, beta, y, mean=None, rstd=None, resid=None, gelu=False, eps=
     return y
 
 
+def ln_fwd_pair(x, gamma, beta, y, mean, rstd, gamma2, beta2, y2, mean2, rstd2, resid=None, eps=1e-5, drop=None):
+    """y = [resid +] drop(LN(x)), y2 = LN2(y): the post-LN of a block and the pre-LN of the next in one launch"""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    rpb = x.shape[1] if x.dim() == 3 else 0
+    xb, xl = _map(x, rpb)
+    yb, yl = _map(y, rpb)
+    rb, rl = _map(resid, rpb)
+    y2b, y2l = _map(y2, rpb)
+    rc = lib().ifseg_ln_fwd_pair(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(resid), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma2),
+                                 _ptr(beta2), _ptr(y2), _ptr(mean2), _ptr(rstd2), c_int(rows), c_int(C), c_float(eps),
+                                 c_int(rpb), c_ll(xb), c_int(xl), c_ll(yb), c_int(yl), c_ll(rb), c_int(rl), c_ll(y2b),
+                                 c_int(y2l), _drop_ref(drop, rpb or rows), _stream())
+    _check(rc, "ln_fwd_pair")
+    return y, y2
+
+
 LN_BWD_BLOCKS = 768   # three resident blocks per CU (146-162 VGPRs): best of a 256..2048 sweep on MI355X
 
 

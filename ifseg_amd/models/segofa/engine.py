@@ -674,9 +674,10 @@ class HipEngine:
             p = "%slayers.%d." % (e, l)
             tg = "e%d" % l
             rel = hip.RelBias(P, g["gcode"], g["code_bias"], e_r2[l], e_r1[l], e_rx[l], grid_w=w)
-            x = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", x, B, T,
-                                     ctx["e_pq"], ctx["e_pk"], rel, False, scaling, site=("e", l, 0))
-            x = self._ffn_fwd(tg, p, x, B * T, site=("e", l, 1), rpb=T)
+            x, xn = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", x, B, T,
+                                         ctx["e_pq"], ctx["e_pk"], rel, False, scaling, site=("e", l, 0),
+                                         next_ln=(p + "final_layer_norm", tg + "_fln1", tg + "_fxn"))
+            x = self._ffn_fwd(tg, p, x, B * T, site=("e", l, 1), rpb=T, xn_pre=xn)
         enc_out = buf("enc_out", (B, T, C))
         mu, rs = self._ln_stats("e_final_ln", B * T)
         hip.ln_fwd(x.view(B * T, C), W(e + "layer_norm.weight"), W(e + "layer_norm.bias"), enc_out.view(B * T, C), mu, rs)
@@ -732,10 +733,12 @@ class HipEngine:
             p = "%slayers.%d." % (d, l)
             tg = "d%d" % l
             rel = hip.RelBias(P, g["gcode"], g["code_bias"], d_r2[l], d_r1[l], d_rx[l], grid_w=w)
-            y = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", y, B, Td,
-                                     ctx["d_spq"], ctx["d_spk"], rel, causal, scaling, site=("d", l, 0))
-            y = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling, site=("d", l, 1))
-            y = self._ffn_fwd(tg, p, y, B * Td, site=("d", l, 2), rpb=Td)
+            y, yn = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", y, B, Td,
+                                         ctx["d_spq"], ctx["d_spk"], rel, causal, scaling, site=("d", l, 0),
+                                         next_ln=(p + "encoder_attn_layer_norm", tg + "_cln1", tg + "_cyn"))
+            y, yn = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling, site=("d", l, 1), yn_pre=yn,
+                                          next_ln=(p + "final_layer_norm", tg + "_fln1", tg + "_fxn"))
+            y = self._ffn_fwd(tg, p, y, B * Td, site=("d", l, 2), rpb=Td, xn_pre=yn)
         ctx["d_y_final"] = y
         # final LN written in reference order [bos, patches] (decoder_module.py:668-675)
         featb = buf("d_feat", (B, Td, C))
@@ -813,8 +816,8 @@ class HipEngine:
                 img = self._resize_hw(img, (oh, oh), (h, w))
                 img = self._resize_hw(img.transpose(1, 2), (oh, oh), (h, w)).transpose(1, 2)
             dense[:, :P, :P] = img
-            x = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", x, B, T, pqk[:, :C],
-                                     pqk[:, C:], None, False, scaling, dense=dense.contiguous())
+            x, _ = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", x, B, T, pqk[:, :C],
+                                        pqk[:, C:], None, False, scaling, dense=dense.contiguous())
             x = self._ffn_fwd(tg, p, x, B * T)
         enc_out = buf("enc_out", (B, T, C))
         hip.ln_fwd(x.view(B * T, C), W(e + "layer_norm.weight"), W(e + "layer_norm.bias"), enc_out.view(B * T, C))
@@ -857,9 +860,9 @@ class HipEngine:
             dense = rel[:, perm][:, :, perm]
             if mask is not None:
                 dense = dense + mask
-            y = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", y, B, Td,
-                                     spqk[:, :C], spqk[:, C:], None, False, scaling, dense=dense.contiguous())
-            y = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling)
+            y, _ = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", y, B, Td,
+                                        spqk[:, :C], spqk[:, C:], None, False, scaling, dense=dense.contiguous())
+            y, _ = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling)
             y = self._ffn_fwd(tg, p, y, B * Td)
         featb = buf("d_feat", (B, Td, C))
         hip.ln_fwd(y[:, :P], W(d + "layer_norm.weight"), W(d + "layer_norm.bias"), featb[:, 1:])
@@ -873,7 +876,9 @@ class HipEngine:
         kind, l, k = site
         return 16 + (l * 4 + k) * 2 + (0 if kind == "e" else 1)
 
-    def _self_block_fwd(self, tg, p, attn, ln1, ln2, x, B, T, pq, pk, rel, causal, scaling, dense=None, site=None):
+    def _self_block_fwd(self, tg, p, attn, ln1, ln2, x, B, T, pq, pk, rel, causal, scaling, dense=None, site=None,
+                        next_ln=None):
+        """-> (block output, pre-LN of the next block or None)"""
         C, H = self.cfg.embed_dim, self.cfg.heads
         W, buf = self.W, self.buf
         a_ = p + attn
@@ -892,20 +897,21 @@ class HipEngine:
         a = buf(tg + "_a", (B * T, C))
         hip.linear_fwd(o.view(B * T, C), W(a_ + ".out_proj.weight"), W(a_ + ".out_proj.bias"), out=a)
         x1 = buf(tg + "_x1", (B, T, C))
-        mu, rs = self._ln_stats(tg + "_ln2", B * T)
         drop = self._dropargs(self._site_id(site), self._dp(*site), T) if (self.drop_on and site is not None) else None
-        hip.ln_fwd(a, W(p + ln2 + ".weight"), W(p + ln2 + ".bias"), x1.view(B * T, C), mu, rs, resid=x.view(B * T, C),
-                   drop=drop)
+        nxt = self._post_ln(a, p + ln2, tg + "_ln2", x.view(B * T, C), x1.view(B * T, C), drop, B * T, next_ln)
         self._save(tg + "_sa", x=x, xn=xn, qkv=qkv, o=o, lse=lse, a=a, rel=rel, gain=gain, causal=causal, site=site)
-        return x1
+        return x1, nxt
 
-    def _cross_block_fwd(self, tg, p, y1, enc_out, B, Td, Te, cpq, cpk, scaling, site=None):
+    def _cross_block_fwd(self, tg, p, y1, enc_out, B, Td, Te, cpq, cpk, scaling, site=None, yn_pre=None, next_ln=None):
+        """yn_pre: encoder_attn_layer_norm(y1) if the previous block already produced it.  -> (y2, next pre-LN or None)"""
         C, H = self.cfg.embed_dim, self.cfg.heads
         W, buf = self.W, self.buf
         a_ = p + "encoder_attn"
-        yn = buf(tg + "_cyn", (B * Td, C))
-        mu, rs = self._ln_stats(tg + "_cln1", B * Td)
-        hip.ln_fwd(y1.view(B * Td, C), W(p + "encoder_attn_layer_norm.weight"), W(p + "encoder_attn_layer_norm.bias"), yn, mu, rs)
+        yn = yn_pre
+        if yn is None:
+            yn = buf(tg + "_cyn", (B * Td, C))
+            mu, rs = self._ln_stats(tg + "_cln1", B * Td)
+            hip.ln_fwd(y1.view(B * Td, C), W(p + "encoder_attn_layer_norm.weight"), W(p + "encoder_attn_layer_norm.bias"), yn, mu, rs)
         q = buf(tg + "_cq", (B, Td, C))
         hip.linear_fwd(yn, W(a_ + ".q_proj.weight"), W(a_ + ".q_proj.bias"), out=q.view(B * Td, C), alpha=scaling)
         kv = buf(tg + "_ckv", (B, Te, 2 * C))
@@ -923,19 +929,20 @@ class HipEngine:
         a = buf(tg + "_ca_a", (B * Td, C))
         hip.linear_fwd(o.view(B * Td, C), W(a_ + ".out_proj.weight"), W(a_ + ".out_proj.bias"), out=a)
         y2 = buf(tg + "_y2", (B, Td, C))
-        mu, rs = self._ln_stats(tg + "_cln2", B * Td)
         drop = self._dropargs(self._site_id(site), self._dp(*site), Td) if (self.drop_on and site is not None) else None
-        hip.ln_fwd(a, W(p + "cross_attn_ln.weight"), W(p + "cross_attn_ln.bias"), y2.view(B * Td, C), mu, rs,
-                   resid=y1.view(B * Td, C), drop=drop)
+        nxt = self._post_ln(a, p + "cross_attn_ln", tg + "_cln2", y1.view(B * Td, C), y2.view(B * Td, C), drop, B * Td, next_ln)
         self._save(tg + "_ca", x=y1, xn=yn, q=q, kv=kv, o=o, lse=lse, a=a, gain=gain, site=site)
-        return y2
+        return y2, nxt
 
-    def _ffn_fwd(self, tg, p, x1, rows, site=None, rpb=None):
+    def _ffn_fwd(self, tg, p, x1, rows, site=None, rpb=None, xn_pre=None):
+        """xn_pre: final_layer_norm(x1) if the previous block already produced it"""
         C, Fd = self.cfg.embed_dim, self.cfg.ffn_dim
         W, buf = self.W, self.buf
-        xn = buf(tg + "_fxn", (rows, C))
-        mu, rs = self._ln_stats(tg + "_fln1", rows)
-        hip.ln_fwd(x1.view(rows, C), W(p + "final_layer_norm.weight"), W(p + "final_layer_norm.bias"), xn, mu, rs)
+        xn = xn_pre
+        if xn is None:
+            xn = buf(tg + "_fxn", (rows, C))
+            mu, rs = self._ln_stats(tg + "_fln1", rows)
+            hip.ln_fwd(x1.view(rows, C), W(p + "final_layer_norm.weight"), W(p + "final_layer_norm.bias"), xn, mu, rs)
         u = buf(tg + "_u", (rows, Fd))
         hip.linear_fwd(xn, W(p + "fc1.weight"), W(p + "fc1.bias"), out=u)
         z = buf(tg + "_z", (rows, Fd))
@@ -953,6 +960,22 @@ class HipEngine:
 
     def _save(self, key, **kw):
         self.saved[key] = kw
+
+    def _post_ln(self, a, pname, stats_tag, resid, out, drop, rows, next_ln):
+        """out = resid + drop(LN(a)); with next_ln = (param prefix, stats tag, buffer name) the pre-LN of the next
+        block is computed in the same launch and returned (else None)."""
+        C = self.cfg.embed_dim
+        W = self.W
+        mu, rs = self._ln_stats(stats_tag, rows)
+        if next_ln is None:
+            hip.ln_fwd(a, W(pname + ".weight"), W(pname + ".bias"), out, mu, rs, resid=resid, drop=drop)
+            return None
+        npname, ntag, nbuf = next_ln
+        xn = self.buf(nbuf, (rows, C))
+        mu2, rs2 = self._ln_stats(ntag, rows)
+        hip.ln_fwd_pair(a, W(pname + ".weight"), W(pname + ".bias"), out, mu, rs, W(npname + ".weight"), W(npname + ".bias"),
+                        xn, mu2, rs2, resid=resid, drop=drop)
+        return xn
 
     # ---------------------------------------------------------------- backward
     def _ln_bwd(self, dy, x, pname, stats_tag, dx, dx_add=None, gelu=False, accumulate=False, drop=None):

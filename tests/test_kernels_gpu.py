@@ -571,3 +571,25 @@ def test_gemm_tn_fused_bias_gradient(M, N, K):
     assert (flat[N * K + N:] == 7.0).all()                       # nothing written past db
     other = torch.empty(N, dtype=torch.bfloat16, device=dev)     # not adjacent: the caller keeps its own path
     assert hip.linear_dw(dy, x, gw, bias_out=other) is False
+
+
+def test_ln_fwd_pair_is_bit_identical_to_two_calls():
+    """ifseg_ln_fwd_pair: post-LN (+dropout, +residual) of a block and pre-LN of the next in one launch."""
+    from ifseg_amd import hip
+    dev = _dev()
+    B, T, C, p, seed = 3, 257, 768, 0.1, 4242
+    rows = B * T
+    a, res = _rand((rows, C), dev, 95), _rand((rows, C), dev, 96)
+    g1, b1, g2, b2 = (_rand((C,), dev, 97 + i, 0.2) + (1 if i % 2 == 0 else 0) for i in range(4))
+    dp = torch.tensor([1 / 0.9, 0.0, 1 / 0.9], device=dev)
+    st = lambda: (torch.empty(rows, device=dev), torch.empty(rows, device=dev))
+    for drop in (None, (p, seed, dp, T)):
+        y_ref, y2_ref = torch.empty_like(a), torch.empty_like(a)
+        (m1, r1), (m2, r2) = st(), st()
+        hip.ln_fwd(a, g1, b1, y_ref, m1, r1, resid=res, drop=drop)
+        hip.ln_fwd(y_ref, g2, b2, y2_ref, m2, r2)
+        y, y2 = torch.empty_like(a), torch.empty_like(a)
+        (n1, s1), (n2, s2) = st(), st()
+        hip.ln_fwd_pair(a, g1, b1, y, n1, s1, g2, b2, y2, n2, s2, resid=res, drop=drop)
+        assert torch.equal(y, y_ref) and torch.equal(y2, y2_ref)
+        assert torch.equal(n1, m1) and torch.equal(s1, r1) and torch.equal(n2, m2) and torch.equal(s2, r2)
