@@ -99,27 +99,37 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const bf16
       for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
     }
   }
-  const float mu = warp_sum(s) / C;
-  float q = 0.f;
+  // gamma == nullptr: the first stage is the identity (y = [resid +] drop(x)), only the second LayerNorm runs
+  float mu = 0.f, rs = 1.f;
+  if (gamma) {
+    mu = warp_sum(s) / C;
+    float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < NCH; ++i)
-    if (lane + i * 64 < nch) {
+    for (int i = 0; i < NCH; ++i)
+      if (lane + i * 64 < nch) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
-    }
-  const float rs = rsqrtf(warp_sum(q) / C + eps);
-  if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
+      }
+    rs = rsqrtf(warp_sum(q) / C + eps);
+    if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+  }
   bf16_t* yp = y + my.off(row);
   const bf16_t* rp = resid ? resid + mr.off(row) : nullptr;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + i * 64;
     if (c < nch) {
-      float g[8], b[8], o[8];
-      unpack8(*reinterpret_cast<const uint4*>(gamma + c * 8), g);
-      unpack8(*reinterpret_cast<const uint4*>(beta + c * 8), b);
+      float o[8];
+      if (gamma) {
+        float g[8], b[8];
+        unpack8(*reinterpret_cast<const uint4*>(gamma + c * 8), g);
+        unpack8(*reinterpret_cast<const uint4*>(beta + c * 8), b);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = v[i][e];
+      }
       if (drop.on) drop8(o, drop, (long long)row * nch + c, row);
       if (rp) {
         float r[8];
@@ -502,6 +512,7 @@ extern "C" int ifseg_ln_fwd_pair(const void* x, const void* gamma, const void* b
                                  int ldy, long long r_bs, int ldr, long long y2_bs, int ldy2, const ifseg_drop_args* drop,
                                  void* stream) {
   if (!y2) return IFSEG_ERR_BAD_ARG;
+  if (!gamma && beta) return IFSEG_ERR_BAD_ARG;
   return ln_fwd_impl(x, gamma, beta, resid, y, mean, rstd, rows, C, eps, 0, rpb, x_bs, ldx, y_bs, ldy, r_bs, ldr, drop, gamma2,
                      beta2, y2, mean2, rstd2, y2_bs, ldy2, stream);
 }

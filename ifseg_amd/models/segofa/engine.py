@@ -670,17 +670,23 @@ class HipEngine:
         (e_r1,) = self._rel_tables_all("e_tok", ["%stoken_rel_pos_table_list.%d.weight" % (e, l) for l in range(cfg.enc_layers)],
                                        [(True, g["enc_idx1d"])])
         (e_rx,) = self._rel_tables_all("e_x", [None] * cfg.enc_layers, [(False, g["enc_idxx"])])
+        x_pre = None
         for l in range(cfg.enc_layers):
             p = "%slayers.%d." % (e, l)
             tg = "e%d" % l
             rel = hip.RelBias(P, g["gcode"], g["code_bias"], e_r2[l], e_r1[l], e_rx[l], grid_w=w)
             x, xn = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", x, B, T,
-                                         ctx["e_pq"], ctx["e_pk"], rel, False, scaling, site=("e", l, 0),
-                                         next_ln=(p + "final_layer_norm", tg + "_fln1", tg + "_fxn"))
-            x = self._ffn_fwd(tg, p, x, B * T, site=("e", l, 1), rpb=T, xn_pre=xn)
+                                         ctx["e_pq"], ctx["e_pk"], rel, False, scaling, site=("e", l, 0), xn_pre=x_pre,
+                                         next_ln=(p + "final_layer_norm", tg + "_fln1", buf(tg + "_fxn", (B * T, C))))
+            if l + 1 < cfg.enc_layers:      # the next layer's pre-LN, or the encoder's final LayerNorm
+                nl = ("%slayers.%d.self_attn_layer_norm" % (e, l + 1), "e%d_ln1" % (l + 1), buf("e%d_xn" % (l + 1), (B * T, C)))
+            else:
+                nl = (e + "layer_norm", "e_final_ln", buf("enc_out", (B, T, C)).view(B * T, C))
+            x, x_pre = self._ffn_fwd(tg, p, x, B * T, site=("e", l, 1), rpb=T, xn_pre=xn, next_ln=nl)
         enc_out = buf("enc_out", (B, T, C))
-        mu, rs = self._ln_stats("e_final_ln", B * T)
-        hip.ln_fwd(x.view(B * T, C), W(e + "layer_norm.weight"), W(e + "layer_norm.bias"), enc_out.view(B * T, C), mu, rs)
+        if x_pre is None:
+            mu, rs = self._ln_stats("e_final_ln", B * T)
+            hip.ln_fwd(x.view(B * T, C), W(e + "layer_norm.weight"), W(e + "layer_norm.bias"), enc_out.view(B * T, C), mu, rs)
         ctx["e_x_final"] = x
         ctx["enc_out"] = enc_out
 
@@ -729,16 +735,19 @@ class HipEngine:
         d_r2, d_r1, d_rx = self._rel_tables_all(
             "d_seg", ["%sseg_rel_pos_table_list.%d.weight" % (d, l) for l in range(cfg.dec_layers)],
             [(True, g["dec_idx2d"]), (True, g["dec_idx1d"]), (True, g["dec_idxx"])])
+        y_pre = None
         for l in range(cfg.dec_layers):
             p = "%slayers.%d." % (d, l)
             tg = "d%d" % l
             rel = hip.RelBias(P, g["gcode"], g["code_bias"], d_r2[l], d_r1[l], d_rx[l], grid_w=w)
             y, yn = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", y, B, Td,
-                                         ctx["d_spq"], ctx["d_spk"], rel, causal, scaling, site=("d", l, 0),
-                                         next_ln=(p + "encoder_attn_layer_norm", tg + "_cln1", tg + "_cyn"))
+                                         ctx["d_spq"], ctx["d_spk"], rel, causal, scaling, site=("d", l, 0), xn_pre=y_pre,
+                                         next_ln=(p + "encoder_attn_layer_norm", tg + "_cln1", buf(tg + "_cyn", (B * Td, C))))
             y, yn = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling, site=("d", l, 1), yn_pre=yn,
-                                          next_ln=(p + "final_layer_norm", tg + "_fln1", tg + "_fxn"))
-            y = self._ffn_fwd(tg, p, y, B * Td, site=("d", l, 2), rpb=Td, xn_pre=yn)
+                                          next_ln=(p + "final_layer_norm", tg + "_fln1", buf(tg + "_fxn", (B * Td, C))))
+            nl = (("%slayers.%d.self_attn_layer_norm" % (d, l + 1), "d%d_ln1" % (l + 1), buf("d%d_xn" % (l + 1), (B * Td, C)))
+                  if l + 1 < cfg.dec_layers else None)
+            y, y_pre = self._ffn_fwd(tg, p, y, B * Td, site=("d", l, 2), rpb=Td, xn_pre=yn, next_ln=nl)
         ctx["d_y_final"] = y
         # final LN written in reference order [bos, patches] (decoder_module.py:668-675)
         featb = buf("d_feat", (B, Td, C))
@@ -818,7 +827,7 @@ class HipEngine:
             dense[:, :P, :P] = img
             x, _ = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", x, B, T, pqk[:, :C],
                                         pqk[:, C:], None, False, scaling, dense=dense.contiguous())
-            x = self._ffn_fwd(tg, p, x, B * T)
+            x, _ = self._ffn_fwd(tg, p, x, B * T)
         enc_out = buf("enc_out", (B, T, C))
         hip.ln_fwd(x.view(B * T, C), W(e + "layer_norm.weight"), W(e + "layer_norm.bias"), enc_out.view(B * T, C))
         ctx["enc_out"] = enc_out
@@ -863,7 +872,7 @@ class HipEngine:
             y, _ = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", y, B, Td,
                                         spqk[:, :C], spqk[:, C:], None, False, scaling, dense=dense.contiguous())
             y, _ = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling)
-            y = self._ffn_fwd(tg, p, y, B * Td)
+            y, _ = self._ffn_fwd(tg, p, y, B * Td)
         featb = buf("d_feat", (B, Td, C))
         hip.ln_fwd(y[:, :P], W(d + "layer_norm.weight"), W(d + "layer_norm.bias"), featb[:, 1:])
         hip.ln_fwd(y[:, P:], W(d + "layer_norm.weight"), W(d + "layer_norm.bias"), featb[:, :1])
@@ -877,14 +886,16 @@ class HipEngine:
         return 16 + (l * 4 + k) * 2 + (0 if kind == "e" else 1)
 
     def _self_block_fwd(self, tg, p, attn, ln1, ln2, x, B, T, pq, pk, rel, causal, scaling, dense=None, site=None,
-                        next_ln=None):
-        """-> (block output, pre-LN of the next block or None)"""
+                        next_ln=None, xn_pre=None):
+        """xn_pre: ln1(x) if the previous layer already produced it.  -> (block output, pre-LN of the next block or None)"""
         C, H = self.cfg.embed_dim, self.cfg.heads
         W, buf = self.W, self.buf
         a_ = p + attn
-        xn = buf(tg + "_xn", (B * T, C))
-        mu, rs = self._ln_stats(tg + "_ln1", B * T)
-        hip.ln_fwd(x.view(B * T, C), W(p + ln1 + ".weight"), W(p + ln1 + ".bias"), xn, mu, rs)
+        xn = xn_pre
+        if xn is None:
+            xn = buf(tg + "_xn", (B * T, C))
+            mu, rs = self._ln_stats(tg + "_ln1", B * T)
+            hip.ln_fwd(x.view(B * T, C), W(p + ln1 + ".weight"), W(p + ln1 + ".bias"), xn, mu, rs)
         qkv = buf(tg + "_qkv", (B, T, 3 * C))
         hip.linear_fwd(xn, self._fused(self.p16, a_ + ".q_proj.weight", 3 * C, C),
                        self._fused(self.p16, a_ + ".q_proj.bias", 3 * C), out=qkv.view(B * T, 3 * C),
@@ -934,8 +945,9 @@ class HipEngine:
         self._save(tg + "_ca", x=y1, xn=yn, q=q, kv=kv, o=o, lse=lse, a=a, gain=gain, site=site)
         return y2, nxt
 
-    def _ffn_fwd(self, tg, p, x1, rows, site=None, rpb=None, xn_pre=None):
-        """xn_pre: final_layer_norm(x1) if the previous block already produced it"""
+    def _ffn_fwd(self, tg, p, x1, rows, site=None, rpb=None, xn_pre=None, next_ln=None):
+        """xn_pre: final_layer_norm(x1) if the previous block already produced it; next_ln as in _post_ln (used when the
+        block output goes through the dropout kernel anyway).  -> (x2, pre-LN of the next layer or None)"""
         C, Fd = self.cfg.embed_dim, self.cfg.ffn_dim
         W, buf = self.W, self.buf
         xn = xn_pre
@@ -949,20 +961,29 @@ class HipEngine:
         mu, rs = self._ln_stats(tg + "_fln2", rows)
         hip.ln_fwd(u, W(p + "ffn_layernorm.weight"), W(p + "ffn_layernorm.bias"), z, mu, rs, gelu=True)
         x2 = buf(tg + "_x2", x1.shape)
+        nxt = None
         if self.drop_on and site is not None:
             t = buf("drop_tmp_%d" % rows, (rows, C))
             hip.linear_fwd(z, W(p + "fc2.weight"), W(p + "fc2.bias"), out=t)
-            self._drop(t, x1.view(rows, C), x2.view(rows, C), self._site_id(site), self._dp(*site), rpb)
+            if next_ln is not None:
+                # dropout + DropPath + residual of this block and the pre-LN of the next layer in one launch
+                npname, ntag, nxt = next_ln
+                mu2, rs2 = self._ln_stats(ntag, rows)
+                hip.ln_fwd_pair(t, None, None, x2.view(rows, C), None, None, W(npname + ".weight"), W(npname + ".bias"), nxt,
+                                mu2, rs2, resid=x1.view(rows, C),
+                                drop=(self.cfg.dropout, self._site_seed(self._site_id(site)), self._dp(*site), rpb))
+            else:
+                self._drop(t, x1.view(rows, C), x2.view(rows, C), self._site_id(site), self._dp(*site), rpb)
         else:
             hip.linear_fwd(z, W(p + "fc2.weight"), W(p + "fc2.bias"), out=x2.view(rows, C), resid=x1.view(rows, C))
         self._save(tg + "_ffn", x1=x1, xn=xn, u=u, z=z, site=site, rpb=rpb)
-        return x2
+        return x2, nxt
 
     def _save(self, key, **kw):
         self.saved[key] = kw
 
     def _post_ln(self, a, pname, stats_tag, resid, out, drop, rows, next_ln):
-        """out = resid + drop(LN(a)); with next_ln = (param prefix, stats tag, buffer name) the pre-LN of the next
+        """out = resid + drop(LN(a)); with next_ln = (param prefix, stats tag, output [rows, C]) the pre-LN of the next
         block is computed in the same launch and returned (else None)."""
         C = self.cfg.embed_dim
         W = self.W
@@ -970,8 +991,7 @@ class HipEngine:
         if next_ln is None:
             hip.ln_fwd(a, W(pname + ".weight"), W(pname + ".bias"), out, mu, rs, resid=resid, drop=drop)
             return None
-        npname, ntag, nbuf = next_ln
-        xn = self.buf(nbuf, (rows, C))
+        npname, ntag, xn = next_ln
         mu2, rs2 = self._ln_stats(ntag, rows)
         hip.ln_fwd_pair(a, W(pname + ".weight"), W(pname + ".bias"), out, mu, rs, W(npname + ".weight"), W(npname + ".bias"),
                         xn, mu2, rs2, resid=resid, drop=drop)

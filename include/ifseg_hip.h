@@ -154,7 +154,9 @@ int ifseg_ln_fwd(const void* x, const void* gamma, const void* beta, const void*
                  long long y_bs, int ldy, long long r_bs, int ldr, const ifseg_drop_args* drop, void* stream);
 /* Two LayerNorms of one residual-stream row in one pass (post-LN of a block + pre-LN of the next,
  * unify_transformer_layer.py:256-292,463-568): y = [resid +] drop(LN(x; gamma, beta)), y2 = LN(y as stored in bf16;
- * gamma2, beta2).  Bit-identical to ifseg_ln_fwd followed by ifseg_ln_fwd on y. */
+ * gamma2, beta2).  Bit-identical to ifseg_ln_fwd followed by ifseg_ln_fwd on y.  gamma == beta == NULL makes the
+ * first stage the identity: y = [resid +] drop(x) (the dropout + residual after fc2, identical to ifseg_dropout),
+ * y2 = LN(y) -- the pre-LN of the next layer. */
 int ifseg_ln_fwd_pair(const void* x, const void* gamma, const void* beta, const void* resid, void* y, float* mean,
                       float* rstd, const void* gamma2, const void* beta2, void* y2, float* mean2, float* rstd2, int rows,
                       int C, float eps, int rpb, long long x_bs, int ldx, long long y_bs, int ldy, long long r_bs, int ldr,

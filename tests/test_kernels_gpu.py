@@ -593,3 +593,23 @@ def test_ln_fwd_pair_is_bit_identical_to_two_calls():
         hip.ln_fwd_pair(a, g1, b1, y, n1, s1, g2, b2, y2, n2, s2, resid=res, drop=drop)
         assert torch.equal(y, y_ref) and torch.equal(y2, y2_ref)
         assert torch.equal(n1, m1) and torch.equal(s1, r1) and torch.equal(n2, m2) and torch.equal(s2, r2)
+
+
+def test_ln_fwd_pair_identity_first_stage_equals_dropout_then_ln():
+    """gamma == NULL: y = resid + drop(x) (the block output after fc2) and y2 = LN(y) of the next layer in one launch."""
+    from ifseg_amd import hip
+    dev = _dev()
+    B, T, C, p, seed = 3, 257, 768, 0.1, 777
+    rows = B * T
+    a, res = _rand((rows, C), dev, 105), _rand((rows, C), dev, 106)
+    g2, b2 = _rand((C,), dev, 107, 0.2) + 1, _rand((C,), dev, 108, 0.2)
+    dp = torch.tensor([1 / 0.9, 0.0, 1 / 0.9], device=dev)
+    y_ref, y2_ref = torch.empty_like(a), torch.empty_like(a)
+    m2, r2 = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    hip.dropout(a, res, y_ref, p, seed, dp, T)
+    hip.ln_fwd(y_ref, g2, b2, y2_ref, m2, r2)
+    y, y2 = torch.empty_like(a), torch.empty_like(a)
+    n2, s2 = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    hip.ln_fwd_pair(a, None, None, y, None, None, g2, b2, y2, n2, s2, resid=res, drop=(p, seed, dp, T))
+    assert torch.equal(y, y_ref) and torch.equal(y2, y2_ref)
+    assert torch.equal(n2, m2) and torch.equal(s2, r2)
