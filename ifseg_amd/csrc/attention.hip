@@ -478,6 +478,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     for (int c = 0; c < NKS / 2; ++c) dk[c][e] = 0.f;
   }
   const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+  // Per-lane LDS offsets of the block's ~40 operand reads.  The swizzles are XORs on the chunk bits, so every read is
+  // one of five bases XOR / plus a literal:
+  //   Q rows   (S):   aQ ^ (ks << 5)                 dO rows (dP): aO ^ (ks << 5)       V rows: aV ^ (ks << 5)
+  //   dO^T (dV): ((aOt ^ (db << 6)) + s2 * 2048), second row group (+ 1024) ^ 32
+  //   Q^T  (dK): ((aQt ^ (cb << 6)) + s2 * 4096), second row group (+ 2048) ^ 32
+  const int aQ = kx_off(lane & 31, half);
+  const int aO = vx_off(lane & 31, half * 16);
+  const int aV = vx_off(wave * 32 + (lane & 31), half * 16);
+  const int colT = g16 * 16 + (i16 & 3) * 4, rT = 4 * half + (i16 >> 2);
+  const int aOt = vx_off(rT, colT * 2);
+  const int aQt = kx_off(rT, colT >> 3) + (colT & 7) * 2;
   const int nblk = min(qe * 2, (a.T + 31) >> 5) - qs * 2;
   if (nblk > 0) issue(qs * 64, 0);
   for (int n = 0; n < nblk; ++n) {
@@ -493,21 +504,42 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       if (skip) continue;
       const bool qb_grid = ib + 31 < a.P;
       const int fast = (a.rel_mode && qb_grid && wave_kgrid) ? 1 : ((!a.rel_mode && !a.causal && ib + 32 <= a.T) ? 2 : 0);
+      // The five bases (and the lane's x coordinate for the histogram) are re-materialised per block: as plain loop
+      // invariants the compiler hoists all ~40 derived addresses and 16 shuffle indices into VGPRs, spills part of
+      // them, and every scratch reload waits with vmcnt(0) -- i.e. for the NEXT block's LDS-DMA -- in the loop.
+      int bQ = aQ, bO = aO, bV = aV, bOt = aOt, bQt = aQt, xl_i = xl;
+      asm volatile("" : "+v"(bQ), "+v"(bO), "+v"(bV), "+v"(bOt), "+v"(bQt), "+v"(xl_i));
       f32x16 s, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+      const bool seeded = row32 && fast == 1;
+      if (seeded) {
+        // the block's queries are one grid row: the bias of element r sits at a constant offset from one address
+        // and seeds the accumulator (natural units)
+        const float* tp = sTbl + (sGc[ib] - cj + 4 * half);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        for (int e = 0; e < 16; ++e) s[e] = tp[(e & 3) + 8 * (e >> 2)];
+      } else {
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        bf16x8 qf = lds_read_b128(sQ + kx_off(lane & 31, ks * 2 + half));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
       }
+      {
+        // all Q fragments are requested before the first MFMA, the dO / V fragments travel while the S MFMAs run:
+        // two exposed LDS latencies per block instead of one per MFMA
+        bf16x8 qf[NKS], of[4], vfr[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 of = lds_read_b128(sO + vx_off(lane & 31, (ks * 2 + half) * 16));
-        bf16x8 vfr = lds_read_b128(sVk + vx_off(wave * 32 + (lane & 31), (ks * 2 + half) * 16));
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, vfr, dp, 0, 0, 0);
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = lds_read_b128(sQ + (bQ ^ (ks << 5)));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          of[ks] = lds_read_b128(sO + (bO ^ (ks << 5)));
+          vfr[ks] = lds_read_b128(sVk + (bV ^ (ks << 5)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[ks], vfr[ks], dp, 0, 0, 0);
       }
       // element r <-> query ib + (r&3) + 8*(r>>2) + 4*half ; key = kj (lane)
       float accA = 0.f, accB = 0.f;
@@ -523,7 +555,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
           const float4 d4 = *reinterpret_cast<const float4*>(sL + 32 + il);
           const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
           float pv[4], dsv[4];
-          if (fast == 1) {
+          if (seeded) {
+            const int di = kj - iq;                // masked (causal) iff kj > i  <=>  di > e
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float p = __builtin_amdgcn_exp2f(fmaf(s[rg * 4 + e], LOG2E, -ls[e]));
+              if (a.causal) p = (di > e) ? 0.f : p;
+              const float ds = p * (gain * dp[rg * 4 + e] - dl[e]);
+              pv[e] = p; dsv[e] = ds;
+              // 32-wide grid, row-aligned blocks: this wave's keys are one grid row (x_j = lane&31) and
+              // the block's queries another (x_i = e + 8*rg + 4*half).  Rotate each register by x_i so
+              // that lane u holds the term of bin dx = x_i - x_j with u = (x_j - x_i) mod 32, and sum
+              // the 16 registers in place: 2 half-wave LDS adds per block instead of 16 full ones
+              // (LDS float atomics are slow: one per element more than doubles the kernel time).
+              const int xs = xl_i + (e + 8 * rg);               // (lane&31) + x_i
+              const float val = __shfl(ds, (xs & 31) | (lane & 32));
+              if (xs <= 31) accA += val; else accB += val;
+            }
+          } else if (fast == 1) {
             const int4 c4 = *reinterpret_cast<const int4*>(sGc + iq);
             const int cis[4] = {c4.x, c4.y, c4.z, c4.w};
             const int di = kj - iq;                // masked (causal) iff kj > i  <=>  di > e
@@ -534,17 +583,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
               if (a.causal) p = (di > e) ? 0.f : p;
               const float ds = p * (gain * dp[rg * 4 + e] - dl[e]);
               pv[e] = p; dsv[e] = ds;
-              if (row32) {
-                // 32-wide grid, row-aligned blocks: this wave's keys are one grid row (x_j = lane&31) and
-                // the block's queries another (x_i = e + 8*rg + 4*half).  Rotate each register by x_i so
-                // that lane u holds the term of bin dx = x_i - x_j with u = (x_j - x_i) mod 32, and sum
-                // the 16 registers in place: 2 half-wave LDS adds per block instead of 16 full ones.
-                const int xs = xl + (e + 8 * rg);                 // (lane&31) + x_i
-                const float val = __shfl(ds, (xs & 31) | (lane & 32));
-                if (xs <= 31) accA += val; else accB += val;
-              } else {
-                atomicAdd(&sHist[hidx], ds);
-              }
+              atomicAdd(&sHist[hidx], ds);
             }
           } else if (fast == 2) {
 #pragma unroll
@@ -596,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         }
         pfr[s2] = up.b; dsf[s2] = ud.b;
       }
-      if (row32 && fast == 1) {
+      if (seeded) {
         accA += __shfl_xor(accA, 32);
         accB += __shfl_xor(accB, 32);
         const int base = sGc[ib] - cj0;        // bin of dx = 0 for this (query row, key row) pair
@@ -611,22 +650,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       // batching both halves at once spills)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const int r0 = 16 * s2 + 4 * half + (i16 >> 2);
+        // rows 16*s2 + 4*half + (i16>>2) (+ 8), columns db*32 / cb*32 + g16*16 + (i16&3)*4 of the stage
         U128 fo[2], fq[NKS / 2];
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          const int colb = (db * 32 + g16 * 16 + (i16 & 3) * 4) * 2;
+          const int o0 = (bOt ^ (db << 6)) + s2 * 2048;
           U64 x, y;
-          x.s = lds_read_tr(sO + vx_off(r0, colb));
-          y.s = lds_read_tr(sO + vx_off(r0 + 8, colb));
+          x.s = lds_read_tr(sO + o0);
+          y.s = lds_read_tr(sO + ((o0 + 1024) ^ 32));
           fo[db].w[0] = x.w[0]; fo[db].w[1] = x.w[1]; fo[db].w[2] = y.w[0]; fo[db].w[3] = y.w[1];
         }
 #pragma unroll
         for (int cb = 0; cb < NKS / 2; ++cb) {
-          const int col = cb * 32 + g16 * 16 + (i16 & 3) * 4;
+          const int o0 = (bQt ^ (cb << 6)) + s2 * 4096;
           U64 x, y;
-          x.s = lds_read_tr(sQ + kx_off(r0, col >> 3) + (col & 7) * 2);
-          y.s = lds_read_tr(sQ + kx_off(r0 + 8, col >> 3) + (col & 7) * 2);
+          x.s = lds_read_tr(sQ + o0);
+          y.s = lds_read_tr(sQ + ((o0 + 2048) ^ 32));
           fq[cb].w[0] = x.w[0]; fq[cb].w[1] = x.w[1]; fq[cb].w[2] = y.w[0]; fq[cb].w[3] = y.w[1];
         }
         __builtin_amdgcn_sched_barrier(0);

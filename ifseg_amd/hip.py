@@ -109,6 +109,9 @@ _splitk_ws = {}
 
 
 GEMM_COLSUM = 8
+# workgroups a dW GEMM is split over: it runs on the side stream next to the dX chain, so filling the chip alone is not
+# the goal (256 / 512 / 128 measured within 1% of each other; fewer slabs = less fp32 workspace traffic)
+DW_TARGET_WGS = int(os.environ.get("IFSEG_DW_WGS", "256"))
 
 
 def linear_dw(dy, x, out, accumulate=False, bias_out=None):
@@ -121,7 +124,9 @@ def linear_dw(dy, x, out, accumulate=False, bias_out=None):
     M, N = dy.shape
     K = x.shape[1]
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    splitk = max(1, min(16, 512 // max(1, tiles), M // 512))
+    splitk = max(1, min(16, DW_TARGET_WGS // max(1, tiles), M // 512))
+    if bias_out is not None and M >= 1024:
+        splitk = max(splitk, 2)      # the fused column sums ride on the split-K reduction
     if splitk > 1 and out.is_contiguous():
         kchunk = (((M + splitk - 1) // splitk) + 63) // 64 * 64
         nsl = (M + kchunk - 1) // kchunk

@@ -41,5 +41,19 @@ def main(kind="enc", iters=5):
     for kd in (4, 5, 6):
         p = hip.prof_read(kd)
         print(kind, p["kind"], "avg us %.1f" % (p["ms"] * 1e3 / max(1, p["launches"])), "alg TF/s %.1f" % (p["flops"] / (p["ms"] * 1e-3) / 1e12))
+    hip.prof_enable(0)
+    def bwd(phases):
+        hip.attn_bwd(q, k, v, pq, pk, out, dout, lse, delta, dqkv[:, :, :C], dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:], dpq, dpk,
+                     B, H, T, S, rel=rel, causal=causal, gain=gain, drel2d_part=parts[0], drel1d_part=parts[1],
+                     drelx_part=parts[2], nparts=nparts, phases=phases)
+    def timeit(fn, n=10):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+    print(kind, "dkv alone            us %.1f" % timeit(lambda: bwd(hip.ATTN_BWD_DKV)))
+    print(kind, "dq kernel alone      us %.1f" % timeit(lambda: bwd(hip.ATTN_BWD_DQ)))
 if __name__ == "__main__":
     main(sys.argv[1] if len(sys.argv) > 1 else "enc")
