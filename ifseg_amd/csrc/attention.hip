@@ -21,6 +21,7 @@
 // Encoder: grid = image patches, tail = text.  Decoder: grid = patches, tail =
 // the single bos token (the host permutes bos to the end; `causal` uses
 // "tail-first" original order: a tail key is visible to every grid query).
+#include <type_traits>
 #include "common.h"
 #include "prof.h"
 #include "../../include/ifseg_hip.h"
@@ -456,17 +457,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     const unsigned base = lds0 + st * STG;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      // wave-uniform bases + 32-bit lane offsets (a row of one batch element is < 2^31 bytes away)
       const int qr = min(ib + q_row[i], a.T - 1);
-      if (q_c[i] < 8) lds_dma16_g(qb_ + (long long)qr * a.ldq + q_c[i] * 8, base + (wv * 2 + i) * 1024);
-      else if (HAS_POS) lds_dma16_g(pqb_ + (long long)qr * a.ldpq + (q_c[i] - 8) * 8, base + (wv * 2 + i) * 1024);
+      if (q_c[i] < 8) lds_dma16_gs(qb_, (qr * a.ldq + q_c[i] * 8) * 2, base + (wv * 2 + i) * 1024);
+      else if (HAS_POS) lds_dma16_gs(pqb_, (qr * a.ldpq + (q_c[i] - 8) * 8) * 2, base + (wv * 2 + i) * 1024);
     }
     {
       const int qr = min(ib + o_row, a.T - 1);
-      lds_dma16_g(dob_ + (long long)qr * a.lddo + o_c * 8, base + 8192 + wv * 1024);
+      lds_dma16_gs(dob_, (qr * a.lddo + o_c * 8) * 2, base + 8192 + wv * 1024);
     }
     if (wv == 0) {
+      // lanes 0..31: lse, lanes 32..63: delta (LDS-DMA places lane i at base + 4*i whichever lanes are active)
       const int qr = min(ib + (lane & 31), a.T - 1);
-      lds_dma4_g((lane < 32 ? lseb : delb) + qr, base + 8192 + 4096);
+      if (lane < 32) lds_dma4_gs(lseb, qr * 4, base + 8192 + 4096);
+      else lds_dma4_gs(delb, qr * 4, base + 8192 + 4096);
     }
   };
 
@@ -513,12 +517,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) dp[e] = 0.f;
       const bool seeded = row32 && fast == 1;
+      int hidx_rw = 0;
+      float hold = 0.f;
       if (seeded) {
         // the block's queries are one grid row: the bias of element r sits at a constant offset from one address
         // and seeds the accumulator (natural units)
-        const float* tp = sTbl + (sGc[ib] - cj + 4 * half);
+        const int code_i = sGc[ib];
+        const float* tp = sTbl + (code_i - cj + 4 * half);
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[e] = tp[(e & 3) + 8 * (e >> 2)];
+        // histogram bin this lane updates at the end of the block: (code_i - cj0) is dx = 0 of this (query row, key row)
+        hidx_rw = code_i - cj0 + (lane < 32 ? -lane : 64 - lane);
+        hold = sHist[lane != 32 ? hidx_rw : 0];
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
@@ -542,8 +552,46 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[ks], vfr[ks], dp, 0, 0, 0);
       }
       // element r <-> query ib + (r&3) + 8*(r>>2) + 4*half ; key = kj (lane)
-      float accA = 0.f, accB = 0.f;
       bf16x8 pfr[2], dsf[2];
+      float hval[16];      // seeded blocks: dS rotated onto its histogram lane (summed after the dV / dK MFMAs)
+      if (seeded) {
+        auto body = [&](auto causal_tag) {
+          constexpr bool CAUSAL = decltype(causal_tag)::value;
+          float dsr[16];
+          U128 up[2], ud[2];
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int il = 8 * rg + 4 * half;
+            const float4 l4 = *reinterpret_cast<const float4*>(sL + il);
+            const float4 d4 = *reinterpret_cast<const float4*>(sL + 32 + il);
+            const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+            const int di = kj - (ib + il);         // masked (causal) iff kj > i  <=>  di > e
+            float pv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float p = __builtin_amdgcn_exp2f(fmaf(s[rg * 4 + e], LOG2E, -ls[e]));
+              if (CAUSAL) p = (di > e) ? 0.f : p;
+              pv[e] = p;
+              dsr[rg * 4 + e] = p * fmaf(gain, dp[rg * 4 + e], -dl[e]);
+            }
+            up[rg >> 1].w[(rg & 1) * 2] = pack2bf(pv[0], pv[1]); up[rg >> 1].w[(rg & 1) * 2 + 1] = pack2bf(pv[2], pv[3]);
+            ud[rg >> 1].w[(rg & 1) * 2] = pack2bf(dsr[rg * 4], dsr[rg * 4 + 1]);
+            ud[rg >> 1].w[(rg & 1) * 2 + 1] = pack2bf(dsr[rg * 4 + 2], dsr[rg * 4 + 3]);
+          }
+          pfr[0] = up[0].b; pfr[1] = up[1].b; dsf[0] = ud[0].b; dsf[1] = ud[1].b;
+          // d rel2d: this wave's keys are one grid row (x_j = lane&31) and the block's queries another
+          // (x_i = (r&3) + 8*(r>>2) + 4*half).  Rotate register r by x_i so that lane u holds the term of bin
+          // dx = x_i - x_j with u = (x_j - x_i) mod 32; the 16 rotated registers are summed in place after the
+          // dV / dK MFMAs (all 16 ds_bpermute in flight at once), then 2 half-wave LDS adds per block
+          // (one LDS float atomic per element instead more than doubles the kernel time).
+          const int hi4 = (lane & 32) << 2, xl4 = xl_i << 2;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            hval[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(((xl4 + 4 * ((r & 3) + 8 * (r >> 2))) & 124) | hi4,
+                                                                  __float_as_int(dsr[r])));
+        };
+        if (a.causal) body(std::true_type{}); else body(std::false_type{});
+      } else
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         U128 up, ud;
@@ -555,24 +603,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
           const float4 d4 = *reinterpret_cast<const float4*>(sL + 32 + il);
           const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
           float pv[4], dsv[4];
-          if (seeded) {
-            const int di = kj - iq;                // masked (causal) iff kj > i  <=>  di > e
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float p = __builtin_amdgcn_exp2f(fmaf(s[rg * 4 + e], LOG2E, -ls[e]));
-              if (a.causal) p = (di > e) ? 0.f : p;
-              const float ds = p * (gain * dp[rg * 4 + e] - dl[e]);
-              pv[e] = p; dsv[e] = ds;
-              // 32-wide grid, row-aligned blocks: this wave's keys are one grid row (x_j = lane&31) and
-              // the block's queries another (x_i = e + 8*rg + 4*half).  Rotate each register by x_i so
-              // that lane u holds the term of bin dx = x_i - x_j with u = (x_j - x_i) mod 32, and sum
-              // the 16 registers in place: 2 half-wave LDS adds per block instead of 16 full ones
-              // (LDS float atomics are slow: one per element more than doubles the kernel time).
-              const int xs = xl_i + (e + 8 * rg);               // (lane&31) + x_i
-              const float val = __shfl(ds, (xs & 31) | (lane & 32));
-              if (xs <= 31) accA += val; else accB += val;
-            }
-          } else if (fast == 1) {
+          if (fast == 1) {
             const int4 c4 = *reinterpret_cast<const int4*>(sGc + iq);
             const int cis[4] = {c4.x, c4.y, c4.z, c4.w};
             const int di = kj - iq;                // masked (causal) iff kj > i  <=>  di > e
@@ -635,15 +666,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         }
         pfr[s2] = up.b; dsf[s2] = ud.b;
       }
-      if (seeded) {
-        accA += __shfl_xor(accA, 32);
-        accB += __shfl_xor(accB, 32);
-        const int base = sGc[ib] - cj0;        // bin of dx = 0 for this (query row, key row) pair
-        if (lane < 32) {
-          atomicAdd(&sHist[base - lane], accA);                     // dx = -u
-          if (lane > 0) atomicAdd(&sHist[base + 32 - lane], accB);  // dx = 32 - u
-        }
-      }
       // dV^T += dO^T P ; dK^T += Q^T dS ; slot (kh,e) <-> query ib + 16*s2 + 4*kh + (e&3) + 8*(e>>2)
       // all transposed operand reads of one s2 half are issued before its MFMAs (the scheduling barrier keeps
       // the compiler from sinking each read next to its MFMA, which serialises LDS latency 6 times per half;
@@ -673,6 +695,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         for (int db = 0; db < 2; ++db) dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[db].b, pfr[s2], dv[db], 0, 0, 0);
 #pragma unroll
         for (int cb = 0; cb < NKS / 2; ++cb) dk[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[cb].b, dsf[s2], dk[cb], 0, 0, 0);
+      }
+      if (seeded) {
+        float accT = 0.f, accA = 0.f;            // all bins / bins of dx <= 0 (no wrap: x_j + ... <= 31)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          accT += hval[r];
+          accA += (xl_i + ((r & 3) + 8 * (r >> 2)) <= 31) ? hval[r] : 0.f;
+        }
+        const float accB = accT - accA;
+        // halves combined in one VALU op: lanes 0..31 end up with the dx = -u total, lanes 32..63 with dx = 32 - u
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(accA), __float_as_uint(accB), false, false);
+        const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        // plain read-modify-write: between two barriers the four waves work on the same query row and four different
+        // key rows, i.e. on four different rows of the table (an LDS float atomic costs ~30 us per layer here)
+        if (lane != 32) sHist[hidx_rw] = hold + tot;
       }
     }
   }
@@ -1047,6 +1084,10 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   int rc = attn_check(a);
   if (rc) return rc;
   if ((x->lddo | x->lddq | x->lddk | x->lddv | x->ldout) & 7) return IFSEG_ERR_BAD_SHAPE;
+  {   // the dK/dV kernel addresses a query row by a 32-bit byte offset from the batch element's base
+    const long long ldmax = a.ldq > a.lddo ? (a.ldq > a.ldpq ? a.ldq : a.ldpq) : (a.lddo > a.ldpq ? a.lddo : a.ldpq);
+    if ((long long)a.T * ldmax * 2 >= (1ll << 31)) return IFSEG_ERR_BAD_SHAPE;
+  }
   const int nkt = (a.S + 127) / 128, nq = (a.T + 127) / 128;
   if (a.rel_mode && a.nparts != a.B * nkt) return IFSEG_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;

@@ -117,6 +117,15 @@ __device__ __forceinline__ void lds_dma16_g(const void* gsrc, unsigned lds_base)
 __device__ __forceinline__ void lds_dma4_g(const void* gsrc, unsigned lds_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
 }
+// the same with a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit per-lane pointers live
+__device__ __forceinline__ void lds_dma16_gs(const void* sbase, int voff_bytes, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :: "v"(voff_bytes), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
+}
+__device__ __forceinline__ void lds_dma4_gs(const void* sbase, int voff_bytes, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+               :: "v"(voff_bytes), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
+}
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ float warp_sum(float v) {
