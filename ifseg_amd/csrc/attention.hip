@@ -76,6 +76,15 @@ __device__ __forceinline__ int vx_off(int r, int colbyte) {
   return r * 128 + ((((colbyte >> 4) ^ hsw) & 7) << 4) + (colbyte & 15);
 }
 
+// Marks a register fragment as used here.  Fragments loaded from global memory in a kernel prologue and first read
+// inside the main loop leave their loads "pending" at the loop header in the compiler's wait-count model; it then puts
+// s_waitcnt vmcnt(N) with small N in front of their uses INSIDE the loop, and from the second iteration on those waits
+// hit the loop's own prefetch (global loads / LDS-DMA for the next tile), serialising it with the MFMAs.
+__device__ __forceinline__ void consume_frag(const bf16x8& f) {
+  typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+  asm volatile("" :: "v"(__builtin_bit_cast(u32x4_t, f)));
+}
+
 struct RelCtx {
   const float* tbl;   // LDS copy of rel2d[h]
   const int* gc;      // LDS copy of gcode
@@ -171,6 +180,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   float m_run = NEG_INF, l_run = 0.f;
 
   if (nsched > 0) { load_kv(tile_of(0) * 64); store_kv(0); }
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) consume_frag(qf[ks]);
   __syncthreads();
 
   for (int it = 0; it < nsched; ++it) {
@@ -494,6 +505,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int aOt = vx_off(rT, colT * 2);
   const int aQt = kx_off(rT, colT >> 3) + (colT & 7) * 2;
   const int nblk = min(qe * 2, (a.T + 31) >> 5) - qs * 2;
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) consume_frag(kf[ks]);
   if (nblk > 0) issue(qs * 64, 0);
   for (int n = 0; n < nblk; ++n) {
     const int ib = (qs * 2 + n) * 32;
@@ -848,6 +861,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int c = 0; c < NKS / 2; ++c) dq[c][e] = 0.f;
 
   if (nsched > 0) { load_kv(tile_of(0) * 64); store_kv(0); }
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) consume_frag(qf[ks]);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) consume_frag(dof[ks]);
   __syncthreads();
   const int i16 = lane & 15, g16 = (lane >> 4) & 1;
 
