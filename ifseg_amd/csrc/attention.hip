@@ -904,6 +904,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, dof[ks], dp, 0, 0, 0);
         }
         bf16x8 dsf[2];
+        // the two hot block kinds get one straight-line body each, chosen ONCE per 32-key block: with the choice inside
+        // the element loops every group of four elements is wrapped in its own wave-uniform branches (68 per tile)
+        auto straight = [&](auto causal_tag) {
+          constexpr bool CAUSAL = decltype(causal_tag)::value;
+          U128 ud[2];
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int dj = j0 + kb * 32 + 8 * rg + 4 * half - qi;     // masked (causal) iff key > query
+            float dsv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float p = __builtin_amdgcn_exp2f(fmaf(s[rg * 4 + e], LOG2E, nlse_q));
+              if (CAUSAL) p = (dj + e > 0) ? 0.f : p;
+              dsv[e] = p * fmaf(gain, dp[rg * 4 + e], -del_q);
+            }
+            ud[rg >> 1].w[(rg & 1) * 2] = pack2bf(dsv[0], dsv[1]);
+            ud[rg >> 1].w[(rg & 1) * 2 + 1] = pack2bf(dsv[2], dsv[3]);
+          }
+          dsf[0] = ud[0].b; dsf[1] = ud[1].b;
+        };
+        if (fast == 1 && row32) {            // bias already in s (seeded accumulator)
+          if (a.causal) straight(std::true_type{}); else straight(std::false_type{});
+        } else if (fast == 2) {              // no bias, no mask
+          straight(std::false_type{});
+        } else
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           U128 ud;
