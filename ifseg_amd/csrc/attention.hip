@@ -103,8 +103,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int nq = (a.T + 127) >> 7;
-  const int bid = xcd_remap(blockIdx.x, nq * a.H * a.B);
-  const int qt = bid % nq, h = (bid / nq) % a.H, b = bid / (nq * a.H);
+  int qt, h, b;
+  if (a.causal) {     // later query tiles see more keys: longest workgroups first
+    int rank, bh;
+    causal_order(blockIdx.x, a.H * a.B, &rank, &bh);
+    qt = nq - 1 - rank; h = bh % a.H; b = bh / a.H;
+  } else {
+    const int bid = xcd_remap(blockIdx.x, nq * a.H * a.B);
+    qt = bid % nq; h = (bid / nq) % a.H; b = bid / (nq * a.H);
+  }
   const int q0 = qt * 128, qw = q0 + wave * 32;
   const int qi = qw + (lane & 31);           // this lane's query row
   const bool qvalid = qi < a.T;
@@ -158,9 +165,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       const int r = (tid >> 3) + 32 * i, c = tid & 7, j = j0 + r;
       rk[i] = make_uint4(0, 0, 0, 0); rk[2 + i] = make_uint4(0, 0, 0, 0); rv[i] = make_uint4(0, 0, 0, 0);
       if (j < a.S) {
-        rk[i] = *reinterpret_cast<const uint4*>(kb_ + (long long)j * a.ldk + c * 8);
-        if (HAS_POS) rk[2 + i] = *reinterpret_cast<const uint4*>(pkb_ + (long long)j * a.ldpk + c * 8);
-        rv[i] = *reinterpret_cast<const uint4*>(vb_ + (long long)j * a.ldv + c * 8);
+        // wave-uniform base + 32-bit lane offset (saddr addressing): no per-lane 64-bit pointers kept across the loop
+        rk[i] = *reinterpret_cast<const uint4*>(kb_ + (unsigned)(j * a.ldk + c * 8));
+        if (HAS_POS) rk[2 + i] = *reinterpret_cast<const uint4*>(pkb_ + (unsigned)(j * a.ldpk + c * 8));
+        rv[i] = *reinterpret_cast<const uint4*>(vb_ + (unsigned)(j * a.ldv + c * 8));
       }
     }
   };
@@ -391,7 +399,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int nkt = (a.S + 127) >> 7;
-  const int bid = xcd_remap(blockIdx.x, nkt * a.H * a.B);
+  int bid = xcd_remap(blockIdx.x, nkt * a.H * a.B);
+  if (a.causal) {     // the tail tile (keys every query sees) and the early key tiles are the long workgroups: first
+    int rank, bh;
+    causal_order(blockIdx.x, a.H * a.B, &rank, &bh);
+    bid = bh * nkt + (rank + nkt - 1) % nkt;
+  }
   const int kt = bid % nkt, h = (bid / nkt) % a.H, b = bid / (nkt * a.H);
   const int k0 = kt * 128;
   const int kw = __builtin_amdgcn_readfirstlane(k0 + wave * 32);
@@ -456,16 +469,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int STG = DKV_STAGE_BYTES;
   const unsigned lds0 = lds_addr(smem);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  int q_row[2], q_c[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    q_row[i] = (wv * 2 + i) * 4 + (lane >> 4);
-    q_c[i] = (lane & 15) ^ (((q_row[i] & 3) << 2) | ((q_row[i] >> 2) & 3));
-  }
-  const int o_row = wv * 8 + (lane >> 3);
-  const int o_c = ((lane & 7) ^ ((((o_row >> 1) & 1) << 2) | ((o_row >> 2) & 3))) & 7;
   auto issue = [&](int ib, int st) {
     const unsigned base = lds0 + st * STG;
+    // lane constants derived from a re-materialised lane id on every call (six VGPRs less across the loop)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    int q_row[2], q_c[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      q_row[i] = (wv * 2 + i) * 4 + (ln >> 4);
+      q_c[i] = (ln & 15) ^ (((q_row[i] & 3) << 2) | ((q_row[i] >> 2) & 3));
+    }
+    const int o_row = wv * 8 + (ln >> 3);
+    const int o_c = ((ln & 7) ^ ((((o_row >> 1) & 1) << 2) | ((o_row >> 2) & 3))) & 7;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       // wave-uniform bases + 32-bit lane offsets (a row of one batch element is < 2^31 bytes away)
@@ -479,8 +495,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
     if (wv == 0) {
       // lanes 0..31: lse, lanes 32..63: delta (LDS-DMA places lane i at base + 4*i whichever lanes are active)
-      const int qr = min(ib + (lane & 31), a.T - 1);
-      if (lane < 32) lds_dma4_gs(lseb, qr * 4, base + 8192 + 4096);
+      const int qr = min(ib + (ln & 31), a.T - 1);
+      if (ln < 32) lds_dma4_gs(lseb, qr * 4, base + 8192 + 4096);
       else lds_dma4_gs(delb, qr * 4, base + 8192 + 4096);
     }
   };
@@ -498,12 +514,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   //   Q rows   (S):   aQ ^ (ks << 5)                 dO rows (dP): aO ^ (ks << 5)       V rows: aV ^ (ks << 5)
   //   dO^T (dV): ((aOt ^ (db << 6)) + s2 * 2048), second row group (+ 1024) ^ 32
   //   Q^T  (dK): ((aQt ^ (cb << 6)) + s2 * 4096), second row group (+ 2048) ^ 32
-  const int aQ = kx_off(lane & 31, half);
-  const int aO = vx_off(lane & 31, half * 16);
-  const int aV = vx_off(wave * 32 + (lane & 31), half * 16);
-  const int colT = g16 * 16 + (i16 & 3) * 4, rT = 4 * half + (i16 >> 2);
-  const int aOt = vx_off(rT, colT * 2);
-  const int aQt = kx_off(rT, colT >> 3) + (colT & 7) * 2;
   const int nblk = min(qe * 2, (a.T + 31) >> 5) - qs * 2;
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) consume_frag(kf[ks]);
@@ -524,8 +534,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       // The five bases (and the lane's x coordinate for the histogram) are re-materialised per block: as plain loop
       // invariants the compiler hoists all ~40 derived addresses and 16 shuffle indices into VGPRs, spills part of
       // them, and every scratch reload waits with vmcnt(0) -- i.e. for the NEXT block's LDS-DMA -- in the loop.
-      int bQ = aQ, bO = aO, bV = aV, bOt = aOt, bQt = aQt, xl_i = xl;
-      asm volatile("" : "+v"(bQ), "+v"(bO), "+v"(bV), "+v"(bOt), "+v"(bQt), "+v"(xl_i));
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int half_i = ln >> 5, colT = ((ln >> 4) & 1) * 16 + (ln & 3) * 4, rT = 4 * half_i + ((ln & 15) >> 2);
+      const int bQ = kx_off(ln & 31, half_i), bO = vx_off(ln & 31, half_i * 16), bV = vx_off(wv * 32 + (ln & 31), half_i * 16);
+      const int bOt = vx_off(rT, colT * 2), bQt = kx_off(rT, colT >> 3) + (colT & 7) * 2;
+      const int xl_i = (ln & 31) + 4 * half_i;
       f32x16 s, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) dp[e] = 0.f;
@@ -780,8 +794,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int nq = (a.T + 127) >> 7;
-  const int bid = xcd_remap(blockIdx.x, nq * a.H * a.B);
-  const int qt = bid % nq, h = (bid / nq) % a.H, b = bid / (nq * a.H);
+  int qt, h, b;
+  if (a.causal) {
+    int rank, bh;
+    causal_order(blockIdx.x, a.H * a.B, &rank, &bh);
+    qt = nq - 1 - rank; h = bh % a.H; b = bh / a.H;
+  } else {
+    const int bid = xcd_remap(blockIdx.x, nq * a.H * a.B);
+    qt = bid % nq; h = (bid / nq) % a.H; b = bid / (nq * a.H);
+  }
   const int q0 = qt * 128, qw = q0 + wave * 32;
   const int qi = qw + (lane & 31);
   const bool qvalid = qi < a.T;
@@ -838,9 +859,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       const int r = (tid >> 3) + 32 * i, c = tid & 7, j = j0 + r;
       rk[i] = make_uint4(0, 0, 0, 0); rk[2 + i] = make_uint4(0, 0, 0, 0); rv[i] = make_uint4(0, 0, 0, 0);
       if (j < a.S) {
-        rk[i] = *reinterpret_cast<const uint4*>(kb_ + (long long)j * a.ldk + c * 8);
-        if (HAS_POS) rk[2 + i] = *reinterpret_cast<const uint4*>(pkb_ + (long long)j * a.ldpk + c * 8);
-        rv[i] = *reinterpret_cast<const uint4*>(vb_ + (long long)j * a.ldv + c * 8);
+        // wave-uniform base + 32-bit lane offset (saddr addressing): no per-lane 64-bit pointers kept across the loop
+        rk[i] = *reinterpret_cast<const uint4*>(kb_ + (unsigned)(j * a.ldk + c * 8));
+        if (HAS_POS) rk[2 + i] = *reinterpret_cast<const uint4*>(pkb_ + (unsigned)(j * a.ldpk + c * 8));
+        rv[i] = *reinterpret_cast<const uint4*>(vb_ + (unsigned)(j * a.ldv + c * 8));
       }
     }
   };
@@ -875,6 +897,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const bool tile_grid = j0 < Pk;
     const bool skip = a.causal && tile_grid && (j0 > qw + 31 || qw >= a.P);
     if (!skip) {
+      // per-lane LDS offsets re-derived per tile from a re-materialised lane id (see the dK/dV kernel): K rows
+      // (bK ^ (ks << 5)) + kb * 8192, V rows (bV ^ (ks << 5)) + kb * 4096, K^T ((bKt ^ (cb << 6)) + (kb * 32 + s2 * 16) * 256)
+      // with the second row group at (+ 2048) ^ 32
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int half_i = ln >> 5, colT = ((ln >> 4) & 1) * 16 + (ln & 3) * 4, rT = 4 * half_i + ((ln & 15) >> 2);
+      const int bK = kx_off(ln & 31, half_i), bV = vx_off(ln & 31, half_i * 16);
+      const int bKt = kx_off(rT, colT >> 3) + (colT & 7) * 2;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const bool wave_grid = __builtin_amdgcn_readfirstlane(qw) + 31 < a.P;
@@ -895,12 +925,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-          bf16x8 kf = lds_read_b128(sKb(cur) + kx_off(kb * 32 + (lane & 31), ks * 2 + half));
+          bf16x8 kf = lds_read_b128(sKb(cur) + ((bK ^ (ks << 5)) + kb * 8192));
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          bf16x8 vfr = lds_read_b128(sVb(cur) + vx_off(kb * 32 + (lane & 31), (ks * 2 + half) * 16));
+          bf16x8 vfr = lds_read_b128(sVb(cur) + ((bV ^ (ks << 5)) + kb * 4096));
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, dof[ks], dp, 0, 0, 0);
         }
         bf16x8 dsf[2];
@@ -988,13 +1018,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const int r0 = kb * 32 + 16 * s2 + 4 * half + (i16 >> 2);
 #pragma unroll
           for (int cb = 0; cb < NKS / 2; ++cb) {
-            const int col = cb * 32 + g16 * 16 + (i16 & 3) * 4;
+            const int o0 = (bKt ^ (cb << 6)) + (kb * 32 + s2 * 16) * 256;
             U64 x, y;
-            x.s = lds_read_tr(sKb(cur) + kx_off(r0, col >> 3) + (col & 7) * 2);
-            y.s = lds_read_tr(sKb(cur) + kx_off(r0 + 8, col >> 3) + (col & 7) * 2);
+            x.s = lds_read_tr(sKb(cur) + o0);
+            y.s = lds_read_tr(sKb(cur) + ((o0 + 2048) ^ 32));
             U128 f; f.w[0] = x.w[0]; f.w[1] = x.w[1]; f.w[2] = y.w[0]; f.w[3] = y.w[1];
             dq[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b, dsf[s2], dq[cb], 0, 0, 0);
           }

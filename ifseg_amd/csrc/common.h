@@ -35,10 +35,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 // two floats -> packed bf16x2 (RNE) in one VALU op (gfx950 v_cvt_pk_bf16_f32)
+// (as a native conversion, not inline asm: the compiler's wait-count pass does not protect an inline-asm DESTINATION
+// against a still-pending ds_read into the same VGPR -- the late LDS data then overwrote freshly packed P values)
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  typedef __attribute__((__vector_size__(2 * sizeof(float)))) float f32x2_t;
+  typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2_t;
+  const f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
 }
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
@@ -117,13 +120,16 @@ __device__ __forceinline__ void lds_dma16_g(const void* gsrc, unsigned lds_base)
 __device__ __forceinline__ void lds_dma4_g(const void* gsrc, unsigned lds_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
 }
+// (s_nop 4: the instruction reads SGPRs -- its base / resource descriptor -- that the compiler may have just reloaded from
+// a spill lane with v_readlane; "VALU writes SGPR -> VMEM reads it" needs 5 wait states on gfx9 and the hazard
+// recognizer cannot see into inline asm.  Observed as garbage dO tiles once the dK/dV kernel spilled a base.)
 // the same with a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit per-lane pointers live
 __device__ __forceinline__ void lds_dma16_gs(const void* sbase, int voff_bytes, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1"
                :: "v"(voff_bytes), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
 }
 __device__ __forceinline__ void lds_dma4_gs(const void* sbase, int voff_bytes, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1"
                :: "v"(voff_bytes), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
 }
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -141,6 +147,19 @@ __device__ __forceinline__ float warp_max(float v) {
 
 // bijective XCD-aware remap of a linear block id: XCD x (= id % 8 as observed)
 // gets one contiguous chunk of the tile space so neighbours share L2 panels.
+// Causal attention: workgroups differ in length (a tile sees only part of the other sequence).  Launch order = tile index
+// slowest (longest first when the caller maps rank 0 to its heaviest tile), (batch, head) fastest, and every (batch, head)
+// stays on one XCD when their number divides by 8: -> (rank of the tile, batch*head index)
+__device__ __forceinline__ void causal_order(int bid, int nbh, int* rank, int* bh) {
+  if ((nbh & 7) == 0) {
+    const int per = nbh >> 3, xcd = bid & 7, loc = bid >> 3;
+    *rank = loc / per;
+    *bh = xcd * per + loc % per;
+  } else {
+    *rank = bid / nbh;
+    *bh = bid % nbh;
+  }
+}
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   const int q = nblk >> 3, r = nblk & 7;
   const int xcd = bid & 7, loc = bid >> 3;

@@ -90,7 +90,7 @@ __device__ __forceinline__ v4i32 make_rsrc(const void* p, unsigned bytes) {
 // Issued from inline asm so the compiler does not serialise the following ds_reads behind it;
 // completion is counted by hand (s_waitcnt vmcnt(0) before the barrier that publishes the tile).
 __device__ __forceinline__ void lds_dma16(v4i32 rs, unsigned lds_base, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                :: "s"(lds_base), "v"(voff), "s"(rs) : "memory");
 }
 
