@@ -317,6 +317,115 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
   }
 }
 
+// ln_bwd (C <= 1024, one wave per row) with a second output dx2 = drop2(dx as stored in bf16): the pre-LN backward that
+// closes a block of the backward and the fc2-dropout adjoint that opens the next one in one launch (bit-identical to
+// ifseg_ln_bwd followed by ifseg_dropout: the arithmetic of stage 1 is ln_bwd_kernel's, statement for statement).
+__global__ __launch_bounds__(256) void ln_bwd_drop_kernel(
+    const bf16_t* dy, const bf16_t* x, const bf16_t* gamma, const float* mean, const float* rstd, const bf16_t* dx_add,
+    bf16_t* dx, float* dgamma_part, float* dbeta_part, bf16_t* dx2, int rows, int C, RowMap mdy, RowMap mx, RowMap mdx,
+    RowMap madd, RowMap mdx2, DropArgs drop2) {
+  constexpr int NCH = 2;
+  __shared__ float red[4 * (64 * 8 + 8)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  float gam[NCH][8], dg[NCH][8], db[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) unpack8(*reinterpret_cast<const uint4*>(gamma + c * 8), gam[i]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; if (c >= nch) gam[i][e] = 0.f; }
+  }
+  const int row0 = blockIdx.x * 4 + wave, rstep = gridDim.x * 4;
+  uint4 rx[NCH], rd[NCH];
+  auto fetch = [&](int row) {
+    const bf16_t* xp = x + mx.off(row);
+    const bf16_t* dyp = dy + mdy.off(row);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        rx[i] = *reinterpret_cast<const uint4*>(xp + c * 8);
+        rd[i] = *reinterpret_cast<const uint4*>(dyp + c * 8);
+      }
+    }
+  };
+  if (row0 < rows) fetch(row0);
+  for (int row = row0; row < rows; row += rstep) {
+    const float mu = mean[row], rs = rstd[row];
+    float xr[NCH][8], gv[NCH][8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        float d[8];
+        unpack8(rx[i], xr[i]);
+        unpack8(rd[i], d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = xr[i][e];
+          const float xh = (a - mu) * rs;
+          const float g = d[e] * gam[i][e];
+          dg[i][e] += d[e] * xh; db[i][e] += d[e];
+          s1 += g; s2 += g * xh;
+          gv[i][e] = g;
+          xr[i][e] = xh;
+        }
+      }
+    }
+    if (row + rstep < rows) fetch(row + rstep);      // in flight under the reduction and the stores below
+    s1 = warp_sum(s1); s2 = warp_sum(s2);
+    s1 /= C; s2 /= C;
+    bf16_t* dxp = dx + mdx.off(row);
+    bf16_t* dx2p = dx2 + mdx2.off(row);
+    const bf16_t* ap = dx_add ? dx_add + madd.off(row) : nullptr;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = xr[i][e], dact = 1.f;
+          o[e] = rs * (gv[i][e] - s1 - xh * s2) * dact;
+        }
+        if (ap) {
+          float r[8];
+          unpack8(*reinterpret_cast<const uint4*>(ap + c * 8), r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += r[e];
+        }
+        const uint4 pk = pack8(o);
+        *reinterpret_cast<uint4*>(dxp + c * 8) = pk;
+        float d2[8];
+        unpack8(pk, d2);                               // the adjoint sees dx as stored
+        if (drop2.on) drop8(d2, drop2, (long long)row * nch + c, row);
+        *reinterpret_cast<uint4*>(dx2p + c * 8) = pack8(d2);
+      }
+    }
+  }
+  if (!dgamma_part) return;
+  // cross-wave reduction of the four rows' partials (chunk by chunk through LDS)
+  float (*r4)[64 * 8 + 8] = reinterpret_cast<float (*)[64 * 8 + 8]>(red);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r4[wave][lane * 8 + e] = pass ? db[i][e] : dg[i][e];
+      __syncthreads();
+      for (int t = threadIdx.x; t < 512; t += 256) {
+        const int c = (t >> 3) + i * 64;
+        if (c < nch) {
+          const float sum = r4[0][t] + r4[1][t] + r4[2][t] + r4[3][t];
+          (pass ? dbeta_part : dgamma_part)[(long long)blockIdx.x * C + c * 8 + (t & 7)] = sum;
+        }
+      }
+    }
+  }
+}
+
 // out[o][i] (+)= sum_p in[o][p][i]
 template <bool OUT_BF16>
 __global__ void reduce_parts_kernel(const float* in, void* out, int outer, int parts, long long n, int accumulate,
@@ -537,6 +646,32 @@ extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, co
   ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 8.0 : 6.0));
   if (C <= 1024) launch_ln_bwd<2, 1>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd, dr);
   else launch_ln_bwd<2, 4>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd, dr);
+  ifseg_prof_end(IFSEG_K_LN_BWD, s);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                                 const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, void* dx2, int nblocks,
+                                 int rows, int C, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx,
+                                 long long dx_bs, int lddx, long long add_bs, int ldadd, long long dx2_bs, int lddx2,
+                                 const ifseg_drop_args* drop2, void* stream) {
+  (void)hipGetLastError();
+  if (rows <= 0) return 0;
+  if ((C & 7) || C > 1024 || nblocks <= 0) return IFSEG_ERR_BAD_SHAPE;
+  if (!dx2) return IFSEG_ERR_BAD_ARG;
+  if (((lddy | ldx | lddx | lddx2) & 7) || (dx_add && (ldadd & 7))) return IFSEG_ERR_BAD_SHAPE;
+  DropArgs dr{};
+  if (drop2) {
+    if (drop2->p < 0.f || drop2->p >= 1.f || drop2->rows_per_batch <= 0) return IFSEG_ERR_BAD_ARG;
+    dr = DropArgs{1, drop2->p, drop2->seed, drop2->drop_path_scale, drop2->rows_per_batch};
+  }
+  RowMap mdy{rpb, dy_bs, lddy}, mx{rpb, x_bs, ldx}, mdx{rpb, dx_bs, lddx}, madd{rpb, add_bs, ldadd}, mdx2{rpb, dx2_bs, lddx2};
+  hipStream_t s = (hipStream_t)stream;
+  ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 10.0 : 8.0));
+  hipLaunchKernelGGL(ln_bwd_drop_kernel, dim3(nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
+                     (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, dgamma_part, dbeta_part,
+                     (bf16_t*)dx2, rows, C, mdy, mx, mdx, madd, mdx2, dr);
   ifseg_prof_end(IFSEG_K_LN_BWD, s);
   IFSEG_CHECK_LAUNCH();
   return 0;

@@ -33,7 +33,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 4:
+        if _lib.ifseg_abi_version() != 5:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -298,6 +298,25 @@ def ln_fwd_pair(x, gamma, beta, y, mean, rstd, gamma2, beta2, y2, mean2, rstd2, 
 
 
 LN_BWD_BLOCKS = 768   # three resident blocks per CU (146-162 VGPRs): best of a 256..2048 sweep on MI355X
+
+
+def ln_bwd_drop(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx2, dx_add=None, drop2=None):
+    """dx = [dx_add +] LN'(x; gamma)(dy) and dx2 = drop2(dx): the pre-LN backward that closes a block of the backward and the
+    fc2-dropout adjoint that opens the next one in one launch"""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    rpb = x.shape[1] if x.dim() == 3 else 0
+    db_, dl = _map(dy, rpb)
+    xb, xl = _map(x, rpb)
+    ob, ol = _map(dx, rpb)
+    ab, al = _map(dx_add, rpb)
+    o2b, o2l = _map(dx2, rpb)
+    rc = lib().ifseg_ln_bwd_drop(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx_add), _ptr(dx),
+                                 _ptr(dgamma_part), _ptr(dbeta_part), _ptr(dx2), c_int(LN_BWD_BLOCKS), c_int(rows), c_int(C),
+                                 c_int(rpb), c_ll(db_), c_int(dl), c_ll(xb), c_int(xl), c_ll(ob), c_int(ol), c_ll(ab),
+                                 c_int(al), c_ll(o2b), c_int(o2l), _drop_ref(drop2, rpb or rows), _stream())
+    _check(rc, "ln_bwd_drop")
+    return dx, dx2
 
 
 def ln_bwd(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx_add=None, gelu=False, drop=None):

@@ -1012,6 +1012,38 @@ class HipEngine:
                                                accumulate=accumulate))
         return dx
 
+    def _ln_part(self, C, stats_tag):
+        return self.buf("ln_dgbp_%d@%s" % (C, stats_tag) if self.overlap else "ln_dgbp_%d" % C,
+                        (2, hip.LN_BWD_BLOCKS, C), torch.float32)
+
+    def _ln_bwd_fused(self, dy, x, pname, stats_tag, dx, dx_add, nxt):
+        """`_ln_bwd` of a block's pre-LN plus, in the same launch, the fc2-dropout adjoint that opens the NEXT block of the
+        backward (`nxt` from `_next_drop`; None: plain `_ln_bwd`)."""
+        C = x.shape[-1]
+        rows = x.numel() // C
+        if nxt is None or C > 1024:
+            self._ln_bwd(dy, x, pname, stats_tag, dx, dx_add=dx_add)
+            if nxt is not None:          # wide models: two launches
+                p_, seed, dp, rpb = nxt["drop"]
+                hip.dropout(dx, None, nxt["out"], p_, seed, dp, rpb)
+            return dx
+        mu, rs = self._ln_stats(stats_tag, rows)
+        part = self._ln_part(C, stats_tag)
+        hip.ln_bwd_drop(dy, x, self.W(pname + ".weight"), mu, rs, dx, part[0], part[1], nxt["out"], dx_add=dx_add,
+                        drop2=nxt["drop"])
+        self._side_do(lambda: hip.reduce_parts(part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C))
+        return dx
+
+    def _next_drop(self, tg, rows):
+        """descriptor of the fc2 dropout adjoint that opens the FFN block of layer `tg` in the backward (None if inactive)"""
+        s = self.saved[tg + "_ffn"]
+        if not (self.drop_on and s["site"] is not None):
+            return None
+        bt, self._bt = self._bt, tg + "f"
+        out = self.gbuf("g_drop_%d" % rows, (rows, self.cfg.embed_dim))
+        self._bt = bt
+        return dict(kind="drop", out=out, drop=(self.cfg.dropout, self._site_seed(self._site_id(s["site"])), self._dp(*s["site"]), s["rpb"]))
+
     def _bias_grad(self, dy2d, gout, accumulate=False):
         N = dy2d.shape[-1]
         part = self.buf("colsum_%d" % N, (hip.COLSUM_BLOCKS, N), torch.float32)
@@ -1028,8 +1060,9 @@ class HipEngine:
             return hip.linear_dx(dy, wname_or_view, out=dx_out, resid=dx_resid, accumulate=dx_accumulate)
         return None
 
-    def _ffn_bwd(self, tg, p, dx2, rows):
-        """dx2: grad of the block output [rows, C]; returns grad of x1 (block input)"""
+    def _ffn_bwd(self, tg, p, dx2, rows, dbr_pre=None, nxt=None):
+        """dx2: grad of the block output [rows, C]; returns grad of x1 (block input).  dbr_pre: the fc2 dropout adjoint of
+        dx2 if the previous block of the backward already produced it; nxt: see `_ln_bwd_fused`."""
         C, Fd = self.cfg.embed_dim, self.cfg.ffn_dim
         s = self.saved[tg + "_ffn"]
         W, G, buf = self.W, self.G, self.buf
@@ -1037,7 +1070,9 @@ class HipEngine:
         gbuf = self.gbuf
         dz = buf("g_dz_%d" % rows, (rows, Fd))
         dbr = dx2
-        if self.drop_on and s["site"] is not None:      # adjoint of dropout + DropPath on the branch
+        if dbr_pre is not None:
+            dbr = dbr_pre
+        elif self.drop_on and s["site"] is not None:      # adjoint of dropout + DropPath on the branch
             dbr = self._drop(dx2, None, gbuf("g_drop_%d" % rows, (rows, C)), self._site_id(s["site"]), self._dp(*s["site"]), s["rpb"])
         self._linear_bwd(dbr, s["z"], W(p + "fc2.weight"), G(p + "fc2.weight"), G(p + "fc2.bias"), dx_out=dz)
         du = gbuf("g_du_%d" % rows, (rows, Fd))
@@ -1045,7 +1080,7 @@ class HipEngine:
         dxn = buf("g_dxn_%d" % rows, (rows, C))
         self._linear_bwd(du, s["xn"], W(p + "fc1.weight"), G(p + "fc1.weight"), G(p + "fc1.bias"), dx_out=dxn)
         dx1 = gbuf("g_dx1_%d" % rows, (rows, C))
-        self._ln_bwd(dxn, s["x1"].view(rows, C), p + "final_layer_norm", tg + "_fln1", dx1, dx_add=dx2)
+        self._ln_bwd_fused(dxn, s["x1"].view(rows, C), p + "final_layer_norm", tg + "_fln1", dx1, dx2, nxt)
         self._side_flush()
         return dx1
 
@@ -1074,7 +1109,7 @@ class HipEngine:
             else:       # one event pair on the main stream around delta + dK/dV + dQ (bench.py's roofline object)
                 t0 = torch.cuda.Event(enable_timing=True)
                 t0.record()
-        if self.overlap:
+        if self.overlap and not os.environ.get("IFSEG_DQ_SERIAL"):
             # dK/dV and dQ are independent once delta exists; each leaves its last round of workgroups partly
             # empty (864 workgroups on 512 slots), so they run on two streams and fill each other's holes
             hip.attn_bwd(*args, phases=hip.ATTN_BWD_DELTA, **kw)
@@ -1115,7 +1150,9 @@ class HipEngine:
             self._tab_touched[key] = tabname
         return self.ws[key]
 
-    def _self_block_bwd(self, tg, p, attn, ln1, ln2, dx1, B, T, pq, pk, scaling, dpq_acc, dpk_acc, first_pos, rel_grads):
+    def _self_block_bwd(self, tg, p, attn, ln1, ln2, dx1, B, T, pq, pk, scaling, dpq_acc, dpk_acc, first_pos, rel_grads,
+                        da_pre=None, nxt=None):
+        """da_pre: the post-LN backward of dx1 if the previous block of the backward already ran it; nxt: `_ln_bwd_fused`"""
         C = self.cfg.embed_dim
         s = self.saved[tg + "_sa"]
         W, G, buf = self.W, self.G, self.buf
@@ -1123,11 +1160,13 @@ class HipEngine:
         rows = B * T
         self._bt = tg + "s"
         gbuf = self.gbuf
-        da = gbuf("g_da_%d" % rows, (rows, C))
-        drop = None
-        if self.drop_on and s["site"] is not None:       # adjoint of the dropout fused into the forward LN
-            drop = self._dropargs(self._site_id(s["site"]), self._dp(*s["site"]), T)
-        self._ln_bwd(dx1, s["a"], p + ln2, tg + "_ln2", da, drop=drop)
+        da = da_pre
+        if da is None:
+            da = gbuf("g_da_%d" % rows, (rows, C))
+            drop = None
+            if self.drop_on and s["site"] is not None:       # adjoint of the dropout fused into the forward LN
+                drop = self._dropargs(self._site_id(s["site"]), self._dp(*s["site"]), T)
+            self._ln_bwd(dx1, s["a"], p + ln2, tg + "_ln2", da, drop=drop)
         do = buf("g_do_%d" % rows, (B, T, C))
         self._linear_bwd(da, s["o"].view(rows, C), W(a_ + ".out_proj.weight"), G(a_ + ".out_proj.weight"),
                          G(a_ + ".out_proj.bias"), dx_out=do.view(rows, C))
@@ -1141,10 +1180,11 @@ class HipEngine:
                          self._fused(self.g16, a_ + ".q_proj.weight", 3 * C, C),
                          self._fused(self.g16, a_ + ".q_proj.bias", 3 * C), dx_out=dxn)
         dx = gbuf("g_dx0_%d" % rows, (rows, C))
-        self._ln_bwd(dxn, s["x"].view(rows, C), p + ln1, tg + "_ln1", dx, dx_add=dx1)
+        self._ln_bwd_fused(dxn, s["x"].view(rows, C), p + ln1, tg + "_ln1", dx, dx1, nxt)
         return dx                # the caller flushes the side queue together with the layer's hook
 
-    def _cross_block_bwd(self, tg, p, dy2, B, Td, Te, cpq, cpk, scaling, d_enc_out, first_cross, dcpq_acc, dcpk_acc):
+    def _cross_block_bwd(self, tg, p, dy2, B, Td, Te, cpq, cpk, scaling, d_enc_out, first_cross, dcpq_acc, dcpk_acc,
+                         da_pre=None, nxt=None):
         C = self.cfg.embed_dim
         s = self.saved[tg + "_ca"]
         W, G, buf = self.W, self.G, self.buf
@@ -1152,11 +1192,13 @@ class HipEngine:
         rows = B * Td
         self._bt = tg + "c"
         gbuf = self.gbuf
-        da = gbuf("g_da_%d" % rows, (rows, C))
-        drop = None
-        if self.drop_on and s["site"] is not None:
-            drop = self._dropargs(self._site_id(s["site"]), self._dp(*s["site"]), Td)
-        self._ln_bwd(dy2, s["a"], p + "cross_attn_ln", tg + "_cln2", da, drop=drop)
+        da = da_pre
+        if da is None:
+            da = gbuf("g_da_%d" % rows, (rows, C))
+            drop = None
+            if self.drop_on and s["site"] is not None:
+                drop = self._dropargs(self._site_id(s["site"]), self._dp(*s["site"]), Td)
+            self._ln_bwd(dy2, s["a"], p + "cross_attn_ln", tg + "_cln2", da, drop=drop)
         do = buf("g_do_%d" % rows, (B, Td, C))
         self._linear_bwd(da, s["o"].view(rows, C), W(a_ + ".out_proj.weight"), G(a_ + ".out_proj.weight"),
                          G(a_ + ".out_proj.bias"), dx_out=do.view(rows, C))
@@ -1178,7 +1220,7 @@ class HipEngine:
             self._fused(self.g16, a_ + ".k_proj.weight", 2 * C, C), self._fused(self.g16, a_ + ".k_proj.bias", 2 * C),
             dx_out=d_enc_out.view(B * Te, C), dx_accumulate=not first_cross))
         dy1 = gbuf("g_dy1c_%d" % rows, (rows, C))
-        self._ln_bwd(dyn, s["x"].view(rows, C), p + "encoder_attn_layer_norm", tg + "_cln1", dy1, dx_add=dy2)
+        self._ln_bwd_fused(dyn, s["x"].view(rows, C), p + "encoder_attn_layer_norm", tg + "_cln1", dy1, dy2, nxt)
         self._side_flush()
         return dy1
 
@@ -1208,16 +1250,21 @@ class HipEngine:
         d_enc_out = buf("g_d_enc_out", (B, T, C))
         dspq, dspk = buf("g_dspq", (Td, C), torch.float32), buf("g_dspk", (Td, C), torch.float32)
         dcpq, dcpk = buf("g_dcpq", (Td, C), torch.float32), buf("g_dcpk", (T, C), torch.float32)
+        fuse = os.environ.get("IFSEG_NO_LN_BWD_DROP") is None
+        dbr = None
         for l in reversed(range(cfg.dec_layers)):
             p = "%slayers.%d." % (d, l)
             tg = "d%d" % l
             first = l == cfg.dec_layers - 1
-            dy = self._ffn_bwd(tg, p, dy, B * Td)
+            # the self block's closing pre-LN backward also produces the fc2-dropout adjoint that opens layer l-1's FFN block
+            nx_f = self._next_drop("d%d" % (l - 1), B * Td) if fuse and l > 0 else None
+            dy = self._ffn_bwd(tg, p, dy, B * Td, dbr_pre=dbr)
             dy = self._cross_block_bwd(tg, p, dy, B, Td, T, ctx["d_cpq"], ctx["d_cpk"], scaling, d_enc_out, first, dcpq, dcpk)
             tabn = "%sseg_rel_pos_table_list.%d.weight" % (d, l)
             dy = self._self_block_bwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", dy, B, Td,
                                       ctx["d_spq"], ctx["d_spk"], scaling, dspq, dspk, first,
-                                      [(tabn, g["dec_idx2d"]), (tabn, g["dec_idx1d"]), (tabn, g["dec_idxx"])])
+                                      [(tabn, g["dec_idx2d"]), (tabn, g["dec_idx1d"]), (tabn, g["dec_idxx"])], nxt=nx_f)
+            dbr = nx_f["out"] if nx_f else None
             self._side_do(lambda p=p: (self._flush_tables(), self._notify(p)))   # final in side-stream order
             self._side_flush()
         # ---- decoder embedding LN (input = [enc_out[:, :P] | embed(bos)])
@@ -1262,16 +1309,19 @@ class HipEngine:
         dx = buf("g_dx_enc", (B * T, C))
         self._ln_bwd(d_enc_out.view(B * T, C), ctx["e_x_final"].view(B * T, C), e + "layer_norm", "e_final_ln", dx)
         depq, depk = buf("g_depq", (T, C), torch.float32), buf("g_depk", (T, C), torch.float32)
+        dbr = None
         for l in reversed(range(cfg.enc_layers)):
             p = "%slayers.%d." % (e, l)
             tg = "e%d" % l
             first = l == cfg.enc_layers - 1
-            dx = self._ffn_bwd(tg, p, dx, B * T)
+            nx_f = self._next_drop("e%d" % (l - 1), B * T) if fuse and l > 0 else None
+            dx = self._ffn_bwd(tg, p, dx, B * T, dbr_pre=dbr)
             dx = self._self_block_bwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", dx, B, T, ctx["e_pq"],
                                       ctx["e_pk"], scaling, depq, depk, first,
                                       [("%simage_rel_pos_table_list.%d.weight" % (e, l), g["enc_idx2d"]),
                                        ("%stoken_rel_pos_table_list.%d.weight" % (e, l), g["enc_idx1d"]),
-                                       (None, None)])
+                                       (None, None)], nxt=nx_f)
+            dbr = nx_f["out"] if nx_f else None
             self._side_do(lambda p=p: (self._flush_tables(), self._notify(p)))
             self._side_flush()
         # ---- encoder abs-pos operands

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 4
+#define IFSEG_ABI_VERSION 5
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -168,6 +168,13 @@ int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, const float* 
                  const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, int nblocks, int rows,
                  int C, int act_gelu, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx,
                  long long dx_bs, int lddx, long long add_bs, int ldadd, const ifseg_drop_args* drop, void* stream);
+/* ifseg_ln_bwd (C <= 1024, no GELU) with a second output dx2 = drop2(dx as stored in bf16): the pre-LN backward that
+ * closes a block of the backward and the adjoint of the dropout + DropPath after fc2 (unify_transformer_layer.py:288-292,
+ * 564-568) that opens the next one, in one launch.  Bit-identical to ifseg_ln_bwd followed by ifseg_dropout. */
+int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                      const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, void* dx2, int nblocks, int rows,
+                      int C, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx, long long dx_bs, int lddx,
+                      long long add_bs, int ldadd, long long dx2_bs, int lddx2, const ifseg_drop_args* drop2, void* stream);
 /* out[o][i] (+)= scale * sum_p in[o][p][i]   (fp32 in; fp32 or bf16 out) */
 int ifseg_reduce_parts(const float* in, void* out, int outer, int parts, long long n, int accumulate,
                        int out_bf16, float scale, void* stream);

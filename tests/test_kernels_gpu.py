@@ -613,3 +613,28 @@ def test_ln_fwd_pair_identity_first_stage_equals_dropout_then_ln():
     hip.ln_fwd_pair(a, None, None, y, None, None, g2, b2, y2, n2, s2, resid=res, drop=(p, seed, dp, T))
     assert torch.equal(y, y_ref) and torch.equal(y2, y2_ref)
     assert torch.equal(n2, m2) and torch.equal(s2, r2)
+
+
+def test_ln_bwd_drop_is_bit_identical_to_two_calls():
+    """ifseg_ln_bwd_drop: pre-LN backward of a block + the fc2 dropout adjoint of the block before it in one launch."""
+    from ifseg_amd import hip
+    dev = _dev()
+    B, T, C, p, seed = 3, 257, 768, 0.1, 999
+    rows = B * T
+    dy, x, add = (_rand((rows, C), dev, 120 + i) for i in range(3))
+    g1 = _rand((C,), dev, 125, 0.2) + 1
+    dp = torch.tensor([1 / 0.9, 0.0, 1 / 0.9], device=dev)
+    m1 = torch.rand(rows, device=dev) - 0.5
+    r1 = torch.rand(rows, device=dev) + 0.5
+    nb = hip.LN_BWD_BLOCKS
+    parts = lambda: (torch.zeros(nb, C, device=dev), torch.zeros(nb, C, device=dev))
+    dx_ref, dx2_ref = torch.empty_like(dy), torch.empty_like(dy)
+    pg1, pb1 = parts()
+    hip.ln_bwd(dy, x, g1, m1, r1, dx_ref, pg1, pb1, dx_add=add)
+    hip.dropout(dx_ref, None, dx2_ref, p, seed, dp, T)
+    dx, dx2 = torch.empty_like(dy), torch.empty_like(dy)
+    qg1, qb1 = parts()
+    hip.ln_bwd_drop(dy, x, g1, m1, r1, dx, qg1, qb1, dx2, dx_add=add, drop2=(p, seed, dp, T))
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref) and torch.equal(dx2, dx2_ref)
+    assert torch.equal(qg1, pg1) and torch.equal(qb1, pb1)
