@@ -39,6 +39,9 @@ struct GemmArgs {
   long long sA, sB, sC, sR;
   int splitk, kchunk; long long sCsplit;
   unsigned nrecA, nrecB;   // bytes addressable through the A / B buffer descriptors (per batch)
+  // optional row-dot epilogue (attention backward's delta): dot_out[(m / dot_T) * (N/64) + n/64][m % dot_T] =
+  // sum over the 64 columns of head n/64 of C[m][n] (as stored in bf16) * dot[m][n]
+  const bf16_t* dot; int ldd; float* dot_out; int dot_T;
 };
 
 // ---- LDS tile images -------------------------------------------------------
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + wm * 64 + i * 32 + (lane & 31);
     if (m >= g.M) continue;
+    float dsum = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
 #pragma unroll
@@ -339,9 +343,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
             uint2 pw = *reinterpret_cast<const uint2*>(cp);
             v[0] += bflo(pw.x); v[1] += bfhi(pw.x); v[2] += bflo(pw.y); v[3] += bfhi(pw.y);
           }
-          *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          const uint2 ow = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          *reinterpret_cast<uint2*>(cp) = ow;
+          if (g.dot) {
+            const uint2 dw = *reinterpret_cast<const uint2*>(g.dot + (long long)m * g.ldd + n);
+            dsum += bflo(ow.x) * bflo(dw.x) + bfhi(ow.x) * bfhi(dw.x) + bflo(ow.y) * bflo(dw.y) + bfhi(ow.y) * bfhi(dw.y);
+          }
         }
       }
+    }
+    if (g.dot) {
+      // the wave's 64 columns are one head; lanes l and l + 32 hold the two interleaved halves of row m
+      dsum += __shfl_xor(dsum, 32);
+      const int hd = (n0 + wn * (BN / 2)) >> 6;
+      if (lane < 32 && (hd << 6) < g.N)
+        g.dot_out[((long long)(m / g.dot_T) * (g.N >> 6) + hd) * g.dot_T + (m % g.dot_T)] = dsum;
     }
   }
 }
@@ -352,10 +368,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 
 }  // namespace
 
-extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C, int M, int N, int K,
-                               int lda, int ldb, int ldc, const void* bias, float alpha, int alpha_ncols,
-                               const void* resid, int ldr, int flags, int batch, long long strideA,
-                               long long strideB, long long strideC, long long strideR, int splitk, void* stream) {
+static int gemm_impl(int layout, const void* A, const void* B, void* C, int M, int N, int K,
+                     int lda, int ldb, int ldc, const void* bias, float alpha, int alpha_ncols,
+                     const void* resid, int ldr, int flags, int batch, long long strideA,
+                     long long strideB, long long strideC, long long strideR, int splitk, void* stream,
+                     const void* dot, int ldd, float* dot_out, int dot_T) {
   (void)hipGetLastError();
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if ((N & 7) || (lda & 7) || (ldb & 7) || (ldc & 3) || (resid && (ldr & 3))) return IFSEG_ERR_BAD_SHAPE;
@@ -368,6 +385,13 @@ extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C
   g.bias = (const bf16_t*)bias; g.resid = (const bf16_t*)resid; g.ldr = ldr;
   g.alpha = alpha; g.alpha_ncols = (alpha == 1.0f) ? 0 : (alpha_ncols < 0 ? N : alpha_ncols);
   g.flags = flags; g.sA = strideA; g.sB = strideB; g.sC = strideC; g.sR = strideR;
+  if (dot) {
+    // plain bf16 output, 128-wide tiles (a wave = 64 columns = one head), one batch
+    if (layout != IFSEG_GEMM_NN || (N & 63) || (ldd & 3) || !dot_out || dot_T <= 0 || batch > 1 || splitk > 1 ||
+        (flags & (IFSEG_GEMM_OUT_F32 | IFSEG_GEMM_COLSUM)))
+      return IFSEG_ERR_BAD_ARG;
+    g.dot = (const bf16_t*)dot; g.ldd = ldd; g.dot_out = dot_out; g.dot_T = dot_T;
+  }
   g.splitk = 1;
   if (splitk > 1) {
     // C must be an fp32 workspace [splitk][M][ldc]; epilogue extras are not applied to partial sums
@@ -417,6 +441,20 @@ extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C
   ifseg_prof_end(IFSEG_K_GEMM_NT + layout, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C, int M, int N, int K,
+                               int lda, int ldb, int ldc, const void* bias, float alpha, int alpha_ncols,
+                               const void* resid, int ldr, int flags, int batch, long long strideA,
+                               long long strideB, long long strideC, long long strideR, int splitk, void* stream) {
+  return gemm_impl(layout, A, B, C, M, N, K, lda, ldb, ldc, bias, alpha, alpha_ncols, resid, ldr, flags, batch, strideA,
+                   strideB, strideC, strideR, splitk, stream, nullptr, 0, nullptr, 0);
+}
+
+extern "C" int ifseg_gemm_nn_rowdot(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                    const void* dot, int ldd, float* dot_out, int rows_per_batch, void* stream) {
+  return gemm_impl(IFSEG_GEMM_NN, A, B, C, M, N, K, lda, ldb, ldc, nullptr, 1.f, 0, nullptr, 0, 0, 1, 0, 0, 0, 0, 1, stream,
+                   dot, ldd, dot_out, rows_per_batch);
 }
 
 // Implicit-GEMM convolution on an NHWC bf16 image with folded FrozenBN:

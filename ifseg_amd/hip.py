@@ -33,7 +33,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 5:
+        if _lib.ifseg_abi_version() != 6:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -102,6 +102,17 @@ def linear_dx(dy, w, out=None, resid=None, accumulate=False):
         out = torch.empty(M, K, dtype=torch.bfloat16, device=dy.device)
     gemm(GEMM_NN, _bf(dy), _bf(w), out, M, K, N, dy.stride(0), w.stride(0), out.stride(0), None, 1.0, -1, resid,
          resid.stride(0) if resid is not None else 0, GEMM_ACCUMULATE if accumulate else 0)
+    return out
+
+
+def linear_dx_rowdot(dy, w, out, dot, dot_out, rows_per_batch):
+    """dx[M,K] = dy[M,N] @ w[N,K] and dot_out[b, h, t] = sum_c dx[b*T+t, 64h+c] * dot[b*T+t, 64h+c] (attention delta)"""
+    M, N = dy.shape
+    K = w.shape[1]
+    rc = lib().ifseg_gemm_nn_rowdot(_ptr(_bf(dy)), _ptr(_bf(w)), _ptr(out), c_int(M), c_int(K), c_int(N), c_int(dy.stride(0)),
+                                    c_int(w.stride(0)), c_int(out.stride(0)), _ptr(dot), c_int(dot.stride(0)), _ptr(dot_out),
+                                    c_int(rows_per_batch), _stream())
+    _check(rc, "gemm_nn_rowdot")
     return out
 
 

@@ -64,6 +64,7 @@ class HipEngine:
         # backward: everything that only produces PARAMETER gradients (dW GEMMs, bias / LayerNorm / table
         # reductions) is enqueued on a second HIP stream and overlaps the dX chain on the main stream
         self.overlap = os.environ.get("IFSEG_NO_OVERLAP") is None
+        self.delta_fused = os.environ.get("IFSEG_NO_DELTA_FUSE") is None     # delta from the out_proj dX GEMM's epilogue
         self._side = None
         self._trunk_stream, self._pf, self._pf_slot = None, None, 0
         self._pf_request = None          # images of the next batch (set by the trainer; consumed by the next forward)
@@ -1084,13 +1085,31 @@ class HipEngine:
         self._side_flush()
         return dx1
 
+    def _out_proj_bwd(self, da, o, a_, do, B, T):
+        """dO = da . W_out (+ dW, db on the side stream) and delta = rowsum(dO * O) per head from the same GEMM epilogue
+        -> delta [B, H, T] fp32 (None: the attention backward computes it in its own launch)"""
+        C, H = self.cfg.embed_dim, self.cfg.heads
+        rows = B * T
+        W, G = self.W, self.G
+        if not self.delta_fused:
+            self._linear_bwd(da, o.view(rows, C), W(a_ + ".out_proj.weight"), G(a_ + ".out_proj.weight"),
+                             G(a_ + ".out_proj.bias"), dx_out=do.view(rows, C))
+            return None
+        self._linear_bwd(da, o.view(rows, C), W(a_ + ".out_proj.weight"), G(a_ + ".out_proj.weight"),
+                         G(a_ + ".out_proj.bias"), need_dx=False)
+        delta = self.gbuf("g_delta_%d" % T, (B, H, T), torch.float32)
+        hip.linear_dx_rowdot(da, W(a_ + ".out_proj.weight"), do.view(rows, C), o.view(rows, C), delta, T)
+        return delta
+
     def _attn_core_bwd(self, tag, q, k, v, pq, pk, o, lse, do, dq, dk, dv, B, T, S, rel, causal, gain, gain_name,
-                       scaling, dpq_acc, dpk_acc, first_pos, rel_grads):
+                       scaling, dpq_acc, dpk_acc, first_pos, rel_grads, delta=None):
         cfg = self.cfg
         C, H = cfg.embed_dim, cfg.heads
         buf = self.buf
         gbuf = self.gbuf
-        delta = gbuf("g_delta_%d" % T, (B, H, T), torch.float32)
+        have_delta = delta is not None
+        if not have_delta:
+            delta = gbuf("g_delta_%d" % T, (B, H, T), torch.float32)
         dpq_part = gbuf("g_dpq_part_%d" % T, (B, T, C), torch.float32)
         dpk_part = gbuf("g_dpk_part_%d" % S, (B, S, C), torch.float32)
         nparts = B * ((S + 127) // 128)
@@ -1112,7 +1131,8 @@ class HipEngine:
         if self.overlap and not os.environ.get("IFSEG_DQ_SERIAL"):
             # dK/dV and dQ are independent once delta exists; each leaves its last round of workgroups partly
             # empty (864 workgroups on 512 slots), so they run on two streams and fill each other's holes
-            hip.attn_bwd(*args, phases=hip.ATTN_BWD_DELTA, **kw)
+            if not have_delta:
+                hip.attn_bwd(*args, phases=hip.ATTN_BWD_DELTA, **kw)
             with self._fork(self._dq_stream_get()):
                 hip.attn_bwd(*args, phases=hip.ATTN_BWD_DQ, **kw)
                 dq_done = self._ev()
@@ -1120,7 +1140,7 @@ class HipEngine:
             hip.attn_bwd(*args, phases=hip.ATTN_BWD_DKV, **kw)
             torch.cuda.current_stream().wait_event(dq_done)
         else:
-            hip.attn_bwd(*args, **kw)
+            hip.attn_bwd(*args, phases=(hip.ATTN_BWD_DKV | hip.ATTN_BWD_DQ) if have_delta else 0, **kw)
         if timing is not None:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record()
@@ -1168,13 +1188,12 @@ class HipEngine:
                 drop = self._dropargs(self._site_id(s["site"]), self._dp(*s["site"]), T)
             self._ln_bwd(dx1, s["a"], p + ln2, tg + "_ln2", da, drop=drop)
         do = buf("g_do_%d" % rows, (B, T, C))
-        self._linear_bwd(da, s["o"].view(rows, C), W(a_ + ".out_proj.weight"), G(a_ + ".out_proj.weight"),
-                         G(a_ + ".out_proj.bias"), dx_out=do.view(rows, C))
+        delta = self._out_proj_bwd(da, s["o"], a_, do, B, T)
         dqkv = gbuf("g_dqkv_%d" % rows, (B, T, 3 * C))
         qkv = s["qkv"]
         self._attn_core_bwd(tg, qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], pq, pk, s["o"], s["lse"], do,
                             dqkv[:, :, :C], dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:], B, T, T, s["rel"], s["causal"],
-                            s["gain"], a_ + ".c_attn", scaling, dpq_acc, dpk_acc, first_pos, rel_grads)
+                            s["gain"], a_ + ".c_attn", scaling, dpq_acc, dpk_acc, first_pos, rel_grads, delta=delta)
         dxn = buf("g_dxn_%d" % rows, (rows, C))
         self._linear_bwd(dqkv.view(rows, 3 * C), s["xn"], self._fused(self.p16, a_ + ".q_proj.weight", 3 * C, C),
                          self._fused(self.g16, a_ + ".q_proj.weight", 3 * C, C),
@@ -1200,14 +1219,13 @@ class HipEngine:
                 drop = self._dropargs(self._site_id(s["site"]), self._dp(*s["site"]), Td)
             self._ln_bwd(dy2, s["a"], p + "cross_attn_ln", tg + "_cln2", da, drop=drop)
         do = buf("g_do_%d" % rows, (B, Td, C))
-        self._linear_bwd(da, s["o"].view(rows, C), W(a_ + ".out_proj.weight"), G(a_ + ".out_proj.weight"),
-                         G(a_ + ".out_proj.bias"), dx_out=do.view(rows, C))
+        delta = self._out_proj_bwd(da, s["o"], a_, do, B, Td)
         dq = gbuf("g_cdq", (B, Td, C))
         dkv = gbuf("g_cdkv", (B, Te, 2 * C))
         kv = s["kv"]
         self._attn_core_bwd(tg + "c", s["q"], kv[:, :, :C], kv[:, :, C:], cpq, cpk, s["o"], s["lse"], do, dq,
                             dkv[:, :, :C], dkv[:, :, C:], B, Td, Te, None, False, s["gain"], a_ + ".c_attn", scaling,
-                            dcpq_acc, dcpk_acc, first_cross, None)
+                            dcpq_acc, dcpk_acc, first_cross, None, delta=delta)
         dyn = buf("g_dxn_%d" % rows, (rows, C))
         self._linear_bwd(dq.view(rows, C), s["xn"], W(a_ + ".q_proj.weight"), G(a_ + ".q_proj.weight"),
                          G(a_ + ".q_proj.bias"), dx_out=dyn)

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 5
+#define IFSEG_ABI_VERSION 6
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -54,6 +54,12 @@ int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C, int M, in
                     int ldb, int ldc, const void* bias, float alpha, int alpha_ncols,
                     const void* resid, int ldr, int flags, int batch, long long strideA,
                     long long strideB, long long strideC, long long strideR, int splitk, void* stream);
+/* C[M,N] = A[M,K] . B[K,N] (NN, bf16 out) and, from the same epilogue, the per-head row dots with a second operand:
+ *   dot_out[(m / rows_per_batch) * (N/64) + h][m % rows_per_batch] = sum_{c<64} C[m][64h+c] (as stored) * dot[m][64h+c]
+ * i.e. the attention backward's delta = rowsum(dO * O) ([B,H,T] fp32) while dO = d(attn_ln input) . W_out is produced
+ * (unify_multihead_attention.py:503-513 backward); N % 64 == 0.  Replaces phase 1 of ifseg_attn_bwd. */
+int ifseg_gemm_nn_rowdot(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                         const void* dot, int ldd, float* dot_out, int rows_per_batch, void* stream);
 
 /* Implicit-GEMM conv on NHWC bf16 with folded FrozenBatchNorm (+residual, +ReLU).
  * `w` is [Cout][KH][KW][Cin] with the BN scale already folded in, `shift` the

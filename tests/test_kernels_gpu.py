@@ -638,3 +638,28 @@ def test_ln_bwd_drop_is_bit_identical_to_two_calls():
     torch.cuda.synchronize()
     assert torch.equal(dx, dx_ref) and torch.equal(dx2, dx2_ref)
     assert torch.equal(qg1, pg1) and torch.equal(qb1, pb1)
+
+
+def test_gemm_nn_rowdot_delta_epilogue():
+    """ifseg_gemm_nn_rowdot: dO = da @ W and delta[b,h,t] = sum_c dO[b,t,64h+c] * O[b,t,64h+c] from the same epilogue."""
+    from ifseg_amd import hip
+    dev = _dev()
+    B, T, H = 3, 257, 12
+    C, M = H * 64, B * T
+    da, w, o = _rand((M, C), dev, 130), _rand((C, C), dev, 131, 0.05), _rand((M, C), dev, 132)
+    ref = hip.linear_dx(da, w)
+    out = torch.empty_like(ref)
+    delta = torch.full((B, H, T), 7.0, device=dev)
+    hip.linear_dx_rowdot(da, w, out, o, delta, T)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)                                   # the GEMM itself is unchanged
+    want = (ref.float().view(B, T, H, 64) * o.float().view(B, T, H, 64)).sum(-1).permute(0, 2, 1)
+    assert (delta - want).abs().max().item() < 1e-3 * want.abs().max().item()
+    # and it is what the attention backward's own delta phase computes
+    d2 = torch.zeros(B, H, T, device=dev)
+    z = torch.zeros(B, T, C, dtype=torch.bfloat16, device=dev)
+    lse = torch.zeros(B, H, T, device=dev)
+    hip.attn_bwd(z, z, z, None, None, o.view(B, T, C), ref.view(B, T, C), lse, d2, z.clone(), z.clone(), z.clone(), None, None,
+                 B, H, T, T, phases=hip.ATTN_BWD_DELTA)
+    torch.cuda.synchronize()
+    assert (delta - d2).abs().max().item() < 1e-4 * want.abs().max().item()
