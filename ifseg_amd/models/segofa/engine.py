@@ -63,6 +63,7 @@ class HipEngine:
         self.step_seed = 0               # set by the trainer (seed + num_updates, trainer.py:1297)
         # backward: everything that only produces PARAMETER gradients (dW GEMMs, bias / LayerNorm / table
         # reductions) is enqueued on a second HIP stream and overlaps the dX chain on the main stream
+        self._pending_checks, self._checked_once = [], False
         self.overlap = os.environ.get("IFSEG_NO_OVERLAP") is None
         self.delta_fused = os.environ.get("IFSEG_NO_DELTA_FUSE") is None     # delta from the out_proj dX GEMM's epilogue
         self._side = None
@@ -587,6 +588,43 @@ class HipEngine:
             self._gctx = None
             hip.set_stream(prev)
 
+    def deferred_check(self, tensor, bad, message):
+        """Input validation without a device sync: `bad(tensor)` (a 0-d bool tensor) is evaluated on the stream and read
+        back once its event has completed -- at the latest by the next call, i.e. the error surfaces one step late instead
+        of draining the queue on every step (each batch is a new tensor, so a cache keyed on the tensor never hits with a
+        real data iterator).  The first call of a process checks synchronously."""
+        if torch.cuda.is_current_stream_capturing():
+            return                                 # a captured forward replays validated inputs (checked at warm-up)
+        if os.environ.get("IFSEG_SYNC_CHECKS"):
+            if bool(bad(tensor)):
+                raise NotImplementedError(message)
+            return
+        pend = self._pending_checks
+        keep = []
+        for flag, ev, msg in pend:
+            if ev.query():
+                if bool(flag):
+                    self._pending_checks = []
+                    raise NotImplementedError(msg)
+            else:
+                keep.append((flag, ev, msg))
+        if len(keep) > 8:                      # never let the list grow: settle the oldest
+            flag, ev, msg = keep.pop(0)
+            ev.synchronize()
+            if bool(flag):
+                self._pending_checks = []
+                raise NotImplementedError(msg)
+        flag = bad(tensor)
+        if not self._checked_once:
+            self._checked_once = True
+            if bool(flag):
+                raise NotImplementedError(message)
+        else:
+            ev = torch.cuda.Event()
+            ev.record()
+            keep.append((flag, ev, message))
+        self._pending_checks = keep
+
     def _forward(self, src_tokens, patch_images, prev_output_tokens=None, full_context_alignment=False,
                  need_grad=True, bag=None):
         """bag = (ids int64 [B, maxlen], ends int64 [B*P]): the image-free entry (encode_with_artificial_image,
@@ -597,12 +635,9 @@ class HipEngine:
         dev = src_tokens.device if bag is not None else patch_images.device
         if not self.packed or self.device != dev:
             self.pack(dev)
-        key = (src_tokens.data_ptr(), src_tokens._version, tuple(src_tokens.shape))
-        if getattr(self, "_checked_src", None) != key:
-            self._checked_src = key if not bool(src_tokens.eq(1).any()) else None
-        if self._checked_src is None:
-            raise NotImplementedError("ifseg_amd HIP engine: padded source tokens are not supported "
-                                      "(every IFSeg sample carries the same unpadded prompt)")
+        self.deferred_check(src_tokens, lambda t: t.eq(1).any(),
+                            "ifseg_amd HIP engine: padded source tokens are not supported "
+                            "(every IFSeg sample carries the same unpadded prompt)")
         B, L = src_tokens.shape
         C, Fd, H = cfg.embed_dim, cfg.ffn_dim, cfg.heads
         scaling = float(cfg.head_dim * cfg.attn_scale_factor) ** -0.5
@@ -1233,10 +1268,20 @@ class HipEngine:
         enc2d = self.ctx["enc_out"].view(B * Te, C)
         # the K|V projections read the encoder output: their dX accumulates into d_enc_out, which nothing needs before
         # the encoder backward starts -- the whole linear backward (dW, db, dX) goes to the side stream, in layer order
-        self._side_do(lambda: self._linear_bwd(
-            dkv.view(B * Te, 2 * C), enc2d, self._fused(self.p16, a_ + ".k_proj.weight", 2 * C, C),
-            self._fused(self.g16, a_ + ".k_proj.weight", 2 * C, C), self._fused(self.g16, a_ + ".k_proj.bias", 2 * C),
-            dx_out=d_enc_out.view(B * Te, C), dx_accumulate=not first_cross))
+        wkv = self._fused(self.p16, a_ + ".k_proj.weight", 2 * C, C)
+        if self.overlap:
+            # dW / db with the rest of the weight-gradient work; the dX that accumulates into d_enc_out goes to the dQ
+            # stream (idle between attentions, in layer order): the decoder->encoder hand-over then waits for a stream
+            # that is a few microseconds behind, not for the whole weight-gradient queue
+            self._side_do(lambda: self._linear_bwd(
+                dkv.view(B * Te, 2 * C), enc2d, wkv, self._fused(self.g16, a_ + ".k_proj.weight", 2 * C, C),
+                self._fused(self.g16, a_ + ".k_proj.bias", 2 * C), need_dx=False))
+            with self._fork(self._dq_stream_get()):
+                hip.linear_dx(dkv.view(B * Te, 2 * C), wkv, out=d_enc_out.view(B * Te, C), accumulate=not first_cross)
+        else:
+            self._linear_bwd(dkv.view(B * Te, 2 * C), enc2d, wkv, self._fused(self.g16, a_ + ".k_proj.weight", 2 * C, C),
+                             self._fused(self.g16, a_ + ".k_proj.bias", 2 * C), dx_out=d_enc_out.view(B * Te, C),
+                             dx_accumulate=not first_cross)
         dy1 = gbuf("g_dy1c_%d" % rows, (rows, C))
         self._ln_bwd_fused(dyn, s["x"].view(rows, C), p + "encoder_attn_layer_norm", tg + "_cln1", dy1, dy2, nxt)
         self._side_flush()
@@ -1287,7 +1332,10 @@ class HipEngine:
             self._side_flush()
         # ---- decoder embedding LN (input = [enc_out[:, :P] | embed(bos)])
         self._bt = "dtop"
-        self._join_side()            # the position-operand accumulators below were filled on the side stream
+        if self.overlap and getattr(self, "_dqs", None) is not None:      # d_enc_out was accumulated on the dQ stream
+            ev = self._ev()
+            ev.record(self._dqs)
+            torch.cuda.current_stream().wait_event(ev)
         dy3 = dy.view(B, Td, C)
         enc_out = ctx["enc_out"]
         dyp, dyb = dy3[:, :P], dy3[:, P:]
@@ -1296,32 +1344,11 @@ class HipEngine:
         scratch = buf("g_bos_scratch", (B, 1, C))
         self._ln_bwd(dyb, self.ws["d_bos"], d + "layernorm_embedding", "d_emb_ln_b", scratch, accumulate=True,
                      drop=self._dropargs(4))
-        # ---- decoder position operands
-        dspqk = buf("g_dspqk", (Td, 2 * C))
-        hip.cast_f32_bf16(dspq, buf("g_tmp_tc", (Td, C)))
-        dspqk[:, :C].copy_(self.ws["g_tmp_tc"])
-        hip.cast_f32_bf16(dspk, self.ws["g_tmp_tc"])
-        dspqk[:, C:].copy_(self.ws["g_tmp_tc"])
-        tp = self.ws["d_tp"]
-        dtp = buf("g_dtp", (Td, C))
-        self._linear_bwd(dspqk, tp, self._fused(self.p16, d + "self_pos_q_linear.weight", 2 * C, C),
-                         self._fused(self.g16, d + "self_pos_q_linear.weight", 2 * C, C),
-                         self._fused(self.g16, d + "self_pos_q_linear.bias", 2 * C), dx_out=dtp)
-        dcpq16 = buf("g_dcpq16", (Td, C))
-        hip.cast_f32_bf16(dcpq, dcpq16)
-        self._linear_bwd(dcpq16, tp, W(d + "cross_pos_q_linear.weight"), G(d + "cross_pos_q_linear.weight"),
-                         G(d + "cross_pos_q_linear.bias"), dx_out=dtp, dx_accumulate=True)
-        segG = G(d + "embed_seg_positions.weight")
-        segtab = W(d + "embed_seg_positions.weight")
-        self._ln_bwd(dtp[:P], segtab[1:1 + P], d + "seg_pos_ln", "d_tp_ln_p", segG[1:1 + P])
-        self._ln_bwd(dtp[P:], segtab[:1], d + "seg_pos_ln", "d_tp_ln_b", segG[:1], accumulate=True)
+        # ---- decoder position operands: parameter gradients only, from accumulators the side stream filled -> the whole
+        # section runs there, in order (no join of the main stream at the decoder -> encoder hand-over)
         pos_all = self.ws["e_pos_all"]
-        dcpk16 = buf("g_dcpk16", (T, C))
-        hip.cast_f32_bf16(dcpk, dcpk16)
         dpos_all = buf("g_dpos_all", (T, C))
-        self._linear_bwd(dcpk16, pos_all, W(d + "cross_pos_k_linear.weight"), G(d + "cross_pos_k_linear.weight"),
-                         G(d + "cross_pos_k_linear.bias"), dx_out=dpos_all)
-        self._side_do(lambda: self._notify(d))
+        self._side_do(lambda: self._dec_pos_bwd(B, P, T, Td, dspq, dspk, dcpq, dcpk, pos_all, dpos_all))
         self._side_flush()
         # ---- encoder
         dx = buf("g_dx_enc", (B * T, C))
@@ -1344,7 +1371,16 @@ class HipEngine:
             self._side_flush()
         # ---- encoder abs-pos operands
         self._bt = "etop"
-        self._join_side()
+        self._side_do(lambda: self._enc_tail_bwd(B, L, P, T, h, w, dx, depq, depk, pos_all, dpos_all))
+        self._join_side()            # (flushes) the optimizer (main stream) reads the whole gradient arena next
+        return self.g16
+
+    def _enc_tail_bwd(self, B, L, P, T, h, w, dx, depq, depk, pos_all, dpos_all):
+        """encoder abs-pos operands and embedding LayerNorms: parameter gradients only -- side stream"""
+        cfg = self.cfg
+        C = cfg.embed_dim
+        W, G, buf = self.W, self.G, self.buf
+        e = "encoder."
         depqk = buf("g_depqk", (T, 2 * C))
         tmp = buf("g_tmp_ec", (T, C))
         hip.cast_f32_bf16(depq, tmp); depqk[:, :C].copy_(tmp)
@@ -1368,10 +1404,39 @@ class HipEngine:
         self._ln_bwd(dxt, self.ws["tok_pre"].view(B, L, C), e + "layernorm_embedding", "tok_ln", dtok,
                      drop=self._dropargs(2))
         gt = G(e + "type_embedding.weight")
-        self._side_do(lambda: (self._bias_grad(dtok.view(B * L, C), gt[0]), self._bias_grad(dimg.view(B * P, C), gt[1]),
-                               self._notify(e)))
-        self._join_side()            # (flushes) the optimizer (main stream) reads the whole gradient arena next
-        return self.g16
+        self._bias_grad(dtok.view(B * L, C), gt[0])
+        self._bias_grad(dimg.view(B * P, C), gt[1])
+        self._notify(e)
+
+    def _dec_pos_bwd(self, B, P, T, Td, dspq, dspk, dcpq, dcpk, pos_all, dpos_all):
+        """gradients of the decoder's position operands (self / cross abs-pos projections, seg positions) -- side stream"""
+        cfg = self.cfg
+        C = cfg.embed_dim
+        W, G, buf = self.W, self.G, self.buf
+        d = "decoder."
+        dspqk = buf("g_dspqk", (Td, 2 * C))
+        hip.cast_f32_bf16(dspq, buf("g_tmp_tc", (Td, C)))
+        dspqk[:, :C].copy_(self.ws["g_tmp_tc"])
+        hip.cast_f32_bf16(dspk, self.ws["g_tmp_tc"])
+        dspqk[:, C:].copy_(self.ws["g_tmp_tc"])
+        tp = self.ws["d_tp"]
+        dtp = buf("g_dtp", (Td, C))
+        self._linear_bwd(dspqk, tp, self._fused(self.p16, d + "self_pos_q_linear.weight", 2 * C, C),
+                         self._fused(self.g16, d + "self_pos_q_linear.weight", 2 * C, C),
+                         self._fused(self.g16, d + "self_pos_q_linear.bias", 2 * C), dx_out=dtp)
+        dcpq16 = buf("g_dcpq16", (Td, C))
+        hip.cast_f32_bf16(dcpq, dcpq16)
+        self._linear_bwd(dcpq16, tp, W(d + "cross_pos_q_linear.weight"), G(d + "cross_pos_q_linear.weight"),
+                         G(d + "cross_pos_q_linear.bias"), dx_out=dtp, dx_accumulate=True)
+        segG = G(d + "embed_seg_positions.weight")
+        segtab = W(d + "embed_seg_positions.weight")
+        self._ln_bwd(dtp[:P], segtab[1:1 + P], d + "seg_pos_ln", "d_tp_ln_p", segG[1:1 + P])
+        self._ln_bwd(dtp[P:], segtab[:1], d + "seg_pos_ln", "d_tp_ln_b", segG[:1], accumulate=True)
+        dcpk16 = buf("g_dcpk16", (T, C))
+        hip.cast_f32_bf16(dcpk, dcpk16)
+        self._linear_bwd(dcpk16, pos_all, W(d + "cross_pos_k_linear.weight"), G(d + "cross_pos_k_linear.weight"),
+                         G(d + "cross_pos_k_linear.bias"), dx_out=dpos_all)
+        self._side_do(lambda: self._notify(d))
 
     def _flush_tables(self):
         for key, tabname in self._tab_touched.items():

@@ -156,12 +156,8 @@ class SegOFAModel(nn.Module):
                 raise RuntimeError("ifseg_amd.SegOFAModel runs only on an MI355X: patch_images must be a device tensor "
                                    "(there is no CPU / PyTorch fallback)")
             if patch_masks is not None:
-                # the check reads the mask back (a device sync): once per mask tensor, not once per step
-                key = (patch_masks.data_ptr(), patch_masks._version, tuple(patch_masks.shape))
-                if getattr(self, "_checked_masks", None) != key:
-                    if not bool(patch_masks.all()):
-                        raise NotImplementedError("masked-out patch images are not supported")
-                    self._checked_masks = key
+                # validated without draining the queue (see HipEngine.deferred_check)
+                eng.deferred_check(patch_masks, lambda t: t.all().logical_not(), "masked-out patch images are not supported")
             x, extra = self._run(src_tokens, patch_images, prev_output_tokens, bool(full_context_alignment), None)
         if aux_input is not None:
             # image-free branch (segofa.py:136-151): encoder on the artificial image, decoder with its defaults

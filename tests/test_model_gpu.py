@@ -536,3 +536,36 @@ def test_update_freq_accumulates_micro_batches():
     want = (grads[0] + grads[1]).to(torch.bfloat16).float()
     assert torch.equal(ta.eng.g16.float(), want)
     assert ta.num_updates == 1
+
+
+def test_unsupported_inputs_are_refused_without_a_per_step_sync():
+    """Padded prompts / masked-out images are refused loudly: synchronously on a process's first forward, afterwards
+    through HipEngine.deferred_check (the flag is read back once its event has completed, at the latest one call later)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    batch = O.synthetic_batch(ocfg, 2, 12)
+    good = dict(src_tokens=batch["src_tokens"].to(dev), patch_images=batch["patch_images"].to(dev),
+                prev_output_tokens=batch["prev_output_tokens"].to(dev))
+    padded = dict(good, src_tokens=good["src_tokens"].clone())
+    padded["src_tokens"][0, -1] = 1
+    m = _build(ocfg, sd, dev)
+    m.eval()
+    with torch.no_grad():
+        with pytest.raises(NotImplementedError):       # first check of the process: synchronous
+            m(**padded)
+        m(**good)
+        with pytest.raises(NotImplementedError):       # later: this call or, once the flag has landed, the next one
+            m(**padded)
+            torch.cuda.synchronize()
+            m(**good)
+        torch.cuda.synchronize()
+        m(**good)                                       # the engine keeps working after a refusal
+        masks = torch.ones(2, dtype=torch.bool, device=dev)
+        masks[1] = False
+        with pytest.raises(NotImplementedError):
+            m(patch_masks=masks, **good)
+            torch.cuda.synchronize()
+            m(**good)

@@ -9,4 +9,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- pytho
 python $GRAFT_REPO_ROOT/tools/prof_summary.py $out/trace 10 "rocprofv3 --kernel-trace --stats, bench.py --steps 5 --warmup 2 (10 steps incl. the 3-step GEMM pass), MI355X, round 1 ($tag)" > $out/summary.md
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 python $GRAFT_REPO_ROOT/tools/queue_kernels.py $(find $out/trace -name "*kernel_trace.csv" | head -1) 2 6 > $out/queues.txt
+python $GRAFT_REPO_ROOT/tools/queue_gaps.py $(find $out/trace -name "*kernel_trace.csv" | head -1) 2 6 > $out/gaps.txt
 find $out/trace -name "*.csv" -size +3M -delete; find $out -name "*.db" -delete
