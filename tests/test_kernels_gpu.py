@@ -135,7 +135,7 @@ def _grid_codes(gh, gw):
     return code, (gh - 1) * (2 * gw - 1) + (gw - 1), (2 * gh - 1) * (2 * gw - 1)
 
 
-@pytest.mark.parametrize("case", ["cross", "enc_rel", "dec_causal", "dec_full", "dense_nopos", "big_enc"])
+@pytest.mark.parametrize("case", ["cross", "enc_rel", "dec_causal", "dec_full", "dense_nopos", "big_enc", "dec_causal_bh8"])
 def test_attn_fwd(case):
     from ifseg_amd import hip
     dev = _dev()
@@ -157,6 +157,12 @@ def test_attn_fwd(case):
         P, Lt = 64, 1
         T = S = P + Lt
         causal = case == "dec_causal"
+    elif case == "dec_causal_bh8":      # B*H divisible by 8: the longest-first launch order keeps a (b, h) on one XCD
+        gh, gw = 32, 32
+        P, Lt = 1024, 1
+        T = S = P + Lt
+        causal = True
+        H, B = 4, 2
     elif case == "dense_nopos":
         T, S = 100, 130
         use_pos = False
@@ -176,7 +182,7 @@ def test_attn_fwd(case):
         rel2d = torch.randn(H, n2d, generator=g)
         rel1d = torch.randn(H, 2 * Lt - 1, generator=g)
         relx = torch.randn(H, 2, generator=g)
-        rel = hip.RelBias(P, gcode.to(dev), code_bias, rel2d.to(dev), rel1d.to(dev), relx.to(dev))
+        rel = hip.RelBias(P, gcode.to(dev), code_bias, rel2d.to(dev), rel1d.to(dev), relx.to(dev), grid_w=gw if case == "dec_causal_bh8" else 0)
         bias = _dense_rel(H, T, S, P, gcode.long(), code_bias, rel2d, rel1d, relx)
     if case == "dense_nopos":
         g = torch.Generator().manual_seed(31)
@@ -195,7 +201,7 @@ def test_attn_fwd(case):
 
 
 # ----------------------------------------------------------------------------- attention backward
-@pytest.mark.parametrize("case", ["cross", "enc_rel", "dec_causal", "dec_full", "big_enc", "dec_wide"])
+@pytest.mark.parametrize("case", ["cross", "enc_rel", "dec_causal", "dec_full", "big_enc", "dec_wide", "dec_causal_bh8"])
 def test_attn_bwd(case):
     from ifseg_amd import hip
     dev = _dev()
@@ -216,6 +222,11 @@ def test_attn_bwd(case):
         gh, gw, P, Lt = 32, 32, 1024, 36
         T = S = P + Lt
         H, B = 3, 2
+    elif case == "dec_causal_bh8":     # the decoder self-attention of the bench geometry; B*H = 8 (XCD-grouped causal order)
+        gh, gw, P, Lt = 32, 32, 1024, 1
+        T = S = P + Lt
+        H, B = 4, 2
+        causal = True
     elif case == "dec_wide":          # 40-wide grid (SegOFA-Large at 640^2): P = 320 is not a multiple of 128,
         gh, gw, P, Lt = 8, 40, 320, 1  # so the bos key shares a 128-key tile with grid keys
         T = S = P + Lt
