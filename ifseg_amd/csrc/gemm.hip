@@ -286,11 +286,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     // every row of accb holds sum_k A[k][m]; lanes 0..31 carry row 0 in register 0.  Slab layout per k-slice:
     // [M x ldc | M] floats, so one reduction pass over M*ldc + M elements yields dW followed by db.
     if (do_colsum && lane < 32) {
-      float* cb = reinterpret_cast<float*>(g.C) + (long long)blockIdx.z * g.sCsplit + (long long)g.M * g.ldc;
+      if (g.splitk > 1) {
+        float* cb = reinterpret_cast<float*>(g.C) + (long long)blockIdx.z * g.sCsplit + (long long)g.M * g.ldc;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + lane;
-        if (m < g.M) cb[m] = accb[i][0];
+        for (int i = 0; i < 2; ++i) {
+          const int m = m0 + wm * 64 + i * 32 + lane;
+          if (m < g.M) cb[m] = accb[i][0];
+        }
+      } else {
+        // no split: the sums are final -- db (bf16) sits right behind dW [M x ldc] in the gradient arena
+        bf16_t* cb = reinterpret_cast<bf16_t*>(g.C) + (long long)g.M * g.ldc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int m = m0 + wm * 64 + i * 32 + lane;
+          if (m < g.M) cb[m] = f2bf(accb[i][0] + ((g.flags & IFSEG_GEMM_ACCUMULATE) ? bf2f(cb[m]) : 0.f));
+        }
       }
     }
   }
@@ -430,7 +440,8 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, int M, i
     case IFSEG_GEMM_NN: LAUNCH2(A_KC, true, 128); break;
     case IFSEG_GEMM_TN:
       if (flags & IFSEG_GEMM_COLSUM) {
-        if (splitk <= 1 || ldc != N) return IFSEG_ERR_BAD_ARG;
+        // split-K: fp32 slabs [M x ldc | M]; no split: bf16 dW with db written right behind it
+        if (ldc != N || (splitk <= 1 && (flags & IFSEG_GEMM_OUT_F32)) || batch > 1) return IFSEG_ERR_BAD_ARG;
         if (two_stage) hipLaunchKernelGGL((gemm_kernel<A_KS, true, 128, GBK, 2, true>), grid, block, 0, s, g);
         else hipLaunchKernelGGL((gemm_kernel<A_KS, true, 128, GBK, 1, true>), grid, block, 0, s, g);
       } else {

@@ -123,6 +123,10 @@ GEMM_COLSUM = 8
 # workgroups a dW GEMM is split over: it runs on the side stream next to the dX chain, so filling the chip alone is not
 # the goal (256 / 512 / 128 measured within 1% of each other; fewer slabs = less fp32 workspace traffic)
 DW_TARGET_WGS = int(os.environ.get("IFSEG_DW_WGS", "256"))
+# dW GEMMs with at least this many 128x128 tiles run without split-K (bf16 dW and db written once, no slabs, no
+# reduction).  Off by default: measured on the Base step, 144-tile GEMMs that walk all 8480 tokens per workgroup make the
+# weight-gradient stream lag (372-382 img/s vs 388 with split-K 2); the path is kept for models with wider layers.
+DW_DIRECT_TILES = int(os.environ.get("IFSEG_DW_DIRECT", "1000000"))
 
 
 def linear_dw(dy, x, out, accumulate=False, bias_out=None):
@@ -136,6 +140,14 @@ def linear_dw(dy, x, out, accumulate=False, bias_out=None):
     K = x.shape[1]
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     splitk = max(1, min(16, DW_TARGET_WGS // max(1, tiles), M // 512))
+    adjacent = (bias_out is not None and N % 4 == 0 and bias_out.dtype == out.dtype and bias_out.is_contiguous()
+                and out.is_contiguous() and bias_out.data_ptr() == out.data_ptr() + out.numel() * out.element_size())
+    if tiles >= DW_DIRECT_TILES and out.dtype == torch.bfloat16 and out.is_contiguous():
+        # enough tiles for a side-stream GEMM: one pass over all M tokens per workgroup, dW (and db) written once as bf16
+        # -- no fp32 slabs, no reduction launch
+        gemm(GEMM_TN, _bf(dy), _bf(x), out, N, K, M, dy.stride(0), x.stride(0), K,
+             flags=(GEMM_ACCUMULATE if accumulate else 0) | (GEMM_COLSUM if adjacent else 0))
+        return adjacent
     if bias_out is not None and M >= 1024:
         splitk = max(splitk, 2)      # the fused column sums ride on the split-K reduction
     if splitk > 1 and out.is_contiguous():

@@ -32,9 +32,10 @@ int ifseg_abi_version(void);
 #define IFSEG_GEMM_RELU 1
 #define IFSEG_GEMM_OUT_F32 2
 #define IFSEG_GEMM_ACCUMULATE 4 /* C += result */
-#define IFSEG_GEMM_COLSUM 8     /* TN + splitk > 1 only: every k-slice slab is [M x N | round4(M)] floats, the extra
-                                   M floats being sum_k A[k][m] -- the bias gradient of a Linear whose weight gradient is
-                                   this GEMM (dW = dY^T X, db = colsum dY); summed by the same ifseg_reduce_parts pass */
+#define IFSEG_GEMM_COLSUM 8     /* TN, ldc == N: also sum_k A[k][m] -- the bias gradient of a Linear whose weight gradient
+                                   is this GEMM (dW = dY^T X, db = colsum dY).  splitk > 1: every k-slice slab is
+                                   [M x N | round4(M)] floats (summed by the same ifseg_reduce_parts pass); splitk == 1 (bf16
+                                   output): db is written as M bf16 right behind dW [M x N] (honours ACCUMULATE) */
 
 /* bf16 MFMA GEMM, fp32 accumulate, epilogue
  *   C = ((A.B + bias[n]) * alpha[for n < alpha_ncols]) + resid[m,n]  (+relu)

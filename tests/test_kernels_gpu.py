@@ -567,12 +567,15 @@ def test_embed_bag_mean_vs_torch():
     assert torch.equal(out[1, 2 + 7].float().cpu(), add.float().cpu().to(torch.bfloat16).float())
 
 
-@pytest.mark.parametrize("M,N,K", [(8480, 768, 768), (2 * 1060, 3072, 768), (8480, 1536, 768)])
-def test_gemm_tn_fused_bias_gradient(M, N, K):
+@pytest.mark.parametrize("M,N,K,direct", [(8480, 768, 768, False), (2 * 1060, 3072, 768, False), (8480, 1536, 768, False),
+                                            (2 * 1060, 3072, 768, True)])
+def test_gemm_tn_fused_bias_gradient(M, N, K, direct, monkeypatch):
     """IFSEG_GEMM_COLSUM: db = colsum(dy) produced by the dW GEMM itself (one more MFMA against an all-ones fragment)
-    and by the same split-K reduction pass, when the bias gradient lies right behind the weight gradient."""
+    and by the same split-K reduction pass, when the bias gradient lies right behind the weight gradient; `direct`: the
+    no-split path (bf16 dW and db written once by the GEMM)."""
     from ifseg_amd import hip
     dev = _dev()
+    monkeypatch.setattr(hip, "DW_DIRECT_TILES", 100 if direct else 10 ** 9)
     dy, x = _rand((M, N), dev, 92, 0.5), _rand((M, K), dev, 93, 0.5)
     flat = torch.full((N * K + N + 8,), 7.0, dtype=torch.bfloat16, device=dev)
     gw, gb = flat[: N * K].view(N, K), flat[N * K: N * K + N]
@@ -580,6 +583,10 @@ def test_gemm_tn_fused_bias_gradient(M, N, K):
     assert _rel(gw, dy.float().t() @ x.float()) < 6e-3
     assert _rel(gb, dy.float().sum(0)) < 6e-3
     assert (flat[N * K + N:] == 7.0).all()                       # nothing written past db
+    assert hip.linear_dw(dy, x, gw, accumulate=True, bias_out=gb) is True      # += (split-K and direct paths alike)
+    assert _rel(gw, 2 * (dy.float().t() @ x.float())) < 8e-3
+    assert _rel(gb, 2 * dy.float().sum(0)) < 8e-3
+    assert (flat[N * K + N:] == 7.0).all()
     other = torch.empty(N, dtype=torch.bfloat16, device=dev)     # not adjacent: the caller keeps its own path
     assert hip.linear_dw(dy, x, gw, bias_out=other) is False
 
