@@ -320,7 +320,7 @@ def ln_fwd_pair(x, gamma, beta, y, mean, rstd, gamma2, beta2, y2, mean2, rstd2, 
     return y, y2
 
 
-LN_BWD_BLOCKS = 768   # three resident blocks per CU (146-162 VGPRs): best of a 256..2048 sweep on MI355X
+LN_BWD_BLOCKS = int(os.environ.get("IFSEG_LN_BWD_BLOCKS", "768"))   # three resident blocks per CU (146-162 VGPRs): best of a 256..2048 sweep on MI355X
 
 
 def ln_bwd_drop(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx2, dx_add=None, drop2=None):
