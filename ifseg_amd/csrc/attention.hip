@@ -378,9 +378,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 // recompute P; the gradient of the bias goes to LDS histograms.
 //
 // (1) dK/dV kernel: one workgroup owns 128 keys (wave = 32 keys, lane = key) and
-//     streams 64-query tiles of Q_ext / dO / lse / delta through LDS.
-//       S[q,key]  = Q_ext K_ext^T          (A = Q tile b128 reads, B = K regs)
-//       dP[q,key] = dO V^T                 (A = dO tile,           B = V regs)
+//     streams 32-query blocks of Q_ext / dO / lse / delta through two LDS stages by LDS-DMA.
+//       S[q,key]  = Q_ext K_ext^T          (A = Q tile b128 reads, B = K regs; on a 32-wide grid the accumulator
+//                                           is seeded with the rel-pos bias)
+//       dP[q,key] = dO V^T                 (A = dO tile,           B = V rows of the workgroup, LDS)
 //       dS = P (gain*dP - delta)
 //       dV^T[d,key]   += dO^T P            (A = dO tile tr-reads,  B = P regs)
 //       dK^T[c,key]   += Q_ext^T dS        (A = Q tile tr-reads,   B = dS regs)
