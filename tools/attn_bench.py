@@ -8,7 +8,7 @@ def main(kind="enc", iters=5):
     dev = torch.device("cuda:0")
     B, H, C = 8, 12, 768
     gh = gw = 32; P = 1024
-    Lt = 1 if kind == "dec" else 36
+    Lt = 1 if kind in ("dec", "decfull") else 36
     T = S = P + Lt
     causal = kind == "dec"
     g = torch.Generator().manual_seed(0)
