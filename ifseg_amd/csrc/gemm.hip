@@ -15,6 +15,7 @@
 // each lane owns 4 consecutive output columns -> 8/16-byte stores.  Split-K (weight gradients) writes fp32
 // slabs that a second launch sums: a fused "last workgroup reduces" was measured 2-3x slower on MI355X -- the
 // agent-scope release/acquire it needs writes back / invalidates the per-XCD L2s.
+#include <cstdlib>
 #include "common.h"
 #include "prof.h"
 #include "../../include/ifseg_hip.h"
@@ -42,6 +43,7 @@ struct GemmArgs {
   // optional row-dot epilogue (attention backward's delta): dot_out[(m / dot_T) * (N/64) + n/64][m % dot_T] =
   // sum over the 64 columns of head n/64 of C[m][n] (as stored in bf16) * dot[m][n]
   const bf16_t* dot; int ldd; float* dot_out; int dot_T;
+  int xcd_groups;          // > 0: split-K slices pinned to XCDs (see the kernel), grid = tiles * splitk workgroups in x
 };
 
 // ---- LDS tile images -------------------------------------------------------
@@ -111,14 +113,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 
   const int tiles_n = (g.N + BN - 1) / BN;
   const int tiles_m = (g.M + BM - 1) / BM;
-  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  // split-K with xcd_groups > 0 (1-D grid of tiles x slices): XCD x = workgroup id & 7 owns k-slice x / groups and the
+  // contiguous tile range x % groups of it, so the rows of A and B a slice touches stream through ONE XCD's L2 instead of
+  // being fetched from HBM by every XCD that happens to hold a few of its tiles (measured 3.6-5.7x over-fetch)
+  int t, bz = blockIdx.z;
+  if (g.xcd_groups > 0) {
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    bz = xcd / g.xcd_groups;
+    t = (xcd % g.xcd_groups) * ((tiles_m * tiles_n) / g.xcd_groups) + loc;
+  } else {
+    t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  }
   const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
   const v4i32 rsA = make_rsrc(g.A + (long long)blockIdx.y * g.sA, g.nrecA);
   const v4i32 rsB = make_rsrc(g.B + (long long)blockIdx.y * g.sB, g.nrecB);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-  // split-K: slice blockIdx.z reduces k in [kbeg, kend) into its own fp32 slab of C
-  const int kbeg = g.splitk > 1 ? blockIdx.z * g.kchunk : 0;
+  // split-K: slice bz reduces k in [kbeg, kend) into its own fp32 slab of C
+  const int kbeg = g.splitk > 1 ? bz * g.kchunk : 0;
   const int kend = g.splitk > 1 ? min(g.K, kbeg + g.kchunk) : g.K;
   const int nk = (kend - kbeg + BK - 1) / BK;
   const bool ktail = (kend - kbeg) & (BK - 1);
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     // [M x ldc | M] floats, so one reduction pass over M*ldc + M elements yields dW followed by db.
     if (do_colsum && lane < 32) {
       if (g.splitk > 1) {
-        float* cb = reinterpret_cast<float*>(g.C) + (long long)blockIdx.z * g.sCsplit + (long long)g.M * g.ldc;
+        float* cb = reinterpret_cast<float*>(g.C) + (long long)bz * g.sCsplit + (long long)g.M * g.ldc;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int m = m0 + wm * 64 + i * 32 + lane;
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (out_f32) {
-          float* cp = reinterpret_cast<float*>(g.C) + (long long)blockIdx.y * g.sC + (long long)blockIdx.z * g.sCsplit +
+          float* cp = reinterpret_cast<float*>(g.C) + (long long)blockIdx.y * g.sC + (long long)bz * g.sCsplit +
                       (long long)m * g.ldc + n;
           float4 o = make_float4(v[0], v[1], v[2], v[3]);
           if (accum) {
@@ -421,6 +433,11 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, int M, i
   const bool narrow = layout == IFSEG_GEMM_NT && g.splitk == 1 && (N <= 64 || tiles128 < 384);
   const int tiles = narrow ? ((M + BM - 1) / BM) * ((N + 63) / 64) : tiles128;
   dim3 grid(tiles, batch > 0 ? batch : 1, g.splitk), block(256);
+  if (layout == IFSEG_GEMM_TN && g.splitk > 1 && batch <= 1 && (8 % g.splitk) == 0 && tiles % (8 / g.splitk) == 0 &&
+      !getenv("IFSEG_GEMM_NO_XCD_SLICES")) {
+    g.xcd_groups = 8 / g.splitk;
+    grid = dim3(tiles * g.splitk, 1, 1);
+  }
   hipStream_t s = (hipStream_t)stream;
   if (layout < 0 || layout > 2) return IFSEG_ERR_BAD_ARG;
   if ((flags & IFSEG_GEMM_COLSUM) && layout != IFSEG_GEMM_TN) return IFSEG_ERR_BAD_ARG;

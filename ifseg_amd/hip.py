@@ -123,6 +123,7 @@ GEMM_COLSUM = 8
 # workgroups a dW GEMM is split over: it runs on the side stream next to the dX chain, so filling the chip alone is not
 # the goal (256 / 512 / 128 measured within 1% of each other; fewer slabs = less fp32 workspace traffic)
 DW_TARGET_WGS = int(os.environ.get("IFSEG_DW_WGS", "256"))
+DW_XCD_SLICES = os.environ.get("IFSEG_DW_NO_XCD_SLICES") is None
 # dW GEMMs with at least this many 128x128 tiles run without split-K (bf16 dW and db written once, no slabs, no
 # reduction).  Off by default: measured on the Base step, 144-tile GEMMs that walk all 8480 tokens per workgroup make the
 # weight-gradient stream lag (372-382 img/s vs 388 with split-K 2); the path is kept for models with wider layers.
@@ -140,6 +141,13 @@ def linear_dw(dy, x, out, accumulate=False, bias_out=None):
     K = x.shape[1]
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     splitk = max(1, min(16, DW_TARGET_WGS // max(1, tiles), M // 512))
+    if DW_XCD_SLICES and M >= 4096:
+        # k-slices pinned to XCDs (ifseg_gemm_bf16, TN): 8 slices for few-tile products, else 4 or 2; the count must divide
+        # 8 and 8/splitk must divide the tile count
+        for cand in (8, 4, 2):
+            if tiles * cand <= max(DW_TARGET_WGS, 288) * (1 if cand == 8 else 2) and tiles % (8 // cand) == 0:
+                splitk = cand
+                break
     adjacent = (bias_out is not None and N % 4 == 0 and bias_out.dtype == out.dtype and bias_out.is_contiguous()
                 and out.is_contiguous() and bias_out.data_ptr() == out.data_ptr() + out.numel() * out.element_size())
     if tiles >= DW_DIRECT_TILES and out.dtype == torch.bfloat16 and out.is_contiguous():
