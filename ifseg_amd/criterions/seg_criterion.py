@@ -12,11 +12,43 @@ histograms) whenever the image is exactly 16x the feature gr
 label smoothing is off; otherwise the same math runs as stock PyTorch ops (eval on odd
 image sizes).  ``compute_loss_torch`` is kept as the in-framework reference of the kernel.
 """
+from dataclasses import dataclass, field
+from typing import Optional
+
 import torch
 import torch.nn.functional as F
 
 from .. import hip
-from ..registry import register_criterion
+from ..registry import CriterionBase, DataclassBase, register_criterion, str_bool
+
+
+def _f(default, help=""):
+    return field(default=default, metadata={"help": help})
+
+
+@dataclass
+class SegCriterionConfig(DataclassBase):
+    """criterions/seg_criterion.py:32-101 (the 'true' / 'false' string flags included)."""
+    label_smoothing: float = _f(0.0, "epsilon for label smoothing, 0 means no label smoothing")
+    report_accuracy: bool = _f(False, "report accuracy metric")
+    ignore_prefix_size: int = _f(0, "Ignore first N tokens")
+    ignore_eos: bool = _f(True, "Ignore eos token")
+    sentence_avg: bool = _f(False, "optimization.sentence_avg")
+    drop_worst_ratio: float = _f(0.0, "ratio for discarding bad samples")
+    drop_worst_after: int = _f(0, "steps for discarding bad samples")
+    use_rdrop: bool = _f(False, "use R-Drop")
+    reg_alpha: float = _f(1.0, "weight for R-Drop")
+    sample_patch_num: int = _f(196, "sample patches for v1")
+    constraint_range: Optional[str] = _f(None, "constraint range")
+    upscale_lprobs: str = _f("true", "true | false")
+    unsupervised_segmentation: str = _f("true", "true | false")
+    criterion_update_freq: int = _f(1, "update frequency used in this criterion")
+    freeze_embedding_iter: int = _f(-1, "Freeze the token embedding after this iteration (ignored if -1)")
+    full_context_alignment: str = _f("false", "whether to apply full attention in decoder")
+    init_seg_with_text: str = _f("true", "whether to lazy initialize the segmentation with text embedding bags")
+    resnet_topk: int = _f(3, "filtering with topk adjacent resnet features")
+    resnet_prob_temperature: float = _f(1.0, "resnet softmax temperature")
+    resnet_iters: int = _f(0, "resnet filtering iterations")
 
 
 class _FusedSegLossFn(torch.autograd.Function):
@@ -42,7 +74,8 @@ class _FusedSegLossFn(torch.autograd.Function):
                      bufs["dl"], bufs["loss"])
         ctx.dl = bufs["dl"]
         ctx.nseg = nseg
-        return bufs["loss"][0], bufs["stats"]
+        # fresh tensors: callers keep them in logging outputs across calls (update_freq > 1, validation loops)
+        return bufs["loss"][0].clone(), bufs["stats"].clone()
 
     @staticmethod
     def backward(ctx, gloss, gstats):
@@ -52,30 +85,72 @@ class _FusedSegLossFn(torch.autograd.Function):
 PAD, EOS = 1, 2
 
 
-@register_criterion("seg_criterion")
-class SegCriterion:
-    def __init__(self, task=None, label_smoothing=0.0, upscale_lprobs=True, unsupervised_segmentation=False,
-                 full_context_alignment=False, num_seg_tokens=None, seg_id_offset=None, resnet_topk=3,
-                 resnet_prob_temperature=1.0, resnet_iters=0):
-        self.task = task
+@register_criterion("seg_criterion", dataclass=SegCriterionConfig)
+class SegCriterion(CriterionBase):
+    def __init__(self, task=None, sentence_avg=False, label_smoothing=0.0, ignore_prefix_size=0, ignore_eos=True,
+                 report_accuracy=False, drop_worst_ratio=0, drop_worst_after=0, use_rdrop=False, reg_alpha=1.0,
+                 sample_patch_num=196, constraint_range=None, upscale_lprobs="true", unsupervised_segmentation="true",
+                 criterion_update_freq=1, freeze_embedding_iter=-1, full_context_alignment="false",
+                 init_seg_with_text="true", resnet_topk=3, resnet_prob_temperature=1.0, resnet_iters=0,
+                 num_seg_tokens=None, seg_id_offset=None):
+        """Signature of the reference (seg_criterion.py:115-161; fairseq's `build_criterion` fills it from
+        SegCriterionConfig by name).  `num_seg_tokens` / `seg_id_offset` stand in for `task.cfg.num_seg_tokens` and
+        `task.target_dictionary.index("<seg_0>")` when the criterion is used without a task."""
+        super().__init__(task)
+        self.sentence_avg = sentence_avg
+        self.eps = label_smoothing
+        self.sample_patch_num = sample_patch_num
+        self.iter = -1
+        self.effective_iter = -1
+        self.criterion_update_freq = criterion_update_freq
+        self.upscale_lprobs = str_bool(upscale_lprobs)
+        self.unsupervised_segmentation = str_bool(unsupervised_segmentation)
+        self.full_context_alignment = str_bool(full_context_alignment)
+        self.init_seg_with_text = str_bool(init_seg_with_text)
         # eval-time top-k neighbour smoothing on the trunk features (seg_criterion.py:93-101,197-213)
         self.resnet_topk, self.resnet_prob_temperature, self.resnet_iters = resnet_topk, resnet_prob_temperature, resnet_iters
-        self.eps = label_smoothing
-        self.upscale_lprobs = upscale_lprobs
-        self.unsupervised_segmentation = unsupervised_segmentation
-        self.full_context_alignment = full_context_alignment
         cfg = getattr(task, "cfg", None)
         self.num_seg = num_seg_tokens if num_seg_tokens is not None else cfg.num_seg_tokens
-        self.seg_id_offset = seg_id_offset if seg_id_offset is not None else task.seg_id_offset
+        self.seg_id_offset = seg_id_offset if seg_id_offset is not None else task.target_dictionary.index("<seg_0>")
+        cats = getattr(cfg, "category_list", "") or ""
+        self.id2rawtext = [x.strip() for x in cats.split(",")] if cats else []
+        if self.id2rawtext and len(self.id2rawtext) != self.num_seg:
+            raise AssertionError("category_list names %d classes, num_seg_tokens is %d" % (len(self.id2rawtext), self.num_seg))
         self.padding_idx = PAD
-        self.iter = -1
 
-    def __call__(self, *a, **k):
-        return self.forward(*a, **k)
+    def _lazy_initialization(self, sample, model, ema_model=None):
+        """seg_criterion.py:373-407: every <seg_i> embedding := mean token embedding of its category name
+        (EmbeddingBag over the frozen token table), written into encoder/decoder.seg_embed_tokens (and the untied
+        projection).  On the device: `ifseg_embed_bag_mean` on the bf16 token table of the engine's arena."""
+        if not self.init_seg_with_text:
+            return
+        task = self.task
+        ids = getattr(task, "category_token_ids", None)
+        if ids is None:
+            if not self.id2rawtext:
+                raise RuntimeError("init_seg_with_text: the task carries neither category_list (+ BPE) nor category_token_ids")
+            ids = [task.encode_category(" %s" % x) for x in self.id2rawtext]
+        ids = [torch.as_tensor(x, dtype=torch.long).reshape(-1) for x in ids]
+        if len(ids) != self.num_seg:
+            raise AssertionError("%d category names for %d seg tokens" % (len(ids), self.num_seg))
+        avg = model.seg_tokens_from_text(ids)
+        model.encoder.seg_embed_tokens.weight.data = avg
+        model.decoder.seg_embed_tokens.weight.data = avg
+        if ema_model is not None:
+            ema_model.encoder.seg_embed_tokens.weight.data = avg
+            ema_model.decoder.seg_embed_tokens.weight.data = avg
+        if not model.decoder.tie_seg_projection:
+            model.decoder.seg_projection.weight.data = avg
+            if ema_model is not None:
+                ema_model.decoder.seg_projection.weight.data = avg
 
     def forward(self, model, sample, update_num=0, reduce=True, ema_model=None):
-        """seg_criterion.py:165-235 (supervised train branch / eval branch)."""
+        """seg_criterion.py:165-235 (lazy init on the first call, image-free / supervised train branches, eval branch)."""
+        if self.iter == -1:
+            self.iter = self.criterion_update_freq * update_num - 1
+            self._lazy_initialization(sample, model, ema_model)
         self.iter += 1
+        self.effective_iter = self.iter // self.criterion_update_freq
         if self.unsupervised_segmentation and model.training:
             # image-free training (seg_criterion.py:179-186): the loss comes from the artificial image; the real
             # images are only evaluated (no grad) for the logged metrics
@@ -97,7 +172,7 @@ class SegCriterion:
             net_output = model(**sample["net_input"], full_context_alignment=self.full_context_alignment)
             seg_loss, metrics, ntokens = self.compute_loss(model, net_output, sample, update_num, reduce=reduce)
             loss, imfree_loss = seg_loss, seg_loss.data.new_zeros(1)
-        sample_size = ntokens
+        sample_size = sample["target"].size(0) if self.sentence_avg else ntokens
         logging_output = {"loss": loss.data, "imfree_loss": imfree_loss.data, "seg_loss": seg_loss.data,
                           "ntokens": sample["ntokens"], "nsentences": sample["nsentences"],
                           "sample_size": sample_size}
@@ -209,13 +284,41 @@ class SegCriterion:
         a_l = torch.histc(target.float(), bins=n, min=0, max=n - 1)
         return a_i, a_p, a_l, a_p + a_l - a_i
 
-    @staticmethod
-    def reduce_metrics(logging_outputs):
-        """mIoU = nanmean(sum intersect / sum union) (seg_criterion.py:533-572)."""
-        ai = sum(l["area_intersect"] for l in logging_outputs)
-        au = sum(l["area_union"] for l in logging_outputs)
-        out = {"loss": sum(float(l["loss"]) for l in logging_outputs) / max(1, len(logging_outputs)),
-               "mIoU": float(torch.nanmean(ai / au))}
+    @classmethod
+    def reduce_metrics(cls, logging_outputs):
+        """seg_criterion.py:414-572: sums over workers / micro-batches, losses per sample_size, aAcc / mIoU / mAcc from
+        the summed area histograms (nanmean over classes).  Logged through fairseq's `metrics` when it is importable
+        (same keys); the aggregate is also returned as a dict for the bundled harness."""
+        tot = lambda k: sum(l.get(k, 0) for l in logging_outputs)
+        ss = tot("sample_size")
+        out = {k: float(tot(k)) / max(float(ss), 1e-9) for k in ("loss", "imfree_loss", "seg_loss", "nll_loss")}
+        out.update(ntokens=tot("ntokens"), nsentences=tot("nsentences"), sample_size=ss)
+        areas = {}
+        for suf in ("", "_resnet_postprocess", "_lowres"):
+            if "area_intersect" + suf not in logging_outputs[0]:
+                continue
+            ai, ap, al, au = (tot("area_%s%s" % (k, suf)) for k in ("intersect", "pred_label", "label", "union"))
+            areas[suf] = (ai, ap, al, au)
+            out["aAcc" + suf] = round(float(ai.sum() / ap.sum()), 4)
+            out["mIoU" + suf] = round(float(torch.nanmean(ai / au)), 4)
+            out["mAcc" + suf] = round(float(torch.nanmean(ai / al)), 4)
+        try:
+            from fairseq import metrics
+        except ImportError:
+            return out
+        ntok = out["ntokens"]
+        metrics.log_scalar("loss", out["loss"], ss, round=3)
+        for k in ("imfree_loss", "seg_loss", "nll_loss"):
+            metrics.log_scalar(k, out[k], ntok, round=3)
+        for k in ("ntokens", "nsentences", "sample_size"):
+            metrics.log_scalar(k, out[k], 1, round=3)
+        for suf, (ai, ap, al, au) in areas.items():
+            for k, v in (("intersect", ai), ("pred_label", ap), ("label", al), ("union", au)):
+                metrics.log_scalar_sum("_area_%s%s" % (k, suf), v, 1)
+            f = lambda a, b, s=suf: (lambda m: round(float(torch.nanmean(m["_area_%s%s" % (a, s)].sum / m["_area_%s%s" % (b, s)].sum)), 4))
+            metrics.log_derived("aAcc" + suf, lambda m, s=suf: round(float(m["_area_intersect" + s].sum.sum() / m["_area_pred_label" + s].sum.sum()), 4))
+            metrics.log_derived("mIoU" + suf, f("intersect", "union"))
+            metrics.log_derived("mAcc" + suf, f("intersect", "label"))
         return out
 
     @staticmethod

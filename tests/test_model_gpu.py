@@ -66,7 +66,7 @@ def test_fixture_forward_backward_vs_oracle(golden_dir):
 
     m = _build(ocfg, sd, dev)
     m.train()
-    crit = SegCriterion(num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+    crit = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
     sample = {"net_input": {"src_tokens": batch["src_tokens"].to(dev), "src_lengths": torch.full((2,), 12).to(dev),
                             "patch_images": batch["patch_images"].to(dev), "patch_masks": batch["patch_masks"].to(dev),
                             "prev_output_tokens": batch["prev_output_tokens"].to(dev)},
@@ -137,7 +137,7 @@ def test_base_config1_vs_reference_golden(golden_dir):
     missing, unexpected = torch.nn.Module.load_state_dict(m, sd, strict=False)
     assert not unexpected
     m.to(dev).train()
-    crit = SegCriterion(num_seg_tokens=15, seg_id_offset=ocfg.seg_id_offset)
+    crit = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=15, seg_id_offset=ocfg.seg_id_offset)
     sample = {"net_input": {k: batch[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks", "prev_output_tokens")},
               "target": batch["target"].to(dev), "ntokens": 1, "nsentences": 1}
     loss, _, logs = crit(m, sample)
@@ -208,7 +208,7 @@ def test_dropout_path_wiring_and_training_mode(golden_dir):
     batch = O.synthetic_batch(ocfg, 2, 12)
     sample = {"net_input": {k: batch[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks", "prev_output_tokens")},
               "target": batch["target"].to(dev), "ntokens": 1, "nsentences": 2}
-    crit = SegCriterion(num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+    crit = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
 
     def run(dropout, dpr, seed):
         m = _build(ocfg, sd, dev)
@@ -244,7 +244,7 @@ def _parity_case(ocfg, batch_size, src_len, image_hw, tol_logits=2e-2, check_gra
     o_logits, o_loss, o_grads, _ = _oracle_all_grads(ocfg, sd, batch, image_hw)
     m = _build(ocfg, sd, dev)
     m.train()
-    crit = SegCriterion(num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+    crit = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
     sample = {"net_input": {k: batch[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks", "prev_output_tokens")},
               "target": batch["target"].to(dev), "ntokens": 1, "nsentences": batch_size}
     loss, _, _ = crit(m, sample)
@@ -342,7 +342,7 @@ def test_image_free_branch_vs_reference_golden(golden_dir):
 
     m = _build(ocfg, sd, dev)
     m.train()
-    crit = SegCriterion(num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset, unsupervised_segmentation=True)
+    crit = SegCriterion(init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset, unsupervised_segmentation=True)
     to = lambda d: {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
     sample = {"net_input": to({"src_tokens": real["src_tokens"], "src_lengths": torch.full((2,), 12),
                                "patch_images": real["patch_images"], "patch_masks": real["patch_masks"],
@@ -405,7 +405,7 @@ def test_eval_branch_vs_reference_golden(golden_dir):
     sd = O.diversify_seg_projection(sd, ocfg, batch)
     m = _build(ocfg, sd, dev)
     m.eval()
-    crit = SegCriterion(num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset, resnet_iters=int(g["iters"]),
+    crit = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset, resnet_iters=int(g["iters"]),
                         resnet_topk=int(g["topk"]))
     sample = {"net_input": {"src_tokens": batch["src_tokens"].to(dev), "src_lengths": torch.full((1,), 12).to(dev),
                             "patch_images": batch["patch_images"].to(dev), "patch_masks": batch["patch_masks"].to(dev),
@@ -458,7 +458,7 @@ def test_training_step_is_deterministic_across_streams():
         task = SegmentationTask(num_seg_tokens=15, patch_image_size=512, arch="segofa_base")
         model = task.build_model()
         model.cfg.dropout, model.cfg.encoder_drop_path_rate, model.cfg.decoder_drop_path_rate = 0.1, 0.1, 0.1
-        tr = Trainer(model, SegCriterion(task), task, device=dev)
+        tr = Trainer(model, SegCriterion(task, unsupervised_segmentation=False, init_seg_with_text=False), task, device=dev)
         tr.eng.overlap = overlap
         ring = []
         for j in range(2):
@@ -521,7 +521,7 @@ def test_update_freq_accumulates_micro_batches():
 
     def make():
         torch.manual_seed(0)
-        return Trainer(task.build_model(), SegCriterion(task), task, device=dev)
+        return Trainer(task.build_model(), SegCriterion(task, unsupervised_segmentation=False, init_seg_with_text=False), task, device=dev)
 
     s1, s2 = task.synthetic_sample(2, dev, seed=1), task.synthetic_sample(2, dev, seed=2)
     ta = make()

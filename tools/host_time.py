@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 task = SegmentationTask(num_seg_tokens=15, patch_image_size=512, arch="segofa_base")
 model = task.build_model()
 model.cfg.dropout, model.cfg.encoder_drop_path_rate, model.cfg.decoder_drop_path_rate = 0.1, 0.1, 0.1
-trainer = Trainer(model, SegCriterion(task), task, device=dev)
+trainer = Trainer(model, SegCriterion(task, unsupervised_segmentation=False, init_seg_with_text=False), task, device=dev)
 sample = task.synthetic_sample(8, dev, seed=1234)
 sample["net_input"]["patch_images"] = sample["net_input"]["patch_images"].to(torch.bfloat16)
 for _ in range(3):

@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 task = SegmentationTask(num_seg_tokens=15, patch_image_size=512, arch="segofa_base")
 model = task.build_model()
 model.cfg.dropout, model.cfg.encoder_drop_path_rate, model.cfg.decoder_drop_path_rate = 0.1, 0.1, 0.1
-trainer = Trainer(model, SegCriterion(task), task, device=dev)
+trainer = Trainer(model, SegCriterion(task, unsupervised_segmentation=False, init_seg_with_text=False), task, device=dev)
 ring = []
 for j in range(2):
     sm = task.synthetic_sample(8, dev, seed=1234 + 7919 * j)
