@@ -3,7 +3,10 @@ SegOFA-Base, bf16).  One "step" = criterion forward (HIP model + upsample/CE los
 backward (HIP) + gradient all-reduce (N>1) + clip + Adam, on one batch of 8 synthetic
 images per GPU that is already resident in HBM.
 
-    python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE in
+the environment) or started plainly -- bench.py then re-executes itself under torch.distributed.run with N ranks, one
+per GPU over RCCL, and fails loudly when the box has fewer than N GPUs.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   "roofline":     dominant kernel family, algorithmic FLOP / measured kernel time (HIP events on
@@ -28,38 +31,98 @@ MFMA_PEAK_TF = 2500.0                      # dense bf16 (MI355X_MICROARCH.md)
 
 
 def cpu_baseline(nseg, src_len):
-    """oracle fwd+bwd on FOUR images of the same workload (half the GPU's batch; ~10 s of CPU work), fp32, host threads"""
+    """SURVEY 8d / BASELINE.md section 4: the CPU restatement (oracle/segofa_ref.py, fp32) on BASELINE configs[0] inputs
+    (B = 2, 512x512, frozen trunk, dropout 0), every host core, 1 warm-up + 3 timed fwd+bwd steps (a bounded sample:
+    ~15-25 s of CPU work on the GPU box)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import segofa_ref as O
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
     cfg = O.base_config(num_seg_tokens=nseg)
     sd = O.procedural_state_dict(cfg)
     spec = O.state_dict_spec(cfg)
     for k, v in sd.items():
         if v.dtype.is_floating_point and "embed_images" not in k and not spec[k][1].startswith("alias"):
             v.requires_grad_(k.startswith(("encoder.layers", "decoder.layers")))
-    nimg = 4
+    nimg, warm, timed = 2, 1, 3
     batch = O.synthetic_batch(cfg, nimg, src_len)
-    t0 = time.time()
-    logits, extra = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"])
-    loss, _, _ = O.seg_loss(cfg, logits, batch["target"], 32, 32, 512, 512)
-    loss.backward()
-    dt = time.time() - t0
+    dts = []
+    for i in range(warm + timed):
+        for v in sd.values():
+            v.grad = None
+        t0 = time.time()
+        logits, extra = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"])
+        loss, _, _ = O.seg_loss(cfg, logits, batch["target"], 32, 32, 512, 512)
+        loss.backward()
+        if i >= warm:
+            dts.append(time.time() - t0)
+    dt = sum(dts) / len(dts)
     return {"value": round(nimg / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d images of the 8-image batch: 1 fwd+bwd step of oracle/segofa_ref.py (fp32, %.1f s)" % (nimg, dt)}
+            "sample": "BASELINE configs[0] inputs (B=2, 512x512, %d classes): %d warm-up + %d timed fwd+bwd steps of "
+                      "oracle/segofa_ref.py, fp32, %d host threads, %.2f s per step" % (nseg, warm, timed, torch.get_num_threads(), dt)}
+
+
+def _self_spawn(n, argv):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU"""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    shared = os.environ.get("IFSEG_DIST_BACKEND") == "gloo" and os.environ.get("IFSEG_ALLOW_SHARED_GPU") == "1"
+    if ndev < n and not shared:
+        sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible on this box -- one rank per GPU is required (functional "
+                         "runs of N ranks on one GPU: IFSEG_DIST_BACKEND=gloo IFSEG_ALLOW_SHARED_GPU=1)\n" % (n, ndev))
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 PROF_STRIDE = 3
 
 
+TRAFFIC_JSON = os.environ.get("IFSEG_TRAFFIC_JSON", "profiles/round2_hbm_traffic.json")
+
+
 def _pmc_traffic(kind):
-    """HBM bytes per launch of a kernel family from the committed PMC collection (profiles/round1_hbm_traffic.json:
-    separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE); None if not collected"""
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_hbm_traffic.json")) as f:
-            return json.load(f)[kind]["bytes_per_launch"]
-    except Exception:
-        return None
+    """HBM bytes per launch of a kernel family.  NOT measured in this run: read from the committed PMC collection
+    (TRAFFIC_JSON: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 x2 correction on
+    FETCH_SIZE, tools/pmc_traffic.sh); the bench line names the file in `traffic_source`.  None if not collected."""
+    for rel in (TRAFFIC_JSON, "profiles/round1_hbm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                return json.load(f)[kind]["bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
+def _traffic_source():
+    for rel in (TRAFFIC_JSON, "profiles/round1_hbm_traffic.json"):
+        if os.path.exists(os.path.join(ROOT, rel)):
+            return rel + " (rocprofv3 --pmc passes of this command, committed; not collected in this run)"
+    return None
+
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _one_roofline(r, steps):
+    """one kernel family from a profiling pass after the timed region (event pairs around every launch of the family)"""
+    sec = r["ms"] * 1e-3
+    if r["kind"].startswith("ln_"):         # HBM-bound row kernels: algorithmic bytes / time vs 8 TB/s
+        ach = r["bytes"] / sec / 1e9 if sec > 0 else 0.0
+        return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / max(1, r["launches"]), 2),
+                "ms_per_step": round(r["ms"] / max(1, steps), 3), "traffic": _pmc_traffic(r["kind"])}
+    ach = r["flops"] / sec / 1e12 if sec > 0 else 0.0
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TF, 4),
+            "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / max(1, r["launches"]), 2),
+            "ms_per_step": round(r["ms"] / max(1, steps), 3), "traffic": _pmc_traffic(r["kind"])}
 
 
 def _group_roofline(rs, steps):
@@ -77,8 +140,8 @@ def _group_roofline(rs, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--nseg", type=int, default=15)
     ap.add_argument("--dropout", type=float, default=0.1, help="dropout (coco_unseen.sh:22)")
@@ -90,6 +153,11 @@ def main():
                          "(EmbeddingBag patches, no trunk) + a no-grad pass over the real images for the metrics")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        _self_spawn(a.gpus, sys.argv[1:])
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %s rank(s)\n" % (a.gpus, os.environ.get("WORLD_SIZE", "1")))
+        sys.exit(2)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -192,6 +260,13 @@ def main():
         one_step()
     torch.cuda.synchronize()
     grs = [hip.prof_read(k) for k in gk]
+    # third view: every other family on its own (attention forward / dQ / dK,dV, LayerNorm), same method
+    ok_ = [k for k in range(len(hip.PROF_KINDS)) if k not in gk]
+    hip.prof_reset(); hip.prof_enable(sum(1 << k for k in ok_))
+    for _ in range(extra):
+        one_step()
+    torch.cuda.synchronize()
+    ors = [hip.prof_read(k) for k in ok_]
     hip.prof_enable(0)
     loss = float(logs[-1]["loss"])
     if rank == 0:
@@ -210,10 +285,12 @@ def main():
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "loss": round(loss, 4)},
             "roofline": {"bound": "mfma", "kernel": dom["kind"], "achieved": round(ach, 2), "peak": MFMA_PEAK_TF,
                          "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": dom["traffic"],
+                         "traffic_source": _traffic_source(),
                          "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(1, dom["launches"]), 2),
                          "sampled": "every %d. launch timed with a HIP event pair on its stream" % PROF_STRIDE,
                          "whole_step_frac": round(value / world * GF_PER_IMG.get(a.nseg, 912.0) / 1e3 / MFMA_PEAK_TF, 4)},
             "roofline_gemm_kernel": _group_roofline(grs, extra),
+            "roofline_other_kernels": {r["kind"]: _one_roofline(r, extra) for r in ors},
             "kernel_families_ms_per_step": {f["kind"]: round(f["ms"], 3) for f in fam},
         }
         if not a.no_cpu_baseline and world == 1:

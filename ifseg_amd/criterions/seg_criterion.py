@@ -248,6 +248,11 @@ class SegCriterion(CriterionBase):
                 and self.num_seg <= 192 and target.shape[1] == h * w + 1):
             if not hasattr(self, bufs_name):
                 setattr(self, bufs_name, {})
+            lo, hi = self.seg_id_offset, self.seg_id_offset + self.num_seg
+            model.engine.deferred_check(
+                target, lambda t: (((t < lo) | (t > hi)) & (t != PAD) & (t != EOS)).any(),
+                "seg_criterion: target label outside [<seg_0>, <seg_%d>] (F.cross_entropy: target out of bounds)" % self.num_seg,
+                exc=IndexError)
             loss, stats = _FusedSegLossFn.apply(scores_low, pad, target.contiguous(), hp, wp, h, w, self.num_seg,
                                                 self.seg_id_offset, getattr(self, bufs_name))
             n = self.num_seg

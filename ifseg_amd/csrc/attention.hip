@@ -45,7 +45,7 @@ struct AttnArgs {
   float *dpq, *dpk;          // [B, T, H*64] / [B, S, H*64] fp32 per-batch partials
   float *drel2d_part, *drel1d_part, *drelx_part;  // [H][nparts][n]
   int nparts;
-  const bf16_t* gain;         // [H] per-head output gain c_attn (bf16 parameter; may be null)
+  const float* gain;          // [H] per-head output gain c_attn (fp32: the optimizer's master copy; may be null)
   float dq_scale, dpq_scale;
   int grid_w;                 // width of the token grid (row-aligned diagonal reduction when 32)
 };
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
   // ---- finalize: lane (q, half) holds O[q][d = db*32 + (r&3) + 8*(r>>2) + 4*half]
   const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = (l_tot > 0.f ? 1.f / l_tot : 0.f) * (a.gain ? bf2f(a.gain[h]) : 1.f);
+  const float inv = (l_tot > 0.f ? 1.f / l_tot : 0.f) * (a.gain ? a.gain[h] : 1.f);
   if (qvalid) {
     bf16_t* op = a.o + (long long)b * a.o_bs + (long long)qi * a.ldo + h * 64;
 #pragma unroll
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   const bool kvalid = kj < a.S;
   const int krow = kvalid ? kj : a.S - 1;
   constexpr int NKS = HAS_POS ? 8 : 4;
-  const float gain = a.gain ? bf2f(a.gain[h]) : 1.f;
+  const float gain = a.gain ? a.gain[h] : 1.f;
 
   bf16x8 kf[NKS];
   {
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const bool qvalid = qi < a.T;
   const int qrow = qvalid ? qi : a.T - 1;
   constexpr int NKS = HAS_POS ? 8 : 4;
-  const float gain = a.gain ? bf2f(a.gain[h]) : 1.f;
+  const float gain = a.gain ? a.gain[h] : 1.f;
 
   bf16x8 qf[NKS], dof[4];
   {
@@ -1111,7 +1111,7 @@ extern "C" int ifseg_attn_fwd(const void* q, const void* k, const void* v, const
   a.B = B; a.H = H; a.T = T; a.S = S; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.ldpq = ldpq; a.ldpk = ldpk; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
   a.rel_mode = rel_mode; a.P = P; a.gcode = gcode; a.code_bias = code_bias; a.n2d = rel_mode ? n2d : 0;
-  a.Lt = T - P; a.rel2d = rel2d; a.rel1d = rel1d; a.relx = relx; a.causal = causal; a.dense = dense_bias; a.gain = (const bf16_t*)gain;
+  a.Lt = T - P; a.rel2d = rel2d; a.rel1d = rel1d; a.relx = relx; a.causal = causal; a.dense = dense_bias; a.gain = (const float*)gain;
   if (!rel_mode && !causal) a.P = S;
   int rc = attn_check(a);
   if (rc) return rc;
@@ -1150,7 +1150,7 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   a.dq_bs = x->dq_bs; a.dk_bs = x->dk_bs; a.dv_bs = x->dv_bs; a.lddq = x->lddq; a.lddk = x->lddk; a.lddv = x->lddv;
   a.dpq = x->dpos_q_part; a.dpk = x->dpos_k_part;
   a.drel2d_part = x->drel2d_part; a.drel1d_part = x->drel1d_part; a.drelx_part = x->drelx_part;
-  a.nparts = x->nparts; a.gain = (const bf16_t*)x->gain; a.dq_scale = x->dq_scale; a.dpq_scale = x->dpq_scale;
+  a.nparts = x->nparts; a.gain = (const float*)x->gain; a.dq_scale = x->dq_scale; a.dpq_scale = x->dpq_scale;
   a.grid_w = x->grid_w;
   if (!a.rel_mode && !a.causal) a.P = a.S;
   int rc = attn_check(a);

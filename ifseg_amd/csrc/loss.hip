@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256) void seg_loss_tile_kernel(const bf16_t* logits
     return v;
   };
   const long long tg = target[b * tbs + (long long)(cy * TS + py) * W + (cx * TS + px)];
-  const bool valid = !(tg == pad_id || tg == eos_id || tg == seg0 + nseg);
+  // labels outside [seg0, seg0 + nseg) that are not pad / eos / ignore would index the LDS histograms out of bounds:
+  // they are dropped here and reported by the criterion's (deferred) range check -- F.cross_entropy raises on them
+  const bool valid = !(tg == pad_id || tg == eos_id || tg == seg0 + nseg) && tg >= seg0 && tg < seg0 + nseg;
   const int label = valid ? (int)(tg - seg0) : 0;
   float m = -INFINITY, sum = 0.f, vl = 0.f;
   int pred = 0;

@@ -41,8 +41,14 @@ __global__ void finish_norm_kernel(const float* part, int nparts, float* out_sum
 __global__ __launch_bounds__(256) void adam_kernel(float* p32, const bf16_t* g, float* m, float* v, bf16_t* p16,
                                                    long long n, float lr, float beta1, float beta2, float eps, float wd,
                                                    float bc1, float bc2, float gscale, float max_norm,
-                                                   const float* sumsq) {
+                                                   const float* sumsq, int* overflow) {
   float coef = gscale;
+  if (sumsq && !isfinite(sumsq[0])) {
+    // trainer.py:895-904: a NaN / Inf gradient norm must not reach the fp32 masters or the Adam moments
+    // (fminf(1, NaN) would evaluate to 1 and apply the poisoned step): skip the update, raise the flag
+    if (overflow && blockIdx.x == 0 && threadIdx.x == 0) overflow[0] = 1;
+    return;
+  }
   if (max_norm > 0.f && sumsq) {
     const float norm = sqrtf(sumsq[0]) * gscale;
     coef *= fminf(1.f, max_norm / (norm + 1e-6f));
@@ -94,12 +100,12 @@ extern "C" int ifseg_grad_sumsq_bf16(const void* g, long long n, float* workspac
 
 extern "C" int ifseg_adam_step(float* p32, const void* g, float* m, float* v, void* p16, long long n, float lr,
                                float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                               float max_norm, const float* sumsq, void* stream) {
+                               float max_norm, const float* sumsq, int* overflow, void* stream) {
   (void)hipGetLastError();
   if (n <= 0) return 0;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, p32, (const bf16_t*)g, m, v,
-                     (bf16_t*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, max_norm, sumsq);
+                     (bf16_t*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, max_norm, sumsq, overflow);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

@@ -73,13 +73,25 @@ __device__ __forceinline__ void drop8(float* f, const DropArgs& d, long long c8,
   }
 }
 
+// LayerNorm gains / biases: bf16 (the model's arena) or fp32 (the fp32 master copy: rounding gamma / beta of ~50
+// LayerNorms to bf16 alone costs 0.9e-2 of logits rel-L2 on SegOFA-Base, tools/err_budget2.py); wave-uniform choice
+__device__ __forceinline__ void ldp8(const bf16_t* p, int c, int pf32, float* o) {
+  if (pf32) {
+    const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + c * 8);
+    const float4 a = q[0], b = q[1];
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  } else {
+    unpack8(*reinterpret_cast<const uint4*>(p + c * 8), o);
+  }
+}
+
 // y = [resid +] drop(LN(act(x)) * gamma + beta) ; one wave per row, NCH 8-element chunks per lane
 template <int NCH, bool GELU>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const bf16_t* gamma, const bf16_t* beta,
                                                      const bf16_t* resid, bf16_t* y, float* mean, float* rstd,
                                                      int rows, int C, float eps, RowMap mx, RowMap my, RowMap mr,
                                                      DropArgs drop, const bf16_t* gamma2, const bf16_t* beta2, bf16_t* y2,
-                                                     float* mean2, float* rstd2, RowMap my2) {
+                                                     float* mean2, float* rstd2, RowMap my2, int pf32) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nch = C >> 3;
@@ -122,8 +134,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const bf16
       float o[8];
       if (gamma) {
         float g[8], b[8];
-        unpack8(*reinterpret_cast<const uint4*>(gamma + c * 8), g);
-        unpack8(*reinterpret_cast<const uint4*>(beta + c * 8), b);
+        ldp8(gamma, c, pf32, g);
+        ldp8(beta, c, pf32, b);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
       } else {
@@ -168,8 +180,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const bf16
       const int c = lane + i * 64;
       if (c < nch) {
         float g[8], b[8], o[8];
-        unpack8(*reinterpret_cast<const uint4*>(gamma2 + c * 8), g);
-        unpack8(*reinterpret_cast<const uint4*>(beta2 + c * 8), b);
+        ldp8(gamma2, c, pf32, g);
+        ldp8(beta2, c, pf32, b);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu2) * rs2 * g[e] + b[e];
         *reinterpret_cast<uint4*>(y2p + c * 8) = pack8(o);
@@ -187,7 +199,7 @@ template <int NCH, bool GELU, int WPR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
                                                      const float* mean, const float* rstd, const bf16_t* dx_add,
                                                      bf16_t* dx, float* dgamma_part, float* dbeta_part, int rows, int C,
-                                                     RowMap mdy, RowMap mx, RowMap mdx, RowMap madd, DropArgs drop) {
+                                                     RowMap mdy, RowMap mx, RowMap mdx, RowMap madd, DropArgs drop, int pf32) {
   __shared__ float red[(WPR == 1) ? 4 * (64 * 8 + 8) : 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C >> 3;
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = tl + i * TS;
-    if (c < nch) unpack8(*reinterpret_cast<const uint4*>(gamma + c * 8), gam[i]);
+    if (c < nch) ldp8(gamma, c, pf32, gam[i]);
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; if (c >= nch) gam[i][e] = 0.f; }
   }
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
 __global__ __launch_bounds__(256) void ln_bwd_drop_kernel(
     const bf16_t* dy, const bf16_t* x, const bf16_t* gamma, const float* mean, const float* rstd, const bf16_t* dx_add,
     bf16_t* dx, float* dgamma_part, float* dbeta_part, bf16_t* dx2, int rows, int C, RowMap mdy, RowMap mx, RowMap mdx,
-    RowMap madd, RowMap mdx2, DropArgs drop2) {
+    RowMap madd, RowMap mdx2, DropArgs drop2, int pf32) {
   constexpr int NCH = 2;
   __shared__ float red[4 * (64 * 8 + 8)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -332,7 +344,7 @@ __global__ __launch_bounds__(256) void ln_bwd_drop_kernel(
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + i * 64;
-    if (c < nch) unpack8(*reinterpret_cast<const uint4*>(gamma + c * 8), gam[i]);
+    if (c < nch) ldp8(gamma, c, pf32, gam[i]);
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; if (c >= nch) gam[i][e] = 0.f; }
   }
@@ -560,20 +572,22 @@ __global__ void nchw_to_nhwc_kernel(const TIN* in, bf16_t* out, int B, int Cc, i
 }
 
 template <int NCH>
-int launch_ln_fwd(bool gelu, dim3 g, hipStream_t s, const bf16_t* x, const bf16_t* gamma, const bf16_t* beta,
+int launch_ln_fwd(int gelu_flags, dim3 g, hipStream_t s, const bf16_t* x, const bf16_t* gamma, const bf16_t* beta,
                   const bf16_t* resid, bf16_t* y, float* mean, float* rstd, int rows, int C, float eps, RowMap mx,
                   RowMap my, RowMap mr, DropArgs dr, const bf16_t* g2 = nullptr, const bf16_t* b2 = nullptr, bf16_t* y2 = nullptr,
                   float* mean2 = nullptr, float* rstd2 = nullptr, RowMap my2 = RowMap{0, 0, 0}) {
-  if (gelu) hipLaunchKernelGGL((ln_fwd_kernel<NCH, true>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr, dr, g2, b2, y2, mean2, rstd2, my2);
-  else hipLaunchKernelGGL((ln_fwd_kernel<NCH, false>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr, dr, g2, b2, y2, mean2, rstd2, my2);
+  const int pf32 = (gelu_flags & IFSEG_LN_PARAMS_F32) ? 1 : 0;
+  if (gelu_flags & IFSEG_LN_GELU) hipLaunchKernelGGL((ln_fwd_kernel<NCH, true>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr, dr, g2, b2, y2, mean2, rstd2, my2, pf32);
+  else hipLaunchKernelGGL((ln_fwd_kernel<NCH, false>), g, dim3(256), 0, s, x, gamma, beta, resid, y, mean, rstd, rows, C, eps, mx, my, mr, dr, g2, b2, y2, mean2, rstd2, my2, pf32);
   return 0;
 }
 template <int NCH, int WPR>
-int launch_ln_bwd(bool gelu, dim3 g, hipStream_t s, const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
+int launch_ln_bwd(int gelu_flags, dim3 g, hipStream_t s, const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
                   const float* mean, const float* rstd, const bf16_t* add, bf16_t* dx, float* dgp, float* dbp, int rows,
                   int C, RowMap mdy, RowMap mx, RowMap mdx, RowMap madd, DropArgs dr) {
-  if (gelu) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, WPR>), g, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgp, dbp, rows, C, mdy, mx, mdx, madd, dr);
-  else hipLaunchKernelGGL((ln_bwd_kernel<NCH, false, WPR>), g, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgp, dbp, rows, C, mdy, mx, mdx, madd, dr);
+  const int pf32 = (gelu_flags & IFSEG_LN_PARAMS_F32) ? 1 : 0;
+  if (gelu_flags & IFSEG_LN_GELU) hipLaunchKernelGGL((ln_bwd_kernel<NCH, true, WPR>), g, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgp, dbp, rows, C, mdy, mx, mdx, madd, dr, pf32);
+  else hipLaunchKernelGGL((ln_bwd_kernel<NCH, false, WPR>), g, dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, dgp, dbp, rows, C, mdy, mx, mdx, madd, dr, pf32);
   return 0;
 }
 
@@ -617,12 +631,13 @@ extern "C" int ifseg_ln_fwd(const void* x, const void* gamma, const void* beta, 
 
 extern "C" int ifseg_ln_fwd_pair(const void* x, const void* gamma, const void* beta, const void* resid, void* y,
                                  float* mean, float* rstd, const void* gamma2, const void* beta2, void* y2, float* mean2,
-                                 float* rstd2, int rows, int C, float eps, int rpb, long long x_bs, int ldx, long long y_bs,
+                                 float* rstd2, int rows, int C, float eps, int flags, int rpb, long long x_bs, int ldx, long long y_bs,
                                  int ldy, long long r_bs, int ldr, long long y2_bs, int ldy2, const ifseg_drop_args* drop,
                                  void* stream) {
   if (!y2) return IFSEG_ERR_BAD_ARG;
   if (!gamma && beta) return IFSEG_ERR_BAD_ARG;
-  return ln_fwd_impl(x, gamma, beta, resid, y, mean, rstd, rows, C, eps, 0, rpb, x_bs, ldx, y_bs, ldy, r_bs, ldr, drop, gamma2,
+  if (flags & IFSEG_LN_GELU) return IFSEG_ERR_BAD_ARG;
+  return ln_fwd_impl(x, gamma, beta, resid, y, mean, rstd, rows, C, eps, flags, rpb, x_bs, ldx, y_bs, ldy, r_bs, ldr, drop, gamma2,
                      beta2, y2, mean2, rstd2, y2_bs, ldy2, stream);
 }
 
@@ -653,7 +668,7 @@ extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, co
 
 extern "C" int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
                                  const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, void* dx2, int nblocks,
-                                 int rows, int C, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx,
+                                 int rows, int C, int flags, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx,
                                  long long dx_bs, int lddx, long long add_bs, int ldadd, long long dx2_bs, int lddx2,
                                  const ifseg_drop_args* drop2, void* stream) {
   (void)hipGetLastError();
@@ -671,7 +686,7 @@ extern "C" int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamm
   ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 10.0 : 8.0));
   hipLaunchKernelGGL(ln_bwd_drop_kernel, dim3(nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
                      (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, dgamma_part, dbeta_part,
-                     (bf16_t*)dx2, rows, C, mdy, mx, mdx, madd, mdx2, dr);
+                     (bf16_t*)dx2, rows, C, mdy, mx, mdx, madd, mdx2, dr, (flags & IFSEG_LN_PARAMS_F32) ? 1 : 0);
   ifseg_prof_end(IFSEG_K_LN_BWD, s);
   IFSEG_CHECK_LAUNCH();
   return 0;

@@ -33,7 +33,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 6:
+        if _lib.ifseg_abi_version() != 7:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -195,6 +195,18 @@ class RelBias:
         self.rel2d, self.rel1d, self.relx = rel2d, rel1d, relx   # fp32 [H,n2d], [H,2Lt-1], [H,2]
 
 
+_F32_KEEP = []
+
+
+def _f32(t):
+    """[H] head gains are read as fp32 by the kernels; a bf16 tensor (tests) is converted (and kept alive until the next call)"""
+    if t is None or t.dtype == torch.float32:
+        return t
+    c = t.float()
+    _F32_KEEP[:] = [c]
+    return c
+
+
 def attn_fwd(q, k, v, pos_q, pos_k, out, lse, B, H, T, S, rel=None, causal=False, P=None, dense_bias=None,
              gain=None):
     """q/k/v/out: [B, T|S, *] bf16 row-strided views (head h at cols h*64..); pos_q/pos_k: [T|S, H*64]."""
@@ -233,7 +245,7 @@ def attn_fwd_gain(q, k, v, pos_q, pos_k, out, lse, B, H, T, S, rel=None, causal=
                           c_int(rel.rel2d.shape[1] if rel is not None else 0),
                           _ptr(rel.rel2d) if rel is not None else None, _ptr(rel.rel1d) if rel is not None else None,
                           _ptr(rel.relx) if rel is not None else None, c_int(1 if causal else 0), _ptr(dense_bias),
-                          _ptr(gain), c_int(rel.grid_w if rel is not None else 0), _stream())
+                          _ptr(_f32(gain)), c_int(rel.grid_w if rel is not None else 0), _stream())
     _check(rc, "attn_fwd")
     return out
 
@@ -251,7 +263,7 @@ def attn_bwd(q, k, v, pos_q, pos_k, out, dout, lse, delta, dq, dk, dv, dpq_part,
         P = S
     for name, t in (("q", q), ("k", k), ("v", v), ("pos_q", pos_q), ("pos_k", pos_k), ("out", out), ("dout", dout),
                     ("lse", lse), ("delta", delta), ("dq", dq), ("dk", dk), ("dv", dv), ("dpos_q_part", dpq_part),
-                    ("dpos_k_part", dpk_part), ("gain", gain), ("drel2d_part", drel2d_part),
+                    ("dpos_k_part", dpk_part), ("gain", _f32(gain)), ("drel2d_part", drel2d_part),
                     ("drel1d_part", drel1d_part), ("drelx_part", drelx_part)):
         setattr(a, name, _p(t))
     a.B, a.H, a.T, a.S = B, H, T, S
@@ -295,6 +307,16 @@ def _drop_ref(drop, rows):
     return ctypes.byref(_DropArgs(p, seed & 0xFFFFFFFFFFFFFFFF, dps.data_ptr() if dps is not None else None, rpb or rows))
 
 
+def _ln_flags(gamma, gelu=False, other=None):
+    """IFSEG_LN_GELU | IFSEG_LN_PARAMS_F32 (gains / biases given as fp32 tensors: the master copy)"""
+    f32 = gamma is not None and gamma.dtype == torch.float32
+    if other is not None and gamma is not None:
+        assert (other.dtype == torch.float32) == f32
+    elif other is not None:
+        f32 = other.dtype == torch.float32
+    return (1 if gelu else 0) | (2 if f32 else 0)
+
+
 def ln_fwd(x, gamma, beta, y, mean=None, rstd=None, resid=None, gelu=False, eps=1e-5, drop=None):
     """x, y, resid: [rows, C] or [B, rpb, C] (strided views allowed, last dim contiguous).
     drop: fused dropout/DropPath of the normalised output before the residual add (see _drop_ref)."""
@@ -305,7 +327,7 @@ def ln_fwd(x, gamma, beta, y, mean=None, rstd=None, resid=None, gelu=False, eps=
     yb, yl = _map(y, rpb)
     rb, rl = _map(resid, rpb)
     rc = lib().ifseg_ln_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(resid), _ptr(y), _ptr(mean), _ptr(rstd),
-                            c_int(rows), c_int(C), c_float(eps), c_int(1 if gelu else 0), c_int(rpb), c_ll(xb),
+                            c_int(rows), c_int(C), c_float(eps), c_int(_ln_flags(gamma, gelu)), c_int(rpb), c_ll(xb),
                             c_int(xl), c_ll(yb), c_int(yl), c_ll(rb), c_int(rl), _drop_ref(drop, rpb or rows), _stream())
     _check(rc, "ln_fwd")
     return y
@@ -322,7 +344,7 @@ def ln_fwd_pair(x, gamma, beta, y, mean, rstd, gamma2, beta2, y2, mean2, rstd2, 
     y2b, y2l = _map(y2, rpb)
     rc = lib().ifseg_ln_fwd_pair(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(resid), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(gamma2),
                                  _ptr(beta2), _ptr(y2), _ptr(mean2), _ptr(rstd2), c_int(rows), c_int(C), c_float(eps),
-                                 c_int(rpb), c_ll(xb), c_int(xl), c_ll(yb), c_int(yl), c_ll(rb), c_int(rl), c_ll(y2b),
+                                 c_int(_ln_flags(gamma, False, gamma2)), c_int(rpb), c_ll(xb), c_int(xl), c_ll(yb), c_int(yl), c_ll(rb), c_int(rl), c_ll(y2b),
                                  c_int(y2l), _drop_ref(drop, rpb or rows), _stream())
     _check(rc, "ln_fwd_pair")
     return y, y2
@@ -344,7 +366,7 @@ def ln_bwd_drop(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx2, dx_a
     o2b, o2l = _map(dx2, rpb)
     rc = lib().ifseg_ln_bwd_drop(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx_add), _ptr(dx),
                                  _ptr(dgamma_part), _ptr(dbeta_part), _ptr(dx2), c_int(LN_BWD_BLOCKS), c_int(rows), c_int(C),
-                                 c_int(rpb), c_ll(db_), c_int(dl), c_ll(xb), c_int(xl), c_ll(ob), c_int(ol), c_ll(ab),
+                                 c_int(_ln_flags(gamma)), c_int(rpb), c_ll(db_), c_int(dl), c_ll(xb), c_int(xl), c_ll(ob), c_int(ol), c_ll(ab),
                                  c_int(al), c_ll(o2b), c_int(o2l), _drop_ref(drop2, rpb or rows), _stream())
     _check(rc, "ln_bwd_drop")
     return dx, dx2
@@ -360,7 +382,7 @@ def ln_bwd(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx_add=None, g
     ab, al = _map(dx_add, rpb)
     rc = lib().ifseg_ln_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx_add), _ptr(dx),
                             _ptr(dgamma_part), _ptr(dbeta_part), c_int(LN_BWD_BLOCKS), c_int(rows), c_int(C),
-                            c_int(1 if gelu else 0), c_int(rpb), c_ll(db_), c_int(dl), c_ll(xb), c_int(xl), c_ll(ob),
+                            c_int(_ln_flags(gamma, gelu)), c_int(rpb), c_ll(db_), c_int(dl), c_ll(xb), c_int(xl), c_ll(ob),
                             c_int(ol), c_ll(ab), c_int(al), _drop_ref(drop, rpb or rows), _stream())
     _check(rc, "ln_bwd")
     return dx
@@ -448,10 +470,10 @@ def grad_sumsq(g, workspace, out):
     return out
 
 
-def adam_step(p32, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, max_norm=0.0, sumsq=None):
+def adam_step(p32, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, max_norm=0.0, sumsq=None, overflow=None):
     _check(lib().ifseg_adam_step(_ptr(p32), _ptr(g), _ptr(m), _ptr(v), _ptr(p16), c_ll(p32.numel()), c_float(lr),
                                  c_float(beta1), c_float(beta2), c_float(eps), c_float(wd), c_int(step),
-                                 c_float(grad_scale), c_float(max_norm), _ptr(sumsq), _stream()), "adam")
+                                 c_float(grad_scale), c_float(max_norm), _ptr(sumsq), _ptr(overflow), _stream()), "adam")
 
 
 def rel_gather(table, idx, out):

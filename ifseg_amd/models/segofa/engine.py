@@ -63,7 +63,8 @@ class HipEngine:
         self.step_seed = 0               # set by the trainer (seed + num_updates, trainer.py:1297)
         # backward: everything that only produces PARAMETER gradients (dW GEMMs, bias / LayerNorm / table
         # reductions) is enqueued on a second HIP stream and overlaps the dX chain on the main stream
-        self._pending_checks, self._checked_once = [], False
+        self._pending_checks, self._checked_kinds = [], set()
+        self.master_owned = False        # True once the bundled Trainer updates `master` and `p16` together
         self.overlap = os.environ.get("IFSEG_NO_OVERLAP") is None
         self.delta_fused = os.environ.get("IFSEG_NO_DELTA_FUSE") is None     # delta from the out_proj dX GEMM's epilogue
         self._side = None
@@ -169,6 +170,13 @@ class HipEngine:
             p16[o:o + v.numel()] = v.to(BF)
             p.data = p16[o:o + v.numel()].view(p.shape)
         self.p16, self.g16, self.master_init = p16, g16, master
+        # fp32 copy of the trainable part of the arena.  The bundled Trainer runs Adam on it (`master_owned`); the kernels
+        # read the SMALL parameters whose bf16 rounding is coherent per channel -- LayerNorm gains / biases and the
+        # per-head c_attn gains -- from here (`Wf`): their rounding alone costs 1.0e-2 of logits rel-L2 on SegOFA-Base
+        # (tools/err_budget2.py).  With an external optimizer (fairseq's, writing the bf16 parameters) the copy is
+        # refreshed from the arena after every backward, i.e. the values are then the bf16 ones.
+        self.master = master
+        self._master_stale = False
         self.offs, self.n_train, self.order = offs, n_train, order
         self.shapes = {n: tuple(names[n].shape) for n in order}
         self.names = names
@@ -200,6 +208,16 @@ class HipEngine:
         if v is None:
             o, sh = self.offs[n], self.shapes[n]
             v = self._views[n] = self.p16[o:o + math.prod(sh)].view(sh)
+        return v
+
+    def Wf(self, n):
+        """fp32 view of a trainable parameter in the master copy (LayerNorm gains / biases, c_attn)"""
+        v = self._views.get(("f", n))
+        if v is None:
+            o, sh = self.offs[n], self.shapes[n]
+            if o >= self.n_train:
+                raise KeyError("%s is not in the fp32 master copy (frozen parameter)" % n)
+            v = self._views[("f", n)] = self.master[o:o + math.prod(sh)].view(sh)
         return v
 
     def G(self, n):
@@ -559,7 +577,7 @@ class HipEngine:
         return self.buf(tag + "_mu", (rows,), torch.float32), self.buf(tag + "_rs", (rows,), torch.float32)
 
     def _gain32(self, tag, name):
-        return self.W(name)        # the kernels read the bf16 parameter directly
+        return self.Wf(name)       # fp32 [H] from the master copy
 
     # ----------------------------------------------------------------- forward
     def forward(self, *args, **kw):
@@ -568,6 +586,10 @@ class HipEngine:
         aux = (not need_grad) and self._gctx is not None
         self.ws, self.saved = (self._ws_aux, self._saved_aux) if aux else (self._ws_grad, self._saved_grad)
         try:
+            if self._master_stale and self.packed and not self.master_owned:
+                # an external optimizer stepped the bf16 parameters since the last forward
+                self.master.copy_(self.p16[: self.n_train])      # parameter plumbing (dtype copy), no activation involved
+                self._master_stale = False
             out = self._forward(*args, **kw)
             if need_grad:
                 self._gctx = self.ctx
@@ -586,9 +608,10 @@ class HipEngine:
             return self._backward(dlogits)
         finally:
             self._gctx = None
+            self._master_stale = not self.master_owned
             hip.set_stream(prev)
 
-    def deferred_check(self, tensor, bad, message):
+    def deferred_check(self, tensor, bad, message, exc=NotImplementedError):
         """Input validation without a device sync: `bad(tensor)` (a 0-d bool tensor) is evaluated on the stream and read
         back once its event has completed -- at the latest by the next call, i.e. the error surfaces one step late instead
         of draining the queue on every step (each batch is a new tensor, so a cache keyed on the tensor never hits with a
@@ -597,7 +620,7 @@ class HipEngine:
             return                                 # a captured forward replays validated inputs (checked at warm-up)
         if os.environ.get("IFSEG_SYNC_CHECKS"):
             if bool(bad(tensor)):
-                raise NotImplementedError(message)
+                raise exc(message)
             return
         pend = self._pending_checks
         keep = []
@@ -605,7 +628,7 @@ class HipEngine:
             if ev.query():
                 if bool(flag):
                     self._pending_checks = []
-                    raise NotImplementedError(msg)
+                    raise msg[1](msg[0])
             else:
                 keep.append((flag, ev, msg))
         if len(keep) > 8:                      # never let the list grow: settle the oldest
@@ -613,16 +636,16 @@ class HipEngine:
             ev.synchronize()
             if bool(flag):
                 self._pending_checks = []
-                raise NotImplementedError(msg)
+                raise msg[1](msg[0])
         flag = bad(tensor)
-        if not self._checked_once:
-            self._checked_once = True
+        if message not in self._checked_kinds:  # the first call of every kind of check is synchronous
+            self._checked_kinds.add(message)
             if bool(flag):
-                raise NotImplementedError(message)
+                raise exc(message)
         else:
             ev = torch.cuda.Event()
             ev.record()
-            keep.append((flag, ev, message))
+            keep.append((flag, ev, (message, exc)))
         self._pending_checks = keep
 
     def _forward(self, src_tokens, patch_images, prev_output_tokens=None, full_context_alignment=False,
@@ -641,7 +664,7 @@ class HipEngine:
         B, L = src_tokens.shape
         C, Fd, H = cfg.embed_dim, cfg.ffn_dim, cfg.heads
         scaling = float(cfg.head_dim * cfg.attn_scale_factor) ** -0.5
-        W, buf = self.W, self.buf
+        W, Wf, buf = self.W, self.Wf, self.buf
         if bag is not None:
             feat, h, w = None, cfg.patch_image_size // 16, cfg.patch_image_size // 16     # encoder_module.py:540
             if bag[1].numel() != B * h * w:
@@ -680,22 +703,22 @@ class HipEngine:
             hip.linear_fwd(feat.view(B * P, 1024), W(e + "image_proj.weight"), bias_img, out=img_pre)
         x = buf("e_x_in", (B, T, C))
         mu, rs = self._ln_stats("img_ln", B * P)
-        hip.ln_fwd(img_pre.view(B, P, C), W(e + "patch_layernorm_embedding.weight"),
-                   W(e + "patch_layernorm_embedding.bias"), x[:, :P], mu, rs, drop=self._dropargs(1))
+        hip.ln_fwd(img_pre.view(B, P, C), Wf(e + "patch_layernorm_embedding.weight"),
+                   Wf(e + "patch_layernorm_embedding.bias"), x[:, :P], mu, rs, drop=self._dropargs(1))
         tok_pre = buf("tok_pre", (B * L, C))
         hip.embed_rows(W(e + "embed_tokens.weight"), src_tokens.reshape(-1).contiguous(),
                        W(e + "type_embedding.weight")[0], tok_pre)
         mu, rs = self._ln_stats("tok_ln", B * L)
-        hip.ln_fwd(tok_pre.view(B, L, C), W(e + "layernorm_embedding.weight"), W(e + "layernorm_embedding.bias"),
+        hip.ln_fwd(tok_pre.view(B, L, C), Wf(e + "layernorm_embedding.weight"), Wf(e + "layernorm_embedding.bias"),
                    x[:, P:], mu, rs, drop=self._dropargs(2))
         # ---- abs-pos operands (encoder_module.py:757-771): LN over the table rows in place
         bsz = cfg.image_bucket_size
         img_pos_view = W(e + "embed_image_positions.weight")[1:1 + bsz * h].view(h, bsz, C)[:, :w]
         pos_all = buf("e_pos_all", (T, C))
         mu, rs = self._ln_stats("ipos_ln", P)
-        hip.ln_fwd(img_pos_view, W(e + "image_pos_ln.weight"), W(e + "image_pos_ln.bias"), pos_all[:P].view(h, w, C), mu, rs)
+        hip.ln_fwd(img_pos_view, Wf(e + "image_pos_ln.weight"), Wf(e + "image_pos_ln.bias"), pos_all[:P].view(h, w, C), mu, rs)
         mu, rs = self._ln_stats("tpos_ln", L)
-        hip.ln_fwd(W(e + "embed_positions.weight")[:L], W(e + "pos_ln.weight"), W(e + "pos_ln.bias"), pos_all[P:], mu, rs)
+        hip.ln_fwd(W(e + "embed_positions.weight")[:L], Wf(e + "pos_ln.weight"), Wf(e + "pos_ln.bias"), pos_all[P:], mu, rs)
         pqk = buf("e_pqk", (T, 2 * C))
         hip.linear_fwd(pos_all, self._fused(self.p16, e + "pos_q_linear.weight", 2 * C, C),
                        self._fused(self.p16, e + "pos_q_linear.bias", 2 * C), out=pqk, alpha=scaling, alpha_ncols=C)
@@ -722,7 +745,7 @@ class HipEngine:
         enc_out = buf("enc_out", (B, T, C))
         if x_pre is None:
             mu, rs = self._ln_stats("e_final_ln", B * T)
-            hip.ln_fwd(x.view(B * T, C), W(e + "layer_norm.weight"), W(e + "layer_norm.bias"), enc_out.view(B * T, C), mu, rs)
+            hip.ln_fwd(x.view(B * T, C), Wf(e + "layer_norm.weight"), Wf(e + "layer_norm.bias"), enc_out.view(B * T, C), mu, rs)
         ctx["e_x_final"] = x
         ctx["enc_out"] = enc_out
 
@@ -746,19 +769,19 @@ class HipEngine:
         hip.embed_rows(W(e + "embed_tokens.weight"), bos.reshape(-1).contiguous(), None, y0b)
         y = buf("d_y_in", (B, Td, C))
         mu, rs = self._ln_stats("d_emb_ln_p", B * P)
-        hip.ln_fwd(enc_out[:, :P], W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), y[:, :P],
+        hip.ln_fwd(enc_out[:, :P], Wf(d + "layernorm_embedding.weight"), Wf(d + "layernorm_embedding.bias"), y[:, :P],
                    mu, rs, drop=self._dropargs(3))
         mu, rs = self._ln_stats("d_emb_ln_b", B)
-        hip.ln_fwd(y0b, W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), y[:, P:], mu, rs,
+        hip.ln_fwd(y0b, Wf(d + "layernorm_embedding.weight"), Wf(d + "layernorm_embedding.bias"), y[:, P:], mu, rs,
                    drop=self._dropargs(4))
         # positions: internal order [grid cells 1..P | slot 0]
         sb = cfg.seg_bucket_size
         segtab = W(d + "embed_seg_positions.weight")
         tp = buf("d_tp", (Td, C))
         mu, rs = self._ln_stats("d_tp_ln_p", P)
-        hip.ln_fwd(segtab[1:1 + P], W(d + "seg_pos_ln.weight"), W(d + "seg_pos_ln.bias"), tp[:P], mu, rs)
+        hip.ln_fwd(segtab[1:1 + P], Wf(d + "seg_pos_ln.weight"), Wf(d + "seg_pos_ln.bias"), tp[:P], mu, rs)
         mu, rs = self._ln_stats("d_tp_ln_b", 1)
-        hip.ln_fwd(segtab[:1], W(d + "seg_pos_ln.weight"), W(d + "seg_pos_ln.bias"), tp[P:], mu, rs)
+        hip.ln_fwd(segtab[:1], Wf(d + "seg_pos_ln.weight"), Wf(d + "seg_pos_ln.bias"), tp[P:], mu, rs)
         spqk = buf("d_spqk", (Td, 2 * C))
         hip.linear_fwd(tp, self._fused(self.p16, d + "self_pos_q_linear.weight", 2 * C, C),
                        self._fused(self.p16, d + "self_pos_q_linear.bias", 2 * C), out=spqk, alpha=scaling, alpha_ncols=C)
@@ -788,9 +811,9 @@ class HipEngine:
         # final LN written in reference order [bos, patches] (decoder_module.py:668-675)
         featb = buf("d_feat", (B, Td, C))
         mu, rs = self._ln_stats("d_final_ln_p", B * P)
-        hip.ln_fwd(y[:, :P], W(d + "layer_norm.weight"), W(d + "layer_norm.bias"), featb[:, 1:], mu, rs)
+        hip.ln_fwd(y[:, :P], Wf(d + "layer_norm.weight"), Wf(d + "layer_norm.bias"), featb[:, 1:], mu, rs)
         mu, rs = self._ln_stats("d_final_ln_b", B)
-        hip.ln_fwd(y[:, P:], W(d + "layer_norm.weight"), W(d + "layer_norm.bias"), featb[:, :1], mu, rs)
+        hip.ln_fwd(y[:, P:], Wf(d + "layer_norm.weight"), Wf(d + "layer_norm.bias"), featb[:, :1], mu, rs)
         logits = buf("logits_pad", (B, Td, self.npad))
         hip.linear_fwd(featb.view(B * Td, C), self.wseg_pad, out=logits.view(B * Td, self.npad))   # :290-294
         self.ctx = ctx
@@ -810,7 +833,7 @@ class HipEngine:
         the trained grid.  The dense biases are built with a few PyTorch ops on PARAMETER-sized tensors
         (no activation is touched); every activation op is still a HIP kernel."""
         cfg, dev = self.cfg, self.device
-        W, buf = self.W, self.buf
+        W, Wf, buf = self.W, self.Wf, self.buf
         self.drop_on = False
         B, L = src_tokens.shape
         C, H = cfg.embed_dim, cfg.heads
@@ -828,12 +851,12 @@ class HipEngine:
         img_pre = buf("img_pre", (B * P, C))
         hip.linear_fwd(feat.view(B * P, 1024), W(e + "image_proj.weight"), bias_img, out=img_pre)
         x = buf("e_x_in", (B, T, C))
-        hip.ln_fwd(img_pre.view(B, P, C), W(e + "patch_layernorm_embedding.weight"),
-                   W(e + "patch_layernorm_embedding.bias"), x[:, :P])
+        hip.ln_fwd(img_pre.view(B, P, C), Wf(e + "patch_layernorm_embedding.weight"),
+                   Wf(e + "patch_layernorm_embedding.bias"), x[:, :P])
         tok_pre = buf("tok_pre", (B * L, C))
         hip.embed_rows(W(e + "embed_tokens.weight"), src_tokens.reshape(-1).contiguous(),
                        W(e + "type_embedding.weight")[0], tok_pre)
-        hip.ln_fwd(tok_pre.view(B, L, C), W(e + "layernorm_embedding.weight"), W(e + "layernorm_embedding.bias"), x[:, P:])
+        hip.ln_fwd(tok_pre.view(B, L, C), Wf(e + "layernorm_embedding.weight"), Wf(e + "layernorm_embedding.bias"), x[:, P:])
         # ---- position embeddings (get_patch_images_info :358-370)
         itab = W(e + "embed_image_positions.weight")
         if P > oh * oh:
@@ -842,8 +865,8 @@ class HipEngine:
         else:
             ipos = itab[ids(h, w, bsz)].contiguous()
         pos_all = buf("e_pos_all", (T, C))
-        hip.ln_fwd(ipos, W(e + "image_pos_ln.weight"), W(e + "image_pos_ln.bias"), pos_all[:P])
-        hip.ln_fwd(W(e + "embed_positions.weight")[:L], W(e + "pos_ln.weight"), W(e + "pos_ln.bias"), pos_all[P:])
+        hip.ln_fwd(ipos, Wf(e + "image_pos_ln.weight"), Wf(e + "image_pos_ln.bias"), pos_all[:P])
+        hip.ln_fwd(W(e + "embed_positions.weight")[:L], Wf(e + "pos_ln.weight"), Wf(e + "pos_ln.bias"), pos_all[P:])
         pqk = buf("e_pqk", (T, 2 * C))
         hip.linear_fwd(pos_all, self._fused(self.p16, e + "pos_q_linear.weight", 2 * C, C),
                        self._fused(self.p16, e + "pos_q_linear.bias", 2 * C), out=pqk, alpha=scaling, alpha_ncols=C)
@@ -865,7 +888,7 @@ class HipEngine:
                                         pqk[:, C:], None, False, scaling, dense=dense.contiguous())
             x, _ = self._ffn_fwd(tg, p, x, B * T)
         enc_out = buf("enc_out", (B, T, C))
-        hip.ln_fwd(x.view(B * T, C), W(e + "layer_norm.weight"), W(e + "layer_norm.bias"), enc_out.view(B * T, C))
+        hip.ln_fwd(x.view(B * T, C), Wf(e + "layer_norm.weight"), Wf(e + "layer_norm.bias"), enc_out.view(B * T, C))
         ctx["enc_out"] = enc_out
         # ---- decoder
         y0b = buf("d_bos", (B, 1, C))
@@ -873,14 +896,14 @@ class HipEngine:
                else torch.zeros(B, 1, dtype=torch.long, device=dev))
         hip.embed_rows(W(e + "embed_tokens.weight"), bos.reshape(-1).contiguous(), None, y0b)
         y = buf("d_y_in", (B, Td, C))
-        hip.ln_fwd(enc_out[:, :P], W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), y[:, :P])
-        hip.ln_fwd(y0b, W(d + "layernorm_embedding.weight"), W(d + "layernorm_embedding.bias"), y[:, P:])
+        hip.ln_fwd(enc_out[:, :P], Wf(d + "layernorm_embedding.weight"), Wf(d + "layernorm_embedding.bias"), y[:, :P])
+        hip.ln_fwd(y0b, Wf(d + "layernorm_embedding.weight"), Wf(d + "layernorm_embedding.bias"), y[:, P:])
         segtab = W(d + "embed_seg_positions.weight")
         old = segtab[ids(sb, sb, sb)].float()
         spos = old if (h, w) == (sb, sb) else self._resize_hw(old.t(), (sb, sb), (h, w)).t()
         tgt = torch.cat([spos, segtab[:1].float()], 0).to(BF).contiguous()                # internal order: bos last
         tp = buf("d_tp", (Td, C))
-        hip.ln_fwd(tgt, W(d + "seg_pos_ln.weight"), W(d + "seg_pos_ln.bias"), tp)
+        hip.ln_fwd(tgt, Wf(d + "seg_pos_ln.weight"), Wf(d + "seg_pos_ln.bias"), tp)
         spqk = buf("d_spqk", (Td, 2 * C))
         hip.linear_fwd(tp, self._fused(self.p16, d + "self_pos_q_linear.weight", 2 * C, C),
                        self._fused(self.p16, d + "self_pos_q_linear.bias", 2 * C), out=spqk, alpha=scaling, alpha_ncols=C)
@@ -910,8 +933,8 @@ class HipEngine:
             y, _ = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling)
             y, _ = self._ffn_fwd(tg, p, y, B * Td)
         featb = buf("d_feat", (B, Td, C))
-        hip.ln_fwd(y[:, :P], W(d + "layer_norm.weight"), W(d + "layer_norm.bias"), featb[:, 1:])
-        hip.ln_fwd(y[:, P:], W(d + "layer_norm.weight"), W(d + "layer_norm.bias"), featb[:, :1])
+        hip.ln_fwd(y[:, :P], Wf(d + "layer_norm.weight"), Wf(d + "layer_norm.bias"), featb[:, 1:])
+        hip.ln_fwd(y[:, P:], Wf(d + "layer_norm.weight"), Wf(d + "layer_norm.bias"), featb[:, :1])
         logits = buf("logits_pad", (B, Td, self.npad))
         hip.linear_fwd(featb.view(B * Td, C), self.wseg_pad, out=logits.view(B * Td, self.npad))
         self.ctx = ctx
@@ -925,13 +948,13 @@ class HipEngine:
                         next_ln=None, xn_pre=None):
         """xn_pre: ln1(x) if the previous layer already produced it.  -> (block output, pre-LN of the next block or None)"""
         C, H = self.cfg.embed_dim, self.cfg.heads
-        W, buf = self.W, self.buf
+        W, Wf, buf = self.W, self.Wf, self.buf
         a_ = p + attn
         xn = xn_pre
         if xn is None:
             xn = buf(tg + "_xn", (B * T, C))
             mu, rs = self._ln_stats(tg + "_ln1", B * T)
-            hip.ln_fwd(x.view(B * T, C), W(p + ln1 + ".weight"), W(p + ln1 + ".bias"), xn, mu, rs)
+            hip.ln_fwd(x.view(B * T, C), Wf(p + ln1 + ".weight"), Wf(p + ln1 + ".bias"), xn, mu, rs)
         qkv = buf(tg + "_qkv", (B, T, 3 * C))
         hip.linear_fwd(xn, self._fused(self.p16, a_ + ".q_proj.weight", 3 * C, C),
                        self._fused(self.p16, a_ + ".q_proj.bias", 3 * C), out=qkv.view(B * T, 3 * C),
@@ -952,13 +975,13 @@ class HipEngine:
     def _cross_block_fwd(self, tg, p, y1, enc_out, B, Td, Te, cpq, cpk, scaling, site=None, yn_pre=None, next_ln=None):
         """yn_pre: encoder_attn_layer_norm(y1) if the previous block already produced it.  -> (y2, next pre-LN or None)"""
         C, H = self.cfg.embed_dim, self.cfg.heads
-        W, buf = self.W, self.buf
+        W, Wf, buf = self.W, self.Wf, self.buf
         a_ = p + "encoder_attn"
         yn = yn_pre
         if yn is None:
             yn = buf(tg + "_cyn", (B * Td, C))
             mu, rs = self._ln_stats(tg + "_cln1", B * Td)
-            hip.ln_fwd(y1.view(B * Td, C), W(p + "encoder_attn_layer_norm.weight"), W(p + "encoder_attn_layer_norm.bias"), yn, mu, rs)
+            hip.ln_fwd(y1.view(B * Td, C), Wf(p + "encoder_attn_layer_norm.weight"), Wf(p + "encoder_attn_layer_norm.bias"), yn, mu, rs)
         q = buf(tg + "_cq", (B, Td, C))
         hip.linear_fwd(yn, W(a_ + ".q_proj.weight"), W(a_ + ".q_proj.bias"), out=q.view(B * Td, C), alpha=scaling)
         kv = buf(tg + "_ckv", (B, Te, 2 * C))
@@ -985,17 +1008,17 @@ class HipEngine:
         """xn_pre: final_layer_norm(x1) if the previous block already produced it; next_ln as in _post_ln (used when the
         block output goes through the dropout kernel anyway).  -> (x2, pre-LN of the next layer or None)"""
         C, Fd = self.cfg.embed_dim, self.cfg.ffn_dim
-        W, buf = self.W, self.buf
+        W, Wf, buf = self.W, self.Wf, self.buf
         xn = xn_pre
         if xn is None:
             xn = buf(tg + "_fxn", (rows, C))
             mu, rs = self._ln_stats(tg + "_fln1", rows)
-            hip.ln_fwd(x1.view(rows, C), W(p + "final_layer_norm.weight"), W(p + "final_layer_norm.bias"), xn, mu, rs)
+            hip.ln_fwd(x1.view(rows, C), Wf(p + "final_layer_norm.weight"), Wf(p + "final_layer_norm.bias"), xn, mu, rs)
         u = buf(tg + "_u", (rows, Fd))
         hip.linear_fwd(xn, W(p + "fc1.weight"), W(p + "fc1.bias"), out=u)
         z = buf(tg + "_z", (rows, Fd))
         mu, rs = self._ln_stats(tg + "_fln2", rows)
-        hip.ln_fwd(u, W(p + "ffn_layernorm.weight"), W(p + "ffn_layernorm.bias"), z, mu, rs, gelu=True)
+        hip.ln_fwd(u, Wf(p + "ffn_layernorm.weight"), Wf(p + "ffn_layernorm.bias"), z, mu, rs, gelu=True)
         x2 = buf(tg + "_x2", x1.shape)
         nxt = None
         if self.drop_on and site is not None:
@@ -1005,7 +1028,7 @@ class HipEngine:
                 # dropout + DropPath + residual of this block and the pre-LN of the next layer in one launch
                 npname, ntag, nxt = next_ln
                 mu2, rs2 = self._ln_stats(ntag, rows)
-                hip.ln_fwd_pair(t, None, None, x2.view(rows, C), None, None, W(npname + ".weight"), W(npname + ".bias"), nxt,
+                hip.ln_fwd_pair(t, None, None, x2.view(rows, C), None, None, Wf(npname + ".weight"), Wf(npname + ".bias"), nxt,
                                 mu2, rs2, resid=x1.view(rows, C),
                                 drop=(self.cfg.dropout, self._site_seed(self._site_id(site)), self._dp(*site), rpb))
             else:
@@ -1022,14 +1045,14 @@ class HipEngine:
         """out = resid + drop(LN(a)); with next_ln = (param prefix, stats tag, output [rows, C]) the pre-LN of the next
         block is computed in the same launch and returned (else None)."""
         C = self.cfg.embed_dim
-        W = self.W
+        W, Wf = self.W, self.Wf
         mu, rs = self._ln_stats(stats_tag, rows)
         if next_ln is None:
-            hip.ln_fwd(a, W(pname + ".weight"), W(pname + ".bias"), out, mu, rs, resid=resid, drop=drop)
+            hip.ln_fwd(a, Wf(pname + ".weight"), Wf(pname + ".bias"), out, mu, rs, resid=resid, drop=drop)
             return None
         npname, ntag, xn = next_ln
         mu2, rs2 = self._ln_stats(ntag, rows)
-        hip.ln_fwd_pair(a, W(pname + ".weight"), W(pname + ".bias"), out, mu, rs, W(npname + ".weight"), W(npname + ".bias"),
+        hip.ln_fwd_pair(a, Wf(pname + ".weight"), Wf(pname + ".bias"), out, mu, rs, Wf(npname + ".weight"), Wf(npname + ".bias"),
                         xn, mu2, rs2, resid=resid, drop=drop)
         return xn
 
@@ -1042,7 +1065,7 @@ class HipEngine:
         # runs on the side stream)
         part = self.buf("ln_dgbp_%d@%s" % (C, stats_tag) if self.overlap else "ln_dgbp_%d" % C,
                         (2, hip.LN_BWD_BLOCKS, C), torch.float32)
-        hip.ln_bwd(dy, x, self.W(pname + ".weight"), mu, rs, dx, part[0], part[1], dx_add=dx_add, gelu=gelu, drop=drop)
+        hip.ln_bwd(dy, x, self.Wf(pname + ".weight"), mu, rs, dx, part[0], part[1], dx_add=dx_add, gelu=gelu, drop=drop)
         # weight and bias of a LayerNorm are adjacent in the arena: one [2, C] reduction
         self._side_do(lambda: hip.reduce_parts(part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C,
                                                accumulate=accumulate))
@@ -1065,7 +1088,7 @@ class HipEngine:
             return dx
         mu, rs = self._ln_stats(stats_tag, rows)
         part = self._ln_part(C, stats_tag)
-        hip.ln_bwd_drop(dy, x, self.W(pname + ".weight"), mu, rs, dx, part[0], part[1], nxt["out"], dx_add=dx_add,
+        hip.ln_bwd_drop(dy, x, self.Wf(pname + ".weight"), mu, rs, dx, part[0], part[1], nxt["out"], dx_add=dx_add,
                         drop2=nxt["drop"])
         self._side_do(lambda: hip.reduce_parts(part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C))
         return dx
@@ -1101,7 +1124,7 @@ class HipEngine:
         dx2 if the previous block of the backward already produced it; nxt: see `_ln_bwd_fused`."""
         C, Fd = self.cfg.embed_dim, self.cfg.ffn_dim
         s = self.saved[tg + "_ffn"]
-        W, G, buf = self.W, self.G, self.buf
+        W, Wf, G, buf = self.W, self.Wf, self.G, self.buf
         self._bt = tg + "f"
         gbuf = self.gbuf
         dz = buf("g_dz_%d" % rows, (rows, Fd))
@@ -1210,7 +1233,7 @@ class HipEngine:
         """da_pre: the post-LN backward of dx1 if the previous block of the backward already ran it; nxt: `_ln_bwd_fused`"""
         C = self.cfg.embed_dim
         s = self.saved[tg + "_sa"]
-        W, G, buf = self.W, self.G, self.buf
+        W, Wf, G, buf = self.W, self.Wf, self.G, self.buf
         a_ = p + attn
         rows = B * T
         self._bt = tg + "s"
@@ -1241,7 +1264,7 @@ class HipEngine:
                          da_pre=None, nxt=None):
         C = self.cfg.embed_dim
         s = self.saved[tg + "_ca"]
-        W, G, buf = self.W, self.G, self.buf
+        W, Wf, G, buf = self.W, self.Wf, self.G, self.buf
         a_ = p + "encoder_attn"
         rows = B * Td
         self._bt = tg + "c"
@@ -1293,7 +1316,7 @@ class HipEngine:
         B, L, P, T, Td, h, w = (ctx[k] for k in ("B", "L", "P", "T", "Td", "h", "w"))
         C, H = cfg.embed_dim, cfg.heads
         scaling = float(cfg.head_dim * cfg.attn_scale_factor) ** -0.5
-        W, G, buf = self.W, self.G, self.buf
+        W, Wf, G, buf = self.W, self.Wf, self.G, self.buf
         g = self._geometry(h, w, L)
         self.g16.zero_()
         self._tab_touched = {}
@@ -1379,7 +1402,7 @@ class HipEngine:
         """encoder abs-pos operands and embedding LayerNorms: parameter gradients only -- side stream"""
         cfg = self.cfg
         C = cfg.embed_dim
-        W, G, buf = self.W, self.G, self.buf
+        W, Wf, G, buf = self.W, self.Wf, self.G, self.buf
         e = "encoder."
         depqk = buf("g_depqk", (T, 2 * C))
         tmp = buf("g_tmp_ec", (T, C))
@@ -1412,7 +1435,7 @@ class HipEngine:
         """gradients of the decoder's position operands (self / cross abs-pos projections, seg positions) -- side stream"""
         cfg = self.cfg
         C = cfg.embed_dim
-        W, G, buf = self.W, self.G, self.buf
+        W, Wf, G, buf = self.W, self.Wf, self.G, self.buf
         d = "decoder."
         dspqk = buf("g_dspqk", (Td, 2 * C))
         hip.cast_f32_bf16(dspq, buf("g_tmp_tc", (Td, C)))

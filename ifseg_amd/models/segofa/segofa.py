@@ -324,8 +324,16 @@ class SegOFAModel(ModelBase):
         """fairseq_model.py:103-118: up-convert, then the plain nn.Module load."""
         self.upgrade_state_dict_named(state_dict, "")
         out = nn.Module.load_state_dict(self, state_dict, strict=strict)
-        if self.engine.packed:
-            self.engine.packed = False          # arenas are rebuilt from the loaded values on the next forward
+        eng = self.engine
+        if eng.packed:
+            # the parameters are views of the bf16 arena (copied into in place above); the fp32 master copy takes the
+            # checkpoint's own values, the folded ResNet / padded seg projection are re-derived
+            for n in eng.trainable_names():
+                if n in state_dict:
+                    eng.Wf(n).copy_(state_dict[n].to(eng.device, torch.float32).view(eng.shapes[n]))
+            eng._master_stale = False
+            eng._pack_resnet()
+            eng.refresh_frozen()
         return out
 
     def seg_tokens_from_text(self, token_ids):

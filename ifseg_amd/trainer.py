@@ -45,19 +45,31 @@ class ArenaReducer:
     def __init__(self, flat, slices, n):
         self.flat, self.slices, self.n = flat, slices, n
         self.works, self.done = [], []
+        # gloo (functional runs: N ranks on one GPU, CPU tests) has no bf16 device reduction: staged through fp32 host
+        # memory, synchronously.  The production backend is "nccl" (= RCCL over xGMI), asynchronous on its own stream.
+        self.staged = dist.is_initialized() and dist.get_backend() == "gloo" and flat.is_cuda
+
+    def _reduce(self, lo, hi):
+        if self.staged:
+            torch.cuda.current_stream().synchronize()       # the hook runs in weight-gradient-stream order
+            cpu = self.flat[lo:hi].float().cpu()
+            dist.all_reduce(cpu)
+            self.flat[lo:hi].copy_(cpu)
+        else:
+            self.works.append(dist.all_reduce(self.flat[lo:hi], async_op=True))
 
     def on_ready(self, prefix):
         if prefix not in self.slices or prefix in ("encoder.", "decoder."):
             return      # top-level tensors become final only at the end of their half of the backward
         lo, hi = self.slices[prefix]
         self.done.append((lo, hi))
-        self.works.append(dist.all_reduce(self.flat[lo:hi], async_op=True))
+        self._reduce(lo, hi)
 
     def finish(self):
         cur = 0
         for lo, hi in sorted(self.done) + [(self.n, self.n)]:
             if lo > cur:
-                self.works.append(dist.all_reduce(self.flat[cur:lo], async_op=True))
+                self._reduce(cur, lo)
             cur = max(cur, hi)
         for w in self.works:
             w.wait()
@@ -84,13 +96,22 @@ class Trainer:
         self.m = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.v = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._ovf_events = []
+        eng.master_owned = True                            # this trainer keeps eng.master in step with eng.p16
         self.ws = torch.zeros(1024, dtype=torch.float32, device=self.device)
         self.reducer = ArenaReducer(eng.g16, layer_slices(eng), eng.n_train)
         if self.world > 1:
             eng.grad_ready_hook = self._on_grads_ready
             # same start on every rank (DDP broadcasts rank 0's parameters at construction)
-            dist.broadcast(eng.p16, 0)
-            dist.broadcast(self.p32, 0)
+            if self.reducer.staged:
+                for t in (eng.p16.view(torch.int16), self.p32):
+                    c = t.cpu()
+                    dist.broadcast(c, 0)
+                    t.copy_(c)
+            else:
+                dist.broadcast(eng.p16, 0)
+                dist.broadcast(self.p32, 0)
 
     # -- DDP over the flat arena ---------------------------------------------------------
     def _on_grads_ready(self, prefix):
@@ -98,15 +119,74 @@ class Trainer:
 
     # -- schedule -------------------------------------------------------------------------
     def get_lr(self):
-        """fairseq cosine schedule without warm-up / restarts (cosine_lr_scheduler.py:52)."""
-        t = min(self.num_updates, self.max_update)
-        return self.min_lr + 0.5 * (self.lr0 - self.min_lr) * (1 + math.cos(math.pi * t / self.max_update))
+        """Learning rate of the NEXT update, as the reference's cosine schedule produces it
+        (fairseq/optim/lr_scheduler/cosine_lr_scheduler.py:74-152, period = total updates via `reinit`, train.py:184):
+        the scheduler is stepped AFTER each update, so update k (1-based) runs at cosine(k - 1) -- except the very first
+        one: the constructor parks the optimizer at `warmup_init_lr = min_lr` (:88-89,:111-112) and `reinit` returns
+        early when `--warmup-ratio` is 0 (:158-159), so update 1 runs at min_lr (0 in the recipe).  Pinned by
+        tests/golden/fixture_optim.npz (the reference's own scheduler object)."""
+        if self.num_updates == 0:
+            return self.min_lr
+        t = self.num_updates
+        i = t // self.max_update                               # restarts shrink by lr_shrink = 0.1 (:139-147)
+        shrink = 0.1 ** i
+        lo, hi = self.min_lr * shrink, self.lr0 * shrink
+        return lo + 0.5 * (hi - lo) * (1 + math.cos(math.pi * (t - i * self.max_update) / self.max_update))
+
+    # -- cross-rank sum of the logging outputs ------------------------------------------------
+    def _sync_logs(self, logs):
+        """trainer.py:1368-1406 (`_fast_stat_sync_sum`) -> fairseq/distributed/utils.py:654-700: every numeric entry
+        of the logging outputs (losses, ntokens, sample_size, the 4 x nseg area histograms the mIoU is computed from,
+        criterions/seg_criterion.py:590-597) is summed over the ranks in ONE all-reduce."""
+        if self.world == 1:
+            return logs
+        keys, flat = [], []
+        for i, lg in enumerate(logs):
+            for k in sorted(lg):
+                v = lg[k]
+                if isinstance(v, torch.Tensor):
+                    t = v.detach().to(self.device, torch.float64).reshape(-1)
+                elif isinstance(v, (int, float)):
+                    t = torch.tensor([float(v)], dtype=torch.float64, device=self.device)
+                else:
+                    continue
+                keys.append((i, k, t.numel(), v.shape if isinstance(v, torch.Tensor) else None))
+                flat.append(t)
+        buf = torch.cat(flat)
+        if dist.get_backend() == "gloo" and buf.is_cuda:        # functional runs of N ranks on one GPU
+            cpu = buf.cpu()
+            dist.all_reduce(cpu)
+            buf = cpu.to(self.device)
+        else:
+            dist.all_reduce(buf)
+        out, o = [dict(lg) for lg in logs], 0
+        for i, k, n, shape in keys:
+            v = buf[o:o + n]
+            o += n
+            out[i][k] = v.reshape(shape).float() if shape is not None else (int(v.item()) if isinstance(logs[i][k], int) else float(v.item()))
+        return out
+
+    def check_overflow(self, wait=False):
+        """trainer.py:895-904: non-finite gradient norm -> FloatingPointError.  The norm never leaves the device:
+        the Adam kernel skips the update and raises a flag; it is read here once its event has completed (at the latest
+        one step late, `wait=True` blocks)."""
+        pend, self._ovf_events = self._ovf_events, []
+        for ev in pend:
+            if wait:
+                ev.synchronize()
+            if not ev.query():
+                self._ovf_events.append(ev)
+        if len(self._ovf_events) < len(pend) or wait:
+            if int(self.overflow.item()):
+                self.overflow.zero_()
+                raise FloatingPointError("gradients are Nan/Inf (the update was skipped)")
 
     # -- steps ------------------------------------------------------------------------------
     def train_step(self, samples, prefetch=None):
         """One update.  `prefetch`: the samples of the NEXT call, if the data iterator already holds them:
         their frozen-trunk features are computed on a second stream underneath this step
         (HipEngine.prefetch_trunk)."""
+        self.check_overflow()
         if prefetch:
             self.eng._pf_request = prefetch[0]["net_input"]["patch_images"]
         torch.manual_seed(self.seed + self.num_updates)
@@ -140,11 +220,20 @@ class Trainer:
             self.reducer.finish()
             total_ss *= self.world          # every rank reports sample_size 1 (seg_criterion.py:345)
         gscale = 1.0 / total_ss             # sum over ranks * (world / total) / world
+        self._last_gscale = gscale
         hip.grad_sumsq(eng.g16, self.ws, self.sumsq)
+        lr = self.get_lr()                  # the schedule is stepped after the update (trainer.py:1062-1066)
         self.num_updates += 1
-        hip.adam_step(self.p32, eng.g16, self.m, self.v, eng.p16[: eng.n_train], self.get_lr(), self.betas[0],
-                      self.betas[1], self.eps, self.wd, self.num_updates, gscale, self.clip, self.sumsq)
-        return logs
+        hip.adam_step(self.p32, eng.g16, self.m, self.v, eng.p16[: eng.n_train], lr, self.betas[0],
+                      self.betas[1], self.eps, self.wd, self.num_updates, gscale, self.clip, self.sumsq, self.overflow)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._ovf_events.append(ev)
+        return self._sync_logs(logs)
+
+    def grad_norm(self):
+        """global gradient norm of the last update, after the world/sample_size scaling (host sync: logging only)"""
+        return float(self.sumsq.sqrt().item()) * self._last_gscale
 
     def valid_step(self, sample):
         return self.task.valid_step(sample, self.model, self.criterion)

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 6
+#define IFSEG_ABI_VERSION 7
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -93,7 +93,7 @@ int ifseg_attn_fwd(const void* q, const void* k, const void* v, const void* pos_
                    int ldpq, int ldpk, long long q_bs, long long k_bs, long long v_bs, long long o_bs,
                    int rel_mode, int P, const int* gcode, int code_bias, int n2d, const float* rel2d,
                    const float* rel1d, const float* relx, int causal, const float* dense_bias,
-                   const void* gain /* bf16 [H] or NULL */,
+                   const void* gain /* fp32 [H] or NULL */,
                    int grid_w /* token-grid width if gcode is the raster code y*(2w-1)+x, else 0; 32 enables
                                  the row-aligned bias lookup */,
                    void* stream);
@@ -101,7 +101,7 @@ int ifseg_attn_fwd(const void* q, const void* k, const void* v, const void* pos_
 /* Backward of ifseg_attn_fwd (autograd of the same reference lines).  Launches
  *   delta[b,h,t] = sum_d dout*out;  a key-stationary dK/dV kernel that also
  *   histograms d(rel2d/rel1d/relx) in LDS;  a query-stationary dQ kernel.
- * `gain` [H] (bf16) is the per-head c_attn applied to `out` by the forward
+ * `gain` [H] (fp32) is the per-head c_attn applied to `out` by the forward
  * (unify_multihead_attention.py:509-512); d(gain)[h] = sum_{b,t} delta / gain[h].
  * dq is scaled by dq_scale (the reference's q scaling), the abs-pos halves of
  * dQ_ext / dK_ext are written as fp32 per-batch partials dpos_q_part [B,T,H*64]
@@ -120,7 +120,7 @@ typedef struct ifseg_attn_bwd_args {
   int rel_mode, P, code_bias, n2d, causal, nparts;
   const int* gcode;
   const float *rel2d, *rel1d, *relx;
-  const void* gain; /* bf16 [H] or NULL */
+  const void* gain; /* fp32 [H] or NULL */
   float *drel2d_part, *drel1d_part, *drelx_part;
   float dq_scale, dpq_scale;
   int grid_w; /* width of the token grid (0 if unknown); 32 enables the row-aligned bias-gradient reduction */
@@ -156,6 +156,10 @@ typedef struct ifseg_drop_args {
   const float* drop_path_scale;  /* [batch] fp32 keep/(1-rate) per sample, or NULL */
   int rows_per_batch;            /* logical rows per sample (indexes drop_path_scale) */
 } ifseg_drop_args;
+/* `act_gelu` / `flags` of the LayerNorm entry points: IFSEG_LN_GELU = the input goes through GELU first (ffn_layernorm(gelu(fc1)));
+ * IFSEG_LN_PARAMS_F32 = gamma / beta (and gamma2 / beta2) point at fp32 values (the optimizer's master copy) instead of bf16. */
+#define IFSEG_LN_GELU 1
+#define IFSEG_LN_PARAMS_F32 2
 int ifseg_ln_fwd(const void* x, const void* gamma, const void* beta, const void* resid, void* y, float* mean,
                  float* rstd, int rows, int C, float eps, int act_gelu, int rpb, long long x_bs, int ldx,
                  long long y_bs, int ldy, long long r_bs, int ldr, const ifseg_drop_args* drop, void* stream);
@@ -166,7 +170,7 @@ int ifseg_ln_fwd(const void* x, const void* gamma, const void* beta, const void*
  * y2 = LN(y) -- the pre-LN of the next layer. */
 int ifseg_ln_fwd_pair(const void* x, const void* gamma, const void* beta, const void* resid, void* y, float* mean,
                       float* rstd, const void* gamma2, const void* beta2, void* y2, float* mean2, float* rstd2, int rows,
-                      int C, float eps, int rpb, long long x_bs, int ldx, long long y_bs, int ldy, long long r_bs, int ldr,
+                      int C, float eps, int flags, int rpb, long long x_bs, int ldx, long long y_bs, int ldy, long long r_bs, int ldr,
                       long long y2_bs, int ldy2, const ifseg_drop_args* drop, void* stream);
 /* dx = [dx_add +] d/dx of the above (dy is first masked like the forward output when `drop` is given);
  * per-block partials of dgamma / dbeta are written to dgamma_part / dbeta_part [nblocks][C]
@@ -180,7 +184,7 @@ int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, const float* 
  * 564-568) that opens the next one, in one launch.  Bit-identical to ifseg_ln_bwd followed by ifseg_dropout. */
 int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
                       const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, void* dx2, int nblocks, int rows,
-                      int C, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx, long long dx_bs, int lddx,
+                      int C, int flags, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx, long long dx_bs, int lddx,
                       long long add_bs, int ldadd, long long dx2_bs, int lddx2, const ifseg_drop_args* drop2, void* stream);
 /* out[o][i] (+)= scale * sum_p in[o][p][i]   (fp32 in; fp32 or bf16 out) */
 int ifseg_reduce_parts(const float* in, void* out, int outer, int parts, long long n, int accumulate,
@@ -273,10 +277,11 @@ int ifseg_seg_eval(const float* scores, int hp, int wp, int n, const long long* 
 int ifseg_grad_sumsq_bf16(const void* g, long long n, float* workspace, float* out_sumsq, void* stream);
 /* Fused grad scaling + clip-by-global-norm + Adam with decoupled weight decay over a
  * flat arena; writes the bf16 model copy.  Mirrors trainer.py:874-907 +
- * fairseq/optim/adam.py:158-240 + fp16_optimizer.py (fp32 masters). */
+ * fairseq/optim/adam.py:158-240 + fp16_optimizer.py (fp32 masters).  A non-finite *sumsq skips the whole update and
+ * sets overflow[0] = 1 (device int, may be NULL): trainer.py:895-904 raises FloatingPointError there. */
 int ifseg_adam_step(float* p32, const void* g, float* m, float* v, void* p16, long long n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float grad_scale, float max_norm,
-                    const float* sumsq, void* stream);
+                    const float* sumsq, int* overflow, void* stream);
 
 /* -------------------------------------------------------------- profiling */
 /* Per-kernel-family timing with HIP events recorded on the launch stream (bench.py's

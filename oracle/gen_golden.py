@@ -280,17 +280,164 @@ def case_eval(cfg, arch, overrides, out_name, ori_hw=(150, 200), iters=25, topk=
     np.savez_compressed(os.path.join(GOLDEN, out_name), **save)
 
 
+def case_optim(cfg, arch, overrides, out_name, n_updates=3, lr=5e-5, total_updates=2000):
+    """Optimizer + harness golden: the REFERENCE's FairseqAdam (fairseq/optim/adam.py:
+    45-240, decoupled weight decay 0.1), `multiply_grads`, `clip_grad_norm(1.0)` (fairseq_optimizer.py:105-113) and
+    its cosine schedule (`reinit(total, 0)` as train.py:184 does -- with warmup_ratio 0 the FIRST update runs at
+    lr = warmup_init_lr = min_lr = 0 and update k >= 2 at cosine(k-1)) driven exactly like trainer.py:745-1050 drives
+    them, for `n_updates` updates on one fixed batch.  Stores losses, grad norms, the lr of every update and the
+    post-update parameters."""
+    _refshim.install()
+    from fairseq.optim.adam import FairseqAdam, FairseqAdamConfig
+    from fairseq.optim.lr_scheduler.cosine_lr_scheduler import CosineLRSchedule, CosineLRScheduleConfig
+    model, sd = build_reference(cfg, arch, overrides)
+    crit = build_criterion(cfg)
+    batch = O.synthetic_batch(cfg, 2, 12)
+    params = [p for p in model.parameters() if p.requires_grad]
+    ocfg = FairseqAdamConfig(adam_betas="(0.9,0.999)", adam_eps=1e-8, weight_decay=0.1)
+    ocfg.lr, ocfg.tpu = [lr], False
+    opt = FairseqAdam(ocfg, params)
+    scfg = CosineLRScheduleConfig()
+    scfg.lr, scfg.max_update = [lr], total_updates
+    sched = CosineLRSchedule(scfg, opt)
+    sched.reinit(total_updates, 0)
+    model.train()
+    save = {"n_updates": n_updates, "lr0": lr, "total_updates": total_updates}
+    losses, gnorms, lrs = [], [], []
+    sample = {"target": batch["target"], "net_input": {"patch_images": batch["patch_images"]}}
+    for k in range(n_updates):
+        opt.zero_grad()
+        out = ref_forward(model, batch, False)
+        loss, metrics, ntok = crit.compute_loss(model, out, sample, k)
+        opt.backward(loss)
+        opt.multiply_grads(1.0 / float(ntok))                     # world 1, sample_size = ntokens = 1
+        gn = opt.clip_grad_norm(1.0)
+        lrs.append(opt.get_lr())
+        opt.step()
+        sched.step_update(k + 1)
+        losses.append(loss.item()); gnorms.append(float(gn))
+        print("[%s] update %d: loss %.6f |g| %.5f lr %.4e" % (out_name, k + 1, losses[-1], gnorms[-1], lrs[-1]))
+    named = dict(model.named_parameters())
+    for k in GRAD_KEYS + ["encoder.layers.1.fc2.weight", "decoder.layers.0.encoder_attn.out_proj.bias"]:
+        if named[k].requires_grad:
+            save["param:" + k] = named[k].detach().numpy().copy()
+            save["init:" + k] = sd[k].numpy()
+    save.update(losses=np.array(losses), gnorms=np.array(gnorms), lrs=np.array(lrs))
+    np.savez_compressed(os.path.join(GOLDEN, out_name), **save)
+    print("  wrote", out_name)
+
+
+def case_upgrade(cfg, arch, overrides, out_name):
+    """Checkpoint up-conversion (models/segofa/segofa.py:197-299, encoder_module.py:943-987, decoder_module.py:
+    892-940): a procedurally filled "OFA" checkpoint (token table one row short, no seg-token tables, a stale
+    `decoder.output_projection`, image-position tables 40 rows short) goes through the reference's
+    `upgrade_state_dict`; the keys, shapes and the rows it appended (torch.manual_seed(7)) are the golden."""
+    model, sd = build_reference(cfg, arch, overrides)
+    ck = {k: v.clone() for k, v in sd.items() if "seg_embed_tokens" not in k and "seg_projection" not in k
+          and "embed_tokens_bag" not in k}
+    for k in ("encoder.embed_tokens.weight", "decoder.embed_tokens.weight"):
+        ck[k] = ck[k][:-1].clone()
+    ck["decoder.output_projection.weight"] = ck["decoder.embed_tokens.weight"].clone()
+    for k in ("encoder.embed_image_positions.weight", "decoder.embed_image_positions.weight"):
+        ck[k] = ck[k][:-40].clone()
+    torch.manual_seed(7)
+    model.upgrade_state_dict(ck)
+    missing, unexpected = torch.nn.Module.load_state_dict(model, ck, strict=True)
+    save = {"keys": np.array(sorted(ck.keys())), "shapes": np.array([str(tuple(ck[k].shape)) for k in sorted(ck.keys())])}
+    save["enc_tok_tail"] = ck["encoder.embed_tokens.weight"][-2:].numpy()
+    save["dec_tok_tail"] = ck["decoder.embed_tokens.weight"][-2:].numpy()
+    save["enc_ipos_tail"] = ck["encoder.embed_image_positions.weight"][-41:].numpy()
+    save["dec_ipos_tail"] = ck["decoder.embed_image_positions.weight"][-41:].numpy()
+    save["seg_embed"] = ck["encoder.seg_embed_tokens.weight"].numpy()
+    np.savez_compressed(os.path.join(GOLDEN, out_name), **save)
+    print("[%s] %d keys after up-conversion; token table %s" % (out_name, len(ck), tuple(ck["encoder.embed_tokens.weight"].shape)))
+
+
+COCO_UNSEEN = ("frisbee, skateboard, cardboard, carrot, scissors, suitcase, giraffe, cow, road, concrete wall, tree, grass, "
+               "river, clouds, playingfield")          # run_scripts/IFSeg/coco_unseen.sh:16
+
+
+def case_lazy_init(cfg, arch, overrides, out_name):
+    """`_lazy_initialization` (criterions/seg_criterion.py:373-407): the category names of the shipped recipe are
+    tokenised by the reference's own GPT-2 BPE + dict.txt (utils/BPE), and the reference criterion writes the mean
+    token embedding of every name into the seg-token tables of the fixture model (token ids folded into the fixture
+    vocabulary).  Golden: the real token ids and the resulting table."""
+    import unittest.mock as mock
+    _refshim.install()
+    from fairseq.data import Dictionary
+    from fairseq.data.encoders.gpt2_bpe import GPT2BPE, GPT2BPEConfig
+    bdir = os.path.join(_refshim.REFERENCE_ROOT, "utils", "BPE")
+    bcfg = GPT2BPEConfig()
+    bcfg.gpt2_encoder_json, bcfg.gpt2_vocab_bpe = os.path.join(bdir, "encoder.json"), os.path.join(bdir, "vocab.bpe")
+    bpe = GPT2BPE(bcfg)
+    d = Dictionary.load(os.path.join(bdir, "dict.txt"))
+    names = [x.strip() for x in COCO_UNSEEN.split(",")]
+
+    def encode_text(text):          # the reference's closure, :375-385
+        line = " ".join(bpe.encode(" {}".format(w.strip())) for w in text.strip().split())
+        return d.encode_line(line=line, add_if_not_exist=False, append_eos=False).long()
+
+    real_ids = [encode_text(" %s" % x) for x in names]
+    prompt = encode_text(" what is the segmentation map of the image? object:")
+    print("[%s] prompt ids %s" % (out_name, prompt.tolist()))
+    cfg15 = O.fixture_config(num_seg_tokens=len(names), vocab_size=cfg.vocab_size)
+    model, sd = build_reference(cfg15, arch, overrides)
+    crit = build_criterion(cfg15)
+    crit.init_seg_with_text = True
+    crit.id2rawtext = names
+    nvocab = cfg15.vocab_size - 1           # fold real ids into the fixture table (keeps specials out)
+    fold = lambda t: 4 + (t % (nvocab - 4))
+
+    class _Bpe:
+        def encode(self, w):
+            return " ".join(str(int(i)) for i in fold(encode_text(w)))
+
+    class _Dict:
+        def encode_line(self, line, add_if_not_exist, append_eos):
+            return torch.tensor([int(x) for x in line.split()], dtype=torch.long)
+
+    crit.task.bpe, crit.task.tgt_dict = _Bpe(), _Dict()
+    with mock.patch.object(torch.Tensor, "cuda", lambda self, *a, **k: self):
+        crit._lazy_initialization(None, model, None)
+    out = model.encoder.seg_embed_tokens.weight.data
+    assert out.data_ptr() == model.decoder.seg_embed_tokens.weight.data.data_ptr()
+    o = torch.stack([sd["encoder.embed_tokens.weight"][fold(t)].mean(0) for t in real_ids])
+    assert (o - out).abs().max().item() <= 1e-6
+    maxlen = max(t.numel() for t in real_ids)
+    ids = np.full((len(names), maxlen), -1, dtype=np.int64)
+    for i, t in enumerate(real_ids):
+        ids[i, : t.numel()] = t.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, out_name), category_ids=ids, prompt_ids=prompt.numpy(), seg_table=out.numpy(),
+                        names=np.array(names), fold_mod=nvocab - 4)
+    print("  lengths %s; wrote %s" % ([t.numel() for t in real_ids], out_name))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-base", action="store_true")
     ap.add_argument("--only-imfree", action="store_true")
     ap.add_argument("--only-eval", action="store_true")
+    ap.add_argument("--only", default="", help="comma list of: optim, upgrade, lazy, base_b2, base_c3")
     a = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
     fx = O.fixture_config()
     ov = dict(encoder_embed_dim=fx.embed_dim, encoder_ffn_embed_dim=fx.ffn_dim, encoder_layers=fx.enc_layers,
               decoder_layers=fx.dec_layers, encoder_attention_heads=fx.heads, decoder_attention_heads=fx.heads)
+    only = [x for x in a.only.split(",") if x]
+    if only:
+        if "optim" in only:
+            case_optim(fx, "tiny", ov, "fixture_optim.npz")
+        if "upgrade" in only:
+            case_upgrade(fx, "tiny", ov, "fixture_upgrade.npz")
+        if "lazy" in only:
+            case_lazy_init(fx, "tiny", ov, "fixture_lazy_init.npz")
+        if "base_b2" in only:      # BASELINE config 1 as written: B = 2
+            case_train(O.base_config(), "base", None, 2, 36, "base_c1_b2.npz", GRAD_KEYS, full_grads=False)
+        if "base_c3" in only:      # BASELINE config 3 geometry on one device: Base width, 150 classes, L = 215 (T_enc 1239)
+            case_train(O.base_config(num_seg_tokens=150, vocab_size=59457 + 151 - 150), "base", None, 1, 215, "base_c3.npz",
+                       GRAD_KEYS, full_grads=False)
+        return
     if a.only_eval:
         case_eval(fx, "tiny", ov, "fixture_eval.npz")
         return

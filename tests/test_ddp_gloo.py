@@ -59,3 +59,46 @@ def test_arena_reducer_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _worker_logs(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ifseg_amd.trainer import Trainer
+    t = Trainer.__new__(Trainer)                      # only the cross-rank sum of the logging outputs is exercised
+    t.world, t.device = world, torch.device("cpu")
+    hist = torch.arange(5, dtype=torch.float32) * (rank + 1)
+    logs = [{"loss": torch.tensor(1.5 + rank), "ntokens": 100 + rank, "nsentences": 2, "sample_size": 1,
+             "area_intersect": hist, "area_union": hist + 1, "note": "strings stay per-rank"},
+            {"loss": torch.tensor(0.25), "ntokens": 7, "nsentences": 2, "sample_size": 1, "area_intersect": hist * 2,
+             "area_union": hist * 2 + 1, "note": "x"}]
+    red = t._sync_logs(logs)
+    r = range(world)
+    ok = abs(float(red[0]["loss"]) - sum(1.5 + k for k in r)) < 1e-6 and red[0]["ntokens"] == sum(100 + k for k in r)
+    ok = ok and red[0]["sample_size"] == world and isinstance(red[0]["ntokens"], int) and red[0]["note"] == logs[0]["note"]
+    ok = ok and torch.equal(red[0]["area_intersect"], sum(torch.arange(5.) * (k + 1) for k in r))
+    ok = ok and torch.equal(red[1]["area_union"], sum(torch.arange(5.) * (k + 1) * 2 + 1 for k in r))
+    # mIoU from the summed histograms (criterions/seg_criterion.py:533-572)
+    from ifseg_amd.criterions import SegCriterion
+    agg = SegCriterion.reduce_metrics([dict(red[0], imfree_loss=0.0, seg_loss=0.0, nll_loss=0.0,
+                                            area_pred_label=red[0]["area_union"], area_label=red[0]["area_union"])])
+    ok = ok and abs(agg["mIoU"] - float(torch.nanmean(red[0]["area_intersect"] / red[0]["area_union"]))) < 1e-4
+    if rank == 0:
+        out.put(bool(ok))
+    dist.destroy_process_group()
+
+
+def test_logging_outputs_and_histograms_are_summed_over_ranks():
+    """trainer.py:1368-1406 / fairseq/distributed/utils.py:654-700: one all-reduce over every numeric logging entry,
+    including the 4 x nseg area histograms the mIoU is computed from."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_logs, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

@@ -111,3 +111,84 @@ def test_arena_lays_every_linear_out_weight_then_bias():
     # the nn.Parameters are views into the arena (state_dict contract is unchanged by the layout)
     w = dict(m.named_parameters())["decoder.layers.1.encoder_attn.q_proj.bias"]
     assert w.data_ptr() == eng.p16.data_ptr() + 2 * off["decoder.layers.1.encoder_attn.q_proj.bias"]
+
+
+def _ofa_like_checkpoint(sd):
+    """what oracle/gen_golden.py:case_upgrade feeds the reference: token table one row short, no seg-token tables, a
+    stale decoder.output_projection, image-position tables 40 rows short"""
+    ck = {k: v.clone() for k, v in sd.items() if "seg_embed_tokens" not in k and "seg_projection" not in k
+          and "embed_tokens_bag" not in k}
+    for k in ("encoder.embed_tokens.weight", "decoder.embed_tokens.weight"):
+        ck[k] = ck[k][:-1].clone()
+    ck["decoder.output_projection.weight"] = ck["decoder.embed_tokens.weight"].clone()
+    for k in ("encoder.embed_image_positions.weight", "decoder.embed_image_positions.weight"):
+        ck[k] = ck[k][:-40].clone()
+    return ck
+
+
+def test_checkpoint_upconversion_matches_reference_golden(golden_dir):
+    """models/segofa/segofa.py:197-299 (+ encoder_module.py:943-987, decoder_module.py:892-940): the same OFA-style
+    checkpoint through the product's upgrade_state_dict_named gives the keys, shapes and the N(0, C^-0.5) rows the
+    REFERENCE produced (tests/golden/fixture_upgrade.npz; same torch seed, same draw order), and then loads strictly."""
+    import numpy as np
+    from ifseg_amd.models.segofa import SegOFAModel, make_config
+    g = np.load(os.path.join(golden_dir, "fixture_upgrade.npz"))
+    ocfg = O.fixture_config()
+    m = SegOFAModel(make_config("segofa_tiny", embed_dim=128, ffn_dim=256, heads=2, enc_layers=2, dec_layers=2,
+                                resnet_layers=(3, 4, 6), num_seg_tokens=5, vocab_size=101, patch_image_size=128,
+                                orig_patch_image_size=128))
+    ck = _ofa_like_checkpoint(O.procedural_state_dict(ocfg))
+    assert ck["encoder.embed_tokens.weight"].shape[0] == 100
+    torch.manual_seed(7)
+    m.upgrade_state_dict_named(ck, "")
+    assert sorted(ck.keys()) == list(g["keys"])
+    assert [str(tuple(ck[k].shape)) for k in sorted(ck.keys())] == list(g["shapes"])
+    for key, name in (("enc_tok_tail", "encoder.embed_tokens.weight"), ("dec_tok_tail", "decoder.embed_tokens.weight")):
+        assert torch.allclose(ck[name][-2:], torch.from_numpy(g[key]), atol=1e-7), name
+    for key, name in (("enc_ipos_tail", "encoder.embed_image_positions.weight"), ("dec_ipos_tail", "decoder.embed_image_positions.weight")):
+        assert torch.allclose(ck[name][-41:], torch.from_numpy(g[key]), atol=1e-7), name
+    ck2 = _ofa_like_checkpoint(O.procedural_state_dict(ocfg))
+    torch.manual_seed(7)
+    missing, unexpected = m.load_state_dict(ck2, strict=True)          # load_state_dict up-converts first (fairseq_model.py:103-118)
+    assert not missing and not unexpected
+    assert torch.allclose(m.encoder.embed_tokens.weight[-2:], torch.from_numpy(g["enc_tok_tail"]), atol=1e-7)
+    # a table with MORE rows than the dictionary + no <mask>: the extra row is dropped (segofa.py:255-265)
+    ck3 = _ofa_like_checkpoint(O.procedural_state_dict(ocfg))
+    for k in ("encoder.embed_tokens.weight", "decoder.embed_tokens.weight"):
+        ck3[k] = torch.cat([ck3[k], torch.ones(2, 128)])
+    m.encoder.dictionary = ()                                            # "<mask>" not in dictionary
+    m.upgrade_state_dict_named(ck3, "")
+    assert ck3["encoder.embed_tokens.weight"].shape[0] == 101 and ck3["decoder.embed_tokens.weight"].shape[0] == 101
+
+
+def test_learning_rate_schedule_matches_reference_golden(golden_dir):
+    """the lr of updates 1..3 as the reference's CosineLRSchedule produced them (fixture_optim.npz): 0 first, then cosine(k-1)"""
+    import math
+    import numpy as np
+    from ifseg_amd.trainer import Trainer
+    g = np.load(os.path.join(golden_dir, "fixture_optim.npz"))
+    t = Trainer.__new__(Trainer)
+    t.lr0, t.min_lr, t.max_update = float(g["lr0"]), 0.0, int(g["total_updates"])
+    for k, want in enumerate(g["lrs"]):
+        t.num_updates = k
+        assert abs(t.get_lr() - float(want)) <= 1e-15, (k, t.get_lr(), want)
+    t.num_updates = 1000
+    assert abs(t.get_lr() - 0.5 * t.lr0 * (1 + math.cos(math.pi * 0.5))) < 1e-12
+
+
+def test_recipe_flags_reach_the_config_without_fairseq():
+    """build_model maps the namespace onto SegOFAConfig (dropout, drop-path, buckets) and refuses what the HIP path lacks"""
+    from ifseg_amd.models.segofa.segofa import SegOFAModel, recipe_args
+    from ifseg_amd.tasks.mm_tasks import SegmentationTask
+    task = SegmentationTask(num_seg_tokens=5, patch_image_size=128, arch="segofa_tiny")
+    m = task.build_model()
+    assert (m.cfg.dropout, m.cfg.encoder_drop_path_rate, m.cfg.decoder_drop_path_rate) == (0.1, 0.1, 0.1)
+    assert m.cfg.num_seg_tokens == 5 and m.cfg.resnet_layers == (3, 4, 6) and m.cfg.embed_dim == 256
+    a = recipe_args("segofa_tiny", num_seg_tokens=5, patch_image_size=128, orig_patch_image_size=128, dropout=0.0,
+                    image_bucket_size=20, attn_scale_factor=4.0)
+    m2 = SegOFAModel.build_model(a, task)
+    assert m2.cfg.dropout == 0.0 and m2.cfg.image_bucket_size == 20 and m2.cfg.attn_scale_factor == 4.0
+    for bad in (dict(attention_dropout=0.1), dict(scale_attn=False), dict(freeze_entire_resnet="false"),
+                dict(decoder_input_type="encoder_input"), dict(tie_seg_projection="false")):
+        with pytest.raises(NotImplementedError):
+            SegOFAModel.build_model(recipe_args("segofa_tiny", num_seg_tokens=5, **bad), task)
