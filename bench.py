@@ -33,10 +33,12 @@ MFMA_PEAK_TF = 2500.0                      # dense bf16 (MI355X_MICROARCH.md)
 def cpu_baseline(nseg, src_len):
     """SURVEY 8d / BASELINE.md section 4: the CPU restatement (oracle/segofa_ref.py, fp32) on BASELINE configs[0] inputs
     (B = 2, 512x512, frozen trunk, dropout 0), every host core, 1 warm-up + 3 timed fwd+bwd steps (a bounded sample:
-    ~15-25 s of CPU work on the GPU box)."""
+    ~10-20 s of CPU work on the GPU box)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import segofa_ref as O
-    ncores = os.cpu_count() or 1
+    # every host core up to 32 threads: the GPU box has 256 hardware threads, on which this op mix (many small fp32
+    # GEMMs / elementwise ops) is pathologically slow -- measured 279 s per step with 256 threads vs ~2 s with 32
+    ncores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(ncores)
     cfg = O.base_config(num_seg_tokens=nseg)
     sd = O.procedural_state_dict(cfg)

@@ -99,8 +99,11 @@ __device__ __forceinline__ void lds_dma16(v4i32 rs, unsigned lds_base, unsigned 
                :: "s"(lds_base), "v"(voff), "s"(rs) : "memory");
 }
 
+// One output tile (and, with split-K, one k-slice of it).  bx / by / bz are the workgroup's tile, batch and k-slice
+// coordinates (blockIdx of the plain kernel; the grouped kernel passes the tile index inside its problem);
+// `remapped`: bx is already an XCD-remapped tile index.
 template <int AMODE, bool B_KS, int BN, int BK, int STAGES, bool COLSUM = false>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int bz_in, const bool remapped) {
   static_assert(BN == 128 || (BN == 64 && !B_KS), "64-wide tiles only for k-contiguous B");
   constexpr int NJ = BN / 64;                 // 32-column MFMA tiles per wave along N
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -116,17 +119,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   // split-K with xcd_groups > 0 (1-D grid of tiles x slices): XCD x = workgroup id & 7 owns k-slice x / groups and the
   // contiguous tile range x % groups of it, so the rows of A and B a slice touches stream through ONE XCD's L2 instead of
   // being fetched from HBM by every XCD that happens to hold a few of its tiles (measured 3.6-5.7x over-fetch)
-  int t, bz = blockIdx.z;
+  int t, bz = bz_in;
   if (g.xcd_groups > 0) {
-    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int xcd = bx & 7, loc = bx >> 3;
     bz = xcd / g.xcd_groups;
     t = (xcd % g.xcd_groups) * ((tiles_m * tiles_n) / g.xcd_groups) + loc;
   } else {
-    t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    t = remapped ? bx : xcd_remap(bx, tiles_m * tiles_n);
   }
   const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
-  const v4i32 rsA = make_rsrc(g.A + (long long)blockIdx.y * g.sA, g.nrecA);
-  const v4i32 rsB = make_rsrc(g.B + (long long)blockIdx.y * g.sB, g.nrecB);
+  const v4i32 rsA = make_rsrc(g.A + (long long)by * g.sA, g.nrecA);
+  const v4i32 rsB = make_rsrc(g.B + (long long)by * g.sB, g.nrecB);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
   // split-K: slice bz reduces k in [kbeg, kend) into its own fp32 slab of C
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   // COLSUM (weight-gradient GEMMs): the column sums of A (= the bias gradient) come out of the same A fragments
   // through one more MFMA against an all-ones B fragment, in the workgroups of the first column tile only
   f32x16 accb[COLSUM ? 2 : 1];
-  const bool do_colsum = COLSUM && n0 == 0 && wn == 0;
+  const bool do_colsum = COLSUM && n0 == 0 && wn == 0 && (g.flags & IFSEG_GEMM_COLSUM);
   if (COLSUM) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   // ---- epilogue: lane owns row m = ..+(lane&31), 4 consecutive columns per reg group
   const bool relu = g.flags & IFSEG_GEMM_RELU, out_f32 = g.flags & IFSEG_GEMM_OUT_F32,
              accum = g.flags & IFSEG_GEMM_ACCUMULATE;
-  const bf16_t* Rb = g.resid ? g.resid + (long long)blockIdx.y * g.sR : nullptr;
+  const bf16_t* Rb = g.resid ? g.resid + (long long)by * g.sR : nullptr;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + wm * 64 + i * 32 + (lane & 31);
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (out_f32) {
-          float* cp = reinterpret_cast<float*>(g.C) + (long long)blockIdx.y * g.sC + (long long)bz * g.sCsplit +
+          float* cp = reinterpret_cast<float*>(g.C) + (long long)by * g.sC + (long long)bz * g.sCsplit +
                       (long long)m * g.ldc + n;
           float4 o = make_float4(v[0], v[1], v[2], v[3]);
           if (accum) {
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
           }
           *reinterpret_cast<float4*>(cp) = o;
         } else {
-          bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (long long)blockIdx.y * g.sC + (long long)m * g.ldc + n;
+          bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (long long)by * g.sC + (long long)m * g.ldc + n;
           if (accum) {
             uint2 pw = *reinterpret_cast<const uint2*>(cp);
             v[0] += bflo(pw.x); v[1] += bfhi(pw.x); v[2] += bflo(pw.y); v[3] += bfhi(pw.y);
@@ -382,6 +385,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         g.dot_out[((long long)(m / g.dot_T) * (g.N >> 6) + hd) * g.dot_T + (m % g.dot_T)] = dsum;
     }
   }
+}
+
+template <int AMODE, bool B_KS, int BN, int BK, int STAGES, bool COLSUM = false>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+  gemm_tile<AMODE, B_KS, BN, BK, STAGES, COLSUM>(g, blockIdx.x, blockIdx.y, blockIdx.z, false);
+}
+
+// Grouped weight-gradient GEMM: up to IFSEG_GEMM_GROUP_MAX independent TN problems (the dW = dY^T X products of one
+// transformer layer's Linear modules) in ONE launch, one workgroup per 128x128 output tile walking ALL tokens -- no
+// split-K, no fp32 slabs, no reduction launches; db rides on the same pass (COLSUM) and dW / db are written once, as
+// bf16, straight into the gradient arena.  A single dW product of SegOFA-Base has 36..144 tiles (it cannot fill 256
+// CUs without split-K); a layer's products together have 432 (encoder) / 576 (decoder).
+struct GroupArgs {
+  int n, total;
+  int start[IFSEG_GEMM_GROUP_MAX + 1];     // first (XCD-remapped) tile of problem i; start[n] = total
+  GemmArgs p[IFSEG_GEMM_GROUP_MAX];
+};
+template <int STAGES>
+__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(GroupArgs ga) {
+  // consecutive remapped ids share an XCD (its L2 then holds the panels neighbouring tiles of one problem share)
+  const int id = xcd_remap(blockIdx.x, ga.total);
+  int pid = 0;
+  for (int i = 1; i < ga.n; ++i) pid = (id >= ga.start[i]) ? i : pid;
+  gemm_tile<A_KS, true, 128, GBK, STAGES, true>(ga.p[pid], id - ga.start[pid], 0, 0, true);
 }
 
 // skinny projection: C[M, N<=32*?] = A[M,K] . B[N,K]^T for tiny N (seg tokens, 15..171):
@@ -477,6 +504,42 @@ extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C
                                long long strideB, long long strideC, long long strideR, int splitk, void* stream) {
   return gemm_impl(layout, A, B, C, M, N, K, lda, ldb, ldc, bias, alpha, alpha_ncols, resid, ldr, flags, batch, strideA,
                    strideB, strideC, strideR, splitk, stream, nullptr, 0, nullptr, 0);
+}
+
+extern "C" int ifseg_gemm_tn_group(int n, const ifseg_gemm_tn_problem* probs, void* stream) {
+  (void)hipGetLastError();
+  if (n <= 0) return 0;
+  if (n > IFSEG_GEMM_GROUP_MAX || !probs) return IFSEG_ERR_BAD_ARG;
+  GroupArgs ga{};
+  ga.n = n;
+  int total = 0;
+  double flops = 0, bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    const ifseg_gemm_tn_problem& q = probs[i];
+    // C[M,N] (bf16, ldc == N, db[M] right behind it when `colsum`) = A[K,M]^T . B[K,N]
+    if (q.M <= 0 || q.N <= 0 || q.K <= 0 || (q.M & 7) || (q.N & 7) || (q.lda & 7) || (q.ldb & 7) || !q.A || !q.B || !q.C)
+      return IFSEG_ERR_BAD_SHAPE;
+    GemmArgs& g = ga.p[i];
+    g.A = (const bf16_t*)q.A; g.B = (const bf16_t*)q.B; g.C = q.C;
+    g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.N;
+    g.alpha = 1.f; g.splitk = 1;
+    g.flags = (q.colsum ? IFSEG_GEMM_COLSUM : 0) | (q.accumulate ? IFSEG_GEMM_ACCUMULATE : 0);
+    const long long nrA = ((long long)(q.K - 1) * q.lda + q.M) * 2, nrB = ((long long)(q.K - 1) * q.ldb + q.N) * 2;
+    if (nrA >= (1ll << 31) || nrB >= (1ll << 31)) return IFSEG_ERR_BAD_SHAPE;
+    g.nrecA = (unsigned)nrA; g.nrecB = (unsigned)nrB;
+    ga.start[i] = total;
+    total += ((q.M + BM - 1) / BM) * ((q.N + 127) / 128);
+    flops += 2.0 * q.M * q.N * q.K;
+    bytes += 2.0 * ((double)q.M * q.K + (double)q.N * q.K + (double)q.M * q.N);
+  }
+  ga.start[n] = total;
+  ga.total = total;
+  hipStream_t s = (hipStream_t)stream;
+  ifseg_prof_begin(IFSEG_K_GEMM_TN, s, flops, bytes);
+  hipLaunchKernelGGL(gemm_tn_group_kernel<2>, dim3(total), dim3(256), 0, s, ga);
+  ifseg_prof_end(IFSEG_K_GEMM_TN, s);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int ifseg_gemm_nn_rowdot(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,

@@ -692,6 +692,26 @@ extern "C" int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamm
   return 0;
 }
 
+namespace {
+// master[i] <- p16[i] wherever the bf16 arena no longer is the rounding of the fp32 master (an external optimizer wrote
+// the bf16 parameters); entries that still agree keep their full-precision value
+__global__ void sync_master_kernel(float* master, const bf16_t* p16, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bf16_t h = p16[i];
+    if (f2bf(master[i]) != h) master[i] = bf2f(h);
+  }
+}
+}  // namespace
+
+extern "C" int ifseg_sync_master(float* master, const void* p16, long long n, void* stream) {
+  (void)hipGetLastError();
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sync_master_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, master, (const bf16_t*)p16, n);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int ifseg_reduce_parts(const float* in, void* out, int outer, int parts, long long n, int accumulate,
                                   int out_bf16, float scale, void* stream) {
   (void)hipGetLastError();

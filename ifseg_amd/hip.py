@@ -178,6 +178,37 @@ def linear_dw(dy, x, out, accumulate=False, bias_out=None):
     return False
 
 
+class _TnProblem(ctypes.Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p)] + [(n, c_int) for n in ("M", "N", "K", "lda", "ldb", "colsum", "accumulate")]
+
+
+GEMM_GROUP_MAX = 8
+
+
+def dw_groupable(dy, x, out, bias_out):
+    """can this dW = dy^T x (+ db) ride in a grouped launch?  bf16 dW contiguous in the arena, db right behind it"""
+    if out.dtype != torch.bfloat16 or not out.is_contiguous() or dy.stride(1) != 1 or x.stride(1) != 1:
+        return False
+    if bias_out is not None and not (bias_out.is_contiguous() and bias_out.dtype == out.dtype and
+                                     bias_out.data_ptr() == out.data_ptr() + out.numel() * out.element_size()):
+        return False
+    return dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0
+
+
+def linear_dw_group(tasks):
+    """tasks: list of (dy [M,N], x [M,K], out [N,K] bf16, bias_out or None): every dW (+ db) in ONE launch
+    (ifseg_gemm_tn_group), at most GEMM_GROUP_MAX per launch"""
+    for i in range(0, len(tasks), GEMM_GROUP_MAX):
+        chunk = tasks[i:i + GEMM_GROUP_MAX]
+        arr = (_TnProblem * len(chunk))()
+        for q, (dy, x, out, bias_out) in zip(arr, chunk):
+            M, N = dy.shape
+            q.A, q.B, q.C = _p(_bf(dy)), _p(_bf(x)), _p(out)
+            q.M, q.N, q.K, q.lda, q.ldb = N, x.shape[1], M, dy.stride(0), x.stride(0)
+            q.colsum, q.accumulate = (1 if bias_out is not None else 0), 0
+        _check(lib().ifseg_gemm_tn_group(c_int(len(chunk)), arr, _stream()), "gemm_tn_group")
+
+
 def conv2d_nhwc(x, w, shift, resid, out, B, H, W, Cin, Cout, KH, KW, stride, pad, relu):
     rc = lib().ifseg_conv2d_nhwc_bf16(_ptr(x), _ptr(w), _ptr(shift), _ptr(resid), _ptr(out), c_int(B), c_int(H),
                                       c_int(W), c_int(Cin), c_int(Cout), c_int(KH), c_int(KW), c_int(stride),
@@ -437,6 +468,10 @@ def embed_rows(table, ids, add, out):
     return out
 
 
+def sync_master(master, p16):
+    _check(lib().ifseg_sync_master(_ptr(master), _ptr(p16), c_ll(master.numel()), _stream()), "sync_master")
+
+
 def cast_f32_bf16(x, out, scale=1.0):
     _check(lib().ifseg_cast_f32_bf16(_ptr(x), _ptr(out), c_ll(x.numel()), c_float(scale), _stream()), "cast")
     return out
@@ -590,3 +625,25 @@ def dropout(x, resid, out, p, seed, drop_path_scale=None, rows_per_batch=None):
                              c_int(rl), c_ll(ob), c_int(ol), _stream())
     _check(rc, "dropout")
     return out
+
+
+# ---------------------------------------------------------------------- dense CRF (crf.py:19-37)
+def crf_bilateral(feat4, gx, gy, qn, out, H, W):
+    """out fp32 [Cp, N] = exact bilateral filter of qn bf16 [Cp, ldq]"""
+    _check(lib().ifseg_crf_bilateral(_ptr(feat4), _ptr(gx), _ptr(gy), _ptr(qn), c_int(qn.stride(0)), _ptr(out),
+                                     c_int(qn.shape[0]), c_int(H), c_int(W), _stream()), "crf_bilateral")
+
+
+def crf_spatial(qn, g, R, out, H, W):
+    _check(lib().ifseg_crf_spatial(_ptr(qn), _ptr(g), c_int(R), _ptr(out), c_int(qn.shape[0]), c_int(H), c_int(W), _stream()), "crf_spatial")
+
+
+def crf_update(prob, mpos, mbi, npos, nbi, wpos, wbi, Q, qpos, qbi):
+    C, N = prob.shape
+    _check(lib().ifseg_crf_update(_ptr(prob), _ptr(mpos), _ptr(mbi), _ptr(npos), _ptr(nbi), c_float(wpos), c_float(wbi),
+                                  _ptr(Q), _ptr(qpos), _ptr(qbi), c_int(qbi.stride(0) if qbi is not None else 0), c_int(C),
+                                  c_int(N), _stream()), "crf_update")
+
+
+def crf_norm(k1, n):
+    _check(lib().ifseg_crf_norm(_ptr(k1), _ptr(n), c_int(n.numel()), _stream()), "crf_norm")

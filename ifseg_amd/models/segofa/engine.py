@@ -71,6 +71,10 @@ class HipEngine:
         self._trunk_stream, self._pf, self._pf_slot = None, None, 0
         self._pf_request = None          # images of the next batch (set by the trainer; consumed by the next forward)
         self._pending, self._in_flush = [], False
+        # weight-gradient GEMMs of a layer are collected and launched as ONE grouped GEMM at the end of the layer's
+        # backward (no split-K slabs / reduction launches: hip.linear_dw_group); IFSEG_NO_DW_GROUP=1: one GEMM each
+        self._dw_tasks = []
+        self.dw_grouped = os.environ.get("IFSEG_NO_DW_GROUP") is None
         self.attn_bwd_timing = None      # {"stride": n, "seen": 0, "pairs": []} while bench.py times the attention backward
         self._bt = ""                    # tag of the backward block being processed (unique gradient buffers)
 
@@ -174,7 +178,7 @@ class HipEngine:
         # read the SMALL parameters whose bf16 rounding is coherent per channel -- LayerNorm gains / biases and the
         # per-head c_attn gains -- from here (`Wf`): their rounding alone costs 1.0e-2 of logits rel-L2 on SegOFA-Base
         # (tools/err_budget2.py).  With an external optimizer (fairseq's, writing the bf16 parameters) the copy is
-        # refreshed from the arena after every backward, i.e. the values are then the bf16 ones.
+        # re-synchronised after every backward: entries whose bf16 value changed take it, the others stay exact.
         self.master = master
         self._master_stale = False
         self.offs, self.n_train, self.order = offs, n_train, order
@@ -588,7 +592,7 @@ class HipEngine:
         try:
             if self._master_stale and self.packed and not self.master_owned:
                 # an external optimizer stepped the bf16 parameters since the last forward
-                self.master.copy_(self.p16[: self.n_train])      # parameter plumbing (dtype copy), no activation involved
+                hip.sync_master(self.master, self.p16[: self.n_train])
                 self._master_stale = False
             out = self._forward(*args, **kw)
             if need_grad:
@@ -1114,7 +1118,11 @@ class HipEngine:
         def wgrad():
             if not hip.linear_dw(dy, x, gw, bias_out=gb) and gb is not None:
                 self._bias_grad(dy, gb)
-        self._side_do(wgrad)
+        if self.overlap and self.dw_grouped and dy.shape[0] >= 4096 and hip.dw_groupable(dy, x, gw, gb):
+            # operands live in per-block buffers (gbuf) / saved activations: still intact at the end of the layer
+            self._dw_tasks.append((dy, x, gw, gb))
+        else:
+            self._side_do(wgrad)
         if need_dx:
             return hip.linear_dx(dy, wname_or_view, out=dx_out, resid=dx_resid, accumulate=dx_accumulate)
         return None
@@ -1394,7 +1402,7 @@ class HipEngine:
             self._side_flush()
         # ---- encoder abs-pos operands
         self._bt = "etop"
-        self._side_do(lambda: self._enc_tail_bwd(B, L, P, T, h, w, dx, depq, depk, pos_all, dpos_all))
+        self._side_do(lambda: (self._dw_flush(), self._enc_tail_bwd(B, L, P, T, h, w, dx, depq, depk, pos_all, dpos_all)))
         self._join_side()            # (flushes) the optimizer (main stream) reads the whole gradient arena next
         return self.g16
 
@@ -1461,7 +1469,13 @@ class HipEngine:
                          G(d + "cross_pos_k_linear.bias"), dx_out=dpos_all)
         self._side_do(lambda: self._notify(d))
 
+    def _dw_flush(self):
+        tasks, self._dw_tasks = self._dw_tasks, []
+        if tasks:
+            hip.linear_dw_group(tasks)
+
     def _flush_tables(self):
+        self._dw_flush()
         for key, tabname in self._tab_touched.items():
             hip.cast_f32_bf16(self.ws[key].view(-1), self.G(tabname).view(-1))
         self._tab_touched = {}

@@ -166,6 +166,19 @@ class SegmentationTask(TaskBase):
                               orig_patch_image_size=self.cfg.orig_patch_image_size, **over)
         return SegOFAModel.build_model(cfg, self)
 
+    def build_generator(self, models, args=None, seq_gen_cls=None, extra_gen_cls_kwargs=None, prefix_allowed_tokens_fn=None):
+        """tasks/ofa_task.py:187-260 with the task's eval_args ({"beam":5,"max_len":1024,"min_len":1024,...},
+        coco_unseen.sh:111): the fixed-length decode of ifseg_amd/sequence_generator.py"""
+        from ...sequence_generator import SequenceGenerator
+        g = lambda k, d: getattr(args, k, d) if args is not None else d
+        return SequenceGenerator(models, self.target_dictionary, beam_size=g("beam", 5), max_len=g("max_len", None),
+                                 min_len=g("min_len", 1), temperature=g("temperature", 1.0))
+
+    def inference_step(self, generator, models, sample, prefix_tokens=None, constraints=None):
+        """fairseq_task.py `inference_step` -> [B, max_len] seg-class indices of the best beam (segmentation.py:266-268)"""
+        with torch.no_grad():
+            return generator.generate(models, sample)
+
     def encode_category(self, text):
         """token ids of one category name (seg_criterion.py:375-385: BPE of ' <word>' per word, dictionary lookup)"""
         if self.bpe is not None:

@@ -105,7 +105,7 @@ class Trainer:
             eng.grad_ready_hook = self._on_grads_ready
             # same start on every rank (DDP broadcasts rank 0's parameters at construction)
             if self.reducer.staged:
-                for t in (eng.p16.view(torch.int16), self.p32):
+                for t in (eng.p16.view(torch.float16), self.p32):      # gloo: no bf16 / int16
                     c = t.cpu()
                     dist.broadcast(c, 0)
                     t.copy_(c)

@@ -55,6 +55,18 @@ int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C, int M, in
                     int ldb, int ldc, const void* bias, float alpha, int alpha_ncols,
                     const void* resid, int ldr, int flags, int batch, long long strideA,
                     long long strideB, long long strideC, long long strideR, int splitk, void* stream);
+/* Grouped weight-gradient GEMM: n <= IFSEG_GEMM_GROUP_MAX independent products C_i[M,N] = A_i[K,M]^T . B_i[K,N]
+ * (dW = dY^T X of the Linear modules of ONE transformer layer: fc1, fc2, q|k|v, out_proj, cross q, cross k|v --
+ * unify_transformer_layer.py:279-283,556-560, unify_multihead_attention.py:327-346,513 under autograd) in one launch,
+ * one workgroup per 128x128 tile over all K tokens: no split-K slabs, no reduction launches.  C_i is bf16 [M, N]
+ * (ldc == N); colsum != 0 also writes db_i[M] = column sums of A_i (bf16) right behind C_i (a Linear's weight and
+ * bias are adjacent in the gradient arena); accumulate != 0 adds to what C_i / db_i hold. */
+#define IFSEG_GEMM_GROUP_MAX 8
+typedef struct {
+  const void* A; const void* B; void* C;
+  int M, N, K, lda, ldb, colsum, accumulate;
+} ifseg_gemm_tn_problem;
+int ifseg_gemm_tn_group(int n, const ifseg_gemm_tn_problem* probs, void* stream);
 /* C[M,N] = A[M,K] . B[K,N] (NN, bf16 out) and, from the same epilogue, the per-head row dots with a second operand:
  *   dot_out[(m / rows_per_batch) * (N/64) + h][m % rows_per_batch] = sum_{c<64} C[m][64h+c] (as stored) * dot[m][64h+c]
  * i.e. the attention backward's delta = rowsum(dO * O) ([B,H,T] fp32) while dO = d(attn_ln input) . W_out is produced
@@ -186,6 +198,9 @@ int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamma, const fl
                       const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, void* dx2, int nblocks, int rows,
                       int C, int flags, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx, long long dx_bs, int lddx,
                       long long add_bs, int ldadd, long long dx2_bs, int lddx2, const ifseg_drop_args* drop2, void* stream);
+/* fp32 master copy <- bf16 arena wherever bf16(master[i]) != p16[i] (an optimizer outside this library stepped the bf16
+ * parameters: fp16_optimizer.py:198-222 writes the model copy); agreeing entries keep their fp32 value. */
+int ifseg_sync_master(float* master, const void* p16, long long n, void* stream);
 /* out[o][i] (+)= scale * sum_p in[o][p][i]   (fp32 in; fp32 or bf16 out) */
 int ifseg_reduce_parts(const float* in, void* out, int outer, int parts, long long n, int accumulate,
                        int out_bf16, float scale, void* stream);
@@ -282,6 +297,21 @@ int ifseg_grad_sumsq_bf16(const void* g, long long n, float* workspace, float* o
 int ifseg_adam_step(float* p32, const void* g, float* m, float* v, void* p16, long long n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float grad_scale, float max_norm,
                     const float* sumsq, int* overflow, void* stream);
+
+/* ------------------------------------------------- dense-CRF post-processing (crf.py:19-37) */
+/* Mean-field inference of the reference's DenseCRF2D (pydensecrf, third party, absent: parity unpinned) with the EXACT
+ * dense kernels instead of the permutohedral-lattice approximation.  All tensors class-major ([C][N], N = H*W pixels).
+ * ifseg_crf_bilateral: out[c][i] = sum_j gx[|xi-xj|] gy[|yi-yj|] exp2(-|f_i - f_j|^2) qn[c][j]; feat4 [N][4] fp32 =
+ *   (pre-scaled r, g, b, bit pattern x | y << 16), qn bf16 [Cp][ldq] (Cp % 32 == 0, ldq % 64 == 0, zero padded), out fp32
+ *   [Cp][N].  ifseg_crf_spatial: the sxy = 1 Gaussian as a (2R+1)^2 stencil on fp32 [C][N].
+ * ifseg_crf_update: Q = softmax_c(log clip(prob, 1e-5, 1) + wpos npos mpos + wbi nbi mbi) -> Q, qpos = npos Q (fp32),
+ *   qbi = nbi Q (bf16 [Cp][ldq]); mpos / mbi / npos / nbi may be NULL.  ifseg_crf_norm: n = rsqrt(k1 + 1e-20). */
+int ifseg_crf_bilateral(const float* feat4, const float* gx, const float* gy, const void* qn, int ldq, float* out, int Cp,
+                        int H, int W, void* stream);
+int ifseg_crf_spatial(const float* qn, const float* g, int R, float* out, int C, int H, int W, void* stream);
+int ifseg_crf_update(const float* prob, const float* mpos, const float* mbi, const float* npos, const float* nbi, float wpos,
+                     float wbi, float* Q, float* qpos, void* qbi, int ldq, int C, int N, void* stream);
+int ifseg_crf_norm(const float* k1, float* n, int N, void* stream);
 
 /* -------------------------------------------------------------- profiling */
 /* Per-kernel-family timing with HIP events recorded on the launch stream (bench.py's

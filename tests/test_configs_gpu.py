@@ -43,7 +43,19 @@ def _sample(batch, dev):
             "target": batch["target"].to(dev), "ntokens": 1, "nsentences": batch["target"].shape[0]}
 
 
-def _golden_case(golden_dir, name, ocfg, B):
+def _argmax_consistent(logits, ref):
+    """argmax agreement over the patch positions, and whether every disagreement lies where the reference itself is
+    undecided: its top-1 / top-2 margin is below 3x the largest logit error of that position (with 150+ near-uniform
+    classes at random init most margins are smaller than any bf16 error; BASELINE.md's 99 % is for the 15-class config)"""
+    lg, rf = logits[:, 1:].float(), ref[:, 1:].float()
+    agree = lg.argmax(-1) == rf.argmax(-1)
+    top2 = rf.topk(2, -1).values
+    margin = top2[..., 0] - top2[..., 1]
+    err = (lg - rf).abs().max(-1).values
+    return agree.float().mean().item(), bool((agree | (margin <= 3 * err)).all())
+
+
+def _golden_case(golden_dir, name, ocfg, B, min_agree=0.99):
     dev = torch.device("cuda:0")
     g = np.load(os.path.join(golden_dir, name))
     assert int(g["batch_size"]) == B
@@ -57,9 +69,9 @@ def _golden_case(golden_dir, name, ocfg, B):
     logits = m.engine.ws["logits_pad"][:, :, :n].float().cpu()
     ref = torch.from_numpy(g["logits_causal"])
     e = _rel(logits, ref)
-    agree = (logits[:, 1:].argmax(-1) == ref[:, 1:].argmax(-1)).float().mean().item()
+    agree, consistent = _argmax_consistent(logits, ref)
     print("%s: logits rel-L2 %.4f, loss %.5f vs reference %.5f, patch argmax agreement %.4f" % (name, e, loss.item(), float(g["loss"]), agree))
-    assert e <= 2e-2 and abs(loss.item() - float(g["loss"])) <= 1e-2 and agree >= 0.99
+    assert e <= 2e-2 and abs(loss.item() - float(g["loss"])) <= 1e-2 and agree >= min_agree and consistent
     named = dict(m.named_parameters())
     for k in g.files:
         if k.startswith("gradnorm:") and not k.endswith("c_attn"):
@@ -79,7 +91,8 @@ def test_base_config1_batch2_vs_reference_golden(golden_dir):
 def test_base_config3_geometry_vs_reference_golden(golden_dir):
     """BASELINE configs[2] per-GPU geometry: Base width, 150 ADE20K classes, L = 215 prompt tokens, T_enc = 1239 (a T
     that is a multiple of nothing), log-spaced token buckets beyond |i-j| = 128 (reference outputs: base_c3.npz)."""
-    _golden_case(golden_dir, "base_c3.npz", O.base_config(num_seg_tokens=150, vocab_size=59458), 1)
+    # 150 near-uniform classes at random init: agreement >= 95 %, every disagreement inside the reference's own margin
+    _golden_case(golden_dir, "base_c3.npz", O.base_config(num_seg_tokens=150, vocab_size=59458), 1, min_agree=0.95)
 
 
 def test_base_config2_batch8_consistent_with_batch2_golden(golden_dir):
@@ -139,10 +152,10 @@ def test_large_full_depth_resnet152_vs_oracle():
     lg, loss, g1 = run()
     _, loss2, g2 = run()
     e = _rel(lg, o_logits)
-    agree = (lg[:, 1:].argmax(-1) == o_logits[:, 1:].argmax(-1)).float().mean().item()
+    agree, consistent = _argmax_consistent(lg, o_logits)
     print("large full depth: logits rel-L2 %.4f, argmax agreement %.4f, loss %.5f" % (e, agree, loss))
-    # 24 bf16 layers: the stated 2e-2 is for Base; Large is held to 3e-2 (measured value printed above)
-    assert e <= 3e-2 and agree >= 0.98
+    # 24 bf16 layers, 171 near-uniform classes: the stated tolerance on the logits holds; argmax as for config 3
+    assert e <= 2e-2 and agree >= 0.95 and consistent
     assert loss == loss2 and torch.equal(g1, g2) and torch.isfinite(g1.float()).all()
     eng = m.engine
     dead = [n for n in eng.trainable_names() if eng.G(n).float().abs().sum().item() == 0]
@@ -238,8 +251,16 @@ def test_two_rank_train_step_on_one_gpu_over_gloo(tmp_path):
     env = dict(os.environ, IFSEG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_two_rank_worker.py"), str(r), "2", port, str(tmp_path)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(2)]
-    outs = [p.communicate(timeout=600)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                                   # this exact child (never by pattern)
+                outs.append(p.communicate()[0])
+    assert all(p.returncode == 0 for p in procs), [o[-3000:] for o in outs]
     r0, r1 = (torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(2))
     assert torch.equal(r0["p16_start"].view(torch.int16), r1["p16_start"].view(torch.int16))     # broadcast from rank 0
     assert torch.equal(r0["p16"].view(torch.int16), r1["p16"].view(torch.int16)) and torch.equal(r0["p32"], r1["p32"])
@@ -309,3 +330,69 @@ def test_out_of_range_label_is_refused():
         crit(m, bad)
         torch.cuda.synchronize()
         crit(m, sample)
+
+
+def test_dense_crf_meanfield_vs_exact_oracle():
+    """crf.py:19-37 (BASELINE config 5 post-processing): 10 mean-field iterations of the DenseCRF2D energy with the
+    recipe's constants on the device against the exact dense restatement (oracle/crf_ref.py; pydensecrf itself is a
+    third-party approximate filter that is not available: parity unpinned, see the oracle's header)."""
+    import crf_ref
+    from ifseg_amd.crf import rgb_dense_crf
+    g = torch.Generator().manual_seed(5)
+    h, w, c = 40, 48, 5
+    # piecewise-constant image + noise: the bilateral term (srgb = 3) only couples nearly identical colours
+    base = torch.randint(0, 256, (4, 3), generator=g).float()
+    region = (torch.arange(h)[:, None] // 20) * 2 + (torch.arange(w)[None, :] // 24)
+    image = (base[region] + torch.randn(h, w, 3, generator=g) * 2.0).clamp(0, 255).round().to(torch.uint8)
+    probs = torch.softmax(torch.randn(c, h, w, generator=g) * 1.5, 0)
+    want = crf_ref.rgb_dense_crf_exact(image.numpy(), probs.numpy(), max_iter=10)
+    got = rgb_dense_crf(image.numpy(), probs.numpy(), max_iter=10)
+    assert isinstance(got, np.ndarray) and got.shape == (c, h, w)
+    got = torch.from_numpy(got)
+    assert torch.allclose(got.sum(0), torch.ones(h, w), atol=1e-4)
+    err = (got - want).abs().max().item()
+    agree = (got.argmax(0) == want.argmax(0)).float().mean().item()
+    changed = (want.argmax(0) != probs.argmax(0)).float().mean().item()
+    print("dense CRF: max |dQ| %.4f, argmax agreement %.4f (CRF changed %.1f %% of the labels)" % (err, agree, 100 * changed))
+    assert changed > 0.05                      # the fixture actually exercises the pairwise terms
+    assert err <= 3e-2 and agree >= 0.99       # bf16 kernel / message operands in the MFMA
+    # full-size property run (512 x 512, 15 classes): finite, normalised, deterministic
+    image = torch.randint(0, 256, (512, 512, 3), generator=g, dtype=torch.uint8)
+    probs = torch.softmax(torch.randn(15, 512, 512, generator=g), 0).cuda()
+    torch.cuda.synchronize()
+    import time
+    t0 = time.time()
+    q1 = rgb_dense_crf(image, probs, max_iter=2)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    q2 = rgb_dense_crf(image, probs, max_iter=2)
+    print("512x512x15, 2 iterations (+ normalisation pass): %.1f ms" % (dt * 1e3))
+    assert torch.equal(q1, q2) and torch.isfinite(q1).all() and torch.allclose(q1.sum(0), torch.ones(512, 512, device=q1.device), atol=1e-4)
+
+
+def test_fixed_length_decode_through_the_task():
+    """BASELINE config 5 decode (models/sequence_generator.py:210-585 semantics, see ifseg_amd/sequence_generator.py):
+    task.build_generator + inference_step on the HIP model: the best beam is the per-position argmax of the causal
+    pass's logits, beams are sorted, scores are cumulative log-probabilities."""
+    import argparse
+    import test_model_gpu as T
+    from ifseg_amd.tasks.mm_tasks import SegmentationTask
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    m = T._build(ocfg, sd, dev).eval()
+    task = SegmentationTask(num_seg_tokens=ocfg.num_seg_tokens, patch_image_size=128, n_base_vocab=ocfg.vocab_size - 1)
+    gen = task.build_generator([m], argparse.Namespace(beam=5, max_len=1024, min_len=1024, no_repeat_ngram_size=0))
+    batch = O.synthetic_batch(ocfg, 2, 12)
+    P = 64
+    net = {k: batch[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks")}
+    net["src_lengths"] = torch.full((2,), 12, device=dev)
+    net["prev_output_tokens"] = torch.zeros(2, P + 1, dtype=torch.long, device=dev)       # max_len = P steps
+    pred = task.inference_step(gen, [m], {"net_input": net})
+    assert pred.shape == (2, P)
+    with torch.no_grad():
+        ol, _ = O.segofa_forward(sd, ocfg, batch["src_tokens"], batch["patch_images"])      # causal, reference order [bos, patches]
+    agree = (pred.cpu() == ol[:, :P].argmax(-1)).float().mean().item()
+    assert agree >= 0.97, agree
+    _, toks, scores = gen._generate([m], {"net_input": net}, return_all_beams=True)
+    assert (scores[:, :-1, -1] >= scores[:, 1:, -1]).all() and torch.equal(toks[:, 0], pred)

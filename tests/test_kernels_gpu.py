@@ -681,3 +681,80 @@ def test_gemm_nn_rowdot_delta_epilogue():
                  B, H, T, T, phases=hip.ATTN_BWD_DELTA)
     torch.cuda.synchronize()
     assert (delta - d2).abs().max().item() < 1e-4 * want.abs().max().item()
+
+
+def test_gemm_tn_group_layer_of_weight_gradients():
+    """ifseg_gemm_tn_group: the dW (+ db) products of one encoder / decoder layer in ONE launch, no split-K: each result
+    against the fp32 product, bias gradients right behind their weights, nothing written outside, and bit-identical to
+    the one-problem launches (a tile's arithmetic does not depend on its group mates)."""
+    from ifseg_amd import hip
+    dev = _dev()
+    M = 8480
+    shapes = [(768, 3072), (3072, 768), (2304, 768), (768, 768), (768, 768), (1536, 768), (768, 768)]   # (N_out, K_in): decoder layer
+    tasks, flats = [], []
+    for i, (N, K) in enumerate(shapes):
+        Mi = M if i != 5 else 8200                                   # cross-attention K|V: rows of the ENCODER output
+        dy, x = _rand((Mi, N + 8), dev, 300 + i, 0.5)[:, :N], _rand((Mi, K), dev, 320 + i, 0.5)      # strided dy (a q|k|v slice)
+        flat = torch.full((N * K + N + 8,), 7.0, dtype=torch.bfloat16, device=dev)
+        has_b = i != 3
+        tasks.append((dy, x, flat[: N * K].view(N, K), flat[N * K: N * K + N] if has_b else None))
+        flats.append(flat)
+    assert all(hip.dw_groupable(*t) for t in tasks)
+    hip.linear_dw_group(tasks)
+    torch.cuda.synchronize()
+    for (dy, x, gw, gb), flat in zip(tasks, flats):
+        N, K = gw.shape
+        assert _rel(gw, dy.float().t() @ x.float()) < 6e-3
+        if gb is not None:
+            assert _rel(gb, dy.float().sum(0)) < 6e-3
+            assert (flat[N * K + N:] == 7.0).all()
+        else:
+            assert (flat[N * K:] == 7.0).all()
+    first = [f.clone() for f in flats]
+    for f in flats:
+        f.fill_(3.0)
+    for t in tasks:
+        hip.linear_dw_group([t])
+    torch.cuda.synchronize()
+    for a, b, (dy, x, gw, gb) in zip(first, flats, tasks):
+        n = gw.numel() + (gb.numel() if gb is not None else 0)
+        assert torch.equal(a[:n], b[:n])
+    # a task whose bias gradient is NOT adjacent is not groupable (the caller keeps its own path)
+    assert not hip.dw_groupable(tasks[0][0], tasks[0][1], tasks[0][2], torch.empty(768, dtype=torch.bfloat16, device=dev))
+
+
+@pytest.mark.parametrize("C,gelu", [(768, False), (3072, True)])
+def test_layernorm_fp32_params_flag(C, gelu):
+    """IFSEG_LN_PARAMS_F32: gains / biases read from fp32 tensors (the master copy) -- forward, pair, backward and
+    backward + dropout all see the unrounded values."""
+    from ifseg_amd import hip
+    import torch.nn.functional as F
+    dev = _dev()
+    rows = 515
+    x = _rand((rows, C), dev, 50)
+    g32 = 1 + 0.1 * _rand((C,), dev, 51).float() + 1e-3 * torch.rand(C, device=dev)      # NOT representable in bf16
+    b32 = 0.1 * _rand((C,), dev, 52).float() + 1e-4 * torch.rand(C, device=dev)
+    y = torch.empty(rows, C, dtype=torch.bfloat16, device=dev)
+    mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    hip.ln_fwd(x, g32, b32, y, mean, rstd, gelu=gelu)
+    a = F.gelu(x.float()) if gelu else x.float()
+    ref = F.layer_norm(a, (C,), g32, b32, 1e-5)
+    e32 = (y.float() - ref).abs().max().item()
+    hip.ln_fwd(x, g32.to(torch.bfloat16), b32.to(torch.bfloat16), y, mean, rstd, gelu=gelu)
+    e16 = (y.float() - ref).abs().max().item()
+    assert _rel(y, ref) < 6e-3 and e32 <= e16
+    dy = _rand((rows, C), dev, 53)
+    dx32 = torch.empty(rows, C, dtype=torch.bfloat16, device=dev)
+    dgp, dbp = torch.zeros(hip.LN_BWD_BLOCKS, C, device=dev), torch.zeros(hip.LN_BWD_BLOCKS, C, device=dev)
+    hip.ln_bwd(dy, x, g32, mean, rstd, dx32, dgp, dbp, gelu=gelu)
+    xf = x.float().clone().requires_grad_(True)
+    (F.layer_norm(F.gelu(xf) if gelu else xf, (C,), g32, b32, 1e-5) * dy.float()).sum().backward()
+    assert _rel(dx32, xf.grad) < 8e-3
+    if not gelu:
+        y2a, y2b = torch.empty_like(y), torch.empty_like(y)
+        m2, r2 = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+        hip.ln_fwd(x, g32, b32, y, mean, rstd)
+        hip.ln_fwd(y, b32 + 1, g32 - 1, y2a, m2, r2)
+        ya = y.clone()
+        hip.ln_fwd_pair(x, g32, b32, y, mean, rstd, b32 + 1, g32 - 1, y2b, m2, r2)
+        assert torch.equal(y, ya) and torch.equal(y2a, y2b)

@@ -192,3 +192,20 @@ def test_recipe_flags_reach_the_config_without_fairseq():
                 dict(decoder_input_type="encoder_input"), dict(tie_seg_projection="false")):
         with pytest.raises(NotImplementedError):
             SegOFAModel.build_model(recipe_args("segofa_tiny", num_seg_tokens=5, **bad), task)
+
+
+def test_fixed_length_beam_search_is_exact_k_best():
+    """ifseg_amd.sequence_generator.beam_search_independent (fairseq BeamSearch semantics on the surrogate decoder's
+    per-step independent distributions): against brute-force enumeration of all V^T sequences."""
+    import itertools
+    from ifseg_amd.sequence_generator import beam_search_independent
+    g = torch.Generator().manual_seed(3)
+    B, T, V, beam = 2, 5, 4, 3
+    lp = torch.log_softmax(torch.randn(B, T, V, generator=g), -1)
+    tokens, scores = beam_search_independent(lp, beam)
+    for b in range(B):
+        allseq = sorted(((sum(lp[b, t, s[t]].item() for t in range(T)), s) for s in itertools.product(range(V), repeat=T)), reverse=True)
+        for k in range(beam):
+            assert tuple(tokens[b, k].tolist()) == allseq[k][1]
+            assert abs(scores[b, k, -1].item() - allseq[k][0]) < 1e-5
+        assert torch.equal(tokens[b, 0], lp[b].argmax(-1))               # best beam = per-position argmax
