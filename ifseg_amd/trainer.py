@@ -104,14 +104,19 @@ class Trainer:
         if self.world > 1:
             eng.grad_ready_hook = self._on_grads_ready
             # same start on every rank (DDP broadcasts rank 0's parameters at construction)
+            # (the frozen ResNet trunk and its FrozenBN statistics live outside the arena: broadcast too, then re-fold)
+            extra = [p.data for n, p in model.named_parameters() if "embed_images" in n]
+            extra += [b.data for n, b in model.named_buffers() if "embed_images" in n and b.dtype.is_floating_point]
             if self.reducer.staged:
-                for t in (eng.p16.view(torch.float16), self.p32):      # gloo: no bf16 / int16
+                for t in [eng.p16.view(torch.float16), self.p32] + extra:      # gloo: no bf16 / int16
                     c = t.cpu()
                     dist.broadcast(c, 0)
                     t.copy_(c)
             else:
-                dist.broadcast(eng.p16, 0)
-                dist.broadcast(self.p32, 0)
+                for t in [eng.p16, self.p32] + extra:
+                    dist.broadcast(t, 0)
+            eng._pack_resnet()
+            eng.refresh_frozen()
 
     # -- DDP over the flat arena ---------------------------------------------------------
     def _on_grads_ready(self, prefix):

@@ -156,7 +156,9 @@ def test_large_full_depth_resnet152_vs_oracle():
     print("large full depth: logits rel-L2 %.4f, argmax agreement %.4f, loss %.5f" % (e, agree, loss))
     # 24 bf16 layers, 171 near-uniform classes: the stated tolerance on the logits holds; argmax as for config 3
     assert e <= 2e-2 and agree >= 0.95 and consistent
-    assert loss == loss2 and torch.equal(g1, g2) and torch.isfinite(g1.float()).all()
+    # the forward is bit-deterministic; on a grid that is not 32 wide (40 x 40 here) the rel-pos table gradient is an LDS
+    # float-atomic histogram (csrc/attention.hip), so the gradient arena is reproducible to rounding, not bitwise
+    assert loss == loss2 and _rel(g1, g2) <= 1e-3 and torch.isfinite(g1.float()).all()
     eng = m.engine
     dead = [n for n in eng.trainable_names() if eng.G(n).float().abs().sum().item() == 0]
     never = ("decoder.embed_positions", "decoder.embed_image_positions", "decoder.pos_ln", "decoder.image_pos_ln",

@@ -77,7 +77,7 @@ def test_fixture_forward_backward_vs_oracle(golden_dir):
     e_loss = abs(loss.item() - o_loss.item())
     agree = (logits.argmax(-1) == o_logits.argmax(-1)).float().mean().item()
     print("fixture: logits rel-L2 %.4f  loss %.5f vs %.5f (d=%.5f)  argmax agree %.4f" % (e_logits, loss.item(), o_loss.item(), e_loss, agree))
-    assert e_logits <= 2e-2 and e_loss <= 1e-2 and agree >= 0.97
+    assert e_logits <= 2e-2 and e_loss <= 1e-2 and agree >= 0.99
     assert abs(loss.item() - float(g["loss"])) <= 1e-2                      # HIP vs reference golden
     assert _rel(logits, torch.from_numpy(g["logits_causal"])) <= 2e-2
     loss.backward()
@@ -148,9 +148,9 @@ def test_base_config1_vs_reference_golden(golden_dir):
     e = _rel(logits, ref)
     agree = (logits[:, :-1].argmax(-1) == ref[:, :-1].argmax(-1)).float().mean().item()
     print("base c1: logits rel-L2 %.4f, loss %.5f vs reference %.5f, patch argmax agreement %.4f" % (e, loss.item(), float(g["loss"]), agree))
-    # 12 bf16 layers deep: measured 2.08e-2 (error budget: tools/err_budget.py -- ResNet 0.7e-2, encoder
-    # 0.9e-2); the loss / argmax (= mIoU) tolerances of BASELINE.md section 5 are met with margin
-    assert e <= 2.5e-2 and abs(loss.item() - float(g["loss"])) <= 1e-2 and agree >= 0.99
+    # BASELINE.md section 5 tolerances as stated (round 1 measured 2.08e-2: rounding LayerNorm gains / biases and the head
+    # gains to bf16 alone cost 1.0e-2 -- tools/err_budget2.py; they are read from the fp32 master copy now)
+    assert e <= 2e-2 and abs(loss.item() - float(g["loss"])) <= 1e-2 and agree >= 0.99
     named = dict(m.named_parameters())
     for k in g.files:
         if not k.startswith("gradnorm:"):
