@@ -41,7 +41,10 @@ __global__ void finish_norm_kernel(const float* part, int nparts, float* out_sum
 __global__ __launch_bounds__(256) void adam_kernel(float* p32, const bf16_t* g, float* m, float* v, bf16_t* p16,
                                                    long long n, float lr, float beta1, float beta2, float eps, float wd,
                                                    float bc1, float bc2, float gscale, float max_norm,
-                                                   const float* sumsq, int* overflow) {
+                                                   const float* sumsq, int* overflow, const float* hyper) {
+  if (hyper) {      // per-update scalars from device memory (a captured step replays with the current schedule)
+    lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; gscale = hyper[3];
+  }
   float coef = gscale;
   if (sumsq && !isfinite(sumsq[0])) {
     // trainer.py:895-904: a NaN / Inf gradient norm must not reach the fp32 masters or the Adam moments
@@ -100,12 +103,12 @@ extern "C" int ifseg_grad_sumsq_bf16(const void* g, long long n, float* workspac
 
 extern "C" int ifseg_adam_step(float* p32, const void* g, float* m, float* v, void* p16, long long n, float lr,
                                float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                               float max_norm, const float* sumsq, int* overflow, void* stream) {
+                               float max_norm, const float* sumsq, int* overflow, const float* hyper, void* stream) {
   (void)hipGetLastError();
   if (n <= 0) return 0;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, p32, (const bf16_t*)g, m, v,
-                     (bf16_t*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, max_norm, sumsq, overflow);
+                     (bf16_t*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, max_norm, sumsq, overflow, hyper);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

@@ -60,12 +60,14 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
 }
 struct DropArgs {   // on == 0: identity
   int on; float p; unsigned long long seed; const float* dpscale; int rows_per_batch;
+  const unsigned long long* seed_add;   // device word added to `seed` (the per-update part: a captured step replays with new masks)
 };
 // f[0..8) *= keep * scale for chunk c8 (= row * C/8 + chunk) of logical row `row`
 __device__ __forceinline__ void drop8(float* f, const DropArgs& d, long long c8, int row) {
   const float sc = (d.dpscale ? d.dpscale[row / d.rows_per_batch] : 1.f) * (d.p > 0.f ? 1.f / (1.f - d.p) : 1.f);
   const unsigned thr = (unsigned)(d.p * 65536.f);
-  const unsigned long long r0 = splitmix64(d.seed + 2ull * (unsigned long long)c8), r1 = splitmix64(d.seed + 2ull * (unsigned long long)c8 + 1ull);
+  const unsigned long long sd = d.seed + (d.seed_add ? *d.seed_add : 0ull);
+  const unsigned long long r0 = splitmix64(sd + 2ull * (unsigned long long)c8), r1 = splitmix64(sd + 2ull * (unsigned long long)c8 + 1ull);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const unsigned bits = (unsigned)(((e < 4 ? r0 : r1) >> (16 * (e & 3))) & 0xFFFFu);
@@ -605,7 +607,7 @@ static int ln_fwd_impl(const void* x, const void* gamma, const void* beta, const
   DropArgs dr{};
   if (drop) {
     if (drop->p < 0.f || drop->p >= 1.f || drop->rows_per_batch <= 0) return IFSEG_ERR_BAD_ARG;
-    dr = DropArgs{1, drop->p, drop->seed, drop->drop_path_scale, drop->rows_per_batch};
+    dr = DropArgs{1, drop->p, drop->seed, drop->drop_path_scale, drop->rows_per_batch, drop->seed_add};
   }
   RowMap mx{rpb, x_bs, ldx}, my{rpb, y_bs, ldy}, mr{rpb, r_bs, ldr}, my2{rpb, y2_bs, ldy2};
   dim3 g((rows + 3) / 4);
@@ -652,7 +654,7 @@ extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, co
   DropArgs dr{};
   if (drop) {
     if (drop->p < 0.f || drop->p >= 1.f || drop->rows_per_batch <= 0) return IFSEG_ERR_BAD_ARG;
-    dr = DropArgs{1, drop->p, drop->seed, drop->drop_path_scale, drop->rows_per_batch};
+    dr = DropArgs{1, drop->p, drop->seed, drop->drop_path_scale, drop->rows_per_batch, drop->seed_add};
   }
   RowMap mdy{rpb, dy_bs, lddy}, mx{rpb, x_bs, ldx}, mdx{rpb, dx_bs, lddx}, madd{rpb, add_bs, ldadd};
   dim3 g(nblocks);
@@ -679,7 +681,7 @@ extern "C" int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamm
   DropArgs dr{};
   if (drop2) {
     if (drop2->p < 0.f || drop2->p >= 1.f || drop2->rows_per_batch <= 0) return IFSEG_ERR_BAD_ARG;
-    dr = DropArgs{1, drop2->p, drop2->seed, drop2->drop_path_scale, drop2->rows_per_batch};
+    dr = DropArgs{1, drop2->p, drop2->seed, drop2->drop_path_scale, drop2->rows_per_batch, drop2->seed_add};
   }
   RowMap mdy{rpb, dy_bs, lddy}, mx{rpb, x_bs, ldx}, mdx{rpb, dx_bs, lddx}, madd{rpb, add_bs, ldadd}, mdx2{rpb, dx2_bs, lddx2};
   hipStream_t s = (hipStream_t)stream;
@@ -893,14 +895,14 @@ extern "C" int ifseg_rel_scatter_add(const float* d, const int* idx, float* acc,
 namespace {
 __global__ void dropout_kernel(const bf16_t* x, const bf16_t* resid, bf16_t* out, long long nchunks, int C, float p,
                                unsigned long long seed, const float* dpscale, int rows_per_batch, RowMap mx, RowMap mr,
-                               RowMap mo) {
+                               RowMap mo, const unsigned long long* seed_add) {
   const long long c8 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (c8 >= nchunks) return;
   const int nch = C >> 3;
   const int row = (int)(c8 / nch), col = (int)(c8 % nch) * 8;
   float f[8];
   unpack8(*reinterpret_cast<const uint4*>(x + mx.off(row) + col), f);
-  drop8(f, DropArgs{1, p, seed, dpscale, rows_per_batch}, c8, row);
+  drop8(f, DropArgs{1, p, seed, dpscale, rows_per_batch, seed_add}, c8, row);
   if (resid) {
     float r[8];
     unpack8(*reinterpret_cast<const uint4*>(resid + mr.off(row) + col), r);
@@ -913,7 +915,8 @@ __global__ void dropout_kernel(const bf16_t* x, const bf16_t* resid, bf16_t* out
 
 extern "C" int ifseg_dropout(const void* x, const void* resid, void* out, long long rows, int C, float p,
                              unsigned long long seed, const float* drop_path_scale, int rows_per_batch, int rpb,
-                             long long x_bs, int ldx, long long r_bs, int ldr, long long o_bs, int ldo, void* stream) {
+                             long long x_bs, int ldx, long long r_bs, int ldr, long long o_bs, int ldo,
+                             const unsigned long long* seed_add, void* stream) {
   (void)hipGetLastError();
   if (rows <= 0) return 0;
   if ((C & 7) || p < 0.f || p >= 1.f || rows_per_batch <= 0) return IFSEG_ERR_BAD_ARG;
@@ -921,7 +924,30 @@ extern "C" int ifseg_dropout(const void* x, const void* resid, void* out, long l
   RowMap mx{rpb, x_bs, ldx}, mr{rpb, r_bs, ldr}, mo{rpb, o_bs, ldo};
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, (const bf16_t*)resid, (bf16_t*)out, nchunks, C, p, seed, drop_path_scale, rows_per_batch,
-                     mx, mr, mo);
+                     mx, mr, mo, seed_add);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+// DropPath keep masks (unify_transformer_layer.py:19-35): out[i][b] = Bernoulli(keep[i]) / keep[i] for residual branch i
+// and sample b, from the same counter-based generator as the dropout masks (replay-safe: no host RNG state)
+namespace {
+__global__ void droppath_scale_kernel(float* out, const float* keep, int n, int B, unsigned long long seed,
+                                      const unsigned long long* seed_add) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * B) return;
+  const unsigned long long sd = seed + (seed_add ? *seed_add : 0ull);
+  const float u = (float)(splitmix64(sd + 0x5851F42D4C957F2Dull * (unsigned long long)(gid + 1)) >> 40) * (1.f / 16777216.f);
+  const float k = keep[gid / B];
+  out[gid] = (u < k) ? 1.f / k : 0.f;
+}
+}  // namespace
+
+extern "C" int ifseg_droppath_scale(float* out, const float* keep, int n, int B, unsigned long long seed,
+                                    const unsigned long long* seed_add, void* stream) {
+  (void)hipGetLastError();
+  if (n * B <= 0) return 0;
+  hipLaunchKernelGGL(droppath_scale_kernel, dim3((n * B + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, keep, n, B, seed, seed_add);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

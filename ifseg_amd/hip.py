@@ -327,7 +327,24 @@ def _map(t, rpb):
 
 
 class _DropArgs(ctypes.Structure):
-    _fields_ = [("p", c_float), ("seed", ctypes.c_ulonglong), ("drop_path_scale", c_void_p), ("rows_per_batch", c_int)]
+    _fields_ = [("p", c_float), ("seed", ctypes.c_ulonglong), ("drop_path_scale", c_void_p), ("rows_per_batch", c_int),
+                ("seed_add", c_void_p)]
+
+
+_seed_add = [None]
+
+
+def set_seed_add(t):
+    """device int64 / uint64 word added to every dropout / DropPath seed (the per-update part of the seed: the engine
+    keeps it in device memory so that a captured step draws new masks on every replay); None: seeds are used as given"""
+    prev = _seed_add[0]
+    _seed_add[0] = t
+    return prev
+
+
+def _seed_add_ptr():
+    t = _seed_add[0]
+    return t.data_ptr() if t is not None else None
 
 
 def _drop_ref(drop, rows):
@@ -335,7 +352,8 @@ def _drop_ref(drop, rows):
     if drop is None:
         return None
     p, seed, dps, rpb = drop
-    return ctypes.byref(_DropArgs(p, seed & 0xFFFFFFFFFFFFFFFF, dps.data_ptr() if dps is not None else None, rpb or rows))
+    return ctypes.byref(_DropArgs(p, seed & 0xFFFFFFFFFFFFFFFF, dps.data_ptr() if dps is not None else None, rpb or rows,
+                                  _seed_add_ptr()))
 
 
 def _ln_flags(gamma, gelu=False, other=None):
@@ -505,10 +523,18 @@ def grad_sumsq(g, workspace, out):
     return out
 
 
-def adam_step(p32, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, max_norm=0.0, sumsq=None, overflow=None):
+def droppath_scale(out, keep, seed):
+    """out fp32 [n, B] = Bernoulli(keep[i]) / keep[i]"""
+    n, B = out.shape
+    _check(lib().ifseg_droppath_scale(_ptr(out), _ptr(keep), c_int(n), c_int(B), ctypes.c_ulonglong(seed & 0xFFFFFFFFFFFFFFFF),
+                                      c_void_p(_seed_add_ptr()), _stream()), "droppath_scale")
+
+
+def adam_step(p32, g, m, v, p16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, max_norm=0.0, sumsq=None, overflow=None,
+              hyper=None):
     _check(lib().ifseg_adam_step(_ptr(p32), _ptr(g), _ptr(m), _ptr(v), _ptr(p16), c_ll(p32.numel()), c_float(lr),
                                  c_float(beta1), c_float(beta2), c_float(eps), c_float(wd), c_int(step),
-                                 c_float(grad_scale), c_float(max_norm), _ptr(sumsq), _ptr(overflow), _stream()), "adam")
+                                 c_float(grad_scale), c_float(max_norm), _ptr(sumsq), _ptr(overflow), _ptr(hyper), _stream()), "adam")
 
 
 def rel_gather(table, idx, out):
@@ -622,7 +648,7 @@ def dropout(x, resid, out, p, seed, drop_path_scale=None, rows_per_batch=None):
     rc = lib().ifseg_dropout(_ptr(x), _ptr(resid), _ptr(out), c_ll(rows), c_int(C), c_float(p),
                              ctypes.c_ulonglong(seed & 0xFFFFFFFFFFFFFFFF), _ptr(drop_path_scale),
                              c_int(rows_per_batch or (rpb if rpb else rows)), c_int(rpb), c_ll(xb), c_int(xl), c_ll(rb),
-                             c_int(rl), c_ll(ob), c_int(ol), _stream())
+                             c_int(rl), c_ll(ob), c_int(ol), c_void_p(_seed_add_ptr()), _stream())
     _check(rc, "dropout")
     return out
 

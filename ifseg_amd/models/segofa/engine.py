@@ -61,6 +61,9 @@ class HipEngine:
         self.grad_ready_hook = None      # callable(prefix) once every gradient under `prefix` is final
         self.drop_on = False
         self.step_seed = 0               # set by the trainer (seed + num_updates, trainer.py:1297)
+        # the per-update part of every dropout / DropPath seed lives in DEVICE memory (`step_dev[0]`, added to the site's
+        # seed by the kernels): a HIP-graph-captured step then draws new masks on every replay
+        self.step_dev, self._step_pin, self._step_pin_i, self._step_dev_val = None, None, 0, None
         # backward: everything that only produces PARAMETER gradients (dW GEMMs, bias / LayerNorm / table
         # reductions) is enqueued on a second HIP stream and overlaps the dX chain on the main stream
         self._pending_checks, self._checked_kinds = [], set()
@@ -449,7 +452,10 @@ class HipEngine:
     def _trunk(self, patch_images):
         pf, self._pf = self._pf, None
         if pf is not None and pf["key"] == self._tkey(patch_images):
-            torch.cuda.current_stream().wait_event(pf["done"])
+            # (a captured step joins the trunk stream at its own end -- Trainer._step_body -- so the features of the
+            # previous replay are complete in stream order; an event of another capture must not be waited on)
+            if pf.get("done") is not None and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream().wait_event(pf["done"])
             return pf["feat"], pf["h"], pf["w"]
         return self._resnet(patch_images)
 
@@ -550,11 +556,11 @@ class HipEngine:
             for l in range(cfg.dec_layers):
                 r = cfg.decoder_drop_path_rate * l / max(1, cfg.dec_layers - 1)
                 rates += [r, r, r]
-            self._dp_keep = 1.0 - torch.tensor(rates, dtype=torch.float32, device=self.device)[:, None]
+            self._dp_keep = (1.0 - torch.tensor(rates, dtype=torch.float32, device=self.device)).contiguous()
             self._dp_key = key
         keep = self._dp_keep
         self.dp_scale = self.buf("dp_scale", (keep.shape[0], B), torch.float32)
-        torch.div((torch.rand(keep.shape[0], B, device=self.device) < keep).float(), keep, out=self.dp_scale)
+        hip.droppath_scale(self.dp_scale, keep, self._site_seed(7))
         self._dp_rows = {}
 
     def _dp(self, kind, layer, k):
@@ -565,7 +571,22 @@ class HipEngine:
         return v
 
     def _site_seed(self, site):
-        return (self.step_seed * 1000003 + site) * 0x100000001B3 + 0x9E3779B97F4A7C15
+        # full seed = (step_seed * 1000003 + site) * 0x100000001B3 + 0x9E3779B97F4A7C15 (mod 2^64); the step part is
+        # `step_dev[0]` on the device (upload_step_seed)
+        return site * 0x100000001B3 + 0x9E3779B97F4A7C15
+
+    def upload_step_seed(self):
+        """step_dev[0] <- step_seed * 1000003 * 0x100000001B3 (mod 2^64), by an async copy from a ring of pinned words"""
+        if self._step_dev_val == self.step_seed and self.step_dev is not None:
+            return
+        if self.step_dev is None or self.step_dev.device != self.device:
+            self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self._step_pin = torch.zeros(64, dtype=torch.int64).pin_memory()
+        v = (self.step_seed * 1000003 * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        i = self._step_pin_i = (self._step_pin_i + 1) % 64
+        self._step_pin[i] = v - (1 << 64) if v >= (1 << 63) else v
+        self.step_dev.copy_(self._step_pin[i:i + 1], non_blocking=True)
+        self._step_dev_val = self.step_seed
 
     def _drop(self, x, resid, out, site, dp=None, rows_per_batch=None):
         hip.dropout(x, resid, out, self.cfg.dropout, self._site_seed(site), dp, rows_per_batch)
@@ -589,7 +610,11 @@ class HipEngine:
         need_grad = kw.get("need_grad", True)
         aux = (not need_grad) and self._gctx is not None
         self.ws, self.saved = (self._ws_aux, self._saved_aux) if aux else (self._ws_grad, self._saved_grad)
+        prev_sa = None
         try:
+            if not torch.cuda.is_current_stream_capturing():
+                self.upload_step_seed()
+            prev_sa = hip.set_seed_add(self.step_dev)
             if self._master_stale and self.packed and not self.master_owned:
                 # an external optimizer stepped the bf16 parameters since the last forward
                 hip.sync_master(self.master, self.p16[: self.n_train])
@@ -600,6 +625,7 @@ class HipEngine:
                 self.ctx["drop_state"] = (self.drop_on, getattr(self, "dp_scale", None), getattr(self, "_dp_rows", None))
             return out
         finally:
+            hip.set_seed_add(prev_sa)
             hip.set_stream(prev)
 
     def backward(self, dlogits):
@@ -608,9 +634,11 @@ class HipEngine:
         prev = hip.set_stream(torch.cuda.current_stream().cuda_stream)
         self.ws, self.saved, self.ctx = self._ws_grad, self._saved_grad, self._gctx
         self.drop_on, self.dp_scale, self._dp_rows = self.ctx["drop_state"]
+        prev_sa = hip.set_seed_add(self.step_dev)
         try:
             return self._backward(dlogits)
         finally:
+            hip.set_seed_add(prev_sa)
             self._gctx = None
             self._master_stale = not self.master_owned
             hip.set_stream(prev)

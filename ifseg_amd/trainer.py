@@ -97,7 +97,9 @@ class Trainer:
         self.v = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._ovf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._ovf_events = []
+        self._graphs, self._hyper, self._last_gscale = {}, None, None
         eng.master_owned = True                            # this trainer keeps eng.master in step with eng.p16
         self.ws = torch.zeros(1024, dtype=torch.float32, device=self.device)
         self.reducer = ArenaReducer(eng.g16, layer_slices(eng), eng.n_train)
@@ -176,28 +178,38 @@ class Trainer:
         the Adam kernel skips the update and raises a flag; it is read here once its event has completed (at the latest
         one step late, `wait=True` blocks)."""
         pend, self._ovf_events = self._ovf_events, []
+        done = False
         for ev in pend:
             if wait:
                 ev.synchronize()
-            if not ev.query():
+            if ev.query():
+                done = True
+            else:
                 self._ovf_events.append(ev)
-        if len(self._ovf_events) < len(pend) or wait:
-            if int(self.overflow.item()):
-                self.overflow.zero_()
-                raise FloatingPointError("gradients are Nan/Inf (the update was skipped)")
+        # the flag was copied to pinned host memory by the step itself (async, in stream order): reading it never
+        # blocks on the queue (a `.item()` here would drain the whole step and stop the host from running ahead)
+        if done and int(self._ovf_host[0]):
+            self._ovf_host.zero_()
+            self.overflow.zero_()
+            raise FloatingPointError("gradients are Nan/Inf (the update was skipped)")
 
     # -- steps ------------------------------------------------------------------------------
-    def train_step(self, samples, prefetch=None):
-        """One update.  `prefetch`: the samples of the NEXT call, if the data iterator already holds them:
-        their frozen-trunk features are computed on a second stream underneath this step
-        (HipEngine.prefetch_trunk)."""
-        self.check_overflow()
-        if prefetch:
-            self.eng._pf_request = prefetch[0]["net_input"]["patch_images"]
-        torch.manual_seed(self.seed + self.num_updates)
-        self.eng.step_seed = self.seed + self.num_updates
-        if not self.model.training:
-            self.model.train()
+    def _upload_hyper(self, lr, step, gscale):
+        """{lr, 1 - beta1^step, 1 - beta2^step, grad_scale} -> device (async copy from a ring of pinned rows): what a
+        captured step's Adam kernel reads on replay"""
+        if self._hyper is None:
+            self._hyper = torch.zeros(4, dtype=torch.float32, device=self.device)
+            self._hyper_pin = torch.zeros(64, 4, dtype=torch.float32).pin_memory()
+            self._hyper_i = 0
+        i = self._hyper_i = (self._hyper_i + 1) % 64
+        row = self._hyper_pin[i]
+        row[0], row[1], row[2], row[3] = lr, 1.0 - self.betas[0] ** step, 1.0 - self.betas[1] ** step, gscale
+        self._hyper.copy_(row, non_blocking=True)
+
+    def _step_body(self, samples, captured=False):
+        """forward + loss + backward (+ cross-rank reduction) + clip + Adam of one update, enqueue only.  `captured`: the
+        calls are being recorded into a HIP graph -- per-update scalars come from device memory (`_hyper`, the engine's
+        `step_dev`), nothing host-side is read back, and the trunk-prefetch stream is joined at the end."""
         logs, sample_sizes = [], []
         eng = self.eng
         accumulate = len(samples) > 1       # update_freq > 1 (trainer.py:745-830; the shipped recipe uses 1)
@@ -228,13 +240,68 @@ class Trainer:
         self._last_gscale = gscale
         hip.grad_sumsq(eng.g16, self.ws, self.sumsq)
         lr = self.get_lr()                  # the schedule is stepped after the update (trainer.py:1062-1066)
-        self.num_updates += 1
+        step = self.num_updates + 1
+        if not captured:
+            self._upload_hyper(lr, step, gscale)
         hip.adam_step(self.p32, eng.g16, self.m, self.v, eng.p16[: eng.n_train], lr, self.betas[0],
-                      self.betas[1], self.eps, self.wd, self.num_updates, gscale, self.clip, self.sumsq, self.overflow)
+                      self.betas[1], self.eps, self.wd, step, gscale, self.clip, self.sumsq, self.overflow, hyper=self._hyper)
+        if captured and eng._pf is not None:
+            torch.cuda.current_stream().wait_event(eng._pf["done"])     # every forked stream rejoins before the capture ends
+        return logs
+
+    def train_step(self, samples, prefetch=None, graph=False):
+        """One update.  `prefetch`: the samples of the NEXT call, if the data iterator already holds them:
+        their frozen-trunk features are computed on a second stream underneath this step
+        (HipEngine.prefetch_trunk).
+        `graph=True` (one GPU, update_freq 1): the whole update -- ~800 kernel launches on four streams -- is captured
+        into a HIP graph the first time a (sample, prefetch) pair of tensors is seen and REPLAYED afterwards: one graph
+        launch instead of ~9 ms of host enqueue per step.  The sample tensors are the graph's static inputs: a data
+        iterator copies each new batch into them (bench.py alternates two resident batches)."""
+        self.check_overflow()
+        eng = self.eng
+        if not self.model.training:
+            self.model.train()
+        eng.step_seed = self.seed + self.num_updates
+        if graph and self.world == 1 and len(samples) == 1:
+            logs = self._graph_step(samples[0], prefetch[0] if prefetch else None)
+        else:
+            if prefetch:
+                eng._pf_request = prefetch[0]["net_input"]["patch_images"]
+            logs = self._step_body(samples)
+        self.num_updates += 1
+        self._ovf_host.copy_(self.overflow, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._ovf_events.append(ev)
+        self._ovf_events = self._ovf_events[-3:] + [ev]
         return self._sync_logs(logs)
+
+    def _graph_step(self, sample, nxt):
+        eng = self.eng
+        key = (id(sample), id(nxt))
+        ent = self._graphs.get(key)
+        # per-update scalars go to the device BEFORE the replay, in stream order
+        eng.upload_step_seed()
+        self._upload_hyper(self.get_lr(), self.num_updates + 1, self._last_gscale or 1.0)
+        if ent is None:
+            if self.num_updates < 2:
+                raise RuntimeError("Trainer.train_step(graph=True): run at least two eager updates first (workspaces, "
+                                   "streams and the trunk prefetch of this batch must exist before the capture)")
+            if nxt is not None:
+                eng._pf_request = nxt["net_input"]["patch_images"]
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                logs = self._step_body([sample], captured=True)
+            if eng._pf is not None:
+                # the graph joins the trunk stream itself; its (captured) event must not be waited on by later steps
+                eng._pf = dict(eng._pf, done=None)
+            ent = self._graphs[key] = (g, logs, sample, nxt, eng._pf)     # keeps the static inputs alive
+        else:
+            # host-side state the enqueue code would have advanced
+            self.criterion.iter += 1
+            eng._pf = ent[4]
+        ent[0].replay()
+        return ent[1]
 
     def grad_norm(self):
         """global gradient norm of the last update, after the world/sample_size scaling (host sync: logging only)"""

@@ -167,6 +167,8 @@ typedef struct ifseg_drop_args {
   unsigned long long seed;
   const float* drop_path_scale;  /* [batch] fp32 keep/(1-rate) per sample, or NULL */
   int rows_per_batch;            /* logical rows per sample (indexes drop_path_scale) */
+  const unsigned long long* seed_add; /* device word added to `seed`, or NULL: the per-update part of the seed lives in
+                                       * device memory so that a HIP-graph-captured step draws new masks on every replay */
 } ifseg_drop_args;
 /* `act_gelu` / `flags` of the LayerNorm entry points: IFSEG_LN_GELU = the input goes through GELU first (ffn_layernorm(gelu(fc1)));
  * IFSEG_LN_PARAMS_F32 = gamma / beta (and gamma2 / beta2) point at fp32 values (the optimizer's master copy) instead of bf16. */
@@ -240,7 +242,11 @@ int ifseg_rel_scatter_add(const float* d, const int* idx, float* acc, int n, int
  * (unify_transformer_layer.py:19-35, residual_connection :196). */
 int ifseg_dropout(const void* x, const void* resid, void* out, long long rows, int C, float p,
                   unsigned long long seed, const float* drop_path_scale, int rows_per_batch, int rpb, long long x_bs,
-                  int ldx, long long r_bs, int ldr, long long o_bs, int ldo, void* stream);
+                  int ldx, long long r_bs, int ldr, long long o_bs, int ldo, const unsigned long long* seed_add, void* stream);
+/* DropPath keep masks (drop_path, unify_transformer_layer.py:19-35): out[i][b] = Bernoulli(keep[i]) / keep[i] for residual
+ * branch i < n and sample b < B, from the counter-based generator of ifseg_dropout (seed + *seed_add). */
+int ifseg_droppath_scale(float* out, const float* keep, int n, int B, unsigned long long seed,
+                         const unsigned long long* seed_add, void* stream);
 
 /* ------------------------------------------------------------ ResNet stem */
 /* conv1 7x7/2 (3->64) + folded FrozenBN + ReLU on an NHWC(4) bf16 image; w fp32
@@ -296,7 +302,9 @@ int ifseg_grad_sumsq_bf16(const void* g, long long n, float* workspace, float* o
  * sets overflow[0] = 1 (device int, may be NULL): trainer.py:895-904 raises FloatingPointError there. */
 int ifseg_adam_step(float* p32, const void* g, float* m, float* v, void* p16, long long n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float grad_scale, float max_norm,
-                    const float* sumsq, int* overflow, void* stream);
+                    const float* sumsq, int* overflow, const float* hyper, void* stream);
+/* `hyper` (device, may be NULL): {lr, 1 - beta1^step, 1 - beta2^step, grad_scale} override the by-value arguments --
+ * a captured training step (HIP graph) is replayed with the schedule's current values. */
 
 /* ------------------------------------------------- dense-CRF post-processing (crf.py:19-37) */
 /* Mean-field inference of the reference's DenseCRF2D (pydensecrf, third party, absent: parity unpinned) with the EXACT

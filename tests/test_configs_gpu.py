@@ -306,6 +306,7 @@ def test_nonfinite_gradient_norm_skips_the_update_and_raises():
     hip.grad_sumsq(tr.eng.g16, tr.ws, tr.sumsq)
     hip.adam_step(tr.p32, tr.eng.g16, tr.m, tr.v, tr.eng.p16[: tr.eng.n_train], 1e-3, 0.9, 0.999, 1e-8, 0.1, 3, 1.0, 1.0,
                   tr.sumsq, tr.overflow)
+    tr._ovf_host.copy_(tr.overflow, non_blocking=True)
     ev = torch.cuda.Event(); ev.record(); tr._ovf_events.append(ev)
     torch.cuda.synchronize()
     assert torch.equal(tr.p32, p_before) and torch.equal(tr.m, m_before)
@@ -398,3 +399,38 @@ def test_fixed_length_decode_through_the_task():
     assert agree >= 0.97, agree
     _, toks, scores = gen._generate([m], {"net_input": net}, return_all_beams=True)
     assert (scores[:, :-1, -1] >= scores[:, 1:, -1]).all() and torch.equal(toks[:, 0], pred)
+
+
+def test_graph_captured_training_step_is_bit_identical_to_eager():
+    """the whole update (forward, loss, backward on four streams, clip + Adam) captured into a HIP
+    graph and replayed -- losses, gradients and parameters bit-identical to the host-enqueued step, with dropout and
+    DropPath ON (the per-update part of the mask seed and the schedule's scalars live in device memory)."""
+    from ifseg_amd.criterions import SegCriterion
+    from ifseg_amd.tasks.mm_tasks import SegmentationTask
+    from ifseg_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+
+    def run(graph):
+        torch.manual_seed(0)
+        task = SegmentationTask(num_seg_tokens=15, patch_image_size=512, arch="segofa_base")
+        model = task.build_model()                                   # recipe: dropout 0.1, drop-path 0.1
+        tr = Trainer(model, SegCriterion(task, unsupervised_segmentation=False, init_seg_with_text=False), task, device=dev)
+        ring = []
+        for j in range(2):
+            sm = task.synthetic_sample(2, dev, seed=200 + j)
+            sm["net_input"]["patch_images"] = sm["net_input"]["patch_images"].to(torch.bfloat16)
+            ring.append(sm)
+        losses = []
+        for i in range(8):
+            logs = tr.train_step([ring[i % 2]], prefetch=[ring[(i + 1) % 2]], graph=graph and i >= 2)
+            losses.append(float(logs[-1]["loss"]))
+        tr.check_overflow(wait=True)
+        torch.cuda.synchronize()
+        return losses, tr.eng.g16.clone(), tr.eng.p16.clone(), tr.p32.clone(), len(tr._graphs)
+
+    le, ge, pe, me, _ = run(False)
+    lg, gg, pg, mg, ngraphs = run(True)
+    assert ngraphs == 2
+    assert le == lg, (le, lg)
+    assert torch.equal(ge, gg) and torch.equal(pe, pg) and torch.equal(me, mg)
+    assert len(set(le)) == len(le)                                   # masks / parameters do change from step to step
