@@ -274,6 +274,7 @@ def test_two_rank_train_step_on_one_gpu_over_gloo(tmp_path):
     for r in range(2):
         torch.manual_seed(0)
         model = task.build_model()
+        model.cfg.dropout = model.cfg.encoder_drop_path_rate = model.cfg.decoder_drop_path_rate = 0.0     # as in the workers
         t = Trainer(model, SegCriterion(task, unsupervised_segmentation=False, init_seg_with_text=False), task, device=dev)
         assert torch.equal(t.eng.p16.cpu().view(torch.int16), r0["p16_start"].view(torch.int16))
         _, _, lg = t.task.train_step(task.synthetic_sample(2, dev, seed=50 + r), t.model, t.criterion, None, 0)
