@@ -70,8 +70,9 @@ class _FusedSegLossFn(torch.autograd.Function):
             bufs["stats"] = torch.empty(nstat, dtype=torch.float32, device=dev)
             bufs["dl"] = torch.empty_like(logits_pad)
             bufs["loss"] = torch.empty(1, dtype=torch.float32, device=dev)
+            bufs["bad"] = torch.zeros(1, dtype=torch.int32, device=dev)
         hip.seg_loss(logits_pad, target, hp, wp, H, W, nseg, seg0, bufs["tile"], bufs["sp"], bufs["stats"],
-                     bufs["dl"], bufs["loss"])
+                     bufs["dl"], bufs["loss"], bad_label=bufs["bad"])
         ctx.dl = bufs["dl"]
         ctx.nseg = nseg
         # fresh tensors: callers keep them in logging outputs across calls (update_freq > 1, validation loops)
@@ -248,13 +249,13 @@ class SegCriterion(CriterionBase):
                 and self.num_seg <= 192 and target.shape[1] == h * w + 1):
             if not hasattr(self, bufs_name):
                 setattr(self, bufs_name, {})
-            lo, hi = self.seg_id_offset, self.seg_id_offset + self.num_seg
-            model.engine.deferred_check(
-                target, lambda t: (((t < lo) | (t > hi)) & (t != PAD) & (t != EOS)).any(),
-                "seg_criterion: target label outside [<seg_0>, <seg_%d>] (F.cross_entropy: target out of bounds)" % self.num_seg,
-                exc=IndexError)
             loss, stats = _FusedSegLossFn.apply(scores_low, pad, target.contiguous(), hp, wp, h, w, self.num_seg,
                                                 self.seg_id_offset, getattr(self, bufs_name))
+            # the loss kernel flags labels that are neither a class nor pad / eos / ignore (read back without a sync)
+            model.engine.deferred_check(
+                getattr(self, bufs_name)["bad"], lambda t: ((t[0] != 0).clone(), t.zero_())[0],
+                "seg_criterion: target label outside [<seg_0>, <seg_%d>] (F.cross_entropy: target out of bounds)" % self.num_seg,
+                exc=IndexError)
             n = self.num_seg
             ai, ap, al = stats[2:2 + n], stats[2 + n:2 + 2 * n], stats[2 + 2 * n:2 + 3 * n]
             metrics = {"area_intersect": ai, "area_pred_label": ap, "area_label": al, "area_union": ap + al - ai,

@@ -402,13 +402,20 @@ struct GroupArgs {
   int start[IFSEG_GEMM_GROUP_MAX + 1];     // first (XCD-remapped) tile of problem i; start[n] = total
   GemmArgs p[IFSEG_GEMM_GROUP_MAX];
 };
+// The grid is capped (gridDim.x <= total, a multiple of 8): a workgroup walks tiles blockIdx.x, + gridDim.x, ... .  The
+// launch runs on the weight-gradient stream NEXT to the dX chain: with one workgroup per CU it leaves half of every
+// CU's LDS and wave slots to the main stream's kernels -- launched with one workgroup per tile, its long-running
+// workgroups (133 k-steps each) filled every CU and the main queue stalled 100-180 us per layer behind them.
 template <int STAGES>
 __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(GroupArgs ga) {
-  // consecutive remapped ids share an XCD (its L2 then holds the panels neighbouring tiles of one problem share)
-  const int id = xcd_remap(blockIdx.x, ga.total);
-  int pid = 0;
-  for (int i = 1; i < ga.n; ++i) pid = (id >= ga.start[i]) ? i : pid;
-  gemm_tile<A_KS, true, 128, GBK, STAGES, true>(ga.p[pid], id - ga.start[pid], 0, 0, true);
+  for (int w = blockIdx.x; w < ga.total; w += gridDim.x) {
+    // consecutive remapped ids share an XCD (its L2 then holds the panels neighbouring tiles of one problem share)
+    const int id = xcd_remap(w, ga.total);
+    int pid = 0;
+    for (int i = 1; i < ga.n; ++i) pid = (id >= ga.start[i]) ? i : pid;
+    gemm_tile<A_KS, true, 128, GBK, STAGES, true>(ga.p[pid], id - ga.start[pid], 0, 0, true);
+    __syncthreads();          // the next tile refills the LDS stages
+  }
 }
 
 // skinny projection: C[M, N<=32*?] = A[M,K] . B[N,K]^T for tiny N (seg tokens, 15..171):
@@ -506,7 +513,7 @@ extern "C" int ifseg_gemm_bf16(int layout, const void* A, const void* B, void* C
                    strideB, strideC, strideR, splitk, stream, nullptr, 0, nullptr, 0);
 }
 
-extern "C" int ifseg_gemm_tn_group(int n, const ifseg_gemm_tn_problem* probs, void* stream) {
+extern "C" int ifseg_gemm_tn_group(int n, const ifseg_gemm_tn_problem* probs, int max_workgroups, void* stream) {
   (void)hipGetLastError();
   if (n <= 0) return 0;
   if (n > IFSEG_GEMM_GROUP_MAX || !probs) return IFSEG_ERR_BAD_ARG;
@@ -536,7 +543,9 @@ extern "C" int ifseg_gemm_tn_group(int n, const ifseg_gemm_tn_problem* probs, vo
   ga.total = total;
   hipStream_t s = (hipStream_t)stream;
   ifseg_prof_begin(IFSEG_K_GEMM_TN, s, flops, bytes);
-  hipLaunchKernelGGL(gemm_tn_group_kernel<2>, dim3(total), dim3(256), 0, s, ga);
+  int grid = total;
+  if (max_workgroups > 0 && max_workgroups < total) grid = max_workgroups >= 8 ? (max_workgroups & ~7) : max_workgroups;
+  hipLaunchKernelGGL(gemm_tn_group_kernel<2>, dim3(grid), dim3(256), 0, s, ga);
   ifseg_prof_end(IFSEG_K_GEMM_TN, s);
   IFSEG_CHECK_LAUNCH();
   return 0;

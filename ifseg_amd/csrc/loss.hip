@@ -24,7 +24,8 @@ constexpr int NS_MAX = 192;  // max classes
 __global__ __launch_bounds__(256) void seg_loss_tile_kernel(const bf16_t* logits, int ldl, long long lbs,
                                                             const long long* target, long long tbs, int hp, int wp,
                                                             int W, int nseg, long long seg0, long long pad_id,
-                                                            long long eos_id, float* tile_partial, float* stats_part) {
+                                                            long long eos_id, float* tile_partial, float* stats_part,
+                                                            int* bad_label) {
   __shared__ float sLog[9][NS_MAX];
   __shared__ float sWY[TS][3], sWX[TS][3];
   __shared__ float sD[256][CH + 1];
@@ -77,6 +78,8 @@ __global__ __launch_bounds__(256) void seg_loss_tile_kernel(const bf16_t* logits
   // they are dropped here and reported by the criterion's (deferred) range check -- F.cross_entropy raises on them
   const bool valid = !(tg == pad_id || tg == eos_id || tg == seg0 + nseg) && tg >= seg0 && tg < seg0 + nseg;
   const int label = valid ? (int)(tg - seg0) : 0;
+  // (rare) report a label that is neither a class nor pad / eos / ignore: the criterion raises on the flag
+  if (bad_label && !valid && !(tg == pad_id || tg == eos_id || tg == seg0 + nseg)) bad_label[0] = 1;
   float m = -INFINITY, sum = 0.f, vl = 0.f;
   int pred = 0;
   for (int c = 0; c < nseg; ++c) {
@@ -163,12 +166,12 @@ __global__ void seg_loss_gather_kernel(const float* tile_partial, const float* s
 extern "C" int ifseg_seg_loss_tiles(const void* logits, int ldl, long long logits_bs, const long long* target,
                                     long long target_bs, int B, int hp, int wp, int H, int W, int nseg,
                                     long long seg_id_offset, long long pad_id, long long eos_id,
-                                    float* tile_partial, float* stats_part, void* stream) {
+                                    float* tile_partial, float* stats_part, int* bad_label, void* stream) {
   (void)hipGetLastError();
   if (H != hp * TS || W != wp * TS || nseg > NS_MAX || nseg < 1) return IFSEG_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(seg_loss_tile_kernel, dim3(B * hp * wp), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)logits, ldl, logits_bs, target, target_bs, hp, wp, W, nseg, seg_id_offset, pad_id,
-                     eos_id, tile_partial, stats_part);
+                     eos_id, tile_partial, stats_part, bad_label);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

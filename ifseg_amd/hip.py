@@ -183,6 +183,7 @@ class _TnProblem(ctypes.Structure):
 
 
 GEMM_GROUP_MAX = 8
+DW_GROUP_WGS = int(os.environ.get("IFSEG_DW_GROUP_WGS", "256"))     # grid cap of the grouped dW GEMM (one workgroup per CU)
 
 
 def dw_groupable(dy, x, out, bias_out):
@@ -206,7 +207,7 @@ def linear_dw_group(tasks):
             q.A, q.B, q.C = _p(_bf(dy)), _p(_bf(x)), _p(out)
             q.M, q.N, q.K, q.lda, q.ldb = N, x.shape[1], M, dy.stride(0), x.stride(0)
             q.colsum, q.accumulate = (1 if bias_out is not None else 0), 0
-        _check(lib().ifseg_gemm_tn_group(c_int(len(chunk)), arr, _stream()), "gemm_tn_group")
+        _check(lib().ifseg_gemm_tn_group(c_int(len(chunk)), arr, c_int(DW_GROUP_WGS), _stream()), "gemm_tn_group")
 
 
 def conv2d_nhwc(x, w, shift, resid, out, B, H, W, Cin, Cout, KH, KW, stride, pad, relu):
@@ -576,14 +577,14 @@ def prof_read(kind):
 
 
 def seg_loss(logits_pad, target, hp, wp, H, W, nseg, seg_id_offset, tile_partial, stats_part, stats, dlogits_pad,
-             loss_out, pad_id=1, eos_id=2):
+             loss_out, pad_id=1, eos_id=2, bad_label=None):
     """fused upsample + CE + grad + histograms; logits_pad / dlogits_pad: bf16 [B, P+1, ldl]"""
     B = logits_pad.shape[0]
     ldl = logits_pad.stride(1)
     _check(lib().ifseg_seg_loss_tiles(_ptr(logits_pad), c_int(ldl), c_ll(logits_pad.stride(0)), _ptr(target),
                                       c_ll(target.stride(0)), c_int(B), c_int(hp), c_int(wp), c_int(H), c_int(W),
                                       c_int(nseg), c_ll(seg_id_offset), c_ll(pad_id), c_ll(eos_id),
-                                      _ptr(tile_partial), _ptr(stats_part), _stream()), "seg_loss_tiles")
+                                      _ptr(tile_partial), _ptr(stats_part), _ptr(bad_label), _stream()), "seg_loss_tiles")
     reduce_parts(stats_part, stats, 1, B * hp * wp, 2 + 3 * nseg)
     _check(lib().ifseg_seg_loss_gather(_ptr(tile_partial), _ptr(stats), _ptr(dlogits_pad), c_int(dlogits_pad.stride(1)),
                                        c_ll(dlogits_pad.stride(0)), c_int(B), c_int(hp), c_int(wp), c_int(nseg),

@@ -429,7 +429,9 @@ class HipEngine:
         if not self.packed or self.device != patch_images.device:
             return
         if self._trunk_stream is None:
-            self._trunk_stream = torch.cuda.Stream(device=self.device)
+            # high priority: the ~100 small convolutions must finish within the step they run under -- at normal priority
+            # they were starved by the main / weight-gradient queues and the NEXT forward waited 2.6 ms for its features
+            self._trunk_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("IFSEG_TRUNK_PRIO", "-1")))
         cur = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(cur)                                   # the images were produced on the caller's stream

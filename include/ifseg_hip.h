@@ -66,7 +66,9 @@ typedef struct {
   const void* A; const void* B; void* C;
   int M, N, K, lda, ldb, colsum, accumulate;
 } ifseg_gemm_tn_problem;
-int ifseg_gemm_tn_group(int n, const ifseg_gemm_tn_problem* probs, void* stream);
+int ifseg_gemm_tn_group(int n, const ifseg_gemm_tn_problem* probs, int max_workgroups, void* stream);
+/* max_workgroups > 0 caps the grid (a workgroup then walks several tiles): 256 = one per CU, so that a launch on a side
+ * stream leaves half of every CU to the kernels of the dependent chain it runs next to; <= 0: one workgroup per tile. */
 /* C[M,N] = A[M,K] . B[K,N] (NN, bf16 out) and, from the same epilogue, the per-head row dots with a second operand:
  *   dot_out[(m / rows_per_batch) * (N/64) + h][m % rows_per_batch] = sum_{c<64} C[m][64h+c] (as stored) * dot[m][64h+c]
  * i.e. the attention backward's delta = rowsum(dO * O) ([B,H,T] fp32) while dO = d(attn_ln input) . W_out is produced
@@ -271,7 +273,8 @@ int ifseg_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, vo
 int ifseg_seg_loss_tiles(const void* logits, int ldl, long long logits_bs, const long long* target,
                          long long target_bs, int B, int hp, int wp, int H, int W, int nseg,
                          long long seg_id_offset, long long pad_id, long long eos_id, float* tile_partial,
-                         float* stats_part, void* stream);
+                         float* stats_part, int* bad_label /* device flag, set to 1 when a target is neither a class nor
+                         pad / eos / ignore (F.cross_entropy would raise); may be NULL */, void* stream);
 int ifseg_seg_loss_gather(const float* tile_partial, const float* stats, void* dlogits, int ldl,
                           long long dlogits_bs, int B, int hp, int wp, int nseg, float* loss_out, void* stream);
 
