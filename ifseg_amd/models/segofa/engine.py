@@ -656,20 +656,30 @@ class HipEngine:
             if bool(bad(tensor)):
                 raise exc(message)
             return
+        # flags travel to PINNED host memory by an async copy in stream order; the host reads the pinned word once the
+        # event behind the copy has completed.  (Reading the device flag with bool()/.item() is a blocking copy queued
+        # behind everything already enqueued: it drained the whole step and cost the host 3 x 3 ms per step.)
         pend = self._pending_checks
-        keep = []
-        for flag, ev, msg in pend:
+        keep, err = [], None
+        for slot, ev, msg in pend:
             if ev.query():
-                if bool(flag):
-                    self._pending_checks = []
-                    raise msg[1](msg[0])
+                self._check_free.append(slot)
+                if int(self._check_pin[slot]) and err is None:
+                    err = msg
             else:
-                keep.append((flag, ev, msg))
-        if len(keep) > 8:                      # never let the list grow: settle the oldest
-            flag, ev, msg = keep.pop(0)
+                keep.append((slot, ev, msg))
+        if err is not None:
+            self._pending_checks = keep
+            raise err[1](err[0])
+        if getattr(self, "_check_pin", None) is None:
+            self._check_pin = torch.zeros(64, dtype=torch.uint8).pin_memory()
+            self._check_free = list(range(64))
+        if not self._check_free:               # never let the list grow: settle the oldest
+            slot, ev, msg = keep.pop(0)
             ev.synchronize()
-            if bool(flag):
-                self._pending_checks = []
+            self._check_free.append(slot)
+            if int(self._check_pin[slot]):
+                self._pending_checks = keep
                 raise msg[1](msg[0])
         flag = bad(tensor)
         if message not in self._checked_kinds:  # the first call of every kind of check is synchronous
@@ -677,9 +687,11 @@ class HipEngine:
             if bool(flag):
                 raise exc(message)
         else:
+            slot = self._check_free.pop()
+            self._check_pin[slot:slot + 1].copy_(flag.reshape(1).to(torch.uint8), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            keep.append((flag, ev, (message, exc)))
+            keep.append((slot, ev, (message, exc)))
         self._pending_checks = keep
 
     def _forward(self, src_tokens, patch_images, prev_output_tokens=None, full_context_alignment=False,
