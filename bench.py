@@ -150,9 +150,11 @@ def main():
     ap.add_argument("--drop-path", type=float, default=0.1, help="encoder/decoder drop-path rate (coco_unseen.sh:20-21)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="run the frozen trunk in line instead of one batch ahead")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="enqueue every step from the host (~800 launches) instead of replaying the HIP-graph-captured step "
-                         "(N = 1 default: the step is captured once per resident batch during warm-up)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the HIP-graph-captured update (Trainer.train_step(graph=True): captured once per resident "
+                         "batch) instead of enqueueing ~800 launches per step from the host.  Off by default: the step is "
+                         "GPU-bound (host enqueue 11.6 ms vs 20.5 ms of GPU time) and hipGraph replays the four-stream step "
+                         "with less cross-branch concurrency than the streams themselves (measured 20.8-32 ms vs 20.5 ms)")
     ap.add_argument("--image-free", action="store_true",
                     help="the recipe's image-free step (SURVEY 8f row 1, coco_unseen.sh:51): loss on an artificial image "
                          "(EmbeddingBag patches, no trunk) + a no-grad pass over the real images for the metrics")
@@ -230,7 +232,7 @@ def main():
     # the dK/dV and dQ kernels of the attention backward run side by side on two streams and share the GPU: they are
     # timed as ONE unit (delta + dK/dV + dQ, an event pair on the main stream around the three launches)
     pair = hip.PROF_KINDS[dominant] in ("attn_bwd_dkv", "attn_bwd_dq") and trainer.eng.overlap
-    graphed = world == 1 and not a.no_graph and not a.image_free and a.warmup >= 3
+    graphed = world == 1 and a.graph and not a.image_free and a.warmup >= 3
     hip.prof_reset()
     hip.prof_enable(0)
 

@@ -26,12 +26,6 @@
 #include "prof.h"
 #include "../../include/ifseg_hip.h"
 
-#ifdef IFSEG_EXP_SETPRIO
-#define EXP_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define EXP_PRIO(x)
-#endif
-
 namespace {
 
 struct AttnArgs {
@@ -574,20 +568,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) qf[ks] = lds_read_b128(sQ + (bQ ^ (ks << 5)));
         __builtin_amdgcn_sched_barrier(0);
-        EXP_PRIO(1);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s, 0, 0, 0);
-        EXP_PRIO(0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           of[ks] = lds_read_b128(sO + (bO ^ (ks << 5)));
           vfr[ks] = lds_read_b128(sVk + (bV ^ (ks << 5)));
         }
         __builtin_amdgcn_sched_barrier(0);
-        EXP_PRIO(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[ks], vfr[ks], dp, 0, 0, 0);
-        EXP_PRIO(0);
       }
       // element r <-> query ib + (r&3) + 8*(r>>2) + 4*half ; key = kj (lane)
       bf16x8 pfr[2], dsf[2];
@@ -729,12 +719,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
           fq[cb].w[0] = x.w[0]; fq[cb].w[1] = x.w[1]; fq[cb].w[2] = y.w[0]; fq[cb].w[3] = y.w[1];
         }
         __builtin_amdgcn_sched_barrier(0);
-        EXP_PRIO(1);
 #pragma unroll
         for (int db = 0; db < 2; ++db) dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[db].b, pfr[s2], dv[db], 0, 0, 0);
 #pragma unroll
         for (int cb = 0; cb < NKS / 2; ++cb) dk[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[cb].b, dsf[s2], dk[cb], 0, 0, 0);
-        EXP_PRIO(0);
       }
       if (seeded) {
         float accT = 0.f, accA = 0.f;            // all bins / bins of dx <= 0 (no wrap: x_j + ... <= 31)
