@@ -1,10 +1,10 @@
 """HBM bytes per launch of each kernel family from two rocprofv3 --pmc passes of bench.py (FETCH_SIZE, WRITE_SIZE).
-usage: pmc_traffic.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> > profiles/round1_hbm_traffic.json
+usage: pmc_traffic.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> > profiles/roundN_hbm_traffic.json
 bytes = 2 x FETCH_SIZE KiB (gfx950: FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section) + WRITE_SIZE KiB"""
 import csv, glob, json, re, sys, collections
 
 FAM = [("attn_bwd_dkv", r"attn_bwd_dkv_kernel"), ("attn_bwd_dq", r"attn_bwd_dq_kernel"), ("attn_fwd", r"attn_fwd_kernel"),
-       ("gemm_nt", r"gemm_kernel<0, false"), ("gemm_nn", r"gemm_kernel<0, true"), ("gemm_tn", r"gemm_kernel<1, true"),
+       ("gemm_nt", r"gemm_kernel<0, false"), ("gemm_nn", r"gemm_kernel<0, true"), ("gemm_tn", r"gemm_kernel<1, true"), ("gemm_tn_group", r"gemm_tn_group_kernel"),
        ("conv", r"gemm_kernel<2, "), ("ln_fwd", r"ln_fwd_kernel"), ("ln_bwd", r"ln_bwd(_drop)?_kernel"), ("adam", r"adam_kernel")]
 
 def collect(d, counter):
@@ -21,7 +21,7 @@ def collect(d, counter):
 
 rd, wr = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
 out = {"_method": "rocprofv3 --pmc FETCH_SIZE and, in a separate run, --pmc WRITE_SIZE of `bench.py --steps 2 --warmup 1 "
-                  "--no-cpu-baseline` (tools/pmc_traffic.sh, MI355X, end of round 1); per-launch averages over all launches of "
+                  "--no-cpu-baseline` (tools/pmc_traffic.sh, MI355X); per-launch averages over all launches of "
                   "the family; bytes = 2 x FETCH_SIZE KiB (gfx950 correction of MI355X_MICROARCH.md, HBM section: FETCH_SIZE "
                   "tallies 128-B requests at 64 B) + WRITE_SIZE KiB; the adam entry is the calibration (30 B/param algorithmic)"}
 for fam, _ in FAM:
