@@ -373,6 +373,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 }
 
 
+
+// Rotation of a register inside each 32-lane half by a compile-time amount (ds_swizzle_b32, rotate mode: offset
+// 0xC000 | dir << 10 | n << 5): lane x receives lane (x + N) & 31 of its half.  No address VGPR, no index arithmetic.
+#ifndef DKV_ROT_DIR
+#define DKV_ROT_DIR 0
+#endif
+template <int N>
+__device__ __forceinline__ float rot32(float v) {
+  if constexpr (N == 0) return v;
+  else return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0xC000 | (DKV_ROT_DIR << 10) | (N << 5)));
+}
+
+
+__device__ __forceinline__ uint4 scale_bf16x8(uint4 v, float f) {
+  unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    w[i] = pack2bf(__uint_as_float(w[i] << 16) * f, __uint_as_float(w[i] & 0xffff0000u) * f);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // ---------------------------------------------------------------- backward
 // Shared element logic: bias value for (query i, key j) is needed only to
 // recompute P; the gradient of the bias goes to LDS histograms.
@@ -426,7 +447,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       const int r = (tid >> 3) + 32 * i, c = tid & 7, j = k0 + r;
       uint4 v4 = make_uint4(0, 0, 0, 0);
       if (j < a.S) v4 = *reinterpret_cast<const uint4*>(a.v + (long long)b * a.v_bs + (long long)j * a.ldv + h * 64 + c * 8);
-      *reinterpret_cast<uint4*>(sVk + vx_off(r, c * 16)) = v4;
+      // stored as -gain * V: with the dP accumulator seeded with delta the MFMAs leave delta - gain * dP = -(dS / P)
+      *reinterpret_cast<uint4*>(sVk + vx_off(r, c * 16)) = scale_bf16x8(v4, -gain);
     }
     if constexpr (HAS_POS) {
       const bf16_t* pp = a.pk + (long long)krow * a.ldpk + h * 64 + half * 8;
@@ -524,14 +546,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     const unsigned char* sQ = smem + (n & 1) * STG;
     const unsigned char* sO = sQ + 8192;
     const float* sL = reinterpret_cast<const float*>(sQ + 8192 + 4096);
+#ifndef DKV_ABL
+#define DKV_ABL 0
+#endif
     lds_dma_wait();
+    if (!(DKV_ABL & 1) || n == 0)
     __syncthreads();              // block n has landed; everyone is done with block n-1 (and the table init)
+    if (!(DKV_ABL & 2))
     if (n + 1 < nblk) issue(ib + 32, (n + 1) & 1);
+    if (DKV_ABL & 16) continue;
     {
-      const bool skip = a.causal && wave_kgrid && ((ib + 31 < kw) || (ib >= a.P));
+      const bool skip = (kw >= a.S) || (a.causal && wave_kgrid && ((ib + 31 < kw) || (ib >= a.P)));
       if (skip) continue;
       const bool qb_grid = ib + 31 < a.P;
-      const int fast = (a.rel_mode && qb_grid && wave_kgrid) ? 1 : ((!a.rel_mode && !a.causal && ib + 32 <= a.T) ? 2 : 0);
+      const int fast = (a.rel_mode && qb_grid && wave_kgrid) ? 1 : 0;
+      // block classes with a straight-line element body (everything else -- text x text, grids that are not 32 wide,
+      // causal layers without a bias -- takes the general per-element path below):
+      //   1 grid x grid on a 32-wide grid: bias from the delta table seeds S, gradient by diagonal sums
+      //   2 grid queries x text keys / text queries x grid keys: the bias is ONE scalar per head (relx[0] / relx[1]),
+      //     its gradient the sum of dS.  P % 32 == 0 and 32-key waves: a block lies entirely on one side.
+      //   3 no relative bias at all (cross attention), not causal
+      const bool qb_text = ib >= a.P;
+      const int cls = (row32 && fast == 1) ? 1
+                    : (a.rel_mode && ((qb_grid && kw >= a.P) || (qb_text && wave_kgrid))) ? 2
+                    : (!a.rel_mode && !a.causal) ? 3 : 0;
+      const bool edge = (ib + 32 > a.T) || (kw + 32 > a.S);      // rows / keys past the end: masked element-wise
       // The five bases (and the lane's x coordinate for the histogram) are re-materialised per block: as plain loop
       // invariants the compiler hoists all ~40 derived addresses and 16 shuffle indices into VGPRs, spills part of
       // them, and every scratch reload waits with vmcnt(0) -- i.e. for the NEXT block's LDS-DMA -- in the loop.
@@ -540,11 +579,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       const int half_i = ln >> 5, colT = ((ln >> 4) & 1) * 16 + (ln & 3) * 4, rT = 4 * half_i + ((ln & 15) >> 2);
       const int bQ = kx_off(ln & 31, half_i), bO = vx_off(ln & 31, half_i * 16), bV = vx_off(wv * 32 + (ln & 31), half_i * 16);
       const int bOt = vx_off(rT, colT * 2), bQt = kx_off(rT, colT >> 3) + (colT & 7) * 2;
-      const int xl_i = (ln & 31) + 4 * half_i;
       f32x16 s, dp;
+      // dP accumulator seeded with delta (V rows are stored as -gain * V): dS = -P * dp
 #pragma unroll
-      for (int e = 0; e < 16; ++e) dp[e] = 0.f;
-      const bool seeded = row32 && fast == 1;
+      for (int rg = 0; rg < 4; ++rg) {
+        const float4 d4 = *reinterpret_cast<const float4*>(sL + 32 + 8 * rg + 4 * half_i);
+        dp[rg * 4] = d4.x; dp[rg * 4 + 1] = d4.y; dp[rg * 4 + 2] = d4.z; dp[rg * 4 + 3] = d4.w;
+      }
+      const bool seeded = cls == 1;
       int hidx_rw = 0;
       float hold = 0.f;
       if (seeded) {
@@ -558,8 +600,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         hidx_rw = code_i - cj0 + (lane < 32 ? -lane : 64 - lane);
         hold = sHist[lane != 32 ? hidx_rw : 0];
       } else {
+        const float c0 = cls == 2 ? (qb_grid ? relx0 : relx1) : 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        for (int e = 0; e < 16; ++e) s[e] = c0;
       }
       {
         // all Q fragments are requested before the first MFMA, the dO / V fragments travel while the S MFMAs run:
@@ -579,46 +622,70 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[ks], vfr[ks], dp, 0, 0, 0);
       }
+      if ((DKV_ABL & 256) && !seeded) continue;
+      if (DKV_ABL & 4) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dv[0][e] += s[e]; dk[0][e] += dp[e]; }
+        continue;
+      }
       // element r <-> query ib + (r&3) + 8*(r>>2) + 4*half ; key = kj (lane)
       bf16x8 pfr[2], dsf[2];
       float hval[16];      // seeded blocks: dS rotated onto its histogram lane (summed after the dV / dK MFMAs)
-      if (seeded) {
-        auto body = [&](auto causal_tag) {
-          constexpr bool CAUSAL = decltype(causal_tag)::value;
+      if (cls) {
+        // FLAGS: 1 diagonal-sum histogram (class 1), 2 causal mask, 4 row / key validity masks, 8 sum of dS (class 2)
+        auto body = [&](auto flags_tag) {
+          constexpr int FLAGS = decltype(flags_tag)::value;
           float dsr[16];
           U128 up[2], ud[2];
+          const int rowlim = a.T - ib;             // FLAGS & 4: query row il + e is real iff il + e < rowlim
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
             const int il = 8 * rg + 4 * half;
             const float4 l4 = *reinterpret_cast<const float4*>(sL + il);
-            const float4 d4 = *reinterpret_cast<const float4*>(sL + 32 + il);
-            const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+            const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
             const int di = kj - (ib + il);         // masked (causal) iff kj > i  <=>  di > e
             float pv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+              if (DKV_ABL & 32) { pv[e] = s[rg * 4 + e]; dsr[rg * 4 + e] = dp[rg * 4 + e]; continue; }
               float p = __builtin_amdgcn_exp2f(fmaf(s[rg * 4 + e], LOG2E, -ls[e]));
-              if (CAUSAL) p = (di > e) ? 0.f : p;
+              if (FLAGS & 2) p = (di > e) ? 0.f : p;
+              if (FLAGS & 4) p = (kvalid && il + e < rowlim) ? p : 0.f;
               pv[e] = p;
-              dsr[rg * 4 + e] = p * fmaf(gain, dp[rg * 4 + e], -dl[e]);
+              dsr[rg * 4 + e] = -p * dp[rg * 4 + e];
             }
             up[rg >> 1].w[(rg & 1) * 2] = pack2bf(pv[0], pv[1]); up[rg >> 1].w[(rg & 1) * 2 + 1] = pack2bf(pv[2], pv[3]);
             ud[rg >> 1].w[(rg & 1) * 2] = pack2bf(dsr[rg * 4], dsr[rg * 4 + 1]);
             ud[rg >> 1].w[(rg & 1) * 2 + 1] = pack2bf(dsr[rg * 4 + 2], dsr[rg * 4 + 3]);
           }
           pfr[0] = up[0].b; pfr[1] = up[1].b; dsf[0] = ud[0].b; dsf[1] = ud[1].b;
-          // d rel2d: this wave's keys are one grid row (x_j = lane&31) and the block's queries another
-          // (x_i = (r&3) + 8*(r>>2) + 4*half).  Rotate register r by x_i so that lane u holds the term of bin
-          // dx = x_i - x_j with u = (x_j - x_i) mod 32; the 16 rotated registers are summed in place after the
-          // dV / dK MFMAs (all 16 ds_bpermute in flight at once), then 2 half-wave LDS adds per block
-          // (one LDS float atomic per element instead more than doubles the kernel time).
-          const int hi4 = (lane & 32) << 2, xl4 = xl_i << 2;
+          if constexpr (FLAGS & 1) {
+            // d rel2d: this wave's keys are one grid row (x_j = lane & 31) and the block's queries another
+            // (x_i = c_r + 4 * half, c_r = (r&3) + 8*(r>>2)).  Register r is rotated inside each half by c_r (an
+            // immediate of ds_swizzle): lane (half, x) then holds the term of bin dx = 4 * half - x (no wrap,
+            // x + c_r <= 31) or dx = 4 * half - x + 32 (wrap).  The 16 rotated registers are summed after the dV / dK
+            // MFMAs (all 16 swizzles in flight at once), then 2 half-wave LDS adds per block (one LDS float atomic
+            // per element instead more than doubles the kernel time).
+            hval[0] = rot32<0>(dsr[0]);   hval[1] = rot32<1>(dsr[1]);   hval[2] = rot32<2>(dsr[2]);   hval[3] = rot32<3>(dsr[3]);
+            hval[4] = rot32<8>(dsr[4]);   hval[5] = rot32<9>(dsr[5]);   hval[6] = rot32<10>(dsr[6]);  hval[7] = rot32<11>(dsr[7]);
+            hval[8] = rot32<16>(dsr[8]);  hval[9] = rot32<17>(dsr[9]);  hval[10] = rot32<18>(dsr[10]); hval[11] = rot32<19>(dsr[11]);
+            hval[12] = rot32<24>(dsr[12]); hval[13] = rot32<25>(dsr[13]); hval[14] = rot32<26>(dsr[14]); hval[15] = rot32<27>(dsr[15]);
+          }
+          if constexpr (FLAGS & 8) {
+            float g = 0.f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            hval[r] = __int_as_float(__builtin_amdgcn_ds_bpermute(((xl4 + 4 * ((r & 3) + 8 * (r >> 2))) & 124) | hi4,
-                                                                  __float_as_int(dsr[r])));
+            for (int e = 0; e < 16; ++e) g += dsr[e];
+            if (qb_grid) gx0 += g; else gx1 += g;
+          }
         };
-        if (a.causal) body(std::true_type{}); else body(std::false_type{});
+        if (cls == 1) {
+          // only blocks crossing the diagonal hold masked elements (blocks entirely above it were skipped)
+          if (a.causal && kw + 31 > ib) body(std::integral_constant<int, 3>{}); else body(std::integral_constant<int, 1>{});
+        } else if (cls == 2) {
+          body(std::integral_constant<int, 12>{});
+        } else {
+          if (edge) body(std::integral_constant<int, 4>{}); else body(std::integral_constant<int, 0>{});
+        }
       } else
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -628,8 +695,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
           const int rg = s2 * 2 + rg2;
           const int iq = ib + 8 * rg + 4 * half, il = 8 * rg + 4 * half;
           const float4 l4 = *reinterpret_cast<const float4*>(sL + il);
-          const float4 d4 = *reinterpret_cast<const float4*>(sL + 32 + il);
-          const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+          const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
           float pv[4], dsv[4];
           if (fast == 1) {
             const int4 c4 = *reinterpret_cast<const int4*>(sGc + iq);
@@ -640,15 +706,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
               const int hidx = cis[e] - cj;
               float p = __builtin_amdgcn_exp2f(fmaf(s[rg * 4 + e] + sTbl[hidx], LOG2E, -ls[e]));
               if (a.causal) p = (di > e) ? 0.f : p;
-              const float ds = p * (gain * dp[rg * 4 + e] - dl[e]);
+              const float ds = -p * dp[rg * 4 + e];
               pv[e] = p; dsv[e] = ds;
               atomicAdd(&sHist[hidx], ds);
-            }
-          } else if (fast == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float p = kvalid ? __builtin_amdgcn_exp2f(fmaf(s[rg * 4 + e], LOG2E, -ls[e])) : 0.f;
-              pv[e] = p; dsv[e] = p * (gain * dp[rg * 4 + e] - dl[e]);
             }
           } else {
             int4 c4 = make_int4(0, 0, 0, 0);
@@ -681,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
                 else masked |= (i >= a.P) && (kj > i);
               }
               const float p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sv, LOG2E, -ls[e]));
-              const float ds = p * (gain * dp[rg * 4 + e] - dl[e]);
+              const float ds = -p * dp[rg * 4 + e];
               pv[e] = p; dsv[e] = ds;
               if (a.rel_mode) {
                 if (qg) { if (k_grid) atomicAdd(&sHist[hidx], ds); else gx0 += ds; }
@@ -693,6 +753,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
           ud.w[rg2 * 2] = pack2bf(dsv[0], dsv[1]); ud.w[rg2 * 2 + 1] = pack2bf(dsv[2], dsv[3]);
         }
         pfr[s2] = up.b; dsf[s2] = ud.b;
+      }
+#ifndef DKV_STOP
+#define DKV_STOP 0
+#endif
+      if (DKV_STOP == 2) {
+        U128 p0, p1, d0, d1; p0.b = pfr[0]; p1.b = pfr[1]; d0.b = dsf[0]; d1.b = dsf[1];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { dv[0][w] += __uint_as_float(p0.w[w] ^ p1.w[w]); dk[0][w] += __uint_as_float(d0.w[w] ^ d1.w[w]); }
+        continue;
       }
       // dV^T += dO^T P ; dK^T += Q^T dS ; slot (kh,e) <-> query ib + 16*s2 + 4*kh + (e&3) + 8*(e>>2)
       // all transposed operand reads of one s2 half are issued before its MFMAs (the scheduling barrier keeps
@@ -706,34 +775,88 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         for (int db = 0; db < 2; ++db) {
           const int o0 = (bOt ^ (db << 6)) + s2 * 2048;
           U64 x, y;
+          if (DKV_ABL & 64) { x.w[0] = o0; x.w[1] = n; y.w[0] = o0 + 1; y.w[1] = n; } else {
           x.s = lds_read_tr(sO + o0);
-          y.s = lds_read_tr(sO + ((o0 + 1024) ^ 32));
+          y.s = lds_read_tr(sO + ((o0 + 1024) ^ 32)); }
           fo[db].w[0] = x.w[0]; fo[db].w[1] = x.w[1]; fo[db].w[2] = y.w[0]; fo[db].w[3] = y.w[1];
         }
 #pragma unroll
         for (int cb = 0; cb < NKS / 2; ++cb) {
           const int o0 = (bQt ^ (cb << 6)) + s2 * 4096;
           U64 x, y;
+          if (DKV_ABL & 64) { x.w[0] = o0; x.w[1] = n; y.w[0] = o0 + 1; y.w[1] = n; } else {
           x.s = lds_read_tr(sQ + o0);
-          y.s = lds_read_tr(sQ + ((o0 + 2048) ^ 32));
+          y.s = lds_read_tr(sQ + ((o0 + 2048) ^ 32)); }
           fq[cb].w[0] = x.w[0]; fq[cb].w[1] = x.w[1]; fq[cb].w[2] = y.w[0]; fq[cb].w[3] = y.w[1];
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (DKV_ABL & 128) {
+          U128 pp, dd; pp.b = pfr[s2]; dd.b = dsf[s2];
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) dv[db][w] += __uint_as_float(fo[db].w[w] ^ pp.w[w]);
+#pragma unroll
+          for (int cb = 0; cb < NKS / 2; ++cb)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) dk[cb][w] += __uint_as_float(fq[cb].w[w] ^ dd.w[w]);
+          continue;
+        }
 #pragma unroll
         for (int db = 0; db < 2; ++db) dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[db].b, pfr[s2], dv[db], 0, 0, 0);
 #pragma unroll
         for (int cb = 0; cb < NKS / 2; ++cb) dk[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[cb].b, dsf[s2], dk[cb], 0, 0, 0);
       }
-      if (seeded) {
-        float accT = 0.f, accA = 0.f;            // all bins / bins of dx <= 0 (no wrap: x_j + ... <= 31)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          accT += hval[r];
-          accA += (xl_i + ((r & 3) + 8 * (r >> 2)) <= 31) ? hval[r] : 0.f;
-        }
+      if (seeded && !(DKV_ABL & 8)) {
+        // accT: every term; accA: the terms without wrap, x + c_r <= 31 -- a compile-time lane interval per
+        // register, applied as an EXEC mask (one masked add instead of compare + select + add)
+        float accT, accA;
+        unsigned long long sv_exec;
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "v_add_f32 %[t], %[h0], %[h1]\n\t"
+            "v_add_f32 %[a], %[h2], %[h3]\n\t"
+            "v_add_f32 %[t], %[t], %[h4]\n\t"
+            "v_add_f32 %[a], %[a], %[h5]\n\t"
+            "v_add_f32 %[t], %[t], %[h6]\n\t"
+            "v_add_f32 %[a], %[a], %[h7]\n\t"
+            "v_add_f32 %[t], %[t], %[h8]\n\t"
+            "v_add_f32 %[a], %[a], %[h9]\n\t"
+            "v_add_f32 %[t], %[t], %[h10]\n\t"
+            "v_add_f32 %[a], %[a], %[h11]\n\t"
+            "v_add_f32 %[t], %[t], %[h12]\n\t"
+            "v_add_f32 %[a], %[a], %[h13]\n\t"
+            "v_add_f32 %[t], %[t], %[h14]\n\t"
+            "v_add_f32 %[a], %[a], %[h15]\n\t"
+            "v_add_f32 %[t], %[t], %[a]\n\t"
+            "v_mov_b32 %[a], %[h0]\n\t"
+            "s_mov_b32 exec_lo, 0x7fffffff\n\ts_mov_b32 exec_hi, 0x7fffffff\n\tv_add_f32 %[a], %[a], %[h1]\n\t"
+            "s_mov_b32 exec_lo, 0x3fffffff\n\ts_mov_b32 exec_hi, 0x3fffffff\n\tv_add_f32 %[a], %[a], %[h2]\n\t"
+            "s_mov_b32 exec_lo, 0x1fffffff\n\ts_mov_b32 exec_hi, 0x1fffffff\n\tv_add_f32 %[a], %[a], %[h3]\n\t"
+            "s_mov_b32 exec_lo, 0x00ffffff\n\ts_mov_b32 exec_hi, 0x00ffffff\n\tv_add_f32 %[a], %[a], %[h4]\n\t"
+            "s_mov_b32 exec_lo, 0x007fffff\n\ts_mov_b32 exec_hi, 0x007fffff\n\tv_add_f32 %[a], %[a], %[h5]\n\t"
+            "s_mov_b32 exec_lo, 0x003fffff\n\ts_mov_b32 exec_hi, 0x003fffff\n\tv_add_f32 %[a], %[a], %[h6]\n\t"
+            "s_mov_b32 exec_lo, 0x001fffff\n\ts_mov_b32 exec_hi, 0x001fffff\n\tv_add_f32 %[a], %[a], %[h7]\n\t"
+            "s_mov_b32 exec_lo, 0x0000ffff\n\ts_mov_b32 exec_hi, 0x0000ffff\n\tv_add_f32 %[a], %[a], %[h8]\n\t"
+            "s_mov_b32 exec_lo, 0x00007fff\n\ts_mov_b32 exec_hi, 0x00007fff\n\tv_add_f32 %[a], %[a], %[h9]\n\t"
+            "s_mov_b32 exec_lo, 0x00003fff\n\ts_mov_b32 exec_hi, 0x00003fff\n\tv_add_f32 %[a], %[a], %[h10]\n\t"
+            "s_mov_b32 exec_lo, 0x00001fff\n\ts_mov_b32 exec_hi, 0x00001fff\n\tv_add_f32 %[a], %[a], %[h11]\n\t"
+            "s_mov_b32 exec_lo, 0x000000ff\n\ts_mov_b32 exec_hi, 0x000000ff\n\tv_add_f32 %[a], %[a], %[h12]\n\t"
+            "s_mov_b32 exec_lo, 0x0000007f\n\ts_mov_b32 exec_hi, 0x0000007f\n\tv_add_f32 %[a], %[a], %[h13]\n\t"
+            "s_mov_b32 exec_lo, 0x0000003f\n\ts_mov_b32 exec_hi, 0x0000003f\n\tv_add_f32 %[a], %[a], %[h14]\n\t"
+            "s_mov_b32 exec_lo, 0x0000001f\n\ts_mov_b32 exec_hi, 0x0000001f\n\tv_add_f32 %[a], %[a], %[h15]\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [t] "=&v"(accT), [a] "=&v"(accA), [sv] "=&s"(sv_exec)
+            : [h0] "v"(hval[0]), [h1] "v"(hval[1]), [h2] "v"(hval[2]), [h3] "v"(hval[3]), [h4] "v"(hval[4]), [h5] "v"(hval[5]),
+              [h6] "v"(hval[6]), [h7] "v"(hval[7]), [h8] "v"(hval[8]), [h9] "v"(hval[9]), [h10] "v"(hval[10]),
+              [h11] "v"(hval[11]), [h12] "v"(hval[12]), [h13] "v"(hval[13]), [h14] "v"(hval[14]), [h15] "v"(hval[15]));
         const float accB = accT - accA;
+        // half 1 holds its bins 4 lanes further on (x_i = c_r + 4): bring bin -x / 32 - x to lane x of half 1 too
+        const float ra = rot32<4>(accA), rb = rot32<4>(accB);
+        const bool lo = lane < 32, in = (lane & 31) <= 27;
+        const float a2 = lo ? accA : (in ? ra : 0.f), b2 = lo ? accB : (in ? rb : ra);
         // halves combined in one VALU op: lanes 0..31 end up with the dx = -u total, lanes 32..63 with dx = 32 - u
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(accA), __float_as_uint(accB), false, false);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a2), __float_as_uint(b2), false, false);
         const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         // plain read-modify-write: between two barriers the four waves work on the same query row and four different
         // key rows, i.e. on four different rows of the table (an LDS float atomic costs ~30 us per layer here)
