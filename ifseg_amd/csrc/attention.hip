@@ -198,10 +198,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     if (it + 1 < nsched) load_kv(tile_of(it + 1) * 64);
     const bool tile_grid = j0 < Pk;
     // wave-level causal skip: every key of a grid tile is beyond every query of this wave
-    const bool skip = a.causal && tile_grid && (j0 > qw + 31 || qw >= a.P);
+    // (waves whose 32 queries all lie past T only help staging the tiles)
+    const bool skip = (qw >= a.T) || (a.causal && tile_grid && (j0 > qw + 31 || qw >= a.P));
     if (!skip) {
-      const bool wave_grid = __builtin_amdgcn_readfirstlane(qw) + 31 < a.P;
+      const int qw_u = __builtin_amdgcn_readfirstlane(qw);
+      const bool wave_grid = qw_u + 31 < a.P;
       const bool gg = a.rel_mode && tile_grid && wave_grid && !a.dense;   // grid x grid: the bulk of self-attention
+      // grid queries x text keys / text queries x grid keys: the bias is one scalar per head; no relative bias at all
+      // (cross attention): both take the straight-line path below.  P % 32 == 0: a wave lies on one side.
+      const bool cbias = a.rel_mode && !a.dense && ((wave_grid && !tile_grid) || (qw_u >= a.P && tile_grid));
+      const bool plain = cbias || (!a.rel_mode && !a.causal && !a.dense);
       f32x16 s[2];
       if (gg && row32) {
         // the block's keys are one grid row (codes cjb + x): the lane's 16 bias values sit at constant
@@ -216,10 +222,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             for (int e = 0; e < 4; ++e) s[kb][rg * 4 + e] = tp[27 - (8 * rg + e)];
         }
       } else {
+        const float c0 = cbias ? (tile_grid ? relx1 : relx0) : 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+          for (int e = 0; e < 16; ++e) s[kb][e] = c0;
       }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             }
           }
         }
-        if (a.causal) {
+        if (a.causal && j0 + 63 > qw_u) {      // only tiles crossing the diagonal hold masked elements
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -263,7 +270,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) m4[e & 3] = fmaxf(m4[e & 3], s[kb][e]);
         mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-      } else if (!a.rel_mode && !a.causal && !a.dense && j0 + 64 <= a.S) {
+      } else if (plain) {
+        if (j0 + 64 > a.S) {           // last tile: keys past S are masked
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int jl = a.S - (j0 + kb * 32 + 8 * rg + 4 * half);     // element e is a real key iff e < jl
+#pragma unroll
+              for (int e = 0; e < 4; ++e) s[kb][rg * 4 + e] = (e < jl) ? s[kb][rg * 4 + e] : NEG_INF;
+            }
+        }
         float m4[4] = {NEG_INF, NEG_INF, NEG_INF, NEG_INF};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -1019,7 +1036,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const int j0 = tile_of(it) * 64;
     if (it + 1 < nsched) load_kv(tile_of(it + 1) * 64);
     const bool tile_grid = j0 < Pk;
-    const bool skip = a.causal && tile_grid && (j0 > qw + 31 || qw >= a.P);
+    // (waves whose 32 queries all lie past T only help staging the tiles)
+    const bool skip = (qw >= a.T) || (a.causal && tile_grid && (j0 > qw + 31 || qw >= a.P));
     if (!skip) {
       // per-lane LDS offsets re-derived per tile from a re-materialised lane id (see the dK/dV kernel): K rows
       // (bK ^ (ks << 5)) + kb * 8192, V rows (bV ^ (ks << 5)) + kb * 4096, K^T ((bKt ^ (cb << 6)) + (kb * 32 + s2 * 16) * 256)
@@ -1031,8 +1049,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       const int bKt = kx_off(rT, colT >> 3) + (colT & 7) * 2;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        const bool wave_grid = __builtin_amdgcn_readfirstlane(qw) + 31 < a.P;
-        const int fast = (a.rel_mode && tile_grid && wave_grid) ? 1 : ((!a.rel_mode && !a.causal && j0 + 64 <= a.S) ? 2 : 0);
+        const int qw_u = __builtin_amdgcn_readfirstlane(qw);
+        const bool wave_grid = qw_u + 31 < a.P;
+        // 1: grid x grid; 2: straight-line body without a per-element bias -- no relative bias at all (cross attention),
+        // or grid queries x text keys / text queries x grid keys, where the bias is one scalar per head (P % 32 == 0:
+        // a wave lies on one side)
+        const bool cbias = a.rel_mode && ((wave_grid && !tile_grid) || (qw_u >= a.P && tile_grid));
+        const int fast = (a.rel_mode && tile_grid && wave_grid) ? 1 : ((cbias || (!a.rel_mode && !a.causal)) ? 2 : 0);
         f32x16 s, dp;
 #pragma unroll
         for (int e = 0; e < 16; ++e) dp[e] = 0.f;
@@ -1044,8 +1067,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[rg * 4 + e] = tp[27 - (8 * rg + e)];
         } else {
+          const float c0 = cbias ? (tile_grid ? relx1 : relx0) : 0.f;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) s[e] = 0.f;
+          for (int e = 0; e < 16; ++e) s[e] = c0;
         }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -1060,17 +1084,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         bf16x8 dsf[2];
         // the two hot block kinds get one straight-line body each, chosen ONCE per 32-key block: with the choice inside
         // the element loops every group of four elements is wrapped in its own wave-uniform branches (68 per tile)
-        auto straight = [&](auto causal_tag) {
-          constexpr bool CAUSAL = decltype(causal_tag)::value;
+        auto straight = [&](auto flags_tag) {
+          constexpr int FLAGS = decltype(flags_tag)::value;       // 1: causal mask, 2: keys past S masked
           U128 ud[2];
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
             const int dj = j0 + kb * 32 + 8 * rg + 4 * half - qi;     // masked (causal) iff key > query
+            const int jl = a.S - (j0 + kb * 32 + 8 * rg + 4 * half);  // element e is a real key iff e < jl
             float dsv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float p = __builtin_amdgcn_exp2f(fmaf(s[rg * 4 + e], LOG2E, nlse_q));
-              if (CAUSAL) p = (dj + e > 0) ? 0.f : p;
+              if (FLAGS & 1) p = (dj + e > 0) ? 0.f : p;
+              if (FLAGS & 2) p = (e < jl) ? p : 0.f;
               dsv[e] = p * fmaf(gain, dp[rg * 4 + e], -del_q);
             }
             ud[rg >> 1].w[(rg & 1) * 2] = pack2bf(dsv[0], dsv[1]);
@@ -1079,9 +1105,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
           dsf[0] = ud[0].b; dsf[1] = ud[1].b;
         };
         if (fast == 1 && row32) {            // bias already in s (seeded accumulator)
-          if (a.causal) straight(std::true_type{}); else straight(std::false_type{});
-        } else if (fast == 2) {              // no bias, no mask
-          straight(std::false_type{});
+          // only blocks crossing the diagonal hold masked elements (blocks entirely above it were skipped)
+          if (a.causal && j0 + kb * 32 + 31 > qw_u) straight(std::integral_constant<int, 1>{});
+          else straight(std::integral_constant<int, 0>{});
+        } else if (fast == 2) {              // bias (if any) already in s
+          if (j0 + kb * 32 + 32 > a.S) straight(std::integral_constant<int, 2>{});
+          else straight(std::integral_constant<int, 0>{});
         } else
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -1109,10 +1138,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 if (a.causal) p = (dj + e > 0) ? 0.f : p;
                 dsv[e] = p * (gain * dp[rg * 4 + e] - del_q);
               }
-            } else if (fast == 2) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                dsv[e] = __builtin_amdgcn_exp2f(fmaf(s[rg * 4 + e], LOG2E, nlse_q)) * (gain * dp[rg * 4 + e] - del_q);
             } else {
               int4 cj = make_int4(0, 0, 0, 0);
               if (a.rel_mode && tile_grid) cj = *reinterpret_cast<const int4*>(sGc + jb);
