@@ -93,6 +93,37 @@ struct RelCtx {
 };
 
 // ---------------------------------------------------------------- forward
+
+// Global -> LDS copy of a small table by a 256-thread workgroup with eight loads in flight per thread (a plain
+// `for (i = tid; i < n; i += 256)` loop issues one load per round trip: 16 serial L2 latencies for a 63 x 63 table).
+template <typename T>
+__device__ __forceinline__ void stage_table(T* dst, const T* __restrict__ src, int n, int tid) {
+  for (int i0 = 0; i0 < n; i0 += 8 * 256) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256 + tid; v[u] = i < n ? src[i] : T(0); }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256 + tid; if (i < n) dst[i] = v[u]; }
+  }
+}
+
+
+// Epilogue of a 32 x 32 accumulator tile whose row (query / key) is the lane: element r of lane (half, x) is column
+// (r&3) + 8*(r>>2) + 4*half, i.e. 8-byte runs.  The two lanes of a row exchange one run each (v_permlane32_swap), so
+// that every lane stores 16 contiguous bytes: half as many store instructions (the store tail is issue-bound).
+__device__ __forceinline__ void store_tile_bf16(bf16_t* rowp, const f32x16& acc, float scale, int half, bool valid) {
+#pragma unroll
+  for (int rgp = 0; rgp < 2; ++rgp) {
+    const int e0 = rgp * 8, e1 = rgp * 8 + 4;
+    const unsigned x0 = pack2bf(acc[e0] * scale, acc[e0 + 1] * scale), x1 = pack2bf(acc[e0 + 2] * scale, acc[e0 + 3] * scale);
+    const unsigned y0 = pack2bf(acc[e1] * scale, acc[e1 + 1] * scale), y1 = pack2bf(acc[e1 + 2] * scale, acc[e1 + 3] * scale);
+    const auto p0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+    const auto p1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+    // lanes 0..31: columns 16*rgp .. +7 (own run, partner's run); lanes 32..63: columns 16*rgp + 8 .. +15
+    if (valid) *reinterpret_cast<uint4*>(rowp + 16 * rgp + 8 * half) = make_uint4(p0[0], p1[0], p0[1], p1[1]);
+  }
+}
+
 template <bool HAS_POS>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -132,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   }
   // ---- rel-pos tables into LDS
   if (a.rel_mode) {
-    for (int i = tid; i < a.n2d; i += 256) sTbl[i] = a.rel2d[(long long)h * a.n2d + i];
-    for (int i = tid; i < a.P; i += 256) sGc[i] = a.gcode[i];
+    stage_table(sTbl, a.rel2d + (long long)h * a.n2d, a.n2d, tid);
+    stage_table(sGc, a.gcode, a.P, tid);
   }
   const bool q_grid = a.rel_mode && qi < a.P;
   const int ci = q_grid ? a.gcode[qi] + a.code_bias : 0;
@@ -373,17 +404,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   // ---- finalize: lane (q, half) holds O[q][d = db*32 + (r&3) + 8*(r>>2) + 4*half]
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = (l_tot > 0.f ? 1.f / l_tot : 0.f) * (a.gain ? a.gain[h] : 1.f);
+  {
+    bf16_t* op = a.o + (long long)b * a.o_bs + (long long)qrow * a.ldo + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) store_tile_bf16(op + db * 32, oacc[db], inv, half, qvalid);
+  }
   if (qvalid) {
-    bf16_t* op = a.o + (long long)b * a.o_bs + (long long)qi * a.ldo + h * 64;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int d = db * 32 + 8 * rg + 4 * half;
-        *reinterpret_cast<uint2*>(op + d) =
-            make_uint2(pack2bf(oacc[db][rg * 4] * inv, oacc[db][rg * 4 + 1] * inv),
-                       pack2bf(oacc[db][rg * 4 + 2] * inv, oacc[db][rg * 4 + 3] * inv));
-      }
     // log2-domain log-sum-exp (natural lse x log2 e): what the backward's exp2 consumes directly
     if (half == 0) a.lse[((long long)b * a.H + h) * a.T + qi] = m_run + __log2f(l_tot);
   }
@@ -474,9 +500,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
   }
   if (a.rel_mode) {
-    for (int i = tid; i < a.n2d; i += 256) { sTbl[i] = a.rel2d[(long long)h * a.n2d + i]; sHist[i] = 0.f; }
+    stage_table(sTbl, a.rel2d + (long long)h * a.n2d, a.n2d, tid);
+    stage_table(sGc, a.gcode, a.P, tid);
+    for (int i = tid; i < a.n2d; i += 256) sHist[i] = 0.f;
     for (int i = tid; i < n1dp + 4; i += 256) sHist1[i] = 0.f;
-    for (int i = tid; i < a.P; i += 256) sGc[i] = a.gcode[i];
   }
   const bool k_grid = kj < a.P;
   const bool wave_kgrid = kw + 31 < a.P;
@@ -563,15 +590,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     const unsigned char* sQ = smem + (n & 1) * STG;
     const unsigned char* sO = sQ + 8192;
     const float* sL = reinterpret_cast<const float*>(sQ + 8192 + 4096);
-#ifndef DKV_ABL
-#define DKV_ABL 0
-#endif
     lds_dma_wait();
-    if (!(DKV_ABL & 1) || n == 0)
     __syncthreads();              // block n has landed; everyone is done with block n-1 (and the table init)
-    if (!(DKV_ABL & 2))
     if (n + 1 < nblk) issue(ib + 32, (n + 1) & 1);
-    if (DKV_ABL & 16) continue;
     {
       const bool skip = (kw >= a.S) || (a.causal && wave_kgrid && ((ib + 31 < kw) || (ib >= a.P)));
       if (skip) continue;
@@ -639,12 +660,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[ks], vfr[ks], dp, 0, 0, 0);
       }
-      if ((DKV_ABL & 256) && !seeded) continue;
-      if (DKV_ABL & 4) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { dv[0][e] += s[e]; dk[0][e] += dp[e]; }
-        continue;
-      }
       // element r <-> query ib + (r&3) + 8*(r>>2) + 4*half ; key = kj (lane)
       bf16x8 pfr[2], dsf[2];
       float hval[16];      // seeded blocks: dS rotated onto its histogram lane (summed after the dV / dK MFMAs)
@@ -664,7 +679,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
             float pv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              if (DKV_ABL & 32) { pv[e] = s[rg * 4 + e]; dsr[rg * 4 + e] = dp[rg * 4 + e]; continue; }
               float p = __builtin_amdgcn_exp2f(fmaf(s[rg * 4 + e], LOG2E, -ls[e]));
               if (FLAGS & 2) p = (di > e) ? 0.f : p;
               if (FLAGS & 4) p = (kvalid && il + e < rowlim) ? p : 0.f;
@@ -771,15 +785,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         }
         pfr[s2] = up.b; dsf[s2] = ud.b;
       }
-#ifndef DKV_STOP
-#define DKV_STOP 0
-#endif
-      if (DKV_STOP == 2) {
-        U128 p0, p1, d0, d1; p0.b = pfr[0]; p1.b = pfr[1]; d0.b = dsf[0]; d1.b = dsf[1];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { dv[0][w] += __uint_as_float(p0.w[w] ^ p1.w[w]); dk[0][w] += __uint_as_float(d0.w[w] ^ d1.w[w]); }
-        continue;
-      }
       // dV^T += dO^T P ; dK^T += Q^T dS ; slot (kh,e) <-> query ib + 16*s2 + 4*kh + (e&3) + 8*(e>>2)
       // all transposed operand reads of one s2 half are issued before its MFMAs (the scheduling barrier keeps
       // the compiler from sinking each read next to its MFMA, which serialises LDS latency 6 times per half;
@@ -792,39 +797,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         for (int db = 0; db < 2; ++db) {
           const int o0 = (bOt ^ (db << 6)) + s2 * 2048;
           U64 x, y;
-          if (DKV_ABL & 64) { x.w[0] = o0; x.w[1] = n; y.w[0] = o0 + 1; y.w[1] = n; } else {
           x.s = lds_read_tr(sO + o0);
-          y.s = lds_read_tr(sO + ((o0 + 1024) ^ 32)); }
+          y.s = lds_read_tr(sO + ((o0 + 1024) ^ 32));
           fo[db].w[0] = x.w[0]; fo[db].w[1] = x.w[1]; fo[db].w[2] = y.w[0]; fo[db].w[3] = y.w[1];
         }
 #pragma unroll
         for (int cb = 0; cb < NKS / 2; ++cb) {
           const int o0 = (bQt ^ (cb << 6)) + s2 * 4096;
           U64 x, y;
-          if (DKV_ABL & 64) { x.w[0] = o0; x.w[1] = n; y.w[0] = o0 + 1; y.w[1] = n; } else {
           x.s = lds_read_tr(sQ + o0);
-          y.s = lds_read_tr(sQ + ((o0 + 2048) ^ 32)); }
+          y.s = lds_read_tr(sQ + ((o0 + 2048) ^ 32));
           fq[cb].w[0] = x.w[0]; fq[cb].w[1] = x.w[1]; fq[cb].w[2] = y.w[0]; fq[cb].w[3] = y.w[1];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (DKV_ABL & 128) {
-          U128 pp, dd; pp.b = pfr[s2]; dd.b = dsf[s2];
-#pragma unroll
-          for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) dv[db][w] += __uint_as_float(fo[db].w[w] ^ pp.w[w]);
-#pragma unroll
-          for (int cb = 0; cb < NKS / 2; ++cb)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) dk[cb][w] += __uint_as_float(fq[cb].w[w] ^ dd.w[w]);
-          continue;
-        }
 #pragma unroll
         for (int db = 0; db < 2; ++db) dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[db].b, pfr[s2], dv[db], 0, 0, 0);
 #pragma unroll
         for (int cb = 0; cb < NKS / 2; ++cb) dk[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[cb].b, dsf[s2], dk[cb], 0, 0, 0);
       }
-      if (seeded && !(DKV_ABL & 8)) {
+      if (seeded) {
         // accT: every term; accA: the terms without wrap, x + c_r <= 31 -- a compile-time lane interval per
         // register, applied as an EXEC mask (one masked add instead of compare + select + add)
         float accT, accA;
@@ -887,16 +878,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     bf16_t* dvp = a.dv + (long long)b * a.dv_bs + (long long)kj * a.lddv + h * 64;
     bf16_t* dkp = a.dk + (long long)b * a.dk_bs + (long long)kj * a.lddk + h * 64;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int d = db * 32 + 8 * rg + 4 * half;
-        *reinterpret_cast<uint2*>(dvp + d) =
-            make_uint2(pack2bf(dv[db][rg * 4] * gain, dv[db][rg * 4 + 1] * gain),
-                       pack2bf(dv[db][rg * 4 + 2] * gain, dv[db][rg * 4 + 3] * gain));
-        *reinterpret_cast<uint2*>(dkp + d) =
-            make_uint2(pack2bf(dk[db][rg * 4], dk[db][rg * 4 + 1]), pack2bf(dk[db][rg * 4 + 2], dk[db][rg * 4 + 3]));
-      }
+    for (int db = 0; db < 2; ++db) {
+      store_tile_bf16(dvp + db * 32, dv[db], gain, half, true);
+      store_tile_bf16(dkp + db * 32, dk[db], 1.f, half, true);
+    }
     if constexpr (HAS_POS) {
       float* pp = a.dpk + ((long long)b * a.S + kj) * (a.H * 64) + h * 64;
 #pragma unroll
@@ -970,8 +955,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const bool row32 = a.rel_mode && a.grid_w == 32;
   const float del_q = qvalid ? a.delta[((long long)b * a.H + h) * a.T + qi] : 0.f;
   if (a.rel_mode) {
-    for (int i = tid; i < a.n2d; i += 256) sTbl[i] = a.rel2d[(long long)h * a.n2d + i];
-    for (int i = tid; i < a.P; i += 256) sGc[i] = a.gcode[i];
+    stage_table(sTbl, a.rel2d + (long long)h * a.n2d, a.n2d, tid);
+    stage_table(sGc, a.gcode, a.P, tid);
   }
   const bool q_grid = a.rel_mode && qi < a.P;
   const int ci = q_grid ? a.gcode[qi] + a.code_bias : 0;
@@ -1186,14 +1171,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   if (qvalid) {
     bf16_t* dqp = a.dq + (long long)b * a.dq_bs + (long long)qi * a.lddq + h * 64;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int d = db * 32 + 8 * rg + 4 * half;
-        *reinterpret_cast<uint2*>(dqp + d) =
-            make_uint2(pack2bf(dq[db][rg * 4] * a.dq_scale, dq[db][rg * 4 + 1] * a.dq_scale),
-                       pack2bf(dq[db][rg * 4 + 2] * a.dq_scale, dq[db][rg * 4 + 3] * a.dq_scale));
-      }
+    for (int db = 0; db < 2; ++db) store_tile_bf16(dqp + db * 32, dq[db], a.dq_scale, half, true);
     if constexpr (HAS_POS) {
       float* pp = a.dpq + ((long long)b * a.T + qi) * (a.H * 64) + h * 64;
 #pragma unroll
