@@ -330,9 +330,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     float dsum = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
+      // bf16 output: the two lanes of a row (l, l + 32) hold alternating 4-column runs; they exchange one run each
+      // (v_permlane32_swap) and store 16 contiguous bytes -- half as many store instructions in the tail of a tile
+      const int nj = n0 + wn * (BN / 2) + j * 32;
+      // (measured per shape on M = 8480: +4..15 % for N >= 2304, -4 % for N = 768, hence the width test)
+      const bool wide = !out_f32 && g.N >= 1024 && nj + 32 <= g.N && !((g.ldc | g.sC) & 7) && !((size_t)g.C & 15);
+      uint2 held[4];
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * rg + 4 * (lane >> 5);
+        const int n = nj + 8 * rg + 4 * (lane >> 5);
+        held[rg] = make_uint2(0, 0);
         if (n >= g.N) continue;
         float v[4];
 #pragma unroll
@@ -369,11 +376,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
             v[0] += bflo(pw.x); v[1] += bfhi(pw.x); v[2] += bflo(pw.y); v[3] += bfhi(pw.y);
           }
           const uint2 ow = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-          *reinterpret_cast<uint2*>(cp) = ow;
+          if (wide) held[rg] = ow; else *reinterpret_cast<uint2*>(cp) = ow;
           if (g.dot) {
             const uint2 dw = *reinterpret_cast<const uint2*>(g.dot + (long long)m * g.ldd + n);
             dsum += bflo(ow.x) * bflo(dw.x) + bfhi(ow.x) * bfhi(dw.x) + bflo(ow.y) * bflo(dw.y) + bfhi(ow.y) * bfhi(dw.y);
           }
+        }
+      }
+      if (wide) {
+        bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (long long)by * g.sC + (long long)m * g.ldc + nj + 8 * (lane >> 5);
+#pragma unroll
+        for (int rgp = 0; rgp < 2; ++rgp) {
+          const auto p0 = __builtin_amdgcn_permlane32_swap(held[2 * rgp].x, held[2 * rgp + 1].x, false, false);
+          const auto p1 = __builtin_amdgcn_permlane32_swap(held[2 * rgp].y, held[2 * rgp + 1].y, false, false);
+          *reinterpret_cast<uint4*>(cp + 16 * rgp) = make_uint4(p0[0], p1[0], p0[1], p1[1]);
         }
       }
     }

@@ -183,7 +183,7 @@ class _TnProblem(ctypes.Structure):
 
 
 GEMM_GROUP_MAX = 8
-DW_GROUP_WGS = int(os.environ.get("IFSEG_DW_GROUP_WGS", "256"))     # grid cap of the grouped dW GEMM (one workgroup per CU)
+DW_GROUP_WGS = int(os.environ.get("IFSEG_DW_GROUP_WGS", "512"))     # grid cap of the grouped dW GEMM (one workgroup per CU)
 
 
 def dw_groupable(dy, x, out, bias_out):

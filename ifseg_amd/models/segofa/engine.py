@@ -78,6 +78,7 @@ class HipEngine:
         # backward (no split-K slabs / reduction launches: hip.linear_dw_group); IFSEG_NO_DW_GROUP=1: one GEMM each
         self._dw_tasks = []
         self.dw_grouped = os.environ.get("IFSEG_NO_DW_GROUP") is None
+        self.dw_split = os.environ.get("IFSEG_DW_SPLIT", "0") == "1"
         self.attn_bwd_timing = None      # {"stride": n, "seen": 0, "pairs": []} while bench.py times the attention backward
         self._bt = ""                    # tag of the backward block being processed (unique gradient buffers)
 
@@ -364,7 +365,7 @@ class HipEngine:
     def _dq_stream_get(self):
         if getattr(self, "_dqs", None) is None:
             self._wgrad_init()
-            self._dqs = torch.cuda.Stream(device=self.device)
+            self._dqs = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("IFSEG_DQ_PRIO", "0")))
         return self._dqs
 
     @contextlib.contextmanager
@@ -1190,6 +1191,8 @@ class HipEngine:
         self._linear_bwd(du, s["xn"], W(p + "fc1.weight"), G(p + "fc1.weight"), G(p + "fc1.bias"), dx_out=dxn)
         dx1 = gbuf("g_dx1_%d" % rows, (rows, C))
         self._ln_bwd_fused(dxn, s["x1"].view(rows, C), p + "final_layer_norm", tg + "_fln1", dx1, dx2, nxt)
+        if self.dw_split:
+            self._side_do(self._dw_flush)      # fc1 / fc2 dW as their own group: runs under the attention backward
         self._side_flush()
         return dx1
 
