@@ -1,5 +1,6 @@
 // Shared device helpers for the ifseg_amd HIP kernels (gfx950 / CDNA4 only).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -134,10 +135,23 @@ __device__ __forceinline__ void lds_dma4_gs(const void* sbase, int voff_bytes, u
 }
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Wave-wide sum, the same value in every lane.  DPP row shifts / row broadcasts feed the adds directly (six VALU
+// instructions and one v_readlane; the butterfly of ds_bpermute it replaces costs six dependent LDS round trips,
+// ~40 % of a LayerNorm-backward row's critical path at three waves per SIMD).  Inactive lanes contribute nothing, so
+// call it from wave-uniform control flow.
 __device__ __forceinline__ float warp_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  auto shr = [](float x, auto ctrl_tag, auto rowmask_tag) {
+    constexpr int CTRL = decltype(ctrl_tag)::value, RM = decltype(rowmask_tag)::value;
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, RM, 0xf, true));
+  };
+  using std::integral_constant;
+  v += shr(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});   // row_shr:1
+  v += shr(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});   // row_shr:2
+  v += shr(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});   // row_shr:4
+  v += shr(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});   // row_shr:8  -> lane 15 of a row: row total
+  v += shr(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});   // row_bcast:15 into rows 1, 3
+  v += shr(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});   // row_bcast:31 into rows 2, 3 -> lane 63: total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float warp_max(float v) {
 #pragma unroll
