@@ -96,14 +96,14 @@ struct RelCtx {
 
 // Global -> LDS copy of a small table by a 256-thread workgroup with eight loads in flight per thread (a plain
 // `for (i = tid; i < n; i += 256)` loop issues one load per round trip: 16 serial L2 latencies for a 63 x 63 table).
-template <typename T>
+template <typename T, bool REVERSE = false>
 __device__ __forceinline__ void stage_table(T* dst, const T* __restrict__ src, int n, int tid) {
   for (int i0 = 0; i0 < n; i0 += 8 * 256) {
     T v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256 + tid; v[u] = i < n ? src[i] : T(0); }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256 + tid; if (i < n) dst[i] = v[u]; }
+    for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256 + tid; if (i < n) dst[REVERSE ? n - 1 - i : i] = v[u]; }
   }
 }
 
@@ -163,11 +163,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   }
   // ---- rel-pos tables into LDS
   if (a.rel_mode) {
-    stage_table(sTbl, a.rel2d + (long long)h * a.n2d, a.n2d, tid);
+    // the table is kept REVERSED in LDS (sTbl[n2d - 1 - i] = rel2d[i]): a lane is a query and its registers are keys of
+    // increasing x, i.e. of decreasing table index; reversed, the 16 seeds of a block are read in register order
+    // (ds_read2_b32 pairs land in the accumulator tuple; in table order every seed needed a v_mov: ~60 per tile)
+    stage_table<float, true>(sTbl, a.rel2d + (long long)h * a.n2d, a.n2d, tid);
     stage_table(sGc, a.gcode, a.P, tid);
   }
   const bool q_grid = a.rel_mode && qi < a.P;
-  const int ci = q_grid ? a.gcode[qi] + a.code_bias : 0;
+  const int ciR = q_grid ? a.n2d - 1 - (a.gcode[qi] + a.code_bias) : 0;    // reversed-table index = ciR + cj
   const int ti = qi - a.P;
   const float relx0 = a.rel_mode ? a.relx[h * 2 + 0] : 0.f, relx1 = a.rel_mode ? a.relx[h * 2 + 1] : 0.f;
   const float* rel1d = a.rel_mode ? a.rel1d + (long long)h * (2 * a.Lt - 1) + (a.Lt - 1) : nullptr;
@@ -240,31 +243,43 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       const bool cbias = a.rel_mode && !a.dense && ((wave_grid && !tile_grid) || (qw_u >= a.P && tile_grid));
       const bool plain = cbias || (!a.rel_mode && !a.causal && !a.dense);
       f32x16 s[2];
+      auto s_mfma = [&]() {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) {
+            bf16x8 kf = lds_read_b128(sKb(cur) + kx_off(kb * 32 + (lane & 31), ks * 2 + half));
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+          }
+        }
+      };
       if (gg && row32) {
         // the block's keys are one grid row (codes cjb + x): the lane's 16 bias values sit at constant
         // offsets from one table address and are loaded straight into the accumulator, so the MFMA adds them
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
           const int cjb = sGc[j0 + kb * 32];
-          const float* tp = sTbl + (ci - cjb - 4 * half - 27);
+          const float* tp = sTbl + (ciR + cjb + 4 * half);
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[kb][rg * 4 + e] = tp[27 - (8 * rg + e)];
+            for (int e = 0; e < 4; ++e) s[kb][rg * 4 + e] = tp[8 * rg + e];
         }
+        s_mfma();
       } else {
-        const float c0 = cbias ? (tile_grid ? relx1 : relx0) : 0.f;
+        // (a separate MFMA chain: zero accumulators cost nothing, the first MFMA takes the constant; a chain shared
+        // with the seeded path makes the compiler splat 32 registers on every tile before it knows the path)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) s[kb][e] = c0;
-      }
+          for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+        s_mfma();
+        if (cbias) {
+          const float c0 = tile_grid ? relx1 : relx0;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+          for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          bf16x8 kf = lds_read_b128(sKb(cur) + kx_off(kb * 32 + (lane & 31), ks * 2 + half));
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+            for (int e = 0; e < 16; ++e) s[kb][e] += c0;
         }
       }
       // ---- bias + mask ; lane element (kb, r) <-> key j0 + kb*32 + (r&3) + 8*(r>>2) + 4*half
@@ -278,10 +293,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             for (int rg = 0; rg < 4; ++rg) {
               const int jb = j0 + kb * 32 + 8 * rg + 4 * half;
               const int4 cj = *reinterpret_cast<const int4*>(sGc + jb);
-              s[kb][rg * 4 + 0] += sTbl[ci - cj.x];
-              s[kb][rg * 4 + 1] += sTbl[ci - cj.y];
-              s[kb][rg * 4 + 2] += sTbl[ci - cj.z];
-              s[kb][rg * 4 + 3] += sTbl[ci - cj.w];
+              s[kb][rg * 4 + 0] += sTbl[ciR + cj.x];
+              s[kb][rg * 4 + 1] += sTbl[ciR + cj.y];
+              s[kb][rg * 4 + 2] += sTbl[ciR + cj.z];
+              s[kb][rg * 4 + 3] += sTbl[ciR + cj.w];
             }
           }
         }
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
               float sv = s[kb][rg * 4 + e];
               if (a.rel_mode) {
                 float bias;
-                if (tile_grid) bias = q_grid ? sTbl[ci - cjs[e]] : relx1;
+                if (tile_grid) bias = q_grid ? sTbl[ciR + cjs[e]] : relx1;
                 else bias = q_grid ? relx0 : ((j < a.S && qvalid) ? rel1d[ti - (j - a.P)] : 0.f);
                 sv += bias;
               }
@@ -955,11 +970,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const bool row32 = a.rel_mode && a.grid_w == 32;
   const float del_q = qvalid ? a.delta[((long long)b * a.H + h) * a.T + qi] : 0.f;
   if (a.rel_mode) {
-    stage_table(sTbl, a.rel2d + (long long)h * a.n2d, a.n2d, tid);
+    // the table is kept REVERSED in LDS (sTbl[n2d - 1 - i] = rel2d[i]): a lane is a query and its registers are keys of
+    // increasing x, i.e. of decreasing table index; reversed, the 16 seeds of a block are read in register order
+    // (ds_read2_b32 pairs land in the accumulator tuple; in table order every seed needed a v_mov: ~60 per tile)
+    stage_table<float, true>(sTbl, a.rel2d + (long long)h * a.n2d, a.n2d, tid);
     stage_table(sGc, a.gcode, a.P, tid);
   }
   const bool q_grid = a.rel_mode && qi < a.P;
-  const int ci = q_grid ? a.gcode[qi] + a.code_bias : 0;
+  const int ciR = q_grid ? a.n2d - 1 - (a.gcode[qi] + a.code_bias) : 0;    // reversed-table index = ciR + cj
   const int ti = qi - a.P;
   const float relx0 = a.rel_mode ? a.relx[h * 2 + 0] : 0.f, relx1 = a.rel_mode ? a.relx[h * 2 + 1] : 0.f;
   const float* rel1d = a.rel_mode ? a.rel1d + (long long)h * (2 * a.Lt - 1) + (a.Lt - 1) : nullptr;
@@ -1044,27 +1062,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         f32x16 s, dp;
 #pragma unroll
         for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+        auto sdp_mfma = [&]() {
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) {
+            bf16x8 kf = lds_read_b128(sKb(cur) + ((bK ^ (ks << 5)) + kb * 8192));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+          }
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 vfr = lds_read_b128(sVb(cur) + ((bV ^ (ks << 5)) + kb * 4096));
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, dof[ks], dp, 0, 0, 0);
+          }
+        };
         if (fast == 1 && row32) {
           // bias values of the key row at constant offsets from one table address seed the accumulator
-          const float* tp = sTbl + (ci - sGc[j0 + kb * 32] - 4 * half - 27);
+          const float* tp = sTbl + (ciR + sGc[j0 + kb * 32] + 4 * half);
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[rg * 4 + e] = tp[27 - (8 * rg + e)];
+            for (int e = 0; e < 4; ++e) s[rg * 4 + e] = tp[8 * rg + e];
+          sdp_mfma();
         } else {
-          const float c0 = cbias ? (tile_grid ? relx1 : relx0) : 0.f;
+          // (its own MFMA chain: see the forward kernel)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) s[e] = c0;
-        }
+          for (int e = 0; e < 16; ++e) s[e] = 0.f;
+          sdp_mfma();
+          if (cbias) {
+            const float c0 = tile_grid ? relx1 : relx0;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          bf16x8 kf = lds_read_b128(sKb(cur) + ((bK ^ (ks << 5)) + kb * 8192));
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          bf16x8 vfr = lds_read_b128(sVb(cur) + ((bV ^ (ks << 5)) + kb * 4096));
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, dof[ks], dp, 0, 0, 0);
+            for (int e = 0; e < 16; ++e) s[e] += c0;
+          }
         }
         bf16x8 dsf[2];
         // the two hot block kinds get one straight-line body each, chosen ONCE per 32-key block: with the choice inside
@@ -1115,7 +1142,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 const int4 cj = *reinterpret_cast<const int4*>(sGc + jb);
                 const int cjs[4] = {cj.x, cj.y, cj.z, cj.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sv[e] = s[rg * 4 + e] + sTbl[ci - cjs[e]];
+                for (int e = 0; e < 4; ++e) sv[e] = s[rg * 4 + e] + sTbl[ciR + cjs[e]];
               }
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -1133,7 +1160,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 float sv = s[rg * 4 + e];
                 if (a.rel_mode) {
                   float bias;
-                  if (tile_grid) bias = q_grid ? sTbl[ci - cjs[e]] : relx1;
+                  if (tile_grid) bias = q_grid ? sTbl[ciR + cjs[e]] : relx1;
                   else bias = q_grid ? relx0 : ((j < a.S && qvalid) ? rel1d[ti - (j - a.P)] : 0.f);
                   sv += bias;
                 }
