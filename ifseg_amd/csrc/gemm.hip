@@ -336,24 +336,29 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   const bool relu = g.flags & IFSEG_GEMM_RELU, out_f32 = g.flags & IFSEG_GEMM_OUT_F32,
              accum = g.flags & IFSEG_GEMM_ACCUMULATE;
   const bf16_t* Rb = g.resid ? g.resid + (long long)by * g.sR : nullptr;
+  // bf16 output of a 128-wide tile leaves through LDS: a lane owns a ROW of the MFMA tile (4-column runs), so direct
+  // stores write 32-byte pieces of 32 different rows per instruction (four requests per 128-byte line).  Each wave
+  // parks its 64 x 64 sub-tile in its own 8 KiB of the (now idle) operand stage -- 16-byte chunks XOR-swizzled by the row
+  // so neither the writes (8 consecutive rows per lane group) nor the reads conflict -- and writes it back as 8 full
+  // 128-byte row segments per instruction.
+  const bool lds_out = BN == 128 && !out_f32 && !accum && !((g.ldc | g.sC) & 7) && !((size_t)g.C & 15);
+  unsigned char* sOut = smem + wave * 8192;
+  if (BN == 128 && STAGES == 2) __syncthreads();      // (the one-stage loop ends with a barrier) operands are dead
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + wm * 64 + i * 32 + (lane & 31);
-    if (m >= g.M) continue;
+    const bool mvalid = m < g.M;
+    if (!lds_out && !mvalid) continue;
     float dsum = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      // bf16 output: the two lanes of a row (l, l + 32) hold alternating 4-column runs; they exchange one run each
-      // (v_permlane32_swap) and store 16 contiguous bytes -- half as many store instructions in the tail of a tile
       const int nj = n0 + wn * (BN / 2) + j * 32;
-      // (measured per shape on M = 8480: +4..15 % for N >= 2304, -4 % for N = 768, hence the width test)
-      const bool wide = !out_f32 && g.N >= 1024 && nj + 32 <= g.N && !((g.ldc | g.sC) & 7) && !((size_t)g.C & 15);
       uint2 held[4];
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int n = nj + 8 * rg + 4 * (lane >> 5);
         held[rg] = make_uint2(0, 0);
-        if (n >= g.N) continue;
+        if (n >= g.N || !mvalid) continue;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
@@ -389,29 +394,42 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
             v[0] += bflo(pw.x); v[1] += bfhi(pw.x); v[2] += bflo(pw.y); v[3] += bfhi(pw.y);
           }
           const uint2 ow = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-          if (wide) held[rg] = ow; else *reinterpret_cast<uint2*>(cp) = ow;
+          if (lds_out) held[rg] = ow; else *reinterpret_cast<uint2*>(cp) = ow;
           if (g.dot) {
             const uint2 dw = *reinterpret_cast<const uint2*>(g.dot + (long long)m * g.ldd + n);
             dsum += bflo(ow.x) * bflo(dw.x) + bfhi(ow.x) * bfhi(dw.x) + bflo(ow.y) * bflo(dw.y) + bfhi(ow.y) * bfhi(dw.y);
           }
         }
       }
-      if (wide) {
-        bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (long long)by * g.sC + (long long)m * g.ldc + nj + 8 * (lane >> 5);
+      if (lds_out) {
+        // the two lanes of a row (l, l + 32) hold alternating 4-column runs: they exchange one run each, so that a lane
+        // holds 8 consecutive columns = one 16-byte chunk (chunk index j*4 + rgp*2 + half of the wave's 64-column row)
+        const int R = i * 32 + (lane & 31);
 #pragma unroll
         for (int rgp = 0; rgp < 2; ++rgp) {
           const auto p0 = __builtin_amdgcn_permlane32_swap(held[2 * rgp].x, held[2 * rgp + 1].x, false, false);
           const auto p1 = __builtin_amdgcn_permlane32_swap(held[2 * rgp].y, held[2 * rgp + 1].y, false, false);
-          *reinterpret_cast<uint4*>(cp + 16 * rgp) = make_uint4(p0[0], p1[0], p0[1], p1[1]);
+          const int c = j * 4 + rgp * 2 + (lane >> 5);
+          *reinterpret_cast<uint4*>(sOut + R * 128 + ((c ^ (R & 7)) << 4)) = make_uint4(p0[0], p1[0], p0[1], p1[1]);
         }
       }
     }
-    if (g.dot) {
+    if (g.dot && mvalid) {
       // the wave's 64 columns are one head; lanes l and l + 32 hold the two interleaved halves of row m
       dsum += __shfl_xor(dsum, 32);
       const int hd = (n0 + wn * (BN / 2)) >> 6;
       if (lane < 32 && (hd << 6) < g.N)
         g.dot_out[((long long)(m / g.dot_T) * (g.N >> 6) + hd) * g.dot_T + (m % g.dot_T)] = dsum;
+    }
+  }
+  if (lds_out) {
+    const int c = lane & 7, nc = n0 + wn * 64 + c * 8;
+    bf16_t* cb = reinterpret_cast<bf16_t*>(g.C) + (long long)by * g.sC + nc;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int R = it * 8 + (lane >> 3), m = m0 + wm * 64 + R;
+      const uint4 v = *reinterpret_cast<const uint4*>(sOut + R * 128 + ((c ^ (R & 7)) << 4));
+      if (m < g.M && nc + 8 <= g.N) *reinterpret_cast<uint4*>(cb + (long long)m * g.ldc) = v;
     }
   }
 }
