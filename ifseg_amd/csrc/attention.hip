@@ -1247,6 +1247,10 @@ static int attn_check(const AttnArgs& a) {
     if (a.P % 64 || a.P > a.T || a.P > a.S) return IFSEG_ERR_BAD_SHAPE;
   }
   if ((a.ldq | a.ldk | a.ldv | a.ldo) & 7) return IFSEG_ERR_BAD_SHAPE;
+  // rows are read and written 16 bytes at a time: bases 16-byte aligned, batch strides multiples of 8 elements
+  if (((size_t)a.q | (size_t)a.k | (size_t)a.v | (size_t)a.o | (size_t)a.dO | (size_t)a.dq | (size_t)a.dk | (size_t)a.dv) & 15)
+    return IFSEG_ERR_BAD_ARG;
+  if ((a.q_bs | a.k_bs | a.v_bs | a.o_bs | a.do_bs | a.dq_bs | a.dk_bs | a.dv_bs) & 7) return IFSEG_ERR_BAD_SHAPE;
   return 0;
 }
 
