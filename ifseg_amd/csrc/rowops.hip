@@ -25,7 +25,7 @@ struct RowMap {  // logical row r -> element offset  (r / rpb) * bs + (r % rpb) 
 // same exponential the Gaussian pdf of the GELU derivative needs, so backward costs one exp per element.
 __device__ __forceinline__ float erf_as(float x, float e) {
   const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);      // v_rcp_f32 (1 ulp); __frcp_rn is a ten-instruction IEEE divide
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float r = 1.f - poly * e;
   return x < 0.f ? -r : r;
