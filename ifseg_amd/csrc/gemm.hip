@@ -253,15 +253,36 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   auto compute = [&](int st) {
     const unsigned char* sA = smem + st * STAGE_BYTES;
     const unsigned char* sB = sA + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < KS_STEPS; ++ks) {
-      bf16x8 fa[2], fb[NJ];
+    auto ldfrag = [&](int ks, bf16x8* fa, bf16x8* fb) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         fa[i] = (AMODE == A_KS) ? frag_ks(sA, wm * 64 + i * 32, ks, lane) : frag_kct<BK>(sA, wm * 64 + i * 32, ks, lane);
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
         fb[j] = B_KS ? frag_ks(sB, wn * (BN / 2) + j * 32, ks, lane) : frag_kct<BK>(sB, wn * (BN / 2) + j * 32, ks, lane);
+    };
+    if constexpr (!COLSUM && AMODE == A_KC && B_KS) {
+      // dX GEMMs (B = W read k-strided: two transposed LDS reads per fragment): the fragments of k-slice ks+1 are requested
+      // before the MFMAs of slice ks (two register sets, 112 -> 124 VGPRs, still four waves per SIMD): -4..17 % on the
+      // shapes of the model.  The same for the NT kernel costs its bias prefetch or a wave per SIMD and loses (measured).
+      bf16x8 fa[2][2], fb[2][NJ];
+      ldfrag(0, fa[0], fb[0]);
+#pragma unroll
+      for (int ks = 0; ks < KS_STEPS; ++ks) {
+        if (ks + 1 < KS_STEPS) ldfrag(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks & 1][j], fa[ks & 1][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+    for (int ks = 0; ks < KS_STEPS; ++ks) {
+      bf16x8 fa[2], fb[NJ];
+      ldfrag(ks, fa, fb);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -275,6 +296,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
           for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one.b, fa[i], accb[i], 0, 0, 0);
         }
       }
+    }
     }
   };
 
