@@ -1242,6 +1242,85 @@ __global__ void attn_delta_kernel(const bf16_t* o, const bf16_t* dO, float* delt
 
 }  // namespace
 
+namespace {
+// One launch for the reductions behind ifseg_attn_bwd's partial outputs; block ranges: [dpos_q | dpos_k | dgain | tables]
+struct ReduceArgs { ifseg_attn_reduce_args a; int nbq, nbk, nbt[3]; };
+__global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(ReduceArgs r) {
+  const ifseg_attn_reduce_args& a = r.a;
+  int blk = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (blk < r.nbq + r.nbk) {
+    const bool isq = blk < r.nbq;
+    if (!isq) blk -= r.nbq;
+    const long long n = (long long)(isq ? a.T : a.S) * a.C;      // C % 4 == 0: float4 columns
+    const float* part = isq ? a.dpos_q_part : a.dpos_k_part;
+    float* acc = isq ? a.dpos_q_acc : a.dpos_k_acc;
+    const long long i = ((long long)blk * 256 + tid) * 4;
+    if (i >= n) return;
+    float4 s = a.accumulate_pos ? *reinterpret_cast<const float4*>(acc + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < a.B; ++b) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (long long)b * n + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(acc + i) = s;
+    return;
+  }
+  blk -= r.nbq + r.nbk;
+  if (blk < a.H) {          // d c_attn[h]
+    if (!a.dgain) return;
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+      const float* d = a.delta + ((long long)b * a.H + blk) * a.T;
+      for (int t = tid; t < a.T; t += 256) s += d[t];
+    }
+    s = warp_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) reinterpret_cast<bf16_t*>(a.dgain)[blk] = f2bf(((red[0] + red[1]) + (red[2] + red[3])) / a.gain[blk]);
+    return;
+  }
+  blk -= a.H;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    if (t >= a.ntab) return;
+    if (blk < r.nbt[t]) {
+      const int n = a.tab_n[t];
+      const int gid = blk * 256 + tid;
+      if (gid >= n * a.H) return;
+      const int h = gid / n, j = gid - h * n;
+      const int bucket = a.tab_idx[t][j];
+      if (bucket < 0) return;
+      const float* p = a.tab_part[t] + (long long)h * a.nparts * n + j;
+      float s = 0.f;
+      for (int q = 0; q < a.nparts; ++q) s += p[(long long)q * n];
+      atomicAdd(&a.tab_acc[t][(long long)bucket * a.H + h], s);      // several entries may share a bucket
+      return;
+    }
+    blk -= r.nbt[t];
+  }
+}
+}  // namespace
+
+extern "C" int ifseg_attn_bwd_reduce(const ifseg_attn_reduce_args* x, void* stream) {
+  (void)hipGetLastError();
+  if (!x || x->B <= 0 || x->H <= 0 || x->T <= 0 || x->S <= 0 || (x->C & 3) || x->ntab < 0 || x->ntab > 3) return IFSEG_ERR_BAD_ARG;
+  ReduceArgs r{};
+  r.a = *x;
+  r.nbq = x->dpos_q_part ? (int)(((long long)x->T * x->C / 4 + 255) / 256) : 0;
+  r.nbk = x->dpos_k_part ? (int)(((long long)x->S * x->C / 4 + 255) / 256) : 0;
+  long long total = (long long)r.nbq + r.nbk + x->H;
+  for (int t = 0; t < x->ntab; ++t) {
+    if (!x->tab_part[t] || !x->tab_idx[t] || !x->tab_acc[t] || x->tab_n[t] <= 0 || x->nparts <= 0) return IFSEG_ERR_BAD_ARG;
+    r.nbt[t] = (int)(((long long)x->tab_n[t] * x->H + 255) / 256);
+    total += r.nbt[t];
+  }
+  if ((x->dgain && (!x->delta || !x->gain)) || total >= (1ll << 31)) return IFSEG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(attn_bwd_reduce_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, r);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
 static int attn_check(const AttnArgs& a) {
   if (a.rel_mode || a.causal) {
     if (a.P % 64 || a.P > a.T || a.P > a.S) return IFSEG_ERR_BAD_SHAPE;

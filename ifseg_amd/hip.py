@@ -33,7 +33,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 7:
+        if _lib.ifseg_abi_version() != 8:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -550,6 +550,28 @@ def rel_gather_multi(tables, idx, out):
     arr = (c_void_p * L)(*[t.data_ptr() for t in tables])
     _check(lib().ifseg_rel_gather_multi(arr, c_int(L), _ptr(idx), _ptr(out), c_int(n), c_int(H), _stream()), "rel_gather_multi")
     return out
+
+
+class _AttnReduceArgs(ctypes.Structure):
+    _fields_ = [("B", c_int), ("H", c_int), ("T", c_int), ("S", c_int), ("C", c_int), ("nparts", c_int),
+                ("accumulate_pos", c_int),
+                ("dpos_q_part", c_void_p), ("dpos_k_part", c_void_p), ("dpos_q_acc", c_void_p), ("dpos_k_acc", c_void_p),
+                ("delta", c_void_p), ("gain", c_void_p), ("dgain", c_void_p), ("ntab", c_int),
+                ("tab_part", c_void_p * 3), ("tab_idx", c_void_p * 3), ("tab_acc", c_void_p * 3), ("tab_n", c_int * 3)]
+
+
+def attn_bwd_reduce(B, H, T, S, C, dpq_part, dpk_part, dpq_acc, dpk_acc, accumulate_pos, delta, gain, dgain, nparts, tables):
+    """every reduction behind attn_bwd's partial outputs in one launch (ifseg_attn_bwd_reduce); tables: list of
+    (part [H,nparts,n] fp32, idx [n] int32, acc [n_bucket,H] fp32)"""
+    a = _AttnReduceArgs()
+    a.B, a.H, a.T, a.S, a.C, a.nparts, a.accumulate_pos = B, H, T, S, C, nparts, 1 if accumulate_pos else 0
+    a.dpos_q_part, a.dpos_k_part, a.dpos_q_acc, a.dpos_k_acc = _p(dpq_part), _p(dpk_part), _p(dpq_acc), _p(dpk_acc)
+    a.delta, a.gain, a.dgain = _p(delta), _p(_f32(gain)), _p(dgain)
+    a.ntab = len(tables)
+    for i, (part, idx, acc) in enumerate(tables):
+        assert part.dtype == torch.float32 and acc.dtype == torch.float32 and idx.dtype == torch.int32 and acc.shape[1] == H
+        a.tab_part[i], a.tab_idx[i], a.tab_acc[i], a.tab_n[i] = _p(part), _p(idx), _p(acc), idx.numel()
+    _check(lib().ifseg_attn_bwd_reduce(ctypes.byref(a), _stream()), "attn_bwd_reduce")
 
 
 def rel_scatter_add(d, idx, acc):

@@ -1257,20 +1257,15 @@ class HipEngine:
             t1.record()
             timing["pairs"].append((t0, t1, 8.0 * 64 * T * S * B * H))   # dV, dP, dK, dQ of the reference at d = 64
         def reductions():
-            hip.reduce_parts(dpq_part, dpq_acc, 1, B, T * C, accumulate=not first_pos)
-            hip.reduce_parts(dpk_part, dpk_acc, 1, B, S * C, accumulate=not first_pos)
-            # d c_attn[h] = sum_{b,t} delta / c_attn[h]   (H scalars)
-            hip.reduce_parts(delta.view(B, H * T), buf("g_dsum_bt", (H * T,), torch.float32), 1, B, H * T)
-            self.G(gain_name).copy_((self.ws["g_dsum_bt"].view(H, T).sum(1) / gain.float()))
+            # one launch: batch sums of the abs-pos operand gradients, d c_attn[h] = sum_{b,t} delta / c_attn[h], and for
+            # every rel-pos table the sum over the workgroup partials scattered into its bucket accumulator
+            tables = []
             if rel is not None:
                 for (tabname, idx), part in zip(rel_grads, parts):
-                    if tabname is None:
-                        continue
-                    n = part.shape[2]
-                    red = buf("g_relred_%d" % n, (H, n), torch.float32)
-                    hip.reduce_parts(part, red, H, nparts, n)
-                    acc = self._table_acc(tabname)
-                    hip.rel_scatter_add(red, idx, acc)
+                    if tabname is not None:
+                        tables.append((part, idx, self._table_acc(tabname)))
+            hip.attn_bwd_reduce(B, H, T, S, C, dpq_part, dpk_part, dpq_acc, dpk_acc, not first_pos, delta, gain,
+                                self.G(gain_name), nparts if rel is not None else 1, tables)
         self._side_do(reductions)
 
     def _table_acc(self, tabname):

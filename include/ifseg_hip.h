@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 7
+#define IFSEG_ABI_VERSION 8
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -146,6 +146,29 @@ typedef struct ifseg_attn_bwd_args {
 #define IFSEG_ATTN_BWD_DKV 2
 #define IFSEG_ATTN_BWD_DQ 4
 int ifseg_attn_bwd(const ifseg_attn_bwd_args* args, void* stream);
+
+/* Everything the partial outputs of ifseg_attn_bwd still need, in ONE launch (the autograd reductions behind
+ * unify_multihead_attention.py:459-512 + the bias construction encoder_module.py:757-809 / decoder_module.py:553-631:
+ * sum over the batch of the abs-pos operand gradients, sum over the workgroup partials of the rel-pos table gradients
+ * followed by embedding_dense_backward into the bucket tables, and the gradient of c_attn):
+ *   dpos_q_acc[T*C]  (=|+=) sum_b dpos_q_part[b]        dpos_k_acc[S*C] (=|+=) sum_b dpos_k_part[b]
+ *   dgain[h] (bf16)  = sum_{b,t} delta[b,h,t] / gain[h]          (delta = rowsum(dO * O), O includes the gain)
+ *   for each of up to 3 tables i:  acc_i[idx_i[j]][h] += sum_p part_i[h][p][j]   (idx < 0: no bucket)
+ * Replaces 2 + 4 + 2 per table launches of ifseg_reduce_parts / ifseg_rel_scatter_add / elementwise kernels. */
+typedef struct ifseg_attn_reduce_args {
+  int B, H, T, S, C, nparts, accumulate_pos;
+  const float *dpos_q_part, *dpos_k_part;   /* [B,T,C], [B,S,C] */
+  float *dpos_q_acc, *dpos_k_acc;           /* [T,C], [S,C] */
+  const float* delta;                       /* [B,H,T] */
+  const float* gain;                        /* fp32 [H] */
+  void* dgain;                              /* bf16 [H] or NULL */
+  int ntab;
+  const float* tab_part[3];                 /* [H,nparts,n_i] */
+  const int* tab_idx[3];                    /* [n_i] bucket of entry j of the delta table */
+  float* tab_acc[3];                        /* fp32 [n_bucket_i, H] accumulators */
+  int tab_n[3];
+} ifseg_attn_reduce_args;
+int ifseg_attn_bwd_reduce(const ifseg_attn_reduce_args* args, void* stream);
 
 /* -------------------------------------------------------------- row ops */
 /* Row addressing used below: logical row r lives at element offset

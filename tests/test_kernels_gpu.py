@@ -758,3 +758,41 @@ def test_layernorm_fp32_params_flag(C, gelu):
         ya = y.clone()
         hip.ln_fwd_pair(x, g32, b32, y, mean, rstd, b32 + 1, g32 - 1, y2b, m2, r2)
         assert torch.equal(y, ya) and torch.equal(y2a, y2b)
+
+
+@pytest.mark.gpu
+def test_attn_bwd_reduce_matches_the_separate_reductions():
+    """ifseg_attn_bwd_reduce (one launch) against its definition: batch sums of the abs-pos operand partials (with and
+    without accumulation), d c_attn from delta, partial sums of the rel-pos tables scattered into bucket accumulators
+    (duplicate buckets and idx < 0 included)."""
+    from ifseg_amd import hip
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    B, H, T, S, C, nparts = 3, 4, 70, 45, 64, 5
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    dpq_part, dpk_part, delta = r(B, T, C), r(B, S, C), r(B, H, T)
+    gain = (torch.rand(H, generator=g) + 0.5).to(dev)
+    tabs = []
+    for n, nb in ((37, 20), (9, 9)):
+        idx = torch.randint(-1, nb, (n,), generator=g).int().to(dev)
+        tabs.append((r(H, nparts, n), idx, r(nb, H)))
+    for accumulate in (False, True):
+        dpq_acc, dpk_acc = r(T, C), r(S, C)
+        want_q = dpq_part.sum(0) + (dpq_acc if accumulate else 0)
+        want_k = dpk_part.sum(0) + (dpk_acc if accumulate else 0)
+        dgain = torch.zeros(H, dtype=torch.bfloat16, device=dev)
+        tables = [(p, i, a.clone()) for p, i, a in tabs]
+        want_tabs = []
+        for p, i, a in tabs:
+            w = a.clone()
+            red = p.sum(1)                                  # [H, n]
+            for j in range(i.numel()):
+                if int(i[j]) >= 0:
+                    w[int(i[j])] += red[:, j]
+            want_tabs.append(w)
+        hip.attn_bwd_reduce(B, H, T, S, C, dpq_part, dpk_part, dpq_acc, dpk_acc, accumulate, delta, gain, dgain, nparts, tables)
+        torch.cuda.synchronize()
+        assert torch.allclose(dpq_acc, want_q, atol=1e-5) and torch.allclose(dpk_acc, want_k, atol=1e-5)
+        assert torch.allclose(dgain.float(), (delta.sum((0, 2)) / gain), rtol=1e-2, atol=1e-2)
+        for (_, _, got), w in zip(tables, want_tabs):
+            assert torch.allclose(got, w, atol=1e-4)
