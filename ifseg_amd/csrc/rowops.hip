@@ -496,6 +496,43 @@ __global__ __launch_bounds__(256) void reduce_parts2d_kernel(const float* in, vo
   }
 }
 
+// several reductions in one launch: block ranges by task
+struct ReduceTasks { ifseg_reduce_task t[16]; int start[17]; int n; };
+__global__ __launch_bounds__(256) void reduce_parts_multi_kernel(ReduceTasks ts) {
+  __shared__ float red[8][33];
+  int k = 0;
+  for (int i = 1; i < ts.n; ++i) k = ((int)blockIdx.x >= ts.start[i]) ? i : k;
+  const ifseg_reduce_task& T = ts.t[k];
+  const int blk = blockIdx.x - ts.start[k];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const long long nchunk = (T.n + 31) / 32;
+  const long long o = blk / nchunk, i = (blk % nchunk) * 32 + c;
+  float s = 0.f;
+  if (i < T.n) {
+    const float* p = T.in + o * T.parts * T.n + i;
+#pragma unroll 8
+    for (int q = g; q < T.parts; q += 8) s += p[(long long)q * T.n];
+  }
+  red[g][c] = s;
+  __syncthreads();
+  if (g == 0 && i < T.n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][c];
+    t *= T.scale;
+    const long long gid = o * T.n + i;
+    if (T.out_bf16) {
+      bf16_t* op = reinterpret_cast<bf16_t*>(T.out) + gid;
+      if (T.accumulate) t += bf2f(*op);
+      *op = f2bf(t);
+    } else {
+      float* op = reinterpret_cast<float*>(T.out) + gid;
+      if (T.accumulate) t += *op;
+      *op = t;
+    }
+  }
+}
+
 // column sums of a bf16 matrix: part[blockIdx.y][n] = sum over the block's row slab
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, float* part, int M, int N, RowMap mx,
                                                      int rows_per_blk) {
@@ -729,6 +766,26 @@ extern "C" int ifseg_reduce_parts(const float* in, void* out, int outer, int par
   dim3 g((unsigned)((total + 255) / 256));
   if (out_bf16) hipLaunchKernelGGL(reduce_parts_kernel<true>, g, dim3(256), 0, (hipStream_t)stream, in, out, outer, parts, n, accumulate, scale);
   else hipLaunchKernelGGL(reduce_parts_kernel<false>, g, dim3(256), 0, (hipStream_t)stream, in, out, outer, parts, n, accumulate, scale);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_reduce_parts_multi(int ntask, const ifseg_reduce_task* tasks, void* stream) {
+  (void)hipGetLastError();
+  if (ntask <= 0) return 0;
+  if (ntask > 16 || !tasks) return IFSEG_ERR_BAD_ARG;
+  ReduceTasks ts{};
+  ts.n = ntask;
+  long long total = 0;
+  for (int i = 0; i < ntask; ++i) {
+    if (!tasks[i].in || !tasks[i].out || tasks[i].outer <= 0 || tasks[i].parts <= 0 || tasks[i].n <= 0) return IFSEG_ERR_BAD_ARG;
+    ts.t[i] = tasks[i];
+    ts.start[i] = (int)total;
+    total += (long long)tasks[i].outer * ((tasks[i].n + 31) / 32);
+    if (total >= (1ll << 31)) return IFSEG_ERR_BAD_SHAPE;
+  }
+  ts.start[ntask] = (int)total;
+  hipLaunchKernelGGL(reduce_parts_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, ts);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

@@ -446,6 +446,22 @@ def reduce_parts(inp, out, outer, parts, n, accumulate=False, scale=1.0):
     return out
 
 
+class _ReduceTask(ctypes.Structure):
+    _fields_ = [("inp", c_void_p), ("out", c_void_p), ("outer", c_int), ("parts", c_int), ("n", c_ll),
+                ("accumulate", c_int), ("out_bf16", c_int), ("scale", c_float)]
+
+
+def reduce_parts_multi(tasks):
+    """tasks: list of (inp, out, outer, parts, n, accumulate) -- ifseg_reduce_parts for each, 16 per launch"""
+    for i in range(0, len(tasks), 16):
+        chunk = tasks[i:i + 16]
+        arr = (_ReduceTask * len(chunk))()
+        for q, (inp, out, outer, parts, n, accumulate) in zip(arr, chunk):
+            q.inp, q.out, q.outer, q.parts, q.n = _p(inp), _p(out), outer, parts, n
+            q.accumulate, q.out_bf16, q.scale = (1 if accumulate else 0), (1 if out.dtype == torch.bfloat16 else 0), 1.0
+        _check(lib().ifseg_reduce_parts_multi(c_int(len(chunk)), arr, _stream()), "reduce_parts_multi")
+
+
 COLSUM_BLOCKS = 256
 
 

@@ -77,6 +77,7 @@ class HipEngine:
         # weight-gradient GEMMs of a layer are collected and launched as ONE grouped GEMM at the end of the layer's
         # backward (no split-K slabs / reduction launches: hip.linear_dw_group); IFSEG_NO_DW_GROUP=1: one GEMM each
         self._dw_tasks = []
+        self._ln_red_tasks, self._ln_red_acc = [], []    # (partials, [2, C] gradient view, ...) of LayerNorm backward launches
         self.dw_grouped = os.environ.get("IFSEG_NO_DW_GROUP") is None
         self.dw_split = os.environ.get("IFSEG_DW_SPLIT", "0") == "1"
         self.attn_bwd_timing = None      # {"stride": n, "seen": 0, "pairs": []} while bench.py times the attention backward
@@ -1110,17 +1111,18 @@ class HipEngine:
         mu, rs = self._ln_stats(stats_tag, rows)
         # per-block partial sums of d(gamma), d(beta); one buffer per LayerNorm site (the reduction below
         # runs on the side stream)
-        part = self.buf("ln_dgbp_%d@%s" % (C, stats_tag) if self.overlap else "ln_dgbp_%d" % C,
-                        (2, hip.LN_BWD_BLOCKS, C), torch.float32)
+        part = self._ln_part(C, stats_tag)
         hip.ln_bwd(dy, x, self.Wf(pname + ".weight"), mu, rs, dx, part[0], part[1], dx_add=dx_add, gelu=gelu, drop=drop)
         # weight and bias of a LayerNorm are adjacent in the arena: one [2, C] reduction
-        self._side_do(lambda: hip.reduce_parts(part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C,
-                                               accumulate=accumulate))
+        # (an accumulating reduction adds to what an earlier LayerNorm launch of the same parameters produced: it must not
+        # share a launch with it)
+        (self._ln_red_acc if accumulate else self._ln_red_tasks).append(
+            (part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C, accumulate))
         return dx
 
     def _ln_part(self, C, stats_tag):
-        return self.buf("ln_dgbp_%d@%s" % (C, stats_tag) if self.overlap else "ln_dgbp_%d" % C,
-                        (2, hip.LN_BWD_BLOCKS, C), torch.float32)
+        # one buffer per LayerNorm site: the reductions of a layer block are batched into one later launch
+        return self.buf("ln_dgbp_%d@%s" % (C, stats_tag), (2, hip.LN_BWD_BLOCKS, C), torch.float32)
 
     def _ln_bwd_fused(self, dy, x, pname, stats_tag, dx, dx_add, nxt):
         """`_ln_bwd` of a block's pre-LN plus, in the same launch, the fc2-dropout adjoint that opens the NEXT block of the
@@ -1137,7 +1139,7 @@ class HipEngine:
         part = self._ln_part(C, stats_tag)
         hip.ln_bwd_drop(dy, x, self.Wf(pname + ".weight"), mu, rs, dx, part[0], part[1], nxt["out"], dx_add=dx_add,
                         drop2=nxt["drop"])
-        self._side_do(lambda: hip.reduce_parts(part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C))
+        self._ln_red_tasks.append((part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C, False))
         return dx
 
     def _next_drop(self, tg, rows):
@@ -1477,6 +1479,8 @@ class HipEngine:
         gt = G(e + "type_embedding.weight")
         self._bias_grad(dtok.view(B * L, C), gt[0])
         self._bias_grad(dimg.view(B * P, C), gt[1])
+        self._dw_flush()                 # the LayerNorm partials of this tail
+        assert not self._ln_red_tasks and not self._ln_red_acc and not self._dw_tasks
         self._notify(e)
 
     def _dec_pos_bwd(self, B, P, T, Td, dspq, dspk, dcpq, dcpk, pos_all, dpos_all):
@@ -1507,12 +1511,19 @@ class HipEngine:
         hip.cast_f32_bf16(dcpk, dcpk16)
         self._linear_bwd(dcpk16, pos_all, W(d + "cross_pos_k_linear.weight"), G(d + "cross_pos_k_linear.weight"),
                          G(d + "cross_pos_k_linear.bias"), dx_out=dpos_all)
+        self._dw_flush()                 # the LayerNorm partials queued since the last layer
         self._side_do(lambda: self._notify(d))
 
     def _dw_flush(self):
         tasks, self._dw_tasks = self._dw_tasks, []
         if tasks:
             hip.linear_dw_group(tasks)
+        # the LayerNorm dgamma / dbeta partials collected since the last flush: one reduction launch
+        for attr in ("_ln_red_tasks", "_ln_red_acc"):
+            red = getattr(self, attr)
+            setattr(self, attr, [])
+            if red:
+                hip.reduce_parts_multi(red)
 
     def _flush_tables(self):
         self._dw_flush()

@@ -231,6 +231,13 @@ int ifseg_sync_master(float* master, const void* p16, long long n, void* stream)
 /* out[o][i] (+)= scale * sum_p in[o][p][i]   (fp32 in; fp32 or bf16 out) */
 int ifseg_reduce_parts(const float* in, void* out, int outer, int parts, long long n, int accumulate,
                        int out_bf16, float scale, void* stream);
+/* Up to 16 such reductions in one launch (the LayerNorm dgamma / dbeta partials of one layer block). */
+typedef struct ifseg_reduce_task {
+  const float* in; void* out;
+  int outer, parts; long long n;
+  int accumulate, out_bf16; float scale;
+} ifseg_reduce_task;
+int ifseg_reduce_parts_multi(int ntask, const ifseg_reduce_task* tasks, void* stream);
 /* part[k][n] = column sums of the k-th row slab of x[M,N] (bias gradients; autograd of
  * the bias add in F.linear). */
 int ifseg_colsum_bf16(const void* x, float* part, int nblk_rows, int M, int N, int rpb, long long x_bs, int ldx,
