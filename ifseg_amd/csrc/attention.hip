@@ -42,7 +42,7 @@ struct AttnArgs {
   const bf16_t* dO; long long do_bs; int lddo;
   const float* delta;
   bf16_t *dq, *dk, *dv; long long dq_bs, dk_bs, dv_bs; int lddq, lddk, lddv;
-  float *dpq, *dpk;          // [B, T, H*64] / [B, S, H*64] fp32 per-batch partials
+  bf16_t *dpq, *dpk;         // [B, T, H*64] / [B, S, H*64] bf16 per-batch partials
   float *drel2d_part, *drel1d_part, *drelx_part;  // [H][nparts][n]
   int nparts;
   const float* gain;          // [H] per-head output gain c_attn (fp32: the optimizer's master copy; may be null)
@@ -898,15 +898,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       store_tile_bf16(dkp + db * 32, dk[db], 1.f, half, true);
     }
     if constexpr (HAS_POS) {
-      float* pp = a.dpk + ((long long)b * a.S + kj) * (a.H * 64) + h * 64;
+      bf16_t* pp = a.dpk + ((long long)b * a.S + kj) * (a.H * 64) + h * 64;
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int d = db * 32 + 8 * rg + 4 * half;
-          *reinterpret_cast<float4*>(pp + d) = make_float4(dk[2 + db][rg * 4], dk[2 + db][rg * 4 + 1],
-                                                           dk[2 + db][rg * 4 + 2], dk[2 + db][rg * 4 + 3]);
-        }
+      for (int db = 0; db < 2; ++db) store_tile_bf16(pp + db * 32, dk[2 + db], 1.f, half, true);
     }
   }
   if (a.rel_mode) {
@@ -1200,16 +1194,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int db = 0; db < 2; ++db) store_tile_bf16(dqp + db * 32, dq[db], a.dq_scale, half, true);
     if constexpr (HAS_POS) {
-      float* pp = a.dpq + ((long long)b * a.T + qi) * (a.H * 64) + h * 64;
+      bf16_t* pp = a.dpq + ((long long)b * a.T + qi) * (a.H * 64) + h * 64;
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int d = db * 32 + 8 * rg + 4 * half;
-          *reinterpret_cast<float4*>(pp + d) =
-              make_float4(dq[2 + db][rg * 4] * a.dpq_scale, dq[2 + db][rg * 4 + 1] * a.dpq_scale,
-                          dq[2 + db][rg * 4 + 2] * a.dpq_scale, dq[2 + db][rg * 4 + 3] * a.dpq_scale);
-        }
+      for (int db = 0; db < 2; ++db) store_tile_bf16(pp + db * 32, dq[2 + db], a.dpq_scale, half, true);
     }
   }
 }
@@ -1253,14 +1240,14 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(ReduceArgs r) {
     const bool isq = blk < r.nbq;
     if (!isq) blk -= r.nbq;
     const long long n = (long long)(isq ? a.T : a.S) * a.C;      // C % 4 == 0: float4 columns
-    const float* part = isq ? a.dpos_q_part : a.dpos_k_part;
+    const bf16_t* part = reinterpret_cast<const bf16_t*>(isq ? a.dpos_q_part : a.dpos_k_part);
     float* acc = isq ? a.dpos_q_acc : a.dpos_k_acc;
     const long long i = ((long long)blk * 256 + tid) * 4;
     if (i >= n) return;
     float4 s = a.accumulate_pos ? *reinterpret_cast<const float4*>(acc + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int b = 0; b < a.B; ++b) {
-      const float4 v = *reinterpret_cast<const float4*>(part + (long long)b * n + i);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      const uint2 v = *reinterpret_cast<const uint2*>(part + (long long)b * n + i);
+      s.x += bflo(v.x); s.y += bfhi(v.x); s.z += bflo(v.y); s.w += bfhi(v.y);
     }
     *reinterpret_cast<float4*>(acc + i) = s;
     return;
@@ -1384,7 +1371,7 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   a.dO = (const bf16_t*)x->dout; a.do_bs = x->do_bs; a.lddo = x->lddo; a.delta = x->delta;
   a.dq = (bf16_t*)x->dq; a.dk = (bf16_t*)x->dk; a.dv = (bf16_t*)x->dv;
   a.dq_bs = x->dq_bs; a.dk_bs = x->dk_bs; a.dv_bs = x->dv_bs; a.lddq = x->lddq; a.lddk = x->lddk; a.lddv = x->lddv;
-  a.dpq = x->dpos_q_part; a.dpk = x->dpos_k_part;
+  a.dpq = (bf16_t*)x->dpos_q_part; a.dpk = (bf16_t*)x->dpos_k_part;
   a.drel2d_part = x->drel2d_part; a.drel1d_part = x->drel1d_part; a.drelx_part = x->drelx_part;
   a.nparts = x->nparts; a.gain = (const float*)x->gain; a.dq_scale = x->dq_scale; a.dpq_scale = x->dpq_scale;
   a.grid_w = x->grid_w;

@@ -289,6 +289,7 @@ def attn_bwd(q, k, v, pos_q, pos_k, out, dout, lse, delta, dq, dk, dv, dpq_part,
              causal=False, P=None, gain=None, dq_scale=1.0, dpq_scale=1.0, drel2d_part=None, drel1d_part=None,
              drelx_part=None, nparts=0, phases=0):
     a = _AttnBwdArgs()
+    assert all(t is None or t.dtype == torch.bfloat16 for t in (dpq_part, dpk_part)), "abs-pos partials are bf16"
     if rel is not None:
         P = rel.P
     if P is None:
@@ -579,6 +580,7 @@ class _AttnReduceArgs(ctypes.Structure):
 def attn_bwd_reduce(B, H, T, S, C, dpq_part, dpk_part, dpq_acc, dpk_acc, accumulate_pos, delta, gain, dgain, nparts, tables):
     """every reduction behind attn_bwd's partial outputs in one launch (ifseg_attn_bwd_reduce); tables: list of
     (part [H,nparts,n] fp32, idx [n] int32, acc [n_bucket,H] fp32)"""
+    assert all(t is None or t.dtype == torch.bfloat16 for t in (dpq_part, dpk_part)), "abs-pos partials are bf16"
     a = _AttnReduceArgs()
     a.B, a.H, a.T, a.S, a.C, a.nparts, a.accumulate_pos = B, H, T, S, C, nparts, 1 if accumulate_pos else 0
     a.dpos_q_part, a.dpos_k_part, a.dpos_q_acc, a.dpos_k_acc = _p(dpq_part), _p(dpk_part), _p(dpq_acc), _p(dpk_acc)

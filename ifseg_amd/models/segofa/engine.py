@@ -1223,8 +1223,8 @@ class HipEngine:
         have_delta = delta is not None
         if not have_delta:
             delta = gbuf("g_delta_%d" % T, (B, H, T), torch.float32)
-        dpq_part = gbuf("g_dpq_part_%d" % T, (B, T, C), torch.float32)
-        dpk_part = gbuf("g_dpk_part_%d" % S, (B, S, C), torch.float32)
+        dpq_part = gbuf("g_dpq_part_%d" % T, (B, T, C))        # bf16 per-batch partials, summed by attn_bwd_reduce
+        dpk_part = gbuf("g_dpk_part_%d" % S, (B, S, C))
         nparts = B * ((S + 127) // 128)
         parts = [None, None, None]
         if rel is not None:

@@ -118,7 +118,7 @@ int ifseg_attn_fwd(const void* q, const void* k, const void* v, const void* pos_
  * `gain` [H] (fp32) is the per-head c_attn applied to `out` by the forward
  * (unify_multihead_attention.py:509-512); d(gain)[h] = sum_{b,t} delta / gain[h].
  * dq is scaled by dq_scale (the reference's q scaling), the abs-pos halves of
- * dQ_ext / dK_ext are written as fp32 per-batch partials dpos_q_part [B,T,H*64]
+ * dQ_ext / dK_ext are written as bf16 per-batch partials dpos_q_part [B,T,H*64]
  * (scaled by dpq_scale) and dpos_k_part [B,S,H*64]; rel-table gradients as
  * per-workgroup partials [H][nparts][n] with nparts = B*ceil(S/128) (sum them with
  * ifseg_reduce_parts).  No atomics on global memory: results are deterministic. */
@@ -127,7 +127,7 @@ typedef struct ifseg_attn_bwd_args {
   const float* lse;
   float* delta;               /* workspace [B,H,T] */
   void *dq, *dk, *dv;
-  float *dpos_q_part, *dpos_k_part;
+  void *dpos_q_part, *dpos_k_part; /* bf16 */
   int B, H, T, S;
   int ldq, ldk, ldv, ldpq, ldpk, ldout, lddo, lddq, lddk, lddv;
   long long q_bs, k_bs, v_bs, out_bs, do_bs, dq_bs, dk_bs, dv_bs;
@@ -157,7 +157,7 @@ int ifseg_attn_bwd(const ifseg_attn_bwd_args* args, void* stream);
  * Replaces 2 + 4 + 2 per table launches of ifseg_reduce_parts / ifseg_rel_scatter_add / elementwise kernels. */
 typedef struct ifseg_attn_reduce_args {
   int B, H, T, S, C, nparts, accumulate_pos;
-  const float *dpos_q_part, *dpos_k_part;   /* [B,T,C], [B,S,C] */
+  const void *dpos_q_part, *dpos_k_part;    /* bf16 [B,T,C], [B,S,C] (as ifseg_attn_bwd writes them) */
   float *dpos_q_acc, *dpos_k_acc;           /* [T,C], [S,C] */
   const float* delta;                       /* [B,H,T] */
   const float* gain;                        /* fp32 [H] */

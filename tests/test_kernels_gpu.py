@@ -261,8 +261,8 @@ def test_attn_bwd(case):
     assert _rel(out, o_ref) < 1e-2
     dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
     delta = torch.zeros(B, H, T, device=dev)
-    dpq = torch.zeros(B, T, C, device=dev)
-    dpk = torch.zeros(B, S, C, device=dev)
+    dpq = torch.zeros(B, T, C, device=dev, dtype=torch.bfloat16)        # per-batch partials
+    dpk = torch.zeros(B, S, C, device=dev, dtype=torch.bfloat16)
     nparts = B * ((S + 127) // 128)
     parts = [None, None, None]
     if rel is not None:
@@ -272,7 +272,7 @@ def test_attn_bwd(case):
                  drelx_part=parts[2], nparts=nparts)
     torch.cuda.synchronize()
     errs = {"dq": _rel(dq, qf.grad * 0.5), "dk": _rel(dk, kf.grad), "dv": _rel(dv, vf.grad),
-            "dpq": _rel(dpq.sum(0), pqf.grad * 0.25), "dpk": _rel(dpk.sum(0), pkf.grad)}
+            "dpq": _rel(dpq.float().sum(0), pqf.grad * 0.25), "dpk": _rel(dpk.float().sum(0), pkf.grad)}
     dgain = (delta.sum((0, 2)) / gain.float())
     errs["dgain"] = _rel(dgain, gf.grad)
     info = {}
@@ -770,7 +770,7 @@ def test_attn_bwd_reduce_matches_the_separate_reductions():
     g = torch.Generator().manual_seed(3)
     B, H, T, S, C, nparts = 3, 4, 70, 45, 64, 5
     r = lambda *s: torch.randn(*s, generator=g).to(dev)
-    dpq_part, dpk_part, delta = r(B, T, C), r(B, S, C), r(B, H, T)
+    dpq_part, dpk_part, delta = r(B, T, C).bfloat16(), r(B, S, C).bfloat16(), r(B, H, T)
     gain = (torch.rand(H, generator=g) + 0.5).to(dev)
     tabs = []
     for n, nb in ((37, 20), (9, 9)):
@@ -778,8 +778,8 @@ def test_attn_bwd_reduce_matches_the_separate_reductions():
         tabs.append((r(H, nparts, n), idx, r(nb, H)))
     for accumulate in (False, True):
         dpq_acc, dpk_acc = r(T, C), r(S, C)
-        want_q = dpq_part.sum(0) + (dpq_acc if accumulate else 0)
-        want_k = dpk_part.sum(0) + (dpk_acc if accumulate else 0)
+        want_q = dpq_part.float().sum(0) + (dpq_acc if accumulate else 0)
+        want_k = dpk_part.float().sum(0) + (dpk_acc if accumulate else 0)
         dgain = torch.zeros(H, dtype=torch.bfloat16, device=dev)
         tables = [(p, i, a.clone()) for p, i, a in tabs]
         want_tabs = []

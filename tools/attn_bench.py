@@ -24,7 +24,7 @@ def main(kind="enc", iters=5):
     gain = torch.ones(H, device=dev, dtype=torch.bfloat16)
     out = torch.zeros(B, T, C, dtype=torch.bfloat16, device=dev); lse = torch.zeros(B, H, T, device=dev)
     dqkv = torch.zeros_like(qkv); delta = torch.zeros(B, H, T, device=dev)
-    dpq = torch.zeros(B, T, C, device=dev); dpk = torch.zeros(B, S, C, device=dev)
+    dpq = torch.zeros(B, T, C, device=dev, dtype=torch.bfloat16); dpk = torch.zeros(B, S, C, device=dev, dtype=torch.bfloat16)
     nparts = B * ((S + 127) // 128)
     parts = [torch.zeros(H, nparts, n, device=dev) for n in (n2d, 2 * Lt - 1, 2)] if rel is not None else [None] * 3
     q, k, v = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
