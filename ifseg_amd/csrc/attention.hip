@@ -1239,17 +1239,24 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(ReduceArgs r) {
   if (blk < r.nbq + r.nbk) {
     const bool isq = blk < r.nbq;
     if (!isq) blk -= r.nbq;
-    const long long n = (long long)(isq ? a.T : a.S) * a.C;      // C % 4 == 0: float4 columns
+    const long long n = (long long)(isq ? a.T : a.S) * a.C;      // C % 8 == 0: eight columns (16 bytes of bf16) per thread
     const bf16_t* part = reinterpret_cast<const bf16_t*>(isq ? a.dpos_q_part : a.dpos_k_part);
     float* acc = isq ? a.dpos_q_acc : a.dpos_k_acc;
-    const long long i = ((long long)blk * 256 + tid) * 4;
+    const long long i = ((long long)blk * 256 + tid) * 8;
     if (i >= n) return;
-    float4 s = a.accumulate_pos ? *reinterpret_cast<const float4*>(acc + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int b = 0; b < a.B; ++b) {
-      const uint2 v = *reinterpret_cast<const uint2*>(part + (long long)b * n + i);
-      s.x += bflo(v.x); s.y += bfhi(v.x); s.z += bflo(v.y); s.w += bfhi(v.y);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (a.accumulate_pos) {
+      const float4 a0 = *reinterpret_cast<const float4*>(acc + i), a1 = *reinterpret_cast<const float4*>(acc + i + 4);
+      s[0] = a0.x; s[1] = a0.y; s[2] = a0.z; s[3] = a0.w; s[4] = a1.x; s[5] = a1.y; s[6] = a1.z; s[7] = a1.w;
     }
-    *reinterpret_cast<float4*>(acc + i) = s;
+#pragma unroll 8
+    for (int b = 0; b < a.B; ++b) {
+      const uint4 v = *reinterpret_cast<const uint4*>(part + (long long)b * n + i);
+      s[0] += bflo(v.x); s[1] += bfhi(v.x); s[2] += bflo(v.y); s[3] += bfhi(v.y);
+      s[4] += bflo(v.z); s[5] += bfhi(v.z); s[6] += bflo(v.w); s[7] += bfhi(v.w);
+    }
+    *reinterpret_cast<float4*>(acc + i) = make_float4(s[0], s[1], s[2], s[3]);
+    *reinterpret_cast<float4*>(acc + i + 4) = make_float4(s[4], s[5], s[6], s[7]);
     return;
   }
   blk -= r.nbq + r.nbk;
@@ -1268,20 +1275,31 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(ReduceArgs r) {
     return;
   }
   blk -= a.H;
+  __shared__ float tred[8][33];
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     if (t >= a.ntab) return;
     if (blk < r.nbt[t]) {
-      const int n = a.tab_n[t];
-      const int gid = blk * 256 + tid;
-      if (gid >= n * a.H) return;
-      const int h = gid / n, j = gid - h * n;
-      const int bucket = a.tab_idx[t][j];
-      if (bucket < 0) return;
-      const float* p = a.tab_part[t] + (long long)h * a.nparts * n + j;
-      float s = 0.f;
-      for (int q = 0; q < a.nparts; ++q) s += p[(long long)q * n];
-      atomicAdd(&a.tab_acc[t][(long long)bucket * a.H + h], s);      // several entries may share a bucket
+      // 32 table entries x 8 groups of partials per block (the partials of one entry are nparts * n floats apart)
+      const int n = a.tab_n[t], nchunk = (n + 31) / 32;
+      const int h = blk / nchunk, j = (blk - h * nchunk) * 32 + (tid & 31), g = tid >> 5;
+      float sum = 0.f;
+      if (j < n) {
+        const float* p = a.tab_part[t] + (long long)h * a.nparts * n + j;
+#pragma unroll 4
+        for (int q = g; q < a.nparts; q += 8) sum += p[(long long)q * n];
+      }
+      tred[g][tid & 31] = sum;
+      __syncthreads();
+      if (g == 0 && j < n) {
+        const int bucket = a.tab_idx[t][j];
+        if (bucket >= 0) {
+          float tot = 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) tot += tred[q][tid];
+          atomicAdd(&a.tab_acc[t][(long long)bucket * a.H + h], tot);      // several entries may share a bucket
+        }
+      }
       return;
     }
     blk -= r.nbt[t];
@@ -1291,15 +1309,15 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(ReduceArgs r) {
 
 extern "C" int ifseg_attn_bwd_reduce(const ifseg_attn_reduce_args* x, void* stream) {
   (void)hipGetLastError();
-  if (!x || x->B <= 0 || x->H <= 0 || x->T <= 0 || x->S <= 0 || (x->C & 3) || x->ntab < 0 || x->ntab > 3) return IFSEG_ERR_BAD_ARG;
+  if (!x || x->B <= 0 || x->H <= 0 || x->T <= 0 || x->S <= 0 || (x->C & 7) || x->ntab < 0 || x->ntab > 3) return IFSEG_ERR_BAD_ARG;
   ReduceArgs r{};
   r.a = *x;
-  r.nbq = x->dpos_q_part ? (int)(((long long)x->T * x->C / 4 + 255) / 256) : 0;
-  r.nbk = x->dpos_k_part ? (int)(((long long)x->S * x->C / 4 + 255) / 256) : 0;
+  r.nbq = x->dpos_q_part ? (int)(((long long)x->T * x->C / 8 + 255) / 256) : 0;
+  r.nbk = x->dpos_k_part ? (int)(((long long)x->S * x->C / 8 + 255) / 256) : 0;
   long long total = (long long)r.nbq + r.nbk + x->H;
   for (int t = 0; t < x->ntab; ++t) {
     if (!x->tab_part[t] || !x->tab_idx[t] || !x->tab_acc[t] || x->tab_n[t] <= 0 || x->nparts <= 0) return IFSEG_ERR_BAD_ARG;
-    r.nbt[t] = (int)(((long long)x->tab_n[t] * x->H + 255) / 256);
+    r.nbt[t] = x->H * ((x->tab_n[t] + 31) / 32);
     total += r.nbt[t];
   }
   if ((x->dgain && (!x->delta || !x->gain)) || total >= (1ll << 31)) return IFSEG_ERR_BAD_ARG;
