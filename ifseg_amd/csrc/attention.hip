@@ -1231,6 +1231,7 @@ __global__ void attn_delta_kernel(const bf16_t* o, const bf16_t* dO, float* delt
 
 namespace {
 // One launch for the reductions behind ifseg_attn_bwd's partial outputs; block ranges: [dpos_q | dpos_k | dgain | tables]
+constexpr int SMALL_TAB_MAX = 2048;
 struct ReduceArgs { ifseg_attn_reduce_args a; int nbq, nbk, nbt[3]; };
 __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(ReduceArgs r) {
   const ifseg_attn_reduce_args& a = r.a;
@@ -1276,9 +1277,43 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(ReduceArgs r) {
   }
   blk -= a.H;
   __shared__ float tred[8][33];
+  __shared__ float tsmall[SMALL_TAB_MAX];
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     if (t >= a.ntab) return;
+    if (blk < r.nbt[t] && a.tab_n[t] <= SMALL_TAB_MAX) {
+      // small table (token offsets, bos row / column): one block per head sums the partials of every entry into LDS,
+      // then thread r adds the entries of bucket r in entry order -- several entries may share a bucket (log-spaced
+      // buckets beyond +-128), and a fixed order keeps the sum bit-reproducible (no atomics)
+      const int n = a.tab_n[t], h = blk;
+      for (int j0 = 0; j0 < n; j0 += 32) {          // 32 entries x 8 groups of partials per pass
+        const int j = j0 + (tid & 31), g = tid >> 5;
+        float sum = 0.f;
+        if (j < n) {
+          const float* p = a.tab_part[t] + (long long)h * a.nparts * n + j;
+#pragma unroll 4
+          for (int q = g; q < a.nparts; q += 8) sum += p[(long long)q * n];
+        }
+        tred[g][tid & 31] = sum;
+        __syncthreads();
+        if (g == 0 && j < n) {
+          float tot = 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) tot += tred[q][tid];
+          tsmall[j] = tot;
+        }
+        __syncthreads();
+      }
+      const int* idx = a.tab_idx[t];
+      for (int rb = tid; rb < a.tab_nbucket[t]; rb += 256) {
+        float tot = 0.f;
+        bool any = false;
+        for (int j = 0; j < n; ++j)
+          if (idx[j] == rb) { tot += tsmall[j]; any = true; }
+        if (any) a.tab_acc[t][(long long)rb * a.H + h] += tot;
+      }
+      return;
+    }
     if (blk < r.nbt[t]) {
       // 32 table entries x 8 groups of partials per block (the partials of one entry are nparts * n floats apart)
       const int n = a.tab_n[t], nchunk = (n + 31) / 32;
@@ -1297,7 +1332,7 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(ReduceArgs r) {
           float tot = 0.f;
 #pragma unroll
           for (int q = 0; q < 8; ++q) tot += tred[q][tid];
-          atomicAdd(&a.tab_acc[t][(long long)bucket * a.H + h], tot);      // several entries may share a bucket
+          atomicAdd(&a.tab_acc[t][(long long)bucket * a.H + h], tot);      // (large tables map entries to buckets one-to-one)
         }
       }
       return;
@@ -1317,7 +1352,8 @@ extern "C" int ifseg_attn_bwd_reduce(const ifseg_attn_reduce_args* x, void* stre
   long long total = (long long)r.nbq + r.nbk + x->H;
   for (int t = 0; t < x->ntab; ++t) {
     if (!x->tab_part[t] || !x->tab_idx[t] || !x->tab_acc[t] || x->tab_n[t] <= 0 || x->nparts <= 0) return IFSEG_ERR_BAD_ARG;
-    r.nbt[t] = x->H * ((x->tab_n[t] + 31) / 32);
+    if (x->tab_nbucket[t] <= 0) return IFSEG_ERR_BAD_ARG;
+    r.nbt[t] = x->tab_n[t] <= SMALL_TAB_MAX ? x->H : x->H * ((x->tab_n[t] + 31) / 32);
     total += r.nbt[t];
   }
   if ((x->dgain && (!x->delta || !x->gain)) || total >= (1ll << 31)) return IFSEG_ERR_BAD_ARG;

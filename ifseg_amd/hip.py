@@ -574,7 +574,8 @@ class _AttnReduceArgs(ctypes.Structure):
                 ("accumulate_pos", c_int),
                 ("dpos_q_part", c_void_p), ("dpos_k_part", c_void_p), ("dpos_q_acc", c_void_p), ("dpos_k_acc", c_void_p),
                 ("delta", c_void_p), ("gain", c_void_p), ("dgain", c_void_p), ("ntab", c_int),
-                ("tab_part", c_void_p * 3), ("tab_idx", c_void_p * 3), ("tab_acc", c_void_p * 3), ("tab_n", c_int * 3)]
+                ("tab_part", c_void_p * 3), ("tab_idx", c_void_p * 3), ("tab_acc", c_void_p * 3), ("tab_n", c_int * 3),
+                ("tab_nbucket", c_int * 3)]
 
 
 def attn_bwd_reduce(B, H, T, S, C, dpq_part, dpk_part, dpq_acc, dpk_acc, accumulate_pos, delta, gain, dgain, nparts, tables):
@@ -588,7 +589,7 @@ def attn_bwd_reduce(B, H, T, S, C, dpq_part, dpk_part, dpq_acc, dpk_acc, accumul
     a.ntab = len(tables)
     for i, (part, idx, acc) in enumerate(tables):
         assert part.dtype == torch.float32 and acc.dtype == torch.float32 and idx.dtype == torch.int32 and acc.shape[1] == H
-        a.tab_part[i], a.tab_idx[i], a.tab_acc[i], a.tab_n[i] = _p(part), _p(idx), _p(acc), idx.numel()
+        a.tab_part[i], a.tab_idx[i], a.tab_acc[i], a.tab_n[i], a.tab_nbucket[i] = _p(part), _p(idx), _p(acc), idx.numel(), acc.shape[0]
     _check(lib().ifseg_attn_bwd_reduce(ctypes.byref(a), _stream()), "attn_bwd_reduce")
 
 

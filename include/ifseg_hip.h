@@ -121,7 +121,7 @@ int ifseg_attn_fwd(const void* q, const void* k, const void* v, const void* pos_
  * dQ_ext / dK_ext are written as bf16 per-batch partials dpos_q_part [B,T,H*64]
  * (scaled by dpq_scale) and dpos_k_part [B,S,H*64]; rel-table gradients as
  * per-workgroup partials [H][nparts][n] with nparts = B*ceil(S/128) (sum them with
- * ifseg_reduce_parts).  No atomics on global memory: results are deterministic. */
+ * ifseg_attn_bwd_reduce).  No atomics on global memory: results are deterministic. */
 typedef struct ifseg_attn_bwd_args {
   const void *q, *k, *v, *pos_q, *pos_k, *out, *dout;
   const float* lse;
@@ -154,6 +154,8 @@ int ifseg_attn_bwd(const ifseg_attn_bwd_args* args, void* stream);
  *   dpos_q_acc[T*C]  (=|+=) sum_b dpos_q_part[b]        dpos_k_acc[S*C] (=|+=) sum_b dpos_k_part[b]
  *   dgain[h] (bf16)  = sum_{b,t} delta[b,h,t] / gain[h]          (delta = rowsum(dO * O), O includes the gain)
  *   for each of up to 3 tables i:  acc_i[idx_i[j]][h] += sum_p part_i[h][p][j]   (idx < 0: no bucket)
+ * Tables of up to 2048 entries (token offsets: several entries may share a bucket) are summed per bucket in entry order,
+ * larger ones (the image / seg grids: entries and buckets one-to-one) by one atomic add per entry: bit-reproducible either way.
  * Replaces 2 + 4 + 2 per table launches of ifseg_reduce_parts / ifseg_rel_scatter_add / elementwise kernels. */
 typedef struct ifseg_attn_reduce_args {
   int B, H, T, S, C, nparts, accumulate_pos;
@@ -167,6 +169,7 @@ typedef struct ifseg_attn_reduce_args {
   const int* tab_idx[3];                    /* [n_i] bucket of entry j of the delta table */
   float* tab_acc[3];                        /* fp32 [n_bucket_i, H] accumulators */
   int tab_n[3];
+  int tab_nbucket[3];                       /* rows of tab_acc_i */
 } ifseg_attn_reduce_args;
 int ifseg_attn_bwd_reduce(const ifseg_attn_reduce_args* args, void* stream);
 
