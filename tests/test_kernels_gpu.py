@@ -796,3 +796,9 @@ def test_attn_bwd_reduce_matches_the_separate_reductions():
         assert torch.allclose(dgain.float(), (delta.sum((0, 2)) / gain), rtol=1e-2, atol=1e-2)
         for (_, _, got), w in zip(tables, want_tabs):
             assert torch.allclose(got, w, atol=1e-4)
+        # duplicate buckets are summed in entry order: a second run is bit-identical
+        again = [(p, i, a.clone()) for p, i, a in tabs]
+        hip.attn_bwd_reduce(B, H, T, S, C, dpq_part, dpk_part, dpq_acc.clone(), dpk_acc.clone(), accumulate, delta, gain, dgain,
+                            nparts, again)
+        torch.cuda.synchronize()
+        assert all(torch.equal(x[2], y[2]) for x, y in zip(tables, again))
