@@ -9,6 +9,10 @@ def main(kind="enc", iters=5):
     B, H, C = 8, 12, 768
     gh = gw = 32; P = 1024
     Lt = 1 if kind in ("dec", "decfull") else 36
+    if os.environ.get("ATTN_BENCH_LARGE"):      # BASELINE configs[3] geometry: 640 x 640 -> 40 x 40 grid, 16 heads, L = 239
+        B, H, C = 4, 16, 1024
+        gh = gw = 40; P = 1600
+        Lt = 1 if kind in ("dec", "decfull") else 239
     T = S = P + Lt
     causal = kind == "dec"
     g = torch.Generator().manual_seed(0)
