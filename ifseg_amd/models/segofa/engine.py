@@ -619,8 +619,11 @@ class HipEngine:
             if not torch.cuda.is_current_stream_capturing():
                 self.upload_step_seed()
             prev_sa = hip.set_seed_add(self.step_dev)
-            if self._master_stale and self.packed and not self.master_owned:
-                # an external optimizer stepped the bf16 parameters since the last forward
+            if self.packed and not self.master_owned and not torch.cuda.is_current_stream_capturing():
+                # an external owner of the bf16 parameters (fairseq's optimizer, an EMA swap, a manual p.data.copy_) may
+                # have edited them since the last forward: the fp32 copy the LayerNorm / c_attn operands are read from
+                # follows on EVERY forward (one pass over the arena; entries whose bf16 rounding still matches keep
+                # their fp32 value).  With the bundled Trainer (`master_owned`) both copies are written by one kernel.
                 hip.sync_master(self.master, self.p16[: self.n_train])
                 self._master_stale = False
             out = self._forward(*args, **kw)

@@ -164,7 +164,25 @@ class SegmentationTask(TaskBase):
             cfg = recipe_args(over.pop("arch", self.arch), num_seg_tokens=self.cfg.num_seg_tokens,
                               patch_image_size=self.cfg.patch_image_size,
                               orig_patch_image_size=self.cfg.orig_patch_image_size, **over)
-        return SegOFAModel.build_model(cfg, self)
+        model = SegOFAModel.build_model(cfg, self)
+        self._build_bpe_from_dir()
+        return model
+
+    def _build_bpe_from_dir(self):
+        """ofa_task.py:167-185: under fairseq the task owns the GPT-2 BPE encoder built from `--bpe-dir`
+        (encoder.json / vocab.bpe); the criterion's lazy seg-token initialisation encodes the category names with it
+        (seg_criterion.py:373-388).  Without fairseq, or when the files are absent, `category_token_ids` must be given
+        (or `--init-seg-with-text=false`): `encode_category` says so."""
+        if self.bpe is not None or not HAVE_FAIRSEQ:
+            return
+        bpe_dir = getattr(self.cfg, "bpe_dir", None)
+        if not bpe_dir:
+            return
+        enc, voc = os.path.join(bpe_dir, "encoder.json"), os.path.join(bpe_dir, "vocab.bpe")
+        if not (os.path.exists(enc) and os.path.exists(voc)):
+            return
+        from omegaconf import DictConfig
+        self.bpe = self.build_bpe(DictConfig({"_name": "gpt2", "gpt2_encoder_json": enc, "gpt2_vocab_bpe": voc}))
 
     def build_generator(self, models, args=None, seq_gen_cls=None, extra_gen_cls_kwargs=None, prefix_allowed_tokens_fn=None):
         """tasks/ofa_task.py:187-260 with the task's eval_args ({"beam":5,"max_len":1024,"min_len":1024,...},
@@ -184,7 +202,8 @@ class SegmentationTask(TaskBase):
         if self.bpe is not None:
             line = " ".join(self.bpe.encode(" {}".format(w.strip())) for w in text.strip().split())
             return self.tgt_dict.encode_line(line=line, add_if_not_exist=False, append_eos=False).long()
-        raise RuntimeError("no BPE encoder on this task: pass category_token_ids=[...] to SegmentationTask")
+        raise RuntimeError("no BPE encoder on this task (fairseq + <bpe-dir>/encoder.json, vocab.bpe build one in "
+                           "build_model): pass category_token_ids=[...] to SegmentationTask or --init-seg-with-text=false")
 
     def synthetic_sample(self, batch, device, seed=1234, image_hw=None):
         """Synthetic batch with the collater's layout (segmentation_dataset.py:41-129)."""

@@ -127,13 +127,11 @@ class Trainer:
     # -- schedule -------------------------------------------------------------------------
     def get_lr(self):
         """Learning rate of the NEXT update, as the reference's cosine schedule produces it
-        (fairseq/optim/lr_scheduler/cosine_lr_scheduler.py:74-152, period = total updates via `reinit`, train.py:184):
-        the scheduler is stepped AFTER each update, so update k (1-based) runs at cosine(k - 1) -- except the very first
-        one: the constructor parks the optimizer at `warmup_init_lr = min_lr` (:88-89,:111-112) and `reinit` returns
-        early when `--warmup-ratio` is 0 (:158-159), so update 1 runs at min_lr (0 in the recipe).  Pinned by
-        tests/golden/fixture_optim.npz (the reference's own scheduler object)."""
-        if self.num_updates == 0:
-            return self.min_lr
+        (fairseq/optim/lr_scheduler/cosine_lr_scheduler.py:74-152, period = total updates via `reinit`, train.py:184).
+        `trainer.begin_epoch` (train.py:304 -> trainer.py:717-721,1126-1134) steps the scheduler with num_updates = 0
+        before the first update and `lr_step_update` steps it after every update (trainer.py:962), so update k (1-based)
+        runs at cosine(k - 1): the peak lr first.  Pinned by tests/golden/fixture_optim.npz (the reference's own
+        scheduler object driven in that order)."""
         t = self.num_updates
         i = t // self.max_update                               # restarts shrink by lr_shrink = 0.1 (:139-147)
         shrink = 0.1 ** i
@@ -189,9 +187,18 @@ class Trainer:
         # the flag was copied to pinned host memory by the step itself (async, in stream order): reading it never
         # blocks on the queue (a `.item()` here would drain the whole step and stop the host from running ahead)
         if done and int(self._ovf_host[0]):
+            # in-flight copies of the flag (later steps already enqueued) land before the pinned word is cleared, so the
+            # same overflow cannot be reported twice
+            for ev in self._ovf_events:
+                ev.synchronize()
+            self._ovf_events = []
             self._ovf_host.zero_()
             self.overflow.zero_()
-            raise FloatingPointError("gradients are Nan/Inf (the update was skipped)")
+            # Fatal-only semantics (the reference raises before anything advances, trainer.py:895-904): here the error
+            # surfaces up to one step late -- the skipped update left the weights untouched, but num_updates, the
+            # schedule, Adam's step count and the dropout seed have advanced and a further update may be applied.
+            raise FloatingPointError("gradients are Nan/Inf (the update was skipped; reported one step late -- restart "
+                                     "from a checkpoint rather than continuing)")
 
     # -- steps ------------------------------------------------------------------------------
     def _upload_hyper(self, lr, step, gscale):
@@ -300,8 +307,12 @@ class Trainer:
             # host-side state the enqueue code would have advanced
             self.criterion.iter += 1
             eng._pf = ent[4]
+            self.criterion.effective_iter = self.criterion.iter // self.criterion.criterion_update_freq
+            self.model.set_num_updates(self.num_updates)
         ent[0].replay()
-        return ent[1]
+        # the captured log tensors are the graph's static outputs, rewritten by every replay: hand out copies, so that a
+        # caller aggregating logs over an interval (fairseq's reduce_metrics) keeps each step's values
+        return [{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in lg.items()} for lg in ent[1]]
 
     def grad_norm(self):
         """global gradient norm of the last update, after the world/sample_size scaling (host sync: logging only)"""

@@ -283,9 +283,10 @@ def case_eval(cfg, arch, overrides, out_name, ori_hw=(150, 200), iters=25, topk=
 def case_optim(cfg, arch, overrides, out_name, n_updates=3, lr=5e-5, total_updates=2000):
     """Optimizer + harness golden: the REFERENCE's FairseqAdam (fairseq/optim/adam.py:
     45-240, decoupled weight decay 0.1), `multiply_grads`, `clip_grad_norm(1.0)` (fairseq_optimizer.py:105-113) and
-    its cosine schedule (`reinit(total, 0)` as train.py:184 does -- with warmup_ratio 0 the FIRST update runs at
-    lr = warmup_init_lr = min_lr = 0 and update k >= 2 at cosine(k-1)) driven exactly like trainer.py:745-1050 drives
-    them, for `n_updates` updates on one fixed batch.  Stores losses, grad norms, the lr of every update and the
+    its cosine schedule driven exactly like train.py / trainer.py drive them: `reinit(total, 0)` (train.py:184), then
+    `begin_epoch` (train.py:304 -> trainer.py:717-721,1126-1134) steps the scheduler once with num_updates = 0 BEFORE
+    the first update -- period is already `total`, so update 1 runs at cosine(0) = the peak lr and update k at
+    cosine(k-1) -- then `step_update(k)` after every update (trainer.py:962), for `n_updates` updates on one fixed batch.  Stores losses, grad norms, the lr of every update and the
     post-update parameters."""
     _refshim.install()
     from fairseq.optim.adam import FairseqAdam, FairseqAdamConfig
@@ -301,6 +302,8 @@ def case_optim(cfg, arch, overrides, out_name, n_updates=3, lr=5e-5, total_updat
     scfg.lr, scfg.max_update = [lr], total_updates
     sched = CosineLRSchedule(scfg, opt)
     sched.reinit(total_updates, 0)
+    sched.step_begin_epoch(1)
+    sched.step_update(0)                                          # trainer.begin_epoch -> lr_step_begin_epoch -> lr_step_update
     model.train()
     save = {"n_updates": n_updates, "lr0": lr, "total_updates": total_updates}
     losses, gnorms, lrs = [], [], []

@@ -176,7 +176,7 @@ def test_large_full_depth_resnet152_vs_oracle():
 def test_trainer_updates_vs_reference_optimizer_golden(golden_dir):
     """f3 + harness: three `Trainer.train_step`s on the fixture against the REFERENCE's FairseqAdam / clip_grad_norm /
     cosine schedule driven like trainer.py:745-1050 (tests/golden/fixture_optim.npz): learning rate of every update
-    (0 for the first!), losses, gradient norms and the post-update parameters."""
+    (the peak lr for the first: begin_epoch steps the scheduler at num_updates 0), losses, gradient norms and the post-update parameters."""
     from ifseg_amd.tasks.mm_tasks import SegmentationTask
     from ifseg_amd.trainer import Trainer
     import test_model_gpu as T

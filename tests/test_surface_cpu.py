@@ -162,7 +162,7 @@ def test_checkpoint_upconversion_matches_reference_golden(golden_dir):
 
 
 def test_learning_rate_schedule_matches_reference_golden(golden_dir):
-    """the lr of updates 1..3 as the reference's CosineLRSchedule produced them (fixture_optim.npz): 0 first, then cosine(k-1)"""
+    """the lr of updates 1..3 as the reference's CosineLRSchedule produced them (fixture_optim.npz): update k runs at cosine(k-1) -- the peak lr first (train.py:304 begin_epoch)"""
     import math
     import numpy as np
     from ifseg_amd.trainer import Trainer
