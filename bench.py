@@ -26,11 +26,19 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-GF_PER_IMG = {15: 912.0, 150: 1003.2}      # algorithmic fwd+bwd GFLOP / image, frozen ResNet
+# BASELINE.json configs measured by this file (--config): c2 is the headline one (the driver's default run)
+CONFIGS = {
+    "c2": dict(arch="segofa_base", nseg=15, size=512, batch=8, tag="BASELINE configs[1]: SegOFA-Base bf16", trunk="ResNet-101"),
+    "c3": dict(arch="segofa_base", nseg=150, size=512, batch=8, tag="BASELINE configs[2] per-GPU share (B=8 of global 64): SegOFA-Base bf16, 150 ADE20K classes", trunk="ResNet-101"),
+    "c4": dict(arch="segofa_large", nseg=171, size=640, batch=8, tag="BASELINE configs[3] per-GPU share: SegOFA-Large bf16, 171 COCO-Stuff classes", trunk="ResNet-152"),
+}
+# algorithmic fwd+bwd GFLOP / image, frozen ResNet (tools/count_flops.py re-derives them on the oracle)
+# (tools/count_flops.py: 912.0 / 1003.2 / 5245.5 -- the last replaces SURVEY 8d's estimate 5252.8 = fwd + 2 (fwd - conv))
+GF_PER_IMG = {("segofa_base", 15): 912.0, ("segofa_base", 150): 1003.2, ("segofa_large", 171): 5245.5}
 MFMA_PEAK_TF = 2500.0                      # dense bf16 (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(nseg, src_len):
+def cpu_baseline(nseg, src_len, arch="segofa_base", size=512):
     """SURVEY 8d / BASELINE.md section 4: the CPU restatement (oracle/segofa_ref.py, fp32) on BASELINE configs[0] inputs
     (B = 2, 512x512, frozen trunk, dropout 0), every host core, 1 warm-up + 3 timed fwd+bwd steps (a bounded sample:
     ~10-20 s of CPU work on the GPU box)."""
@@ -40,28 +48,31 @@ def cpu_baseline(nseg, src_len):
     # GEMMs / elementwise ops) is pathologically slow -- measured 279 s per step with 256 threads vs ~2 s with 32
     ncores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(ncores)
-    cfg = O.base_config(num_seg_tokens=nseg)
+    large = arch == "segofa_large"
+    cfg = (O.large_config if large else O.base_config)(num_seg_tokens=nseg, patch_image_size=size, orig_patch_image_size=size)
     sd = O.procedural_state_dict(cfg)
     spec = O.state_dict_spec(cfg)
     for k, v in sd.items():
         if v.dtype.is_floating_point and "embed_images" not in k and not spec[k][1].startswith("alias"):
             v.requires_grad_(k.startswith(("encoder.layers", "decoder.layers")))
-    nimg, warm, timed = 2, 1, 3
-    batch = O.synthetic_batch(cfg, nimg, src_len)
+    nimg, warm, timed = (1, 0, 1) if large else (2, 1, 3)      # Large / 640: ~6x the work per image
+    batch = O.synthetic_batch(cfg, nimg, src_len, image_size=size)
     dts = []
     for i in range(warm + timed):
         for v in sd.values():
             v.grad = None
         t0 = time.time()
         logits, extra = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"])
-        loss, _, _ = O.seg_loss(cfg, logits, batch["target"], 32, 32, 512, 512)
+        loss, _, _ = O.seg_loss(cfg, logits, batch["target"], size // 16, size // 16, size, size)
         loss.backward()
         if i >= warm:
             dts.append(time.time() - t0)
     dt = sum(dts) / len(dts)
     return {"value": round(nimg / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "BASELINE configs[0] inputs (B=2, 512x512, %d classes): %d warm-up + %d timed fwd+bwd steps of "
-                      "oracle/segofa_ref.py, fp32, %d host threads, %.2f s per step" % (nseg, warm, timed, torch.get_num_threads(), dt)}
+            "sample": "%s inputs (B=%d, %dx%d, %d classes): %d warm-up + %d timed fwd+bwd steps of "
+                      "oracle/segofa_ref.py, fp32, %d host threads, %.2f s per step" % (
+                          "BASELINE configs[0]" if (not large and nseg == 15) else arch, nimg, size, size, nseg, warm, timed,
+                          torch.get_num_threads(), dt)}
 
 
 def _self_spawn(n, argv):
@@ -144,8 +155,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--nseg", type=int, default=15)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="BASELINE.json configuration: c2 = configs[1] (headline, default), c3 = configs[2] (150 classes, L=215) "
+                         "and c4 = configs[3] (Large, 640x640, 171 classes) at their per-GPU size")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the configuration's, 8)")
+    ap.add_argument("--nseg", type=int, default=None, help="override the configuration's class count")
+    ap.add_argument("--steady-steps", type=int, default=200,
+                    help="steps of the steady-state cross-check run right after the timed region (0: skip)")
     ap.add_argument("--dropout", type=float, default=0.1, help="dropout (coco_unseen.sh:22)")
     ap.add_argument("--drop-path", type=float, default=0.1, help="encoder/decoder drop-path rate (coco_unseen.sh:20-21)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -159,6 +175,13 @@ def main():
                     help="the recipe's image-free step (SURVEY 8f row 1, coco_unseen.sh:51): loss on an artificial image "
                          "(EmbeddingBag patches, no trunk) + a no-grad pass over the real images for the metrics")
     a = ap.parse_args()
+    C = CONFIGS[a.config]
+    if a.batch is None:
+        a.batch = C["batch"]
+    if a.nseg is None:
+        a.nseg = C["nseg"]
+    arch, size = C["arch"], C["size"]
+    gf_img = GF_PER_IMG.get((arch, a.nseg))
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         _self_spawn(a.gpus, sys.argv[1:])
@@ -187,7 +210,7 @@ def main():
     from ifseg_amd.trainer import Trainer
 
     torch.manual_seed(0)
-    task = SegmentationTask(num_seg_tokens=a.nseg, patch_image_size=512, arch="segofa_base")
+    task = SegmentationTask(num_seg_tokens=a.nseg, patch_image_size=size, arch=arch)
     model = task.build_model()
     model.cfg.dropout, model.cfg.encoder_drop_path_rate, model.cfg.decoder_drop_path_rate = a.dropout, a.drop_path, a.drop_path
     crit = SegCriterion(task, unsupervised_segmentation=a.image_free, init_seg_with_text=False)
@@ -222,13 +245,14 @@ def main():
         one_step()
     torch.cuda.synchronize()
     fam = [hip.prof_read(k) for k in range(len(hip.PROF_KINDS))]
-    dominant = max(range(len(fam)), key=lambda k: fam[k]["ms"]) if a.warmup > 0 else 0
-    # "gemm_tn" / "gemm_nt" ... are FAMILIES of several instantiations of gemm_kernel (covered by roofline_gemm_kernel
-    # below); the largest SINGLE kernel in the rocprofv3 statistics is attn_bwd_dkv_kernel (profiles/), so the roofline
-    # object stays on the attention backward as long as it is within 30 % of the largest family
-    ab = [k for k, n in enumerate(hip.PROF_KINDS) if n == "attn_bwd_dkv"]
-    if a.warmup > 0 and ab and fam[ab[0]]["ms"] >= 0.7 * fam[dominant]["ms"]:
-        dominant = ab[0]
+    # the `roofline` object goes to the largest family BY MEASURED KERNEL TIME of this run (discovery pass above).  The
+    # attention backward is one operation executed as two concurrent kernels (dK/dV and dQ): they count as one family
+    # (sum of their kernel times); every family keeps its own entry in roofline_gemm_kernel / roofline_other_kernels.
+    kinds = list(hip.PROF_KINDS)
+    fam_ms = {n: f["ms"] for n, f in zip(kinds, fam)}
+    merged = {n: m for n, m in fam_ms.items() if n not in ("attn_bwd_dkv", "attn_bwd_dq")}
+    merged["attn_bwd_dkv"] = fam_ms.get("attn_bwd_dkv", 0.0) + fam_ms.get("attn_bwd_dq", 0.0)
+    dominant = kinds.index(max(merged, key=merged.get)) if a.warmup > 0 else kinds.index("attn_bwd_dkv")
     # the dK/dV and dQ kernels of the attention backward run side by side on two streams and share the GPU: they are
     # timed as ONE unit (delta + dK/dV + dQ, an event pair on the main stream around the three launches)
     pair = hip.PROF_KINDS[dominant] in ("attn_bwd_dkv", "attn_bwd_dq") and trainer.eng.overlap
@@ -266,6 +290,27 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = tt.item()
     loss = float(logs[-1]["loss"])
+    # steady-state cross-check of the (short) driver-timed region: the same step, >= 200 times / >= 3 s, measured the same
+    # way right after it -- long enough for an external utilisation sampler to see a busy GPU
+    steady = None
+    if a.steady_steps > 0:
+        n_ss, t_ss = 0, 0.0
+        sync()
+        t1 = time.time()
+        while n_ss < a.steady_steps or (time.time() - t1) < 3.0:
+            for _ in range(20):
+                one_step()
+            n_ss += 20
+            if n_ss >= 4000:
+                break
+        sync()
+        t_ss = time.time() - t1
+        ts = torch.tensor([t_ss], device=dev)
+        if world > 1:
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        t_ss = ts.item()
+        steady = {"steps": n_ss, "seconds": round(t_ss, 3), "ms_per_step": round(t_ss / n_ss * 1e3, 3),
+                  "images_per_sec": round(a.batch * world * n_ss / t_ss, 2)}
     if graphed:
         use_graph[0] = False
         dominant_pass(min(10, a.steps))
@@ -303,12 +348,13 @@ def main():
         value = imgs / dt
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         out = {
-            "metric": "images/sec (512x512, SegOFA-Base fwd+bwd)", "value": round(value, 2), "unit": "images/sec",
+            "metric": "images/sec (%dx%d, SegOFA-%s fwd+bwd)" % (size, size, "Large" if arch == "segofa_large" else "Base"),
+            "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("IMAGE-FREE step (not the headline config) -- " if a.image_free else "") + "BASELINE configs[1]: SegOFA-Base bf16, batch %d/GPU, 512x512, %d classes (L=%d), "
-                                   "frozen ResNet-101 trunk%s, dropout %.2f / drop-path %.2f; step = fwd + upsample/CE loss + bwd + clip + Adam%s"
-                                   % (a.batch, a.nseg, task.src_len,
+            "config": {"workload": ("IMAGE-FREE step (not the headline config) -- " if a.image_free else "") + C["tag"] + ", batch %d/GPU, %dx%d, %d classes (L=%d), "
+                                   "frozen %s trunk%s, dropout %.2f / drop-path %.2f; step = fwd + upsample/CE loss + bwd + clip + Adam%s"
+                                   % (a.batch, size, size, a.nseg, task.src_len, C["trunk"],
                                       "" if a.no_prefetch else " (run one batch ahead on a second stream; two alternating batches)",
                                       a.dropout, a.drop_path,
                                       "; every step is one replay of the HIP-graph-captured update" if graphed else "; steps enqueued from the host"),
@@ -319,13 +365,16 @@ def main():
                          "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(1, dom["launches"]), 2),
                          "sampled": "every %d. launch timed with a HIP event pair on its stream%s" % (
                              PROF_STRIDE, " (on %d eagerly enqueued steps after the timed graph replays)" % min(10, a.steps) if graphed else ""),
-                         "whole_step_frac": round(value / world * GF_PER_IMG.get(a.nseg, 912.0) / 1e3 / MFMA_PEAK_TF, 4)},
+                         "whole_step_frac": round(value / world * gf_img / 1e3 / MFMA_PEAK_TF, 4) if gf_img else None,
+                         "gflop_per_image": gf_img},
             "roofline_gemm_kernel": _group_roofline(grs, extra),
             "roofline_other_kernels": {r["kind"]: _one_roofline(r, extra) for r in ors},
             "kernel_families_ms_per_step": {f["kind"]: round(f["ms"], 3) for f in fam},
         }
+        if steady is not None:
+            out["steady_state"] = steady
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(a.nseg, task.src_len)
+            out["cpu_baseline"] = cpu_baseline(a.nseg, task.src_len, arch, size)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

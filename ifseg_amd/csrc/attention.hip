@@ -473,9 +473,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   unsigned char* sVk = smem + KT_BYTES + VT_BYTES + 512;                       // V rows of this WG's 128 keys
   float* sTbl = reinterpret_cast<float*>(sVk + 2 * VT_BYTES);                  // rel2d[h]
   float* sHist = sTbl + n2dp;                                                  // d rel2d[h]
-  float* sHist1 = sHist + n2dp;
-  float* sX = sHist1 + n1dp;          // relx0 / relx1 gradient accumulators
-  int* sGc = reinterpret_cast<int*>(sX + 4);
+  // token-offset histogram and relx0 / relx1 accumulators: ONE COPY PER WAVE, summed in wave order at the end -- waves
+  // adding to shared bins with LDS float atomics do so in an order that depends on their relative timing, and float
+  // addition is not associative: the gradients then differ in the last bit from run to run
+  float* sHist1 = sHist + n2dp;       // [4][n1dp]
+  float* sX = sHist1 + 4 * n1dp;      // [4][2]
+  int* sGc = reinterpret_cast<int*>(sX + 8);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int nkt = (a.S + 127) >> 7;
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     stage_table(sTbl, a.rel2d + (long long)h * a.n2d, a.n2d, tid);
     stage_table(sGc, a.gcode, a.P, tid);
     for (int i = tid; i < a.n2d; i += 256) sHist[i] = 0.f;
-    for (int i = tid; i < n1dp + 4; i += 256) sHist1[i] = 0.f;
+    for (int i = tid; i < 4 * n1dp + 8; i += 256) sHist1[i] = 0.f;
   }
   const bool k_grid = kj < a.P;
   const bool wave_kgrid = kw + 31 < a.P;
@@ -791,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
               pv[e] = p; dsv[e] = ds;
               if (a.rel_mode) {
                 if (qg) { if (k_grid) atomicAdd(&sHist[hidx], ds); else gx0 += ds; }
-                else { if (k_grid) gx1 += ds; else if (kvalid && i < a.T) atomicAdd(&sHist1[hidx], ds); }
+                else { if (k_grid) gx1 += ds; else if (kvalid && i < a.T) atomicAdd(&sHist1[wv * n1dp + hidx], ds); }
               }
             }
           }
@@ -905,14 +908,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   }
   if (a.rel_mode) {
     gx0 = warp_sum(gx0); gx1 = warp_sum(gx1);
-    if (lane == 0) { atomicAdd(&sX[0], gx0); atomicAdd(&sX[1], gx1); }
+    if (lane == 0) { sX[wv * 2] = gx0; sX[wv * 2 + 1] = gx1; }
     __syncthreads();
     const int part = b * nkt + kt;
     float* o2 = a.drel2d_part + ((long long)h * a.nparts + part) * a.n2d;
     for (int i = tid; i < a.n2d; i += 256) o2[i] = sHist[i];
     float* o1 = a.drel1d_part + ((long long)h * a.nparts + part) * n1d;
-    for (int i = tid; i < n1d; i += 256) o1[i] = sHist1[i];
-    if (tid < 2) a.drelx_part[((long long)h * a.nparts + part) * 2 + tid] = sX[tid];
+    for (int i = tid; i < n1d; i += 256) o1[i] = (sHist1[i] + sHist1[n1dp + i]) + (sHist1[2 * n1dp + i] + sHist1[3 * n1dp + i]);
+    if (tid < 2) a.drelx_part[((long long)h * a.nparts + part) * 2 + tid] = (sX[tid] + sX[2 + tid]) + (sX[4 + tid] + sX[6 + tid]);
   }
 }
 
@@ -1448,7 +1451,7 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   }
   const size_t n2dp = ((size_t)a.n2d + 3) & ~(size_t)3;
   const size_t n1dp = a.rel_mode ? (((size_t)(2 * a.Lt - 1) + 3) & ~(size_t)3) : 0;
-  const size_t lds_kv = (KT_BYTES + VT_BYTES + 512) + 2 * VT_BYTES + (a.rel_mode ? (2 * n2dp + n1dp + 4) * 4 + (size_t)a.P * 4 : 0);
+  const size_t lds_kv = (KT_BYTES + VT_BYTES + 512) + 2 * VT_BYTES + (a.rel_mode ? (2 * n2dp + 4 * n1dp + 8) * 4 + (size_t)a.P * 4 : 0);
   const size_t lds_q = 2 * (KT_BYTES + VT_BYTES) + (a.rel_mode ? n2dp * 4 + (size_t)a.P * 4 : 0);
   if (lds_kv > 160 * 1024 || lds_q > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
   const bool do_kv = ph & IFSEG_ATTN_BWD_DKV, do_q = ph & IFSEG_ATTN_BWD_DQ;
