@@ -42,9 +42,18 @@ class ArenaReducer:
     not covered (top-level tensors) and waits.  The reference gets the same effect from
     torch DDP's 25 MB buckets (distributed_fairseq_model.py:57-67)."""
 
-    def __init__(self, flat, slices, n):
+    def __init__(self, flat, slices, n, fp32_accumulate=None):
         self.flat, self.slices, self.n = flat, slices, n
         self.works, self.done = [], []
+        # fp32_accumulate (IFSEG_REDUCE_FP32=1): a bf16 ring sum over 8 ranks rounds after every hop (~3 bits of the sum);
+        # with this option every slice travels and is summed in fp32 (twice the bytes on the links: 427 MB instead of
+        # 213 MB for SegOFA-Base, ~0.7 ms over the full xGMI mesh) and is rounded to bf16 ONCE, after the sum.  The
+        # default stays the reference's own behaviour under --bf16 (DDP reduces the bf16 gradients as they are).
+        if fp32_accumulate is None:
+            import os
+            fp32_accumulate = os.environ.get("IFSEG_REDUCE_FP32") == "1"
+        self.fp32 = bool(fp32_accumulate) and flat.dtype != torch.float32
+        self._wide = []
         # gloo (functional runs: N ranks on one GPU, CPU tests) has no bf16 device reduction: staged through fp32 host
         # memory, synchronously.  The production backend is "nccl" (= RCCL over xGMI), asynchronous on its own stream.
         self.staged = dist.is_initialized() and dist.get_backend() == "gloo" and flat.is_cuda
@@ -55,6 +64,10 @@ class ArenaReducer:
             cpu = self.flat[lo:hi].float().cpu()
             dist.all_reduce(cpu)
             self.flat[lo:hi].copy_(cpu)
+        elif self.fp32:
+            wide = self.flat[lo:hi].float()
+            self._wide.append((lo, hi, wide))
+            self.works.append(dist.all_reduce(wide, async_op=True))
         else:
             self.works.append(dist.all_reduce(self.flat[lo:hi], async_op=True))
 
@@ -73,7 +86,9 @@ class ArenaReducer:
             cur = max(cur, hi)
         for w in self.works:
             w.wait()
-        self.works, self.done = [], []
+        for lo, hi, wide in self._wide:
+            self.flat[lo:hi].copy_(wide)            # one rounding, after the fp32 sum
+        self.works, self.done, self._wide = [], [], []
 
 
 class Trainer:
@@ -103,8 +118,14 @@ class Trainer:
         eng.master_owned = True                            # this trainer keeps eng.master in step with eng.p16
         self.ws = torch.zeros(1024, dtype=torch.float32, device=self.device)
         self.reducer = ArenaReducer(eng.g16, layer_slices(eng), eng.n_train)
-        if self.world > 1:
+        # IFSEG_FORCE_GRAD_HOOK=1 with an initialised process group of ONE rank: the whole data-parallel leg (per-layer
+        # all-reduce issued from the weight-gradient stream, finish()'s waits, the log all-reduce) runs through the real
+        # backend -- how the RCCL path is exercised on a one-GPU box (tests/test_configs_gpu.py)
+        import os
+        self.dist_on = self.world > 1 or (dist.is_initialized() and os.environ.get("IFSEG_FORCE_GRAD_HOOK") == "1")
+        if self.dist_on:
             eng.grad_ready_hook = self._on_grads_ready
+        if self.world > 1:
             # same start on every rank (DDP broadcasts rank 0's parameters at construction)
             # (the frozen ResNet trunk and its FrozenBN statistics live outside the arena: broadcast too, then re-fold)
             extra = [p.data for n, p in model.named_parameters() if "embed_images" in n]
@@ -143,7 +164,7 @@ class Trainer:
         """trainer.py:1368-1406 (`_fast_stat_sync_sum`) -> fairseq/distributed/utils.py:654-700: every numeric entry
         of the logging outputs (losses, ntokens, sample_size, the 4 x nseg area histograms the mIoU is computed from,
         criterions/seg_criterion.py:590-597) is summed over the ranks in ONE all-reduce."""
-        if self.world == 1:
+        if not getattr(self, "dist_on", self.world > 1):
             return logs
         keys, flat = [], []
         for i, lg in enumerate(logs):
@@ -240,7 +261,7 @@ class Trainer:
         if accumulate:
             eng.g16.copy_(self._gacc)
         total_ss = float(sum(sample_sizes))
-        if self.world > 1:
+        if self.dist_on:
             self.reducer.finish()
             total_ss *= self.world          # every rank reports sample_size 1 (seg_criterion.py:345)
         gscale = 1.0 / total_ss             # sum over ranks * (world / total) / world

@@ -125,11 +125,31 @@ def oracle_train(cfg, sd, batch, grad_keys):
     return logits.detach(), loss.detach(), {k: sdg[k].grad for k in grad_keys}, O.seg_metric(s.detach(), t, cfg.num_seg_tokens)
 
 
-def case_train(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys, full_grads=True):
+SUB_N = 4096
+
+
+def sub_index(name, numel, n=SUB_N):
+    """positions of the seeded subsample of a gradient tensor stored as `gsub:<name>` (all of it when numel <= n);
+    tests/test_configs_gpu.py rebuilds the same indices from the name"""
+    if numel <= n:
+        return torch.arange(numel)
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    return torch.randperm(numel, generator=g)[:n].sort().values
+
+
+def case_train(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys, full_grads=True, diversify=False, sub_all=False):
+    """diversify: the (frozen, tied) seg projection is replaced by O.diversify_seg_projection(...) on both sides, so the
+    per-patch argmax has real margins at random init (150 / 171 near-uniform classes otherwise); sub_all: every parameter
+    the reference gives a gradient contributes a seeded SUB_N-element subsample of it (`gsub:<name>`)."""
     t0 = time.time()
     model, sd = build_reference(cfg, arch, overrides)
     crit = build_criterion(cfg)
     batch = O.synthetic_batch(cfg, batch_size, src_len)
+    if diversify:
+        sd = O.diversify_seg_projection(sd, cfg, batch)
+        missing, unexpected = torch.nn.Module.load_state_dict(model, sd, strict=False)
+        assert not unexpected
     model.train()
     params = dict(model.named_parameters())
     for k in grad_keys:
@@ -155,7 +175,15 @@ def case_train(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys, f
     assert abs(o_loss.item() - loss.item()) <= 2e-6
     save = {"logits_causal": ref_logits.numpy(), "logits_full": ref_full.numpy(),
             "loss": np.float64(loss.item()),
-            "batch_size": batch_size, "src_len": src_len}
+            "batch_size": batch_size, "src_len": src_len, "diversified": int(diversify)}
+    if sub_all:
+        nsub = 0
+        for k, p_ in params.items():
+            if p_.grad is None or "embed_images" in k or float(p_.grad.abs().sum()) == 0.0:
+                continue
+            save["gsub:" + k] = p_.grad.reshape(-1)[sub_index(k, p_.grad.numel())].numpy().astype(np.float32)
+            nsub += 1
+        print("  gradient subsamples of %d tensors" % nsub)
     for name in ("area_intersect", "area_pred_label", "area_label", "area_union"):
         save[name] = metrics[name].numpy()
     for a, b in zip(o_metric, (metrics["area_intersect"], metrics["area_pred_label"],
@@ -436,10 +464,10 @@ def main():
         if "lazy" in only:
             case_lazy_init(fx, "tiny", ov, "fixture_lazy_init.npz")
         if "base_b2" in only:      # BASELINE config 1 as written: B = 2
-            case_train(O.base_config(), "base", None, 2, 36, "base_c1_b2.npz", GRAD_KEYS, full_grads=False)
+            case_train(O.base_config(), "base", None, 2, 36, "base_c1_b2.npz", GRAD_KEYS, full_grads=False, sub_all=True)
         if "base_c3" in only:      # BASELINE config 3 geometry on one device: Base width, 150 classes, L = 215 (T_enc 1239)
             case_train(O.base_config(num_seg_tokens=150, vocab_size=59457 + 151 - 150), "base", None, 1, 215, "base_c3.npz",
-                       GRAD_KEYS, full_grads=False)
+                       GRAD_KEYS, full_grads=False, diversify=True, sub_all=True)
         return
     if a.only_eval:
         case_eval(fx, "tiny", ov, "fixture_eval.npz")

@@ -29,7 +29,7 @@ out = {"p16_start": tr.eng.p16.clone().cpu()}
 logs = tr.train_step([sample])
 torch.cuda.synchronize()
 g_first = tr.eng.g16.float().cpu()           # sum over ranks of the first step's gradients
-logs2 = tr.train_step([sample])              # second update runs at lr > 0 (the first one at min_lr = 0)
+logs2 = tr.train_step([sample])
 torch.cuda.synchronize()
 out.update(g16=g_first, p16=tr.eng.p16.clone().cpu(), p32=tr.p32.clone().cpu(),
            logs={k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in logs[0].items()})

@@ -61,12 +61,49 @@ def _argmax_consistent(logits, ref):
     return agree.float().mean().item(), agree_decided, bool((agree | (margin <= 3 * err)).all())
 
 
-def _golden_case(golden_dir, name, ocfg, B, min_agree=0.99):
+def _sub_index(name, numel, n=4096):
+    """positions of the seeded gradient subsample `gsub:<name>` (oracle/gen_golden.py: sub_index)"""
+    if numel <= n:
+        return torch.arange(numel)
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    return torch.randperm(numel, generator=g)[:n].sort().values
+
+
+def _check_grad_subsamples(g, grad_of, what):
+    """every trainable tensor the reference gives a gradient, ELEMENT-WISE on a seeded 4096-element subsample of the
+    reference's gradient (rel-L2 <= 6e-2 per tensor, c_attn included): a sign / permutation error confined to a
+    Base-only code path (XCD-pinned split-K, grouped dW at K = 8480, the 32-wide rotation reduction) cannot hide behind a
+    matching norm"""
+    worst, n = ("", 0.0), 0
+    for key in g.files:
+        if not key.startswith("gsub:"):
+            continue
+        name = key[5:]
+        ref = torch.from_numpy(g[key])
+        got = grad_of(name)
+        assert got is not None, name
+        got = got.float().reshape(-1).cpu()[_sub_index(name, got.numel())]
+        r = _rel(got, ref)
+        n += 1
+        if r > worst[1]:
+            worst = (name, r)
+        # (rel-pos tables: most sampled entries are exact zeros -- buckets the geometry never reaches -- on both sides)
+        assert r <= 6e-2, "%s gradient of %s: rel-L2 %.4f on the sampled elements" % (what, name, r)
+    assert n >= 300, n
+    print("%s: %d gradient tensors compared element-wise on subsamples, worst rel-L2 %.4f (%s)" % (what, n, worst[1], worst[0]))
+
+
+def _golden_case(golden_dir, name, ocfg, B):
     dev = torch.device("cuda:0")
     g = np.load(os.path.join(golden_dir, name))
     assert int(g["batch_size"]) == B
     sd = O.procedural_state_dict(ocfg)
     batch = O.synthetic_batch(ocfg, B, int(g["src_len"]))
+    if "diversified" in g.files and int(g["diversified"]):
+        # seg projection with real per-patch margins, rebuilt exactly like oracle/gen_golden.py did (deterministic)
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        sd = O.diversify_seg_projection(sd, ocfg, batch)
     m = _base_model(ocfg, sd, dev).train()
     n = ocfg.num_seg_tokens
     loss, _, logs = _crit(ocfg)(m, _sample(batch, dev))
@@ -78,15 +115,27 @@ def _golden_case(golden_dir, name, ocfg, B, min_agree=0.99):
     agree, decided, consistent = _argmax_consistent(logits, ref)
     print("%s: logits rel-L2 %.4f, loss %.5f vs reference %.5f, patch argmax agreement %.4f (decided positions %.4f)"
           % (name, e, loss.item(), float(g["loss"]), agree, decided))
-    assert e <= 2e-2 and abs(loss.item() - float(g["loss"])) <= 1e-2 and agree >= min_agree and decided >= 0.99 and consistent
+    # the stated tolerances, plainly: logits 2e-2, loss 1e-2, per-patch argmax agreement >= 99 %
+    assert e <= 2e-2 and abs(loss.item() - float(g["loss"])) <= 1e-2 and agree >= 0.99 and consistent
     named = dict(m.named_parameters())
     for k in g.files:
         if k.startswith("gradnorm:") and not k.endswith("c_attn"):
             hn, rn = named[k[9:]].grad.float().norm().item(), float(g[k])
             assert abs(hn - rn) <= 0.08 * rn + 1e-6, (k, hn, rn)
+    _check_grad_subsamples(g, lambda nme: named[nme].grad, name + " (autograd_mode=inputs)")
     al = logs["area_label"].cpu().numpy()
     assert np.array_equal(al, g["area_label"])                       # integer target histogram: exact
     assert np.abs(logs["area_intersect"].cpu().numpy() - g["area_intersect"]).sum() <= 0.02 * g["area_label"].sum()
+    # the mode everything timed runs in (bench.py, Trainer): gradients stay in the flat arena -- same comparison
+    m.zero_grad(set_to_none=True)
+    m.autograd_mode = "arena"
+    loss2, _, _ = _crit(ocfg)(m, _sample(batch, dev))
+    loss2.backward()
+    torch.cuda.synchronize()
+    assert loss2.item() == loss.item()
+    eng = m.engine
+    _check_grad_subsamples(g, lambda nme: eng.G(nme) if eng.offs[nme] < eng.n_train else None, name + " (autograd_mode=arena)")
+    m.autograd_mode = "inputs"
     return m, batch, logits, g
 
 
@@ -97,9 +146,50 @@ def test_base_config1_batch2_vs_reference_golden(golden_dir):
 
 def test_base_config3_geometry_vs_reference_golden(golden_dir):
     """BASELINE configs[2] per-GPU geometry: Base width, 150 ADE20K classes, L = 215 prompt tokens, T_enc = 1239 (a T
-    that is a multiple of nothing), log-spaced token buckets beyond |i-j| = 128 (reference outputs: base_c3.npz)."""
-    # 150 near-uniform classes at random init: agreement >= 95 %, every disagreement inside the reference's own margin
-    _golden_case(golden_dir, "base_c3.npz", O.base_config(num_seg_tokens=150, vocab_size=59458), 1, min_agree=0.90)
+    that is a multiple of nothing), log-spaced token buckets beyond |i-j| = 128 (reference outputs: base_c3.npz, generated
+    with the diversified seg projection: plain per-patch argmax agreement >= 99 %)."""
+    _golden_case(golden_dir, "base_c3.npz", O.base_config(num_seg_tokens=150, vocab_size=59458), 1)
+
+
+def test_base_config3_batch8_per_gpu_size(golden_dir):
+    """BASELINE configs[2] at its PER-GPU size: Base, 150 classes, L = 215 (T_enc = 1239), B = 8 -- the 150-class loss
+    kernel, the L = 215 text tile and T_enc = 1239 at the batch the configuration runs.  Sample 0 of the batch is the
+    B = 1 golden's image (same generator prefix): its logits equal the HIP B = 1 run bit for bit and the reference golden
+    within tolerance; the loss kernel at B = 8 against the fp32 CE of its own logits; the step is bit-deterministic."""
+    dev = torch.device("cuda:0")
+    ocfg = O.base_config(num_seg_tokens=150, vocab_size=59458)
+    g = np.load(os.path.join(golden_dir, "base_c3.npz"))
+    sd = O.procedural_state_dict(ocfg)
+    b1, b8 = O.synthetic_batch(ocfg, 1, 215), O.synthetic_batch(ocfg, 8, 215)
+    assert torch.equal(b1["patch_images"], b8["patch_images"][:1]) and torch.equal(b1["src_tokens"], b8["src_tokens"][:1])
+    if "diversified" in g.files and int(g["diversified"]):
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        sd = O.diversify_seg_projection(sd, ocfg, b1)
+    m = _base_model(ocfg, sd, dev).train()
+    crit = _crit(ocfg)
+
+    def run(batch):
+        m.zero_grad(set_to_none=True)
+        loss, _, logs = crit(m, _sample(batch, dev))
+        loss.backward()
+        torch.cuda.synchronize()
+        return m.engine.ws["logits_pad"][:, :, :150].float().cpu().clone(), loss.item(), m.engine.g16.clone(), logs
+
+    l1, _, _, _ = run(b1)
+    l8, loss8, g8, logs8 = run(b8)
+    l8b, loss8b, g8b, _ = run(b8)
+    assert torch.equal(l8, l8b) and loss8 == loss8b and torch.equal(g8, g8b)
+    assert torch.equal(l8[:1], l1), _rel(l8[:1], l1)
+    ref = torch.from_numpy(g["logits_causal"])
+    agree = (l8[:1, 1:].argmax(-1) == ref[:, 1:].argmax(-1)).float().mean().item()
+    assert _rel(l8[:1], ref) <= 2e-2 and agree >= 0.99, (_rel(l8[:1], ref), agree)
+    assert torch.isfinite(g8.float()).all() and np.isfinite(loss8)
+    with torch.no_grad():
+        ol, s_, t_ = O.seg_loss(ocfg, l8, b8["target"], 32, 32, 512, 512)
+        hist = O.seg_metric(s_, t_, 150)
+    assert abs(loss8 - ol.item()) <= 2e-3, (loss8, ol.item())
+    assert np.array_equal(logs8["area_label"].cpu().numpy(), hist[2].numpy())         # integer target histogram: exact
+    assert (logs8["area_pred_label"].cpu() - hist[1]).abs().sum().item() <= 0.002 * hist[2].sum().item()
 
 
 def test_base_config2_batch8_consistent_with_batch2_golden(golden_dir):
@@ -144,6 +234,7 @@ def test_large_full_depth_resnet152_vs_oracle():
     ocfg = O.large_config(num_seg_tokens=171, vocab_size=59458, patch_image_size=640, orig_patch_image_size=640)
     sd = O.procedural_state_dict(ocfg)
     batch = O.synthetic_batch(ocfg, 1, 239)
+    sd = O.diversify_seg_projection(sd, ocfg, batch)      # per-patch margins that mean something: plain argmax >= 99 %
     with torch.no_grad():
         o_logits, _ = O.segofa_forward(sd, ocfg, batch["src_tokens"], batch["patch_images"])
     m = _base_model(ocfg, sd, dev, arch="segofa_large").train()
@@ -161,8 +252,8 @@ def test_large_full_depth_resnet152_vs_oracle():
     e = _rel(lg, o_logits)
     agree, decided, consistent = _argmax_consistent(lg, o_logits)
     print("large full depth: logits rel-L2 %.4f, argmax agreement %.4f (decided positions %.4f), loss %.5f" % (e, agree, decided, loss))
-    # 24 bf16 layers, 171 near-uniform classes: the stated tolerance on the logits holds; argmax as for config 3
-    assert e <= 2e-2 and decided >= 0.99 and agree >= 0.90 and consistent
+    # 24 bf16 layers, 171 classes: the stated tolerances, plainly
+    assert e <= 2e-2 and agree >= 0.99 and consistent
     # the forward is bit-deterministic; on a grid that is not 32 wide (40 x 40 here) the rel-pos table gradient is an LDS
     # float-atomic histogram (csrc/attention.hip), so the gradient arena is reproducible to rounding, not bitwise
     assert loss == loss2 and _rel(g1, g2) <= 1e-3 and torch.isfinite(g1.float()).all()
@@ -245,6 +336,31 @@ def test_lazy_seg_token_init_vs_reference_golden(golden_dir):
     assert _rel(m.engine.ws["logits_pad"][:, :, :15], ol) <= 2e-2
     crit(m, _sample(batch, dev))                             # second call: no re-initialisation
     assert crit.iter == 1
+
+
+def test_rccl_world1_hooked_step_is_bit_equal_and_not_slower(tmp_path):
+    """the RCCL leg on one GPU.  Process group "nccl" with ONE rank, the per-layer gradient hook forced
+    on: the bf16 slices are all-reduced asynchronously from the weight-gradient stream, `finish()` waits before the
+    optimizer, the logs are summed through an fp64 all-reduce -- Base, B = 8, dropout on.  The parameters after 6 updates
+    equal the hook-less run bit for bit and the step time stays within 3 % (+ 0.3 ms of timer noise)."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
+    out = os.path.join(str(tmp_path), "rccl.json")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("IFSEG_DIST_BACKEND", None)
+    p = subprocess.Popen([sys.executable, os.path.join(HERE, "_rccl_worker.py"), port, out], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, env=env)
+    try:
+        log = p.communicate(timeout=420)[0]
+    finally:
+        if p.poll() is None:
+            p.kill()                                       # this exact child (never by pattern)
+            log = p.communicate()[0]
+    assert p.returncode == 0, log[-4000:]
+    r = json.load(open(out))
+    print("RCCL world-1 leg: %d slices reduced per step; step %.3f ms hooked vs %.3f ms plain" % (r["slices"], r["ms_rccl"], r["ms_plain"]))
+    assert r["backend"] == "nccl" and r["losses_equal"] and r["g16_equal"] and r["p16_equal"] and r["p32_equal"], r
+    assert r["ms_rccl"] <= 1.03 * r["ms_plain"] + 0.3, r
 
 
 def test_two_rank_train_step_on_one_gpu_over_gloo(tmp_path):

@@ -48,6 +48,43 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _worker_fp32(rank, world, port, out):
+    """bf16 arena, fp32-accumulate option: every slice is summed in fp32 over the ranks and rounded to bf16 once"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ifseg_amd.trainer import ArenaReducer
+    n = 6000
+    slices = {"encoder.": (0, 500), "encoder.layers.0.": (500, 3000), "decoder.layers.0.": (3100, 5800)}
+    g = torch.Generator().manual_seed(7 + rank)
+    flat = torch.randn(n, generator=g).to(torch.bfloat16)
+    mine = flat.float()
+    red = ArenaReducer(flat, slices, n, fp32_accumulate=True)
+    assert red.fp32
+    for p in ("decoder.layers.0.", "encoder.layers.0.", "encoder."):
+        red.on_ready(p)
+    red.finish()
+    gathered = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    expect = sum(gathered).to(torch.bfloat16)              # fp32 sum of the ranks' bf16 values, ONE rounding
+    if rank == 0:
+        out.put(bool(torch.equal(flat.view(torch.int16), expect.view(torch.int16))))
+    dist.destroy_process_group()
+
+
+def test_arena_reducer_fp32_accumulate_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fp32, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_arena_reducer_world2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
