@@ -214,7 +214,7 @@ def main():
     model = task.build_model()
     model.cfg.dropout, model.cfg.encoder_drop_path_rate, model.cfg.decoder_drop_path_rate = a.dropout, a.drop_path, a.drop_path
     crit = SegCriterion(task, unsupervised_segmentation=a.image_free, init_seg_with_text=False)
-    trainer = Trainer(model, crit, task, device=dev)
+    trainer = Trainer(model, crit, task, device=dev, lazy_logs=True)
     # two different synthetic batches, alternated: batch i+1 is handed to the trainer as `prefetch` (what a data
     # iterator holds one step ahead), so its frozen-trunk pass runs underneath step i on a second stream
     ring = []

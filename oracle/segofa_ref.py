@@ -660,6 +660,23 @@ def neighbour_smoothing(logits, resnet_feature, iters=25, topk=3, temperature=1.
     return torch.cat([prob, prob.new_zeros(B, 1, prob.size(-1))], dim=1)
 
 
+def round_weights_bf16(sd):
+    """Test helper: every floating-point tensor outside the (BN-folded) trunk is replaced by its bf16 rounding, held in
+    fp32 -- the fp32 reference / oracle and the bf16 HIP path then run on IDENTICAL weight values (BASELINE.md section 5:
+    "identical inputs/weights"), so what a parity test measures is the arithmetic, not the one-off rounding of procedural
+    fp32 weights.  Aliased tensors stay aliased.  Returns a new state dict."""
+    out, done = {}, {}
+    for k, v in sd.items():
+        if not v.dtype.is_floating_point or "embed_images" in k:
+            out[k] = v
+            continue
+        key = v.data_ptr()
+        if key not in done:
+            done[key] = v.detach().to(torch.bfloat16).to(torch.float32)
+        out[k] = done[key]
+    return out
+
+
 def diversify_seg_projection(sd, cfg, batch, gain=6.0):
     """Test helper for the eval fixtures: with the procedural weights every patch predicts the same class (the
     class offsets W x_mean dominate the logits), which would make argmax / histogram checks vacuous.  Project the

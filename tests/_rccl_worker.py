@@ -39,7 +39,7 @@ def run(forced, nsteps=6, timed=30):
         os.environ.pop("IFSEG_FORCE_GRAD_HOOK", None)
     torch.manual_seed(0)
     model = task.build_model()                       # recipe: dropout 0.1, drop-path 0.1
-    tr = Trainer(model, SegCriterion(task, unsupervised_segmentation=False, init_seg_with_text=False), task, device=dev)
+    tr = Trainer(model, SegCriterion(task, unsupervised_segmentation=False, init_seg_with_text=False), task, device=dev, lazy_logs=True)
     assert (tr.eng.grad_ready_hook is not None) == forced and tr.dist_on == forced
     losses = []
     for i in range(nsteps):

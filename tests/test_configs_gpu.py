@@ -75,7 +75,8 @@ def _check_grad_subsamples(g, grad_of, what):
     reference's gradient (rel-L2 <= 6e-2 per tensor, c_attn included): a sign / permutation error confined to a
     Base-only code path (XCD-pinned split-K, grouped dW at K = 8480, the 32-wide rotation reduction) cannot hide behind a
     matching norm"""
-    worst, n = ("", 0.0), 0
+    worst, n, nz = ("", 0.0), 0, 0
+    scale = max(float(np.sqrt((g[k].astype(np.float64) ** 2).mean())) for k in g.files if k.startswith("gsub:"))
     for key in g.files:
         if not key.startswith("gsub:"):
             continue
@@ -84,6 +85,12 @@ def _check_grad_subsamples(g, grad_of, what):
         got = grad_of(name)
         assert got is not None, name
         got = got.float().reshape(-1).cpu()[_sub_index(name, got.numel())]
+        if ref.pow(2).mean().sqrt().item() <= 1e-6 * scale:
+            # mathematically zero gradients the reference holds as float noise (softmax is invariant to a per-query
+            # constant: every k_proj.bias / pos_k_linear.bias): ours must be noise too
+            assert got.pow(2).mean().sqrt().item() <= 1e-3 * scale, (name, got.abs().max().item())
+            nz += 1
+            continue
         r = _rel(got, ref)
         n += 1
         if r > worst[1]:
@@ -91,7 +98,18 @@ def _check_grad_subsamples(g, grad_of, what):
         # (rel-pos tables: most sampled entries are exact zeros -- buckets the geometry never reaches -- on both sides)
         assert r <= 6e-2, "%s gradient of %s: rel-L2 %.4f on the sampled elements" % (what, name, r)
     assert n >= 300, n
-    print("%s: %d gradient tensors compared element-wise on subsamples, worst rel-L2 %.4f (%s)" % (what, n, worst[1], worst[0]))
+    print("%s: %d gradient tensors compared element-wise on subsamples (+ %d zero gradients), worst rel-L2 %.4f (%s)"
+          % (what, n, nz, worst[1], worst[0]))
+
+
+def _golden_weights(g, sd, ocfg, batch):
+    """the weight transformations oracle/gen_golden.py applied before running the reference (deterministic)"""
+    if "bf16_weights" in g.files and int(g["bf16_weights"]):
+        sd = O.round_weights_bf16(sd)          # identical weight values on both sides: the test measures the arithmetic
+    if "diversified" in g.files and int(g["diversified"]):
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        sd = O.diversify_seg_projection(sd, ocfg, batch)
+    return sd
 
 
 def _golden_case(golden_dir, name, ocfg, B):
@@ -100,10 +118,7 @@ def _golden_case(golden_dir, name, ocfg, B):
     assert int(g["batch_size"]) == B
     sd = O.procedural_state_dict(ocfg)
     batch = O.synthetic_batch(ocfg, B, int(g["src_len"]))
-    if "diversified" in g.files and int(g["diversified"]):
-        # seg projection with real per-patch margins, rebuilt exactly like oracle/gen_golden.py did (deterministic)
-        torch.set_num_threads(min(32, os.cpu_count() or 1))
-        sd = O.diversify_seg_projection(sd, ocfg, batch)
+    sd = _golden_weights(g, sd, ocfg, batch)
     m = _base_model(ocfg, sd, dev).train()
     n = ocfg.num_seg_tokens
     loss, _, logs = _crit(ocfg)(m, _sample(batch, dev))
@@ -147,7 +162,8 @@ def test_base_config1_batch2_vs_reference_golden(golden_dir):
 def test_base_config3_geometry_vs_reference_golden(golden_dir):
     """BASELINE configs[2] per-GPU geometry: Base width, 150 ADE20K classes, L = 215 prompt tokens, T_enc = 1239 (a T
     that is a multiple of nothing), log-spaced token buckets beyond |i-j| = 128 (reference outputs: base_c3.npz, generated
-    with the diversified seg projection: plain per-patch argmax agreement >= 99 %)."""
+    on bf16-representable weights: both sides run on identical weight values and the plain per-patch argmax agreement
+    >= 99 % is asserted)."""
     _golden_case(golden_dir, "base_c3.npz", O.base_config(num_seg_tokens=150, vocab_size=59458), 1)
 
 
@@ -162,9 +178,7 @@ def test_base_config3_batch8_per_gpu_size(golden_dir):
     sd = O.procedural_state_dict(ocfg)
     b1, b8 = O.synthetic_batch(ocfg, 1, 215), O.synthetic_batch(ocfg, 8, 215)
     assert torch.equal(b1["patch_images"], b8["patch_images"][:1]) and torch.equal(b1["src_tokens"], b8["src_tokens"][:1])
-    if "diversified" in g.files and int(g["diversified"]):
-        torch.set_num_threads(min(32, os.cpu_count() or 1))
-        sd = O.diversify_seg_projection(sd, ocfg, b1)
+    sd = _golden_weights(g, sd, ocfg, b1)
     m = _base_model(ocfg, sd, dev).train()
     crit = _crit(ocfg)
 
@@ -234,7 +248,7 @@ def test_large_full_depth_resnet152_vs_oracle():
     ocfg = O.large_config(num_seg_tokens=171, vocab_size=59458, patch_image_size=640, orig_patch_image_size=640)
     sd = O.procedural_state_dict(ocfg)
     batch = O.synthetic_batch(ocfg, 1, 239)
-    sd = O.diversify_seg_projection(sd, ocfg, batch)      # per-patch margins that mean something: plain argmax >= 99 %
+    sd = O.round_weights_bf16(sd)          # identical weight values on both sides: the test measures the arithmetic
     with torch.no_grad():
         o_logits, _ = O.segofa_forward(sd, ocfg, batch["src_tokens"], batch["patch_images"])
     m = _base_model(ocfg, sd, dev, arch="segofa_large").train()
