@@ -470,7 +470,7 @@ def main():
         if "lazy" in only:
             case_lazy_init(fx, "tiny", ov, "fixture_lazy_init.npz")
         if "base_b2" in only:      # BASELINE config 1 as written: B = 2
-            case_train(O.base_config(), "base", None, 2, 36, "base_c1_b2.npz", GRAD_KEYS, full_grads=False, sub_all=True)
+            case_train(O.base_config(), "base", None, 2, 36, "base_c1_b2.npz", GRAD_KEYS, full_grads=False, sub_all=True, bf16_weights=True)
         if "base_c3" in only:      # BASELINE config 3 geometry on one device: Base width, 150 classes, L = 215 (T_enc 1239)
             case_train(O.base_config(num_seg_tokens=150, vocab_size=59457 + 151 - 150), "base", None, 1, 215, "base_c3.npz",
                        GRAD_KEYS, full_grads=False, sub_all=True, bf16_weights=True)
