@@ -175,6 +175,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const float relx0 = a.rel_mode ? a.relx[h * 2 + 0] : 0.f, relx1 = a.rel_mode ? a.relx[h * 2 + 1] : 0.f;
   const float* rel1d = a.rel_mode ? a.rel1d + (long long)h * (2 * a.Lt - 1) + (a.Lt - 1) : nullptr;
   const bool row32 = a.rel_mode && a.grid_w == 32;   // raster grid, 32 wide: a 32-key block is one grid row
+  // any grid width that is a multiple of 8 (>= 32): a 32-key block spans at most two grid rows and every aligned group of
+  // 8 keys -- the 4-key runs a lane holds -- lies inside one row: the seeds sit at constant offsets from ONE ADDRESS PER
+  // GROUP instead of one per block (BASELINE configs[3]: 640 x 640 -> a 40-wide grid)
+  const bool rowseg = a.rel_mode && !row32 && a.grid_w >= 32 && (a.grid_w & 7) == 0;
 
   // ---- tile schedule (causal: skip grid tiles wholly above the diagonal)
   const int ntile = (a.S + 63) >> 6;
@@ -266,6 +270,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             for (int e = 0; e < 4; ++e) s[kb][rg * 4 + e] = tp[8 * rg + e];
         }
         s_mfma();
+      } else if (gg && rowseg) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const float* tp = sTbl + (ciR + sGc[j0 + kb * 32 + 8 * rg] + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[kb][rg * 4 + e] = tp[e];
+          }
+        }
+        s_mfma();
       } else {
         // (a separate MFMA chain: zero accumulators cost nothing, the first MFMA takes the constant; a chain shared
         // with the seeded path makes the compiler splat 32 registers on every tile before it knows the path)
@@ -286,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       // (scores stay in natural units; log2 e is folded into the exponent's fma)
       float mx = NEG_INF;
       if (gg) {
-        if (!row32) {
+        if (!row32 && !rowseg) {
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -452,6 +467,54 @@ __device__ __forceinline__ uint4 scale_bf16x8(uint4 v, float f) {
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// (dK/dV kernel, grids of any width that is a multiple of 8 and >= 32)  One rotated dS register h -- rotation amount C = c_r,
+// so lane x holds the term of key lane (x + C) & 31 -- added to the four class sums of its query set:
+//   T every lane;  W lanes whose term wrapped around the 32-lane half (x + C >= 32: a compile-time lane interval);
+//   K lanes whose term belongs to a key in the wave's SECOND grid row (bit (x + C) & 31 of `mk`, i.e. mk rotated right by C);
+//   WK both.  The masks are applied as EXEC masks, the same for both halves of the wave.
+template <int C>
+__device__ __forceinline__ void seg_add(float h, unsigned mk, float& T, float& W, float& K, float& WK) {
+  unsigned long long sv;
+  if constexpr (C == 0) {
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_add_f32 %[T], %[T], %[h]\n\t"
+        "s_mov_b32 exec_lo, %[mk]\n\ts_mov_b32 exec_hi, %[mk]\n\tv_add_f32 %[K], %[K], %[h]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [T] "+v"(T), [K] "+v"(K), [sv] "=&s"(sv)
+        : [h] "v"(h), [mk] "s"(mk));
+  } else {
+    constexpr unsigned WM = 0xFFFFFFFFu << (32 - C);
+    unsigned t0, t1;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_add_f32 %[T], %[T], %[h]\n\t"
+        "s_mov_b32 exec_lo, %[wm]\n\ts_mov_b32 exec_hi, %[wm]\n\tv_add_f32 %[W], %[W], %[h]\n\t"
+        "s_lshr_b32 %[t0], %[mk], %[c]\n\ts_lshl_b32 %[t1], %[mk], %[ci]\n\ts_or_b32 %[t0], %[t0], %[t1]\n\t"
+        "s_mov_b32 exec_lo, %[t0]\n\ts_mov_b32 exec_hi, %[t0]\n\tv_add_f32 %[K], %[K], %[h]\n\t"
+        "s_and_b32 %[t0], %[t0], %[wm]\n\t"
+        "s_mov_b32 exec_lo, %[t0]\n\ts_mov_b32 exec_hi, %[t0]\n\tv_add_f32 %[WK], %[WK], %[h]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [T] "+v"(T), [W] "+v"(W), [K] "+v"(K), [WK] "+v"(WK), [sv] "=&s"(sv), [t0] "=&s"(t0), [t1] "=&s"(t1)
+        : [h] "v"(h), [mk] "s"(mk), [wm] "n"((int)WM), [c] "n"(C), [ci] "n"(32 - C)
+        : "scc");
+  }
+}
+// class sums of the rotated registers R .. R1-1 (rotation amount of register r: (r & 3) + 8 (r >> 2))
+template <int R, int R1>
+__device__ __forceinline__ void seg_sums_rec(const float (&h)[16], unsigned mk, float& T, float& W, float& K, float& WK) {
+  if constexpr (R < R1) {
+    seg_add<(R & 3) + 8 * (R >> 2)>(h[R], mk, T, W, K, WK);
+    seg_sums_rec<R + 1, R1>(h, mk, T, W, K, WK);
+  }
+}
+template <int R0, int R1>
+__device__ __forceinline__ void seg_sums(const float (&h)[16], unsigned mk, float (&o)[4]) {
+  float T = 0.f, W = 0.f, K = 0.f, WK = 0.f;
+  seg_sums_rec<R0, R1>(h, mk, T, W, K, WK);
+  o[0] = T; o[1] = W; o[2] = K; o[3] = WK;
+}
+
 // ---------------------------------------------------------------- backward
 // Shared element logic: bias value for (query i, key j) is needed only to
 // recompute P; the gradient of the bias goes to LDS histograms.
@@ -479,6 +542,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   float* sHist1 = sHist + n2dp;       // [4][n1dp]
   float* sX = sHist1 + 4 * n1dp;      // [4][2]
   int* sGc = reinterpret_cast<int*>(sX + 8);
+  // general grid width: per-block exchange area of the rel-pos gradient terms, [2 buffers][4 waves][header 4 | 3 x 64]
+  constexpr int XW = 4 + 3 * 64;
+  float* sXc = reinterpret_cast<float*>(sGc + ((a.P + 3) & ~3));
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int nkt = (a.S + 127) >> 7;
@@ -522,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     stage_table(sGc, a.gcode, a.P, tid);
     for (int i = tid; i < a.n2d; i += 256) sHist[i] = 0.f;
     for (int i = tid; i < 4 * n1dp + 8; i += 256) sHist1[i] = 0.f;
+    for (int i = tid; i < 2 * 4 * XW; i += 256) sXc[i] = 0.f;
   }
   const bool k_grid = kj < a.P;
   const bool wave_kgrid = kw + 31 < a.P;
@@ -533,6 +600,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   const bool row32 = a.rel_mode && a.grid_w == 32;
   const int cj0 = __builtin_amdgcn_readfirstlane(cj);     // code of the wave's first key (x = 0 when row32)
   const int xl = (lane & 31) + 4 * half;
+  // Grids of any other width that is a multiple of 8 (>= 32; BASELINE configs[3]: 40): the wave's 32 keys span at most two
+  // grid rows, a block's 32 queries likewise, and every aligned group of 8 lies in one row.  `mk`: key lanes in the wave's
+  // second row (a code jumps by w instead of 1 at a row end).  Seeds: one table address per group of 8 queries.  Gradient:
+  // the same in-register rotation as on a 32-wide grid, the rotated terms summed per (query row, key row, wrap) class
+  // (seg_sums) -- three bins per lane and block, handed through `sXc` to ONE wave per block that adds them to the table in
+  // a fixed order: bit-reproducible, no LDS float atomics (the 4 waves share table rows here).
+  const bool rowseg = a.rel_mode && !row32 && a.grid_w >= 32 && (a.grid_w & 7) == 0;
+  const unsigned mk = rowseg ? (unsigned)__builtin_amdgcn_ballot_w64(k_grid && (cj - cj0 != (lane & 31))) : 0u;
+  auto seg_duty = [&](int buf) {
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+      const float* xs = sXc + (buf * 4 + w) * XW;
+      if (__builtin_amdgcn_readfirstlane(__float_as_int(xs[0])) == 0) continue;
+      const int bq = __builtin_amdgcn_readfirstlane(__float_as_int(xs[1])) + (lane < 32 ? -lane : 64 - lane);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int bin = bq + (d - 1) * (a.grid_w - 1);
+        const float v = xs[4 + d * 64 + lane];
+        // the lanes of one instruction address distinct bins; steps follow each other in program order on ONE wave
+        if (lane != 32 && bin >= 0 && bin < a.n2d) sHist[bin] += v;
+      }
+    }
+  };
 
   // ---- q-tile schedule
   const int nqt = (a.T + 63) >> 6;
@@ -611,6 +701,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     lds_dma_wait();
     __syncthreads();              // block n has landed; everyone is done with block n-1 (and the table init)
     if (n + 1 < nblk) issue(ib + 32, (n + 1) & 1);
+    if (rowseg) {
+      if (n > 0 && wv == ((n - 1) & 3)) seg_duty((n - 1) & 1);       // the terms of block n-1, by one wave
+      if (lane == 0) sXc[((n & 1) * 4 + wv) * XW] = __int_as_float(0);   // this wave's slot of block n: empty so far
+    }
     {
       const bool skip = (kw >= a.S) || (a.causal && wave_kgrid && ((ib + 31 < kw) || (ib >= a.P)));
       if (skip) continue;
@@ -623,7 +717,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       //     its gradient the sum of dS.  P % 32 == 0 and 32-key waves: a block lies entirely on one side.
       //   3 no relative bias at all (cross attention), not causal
       const bool qb_text = ib >= a.P;
+      //   4 grid x grid on a grid of another width that is a multiple of 8 (see `rowseg` above)
       const int cls = (row32 && fast == 1) ? 1
+                    : (rowseg && fast == 1) ? 4
                     : (a.rel_mode && ((qb_grid && kw >= a.P) || (qb_text && wave_kgrid))) ? 2
                     : (!a.rel_mode && !a.causal) ? 3 : 0;
       const bool edge = (ib + 32 > a.T) || (kw + 32 > a.S);      // rows / keys past the end: masked element-wise
@@ -643,7 +739,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         dp[rg * 4] = d4.x; dp[rg * 4 + 1] = d4.y; dp[rg * 4 + 2] = d4.z; dp[rg * 4 + 3] = d4.w;
       }
       const bool seeded = cls == 1;
-      int hidx_rw = 0;
+      int hidx_rw = 0, seg_c0 = 0, seg_nq0 = 4;
       float hold = 0.f;
       if (seeded) {
         // the block's queries are one grid row: the bias of element r sits at a constant offset from one address
@@ -655,6 +751,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         // histogram bin this lane updates at the end of the block: (code_i - cj0) is dx = 0 of this (query row, key row)
         hidx_rw = code_i - cj0 + (lane < 32 ? -lane : 64 - lane);
         hold = sHist[lane != 32 ? hidx_rw : 0];
+      } else if (cls == 4) {
+        // one table address per group of 8 queries; nq0 = groups in the block's first grid row
+        int cg[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) cg[rg] = sGc[ib + 8 * rg];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const float* tp = sTbl + (cg[rg] - cj + 4 * half);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[rg * 4 + e] = tp[e];
+        }
+        seg_c0 = __builtin_amdgcn_readfirstlane(cg[0]);
+        seg_nq0 = 1 + (cg[1] - cg[0] == 8) + (cg[2] - cg[0] == 16) + (cg[3] - cg[0] == 24);
+        seg_nq0 = __builtin_amdgcn_readfirstlane(seg_nq0);
       } else {
         const float c0 = cls == 2 ? (qb_grid ? relx0 : relx1) : 0.f;
 #pragma unroll
@@ -727,7 +837,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
             if (qb_grid) gx0 += g; else gx1 += g;
           }
         };
-        if (cls == 1) {
+        if (cls == 1 || cls == 4) {
           // only blocks crossing the diagonal hold masked elements (blocks entirely above it were skipped)
           if (a.causal && kw + 31 > ib) body(std::integral_constant<int, 3>{}); else body(std::integral_constant<int, 1>{});
         } else if (cls == 2) {
@@ -887,8 +997,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         // plain read-modify-write: between two barriers the four waves work on the same query row and four different
         // key rows, i.e. on four different rows of the table (an LDS float atomic costs ~30 us per layer here)
         if (lane != 32) sHist[hidx_rw] = hold + tot;
+      } else if (cls == 4) {
+        // class sums of the query groups in the block's first grid row (set 0) and in its second (set 1)
+        float c0[4], c1[4];
+        switch (seg_nq0) {
+          case 1: seg_sums<0, 4>(hval, mk, c0); seg_sums<4, 16>(hval, mk, c1); break;
+          case 2: seg_sums<0, 8>(hval, mk, c0); seg_sums<8, 16>(hval, mk, c1); break;
+          case 3: seg_sums<0, 12>(hval, mk, c0); seg_sums<12, 16>(hval, mk, c1); break;
+          default: seg_sums<0, 16>(hval, mk, c0); seg_sums<16, 16>(hval, mk, c1); break;
+        }
+        // {T, W, K, WK} -> (no wrap, wrap) sums per row offset d = [query in 2nd row] - [key in 2nd row]:
+        //   set 0: first-row keys d = 0, second-row keys d = -1;  set 1: first-row keys d = +1, second-row keys d = 0
+        const float nw[3] = {c0[2] - c0[3], (c0[0] - c0[1] - c0[2] + c0[3]) + (c1[2] - c1[3]), c1[0] - c1[1] - c1[2] + c1[3]};
+        const float wr[3] = {c0[3], (c0[1] - c0[3]) + c1[3], c1[1] - c1[3]};
+        float* xs = sXc + ((n & 1) * 4 + wv) * XW;
+        const bool lo = lane < 32, in = (lane & 31) <= 27;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          // (as on the 32-wide grid) half 1 holds its bins 4 lanes further on; lanes 0..31 end up with the dx = -u
+          // totals, lanes 32..63 with the dx = 32 - u ones
+          const float ra = rot32<4>(nw[d]), rb = rot32<4>(wr[d]);
+          const float a2 = lo ? nw[d] : (in ? ra : 0.f), b2 = lo ? wr[d] : (in ? rb : ra);
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a2), __float_as_uint(b2), false, false);
+          xs[4 + d * 64 + lane] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        if (lane == 0) { xs[1] = __int_as_float(seg_c0 - cj0); xs[0] = __int_as_float(1); }
       }
     }
+  }
+  if (rowseg && nblk > 0) {
+    __syncthreads();
+    if (wv == ((nblk - 1) & 3)) seg_duty((nblk - 1) & 1);
   }
 
   // ---- write dV, dK, dpos_k partial: lane = key, reg r <-> column (r&3) + 8*(r>>2) + 4*half
@@ -965,6 +1104,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   }
   const float nlse_q = qvalid ? -a.lse[((long long)b * a.H + h) * a.T + qi] : -INFINITY;   // log2 units
   const bool row32 = a.rel_mode && a.grid_w == 32;
+  const bool rowseg = a.rel_mode && !row32 && a.grid_w >= 32 && (a.grid_w & 7) == 0;    // see the forward kernel
   const float del_q = qvalid ? a.delta[((long long)b * a.H + h) * a.T + qi] : 0.f;
   if (a.rel_mode) {
     // the table is kept REVERSED in LDS (sTbl[n2d - 1 - i] = rel2d[i]): a lane is a query and its registers are keys of
@@ -1079,6 +1219,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[rg * 4 + e] = tp[8 * rg + e];
           sdp_mfma();
+        } else if (fast == 1 && rowseg) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const float* tp = sTbl + (ciR + sGc[j0 + kb * 32 + 8 * rg] + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[rg * 4 + e] = tp[e];
+          }
+          sdp_mfma();
         } else {
           // (its own MFMA chain: see the forward kernel)
 #pragma unroll
@@ -1113,7 +1261,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
           }
           dsf[0] = ud[0].b; dsf[1] = ud[1].b;
         };
-        if (fast == 1 && row32) {            // bias already in s (seeded accumulator)
+        if (fast == 1 && (row32 || rowseg)) {            // bias already in s (seeded accumulator)
           // only blocks crossing the diagonal hold masked elements (blocks entirely above it were skipped)
           if (a.causal && j0 + kb * 32 + 31 > qw_u) straight(std::integral_constant<int, 1>{});
           else straight(std::integral_constant<int, 0>{});
@@ -1451,7 +1599,7 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   }
   const size_t n2dp = ((size_t)a.n2d + 3) & ~(size_t)3;
   const size_t n1dp = a.rel_mode ? (((size_t)(2 * a.Lt - 1) + 3) & ~(size_t)3) : 0;
-  const size_t lds_kv = (KT_BYTES + VT_BYTES + 512) + 2 * VT_BYTES + (a.rel_mode ? (2 * n2dp + 4 * n1dp + 8) * 4 + (size_t)a.P * 4 : 0);
+  const size_t lds_kv = (KT_BYTES + VT_BYTES + 512) + 2 * VT_BYTES + (a.rel_mode ? (2 * n2dp + 4 * n1dp + 8) * 4 + (((size_t)a.P + 3) & ~(size_t)3) * 4 + 2 * 4 * (4 + 3 * 64) * 4 : 0);
   const size_t lds_q = 2 * (KT_BYTES + VT_BYTES) + (a.rel_mode ? n2dp * 4 + (size_t)a.P * 4 : 0);
   if (lds_kv > 160 * 1024 || lds_q > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
   const bool do_kv = ph & IFSEG_ATTN_BWD_DKV, do_q = ph & IFSEG_ATTN_BWD_DQ;

@@ -135,7 +135,8 @@ def _grid_codes(gh, gw):
     return code, (gh - 1) * (2 * gw - 1) + (gw - 1), (2 * gh - 1) * (2 * gw - 1)
 
 
-@pytest.mark.parametrize("case", ["cross", "enc_rel", "dec_causal", "dec_full", "dense_nopos", "big_enc", "dec_causal_bh8"])
+@pytest.mark.parametrize("case", ["cross", "enc_rel", "dec_causal", "dec_full", "dense_nopos", "big_enc", "dec_causal_bh8",
+                                  "enc_w40", "dec_w40", "enc_w48"])
 def test_attn_fwd(case):
     from ifseg_amd import hip
     dev = _dev()
@@ -172,6 +173,13 @@ def test_attn_fwd(case):
         T = S = P + Lt
         H = 12
         B = 1
+    elif case in ("enc_w40", "dec_w40", "enc_w48"):
+        # grids whose width is a multiple of 8 but not 32 (SegOFA-Large at 640^2: 40 x 40): seeds per group of 8 keys
+        gh, gw = (16, 40) if case != "enc_w48" else (8, 48)
+        P, Lt = gh * gw, (1 if case == "dec_w40" else 37)
+        T = S = P + Lt
+        causal = case == "dec_w40"
+    wide = case in ("dec_causal_bh8", "enc_w40", "dec_w40", "enc_w48")
     C = H * 64
     q, k, v = _rand((B, T, C), dev, 20, 0.35), _rand((B, S, C), dev, 21), _rand((B, S, C), dev, 22)
     pq, pk = (_rand((T, C), dev, 23, 0.35), _rand((S, C), dev, 24)) if use_pos else (None, None)
@@ -182,7 +190,7 @@ def test_attn_fwd(case):
         rel2d = torch.randn(H, n2d, generator=g)
         rel1d = torch.randn(H, 2 * Lt - 1, generator=g)
         relx = torch.randn(H, 2, generator=g)
-        rel = hip.RelBias(P, gcode.to(dev), code_bias, rel2d.to(dev), rel1d.to(dev), relx.to(dev), grid_w=gw if case == "dec_causal_bh8" else 0)
+        rel = hip.RelBias(P, gcode.to(dev), code_bias, rel2d.to(dev), rel1d.to(dev), relx.to(dev), grid_w=gw if wide else 0)
         bias = _dense_rel(H, T, S, P, gcode.long(), code_bias, rel2d, rel1d, relx)
     if case == "dense_nopos":
         g = torch.Generator().manual_seed(31)
@@ -201,7 +209,8 @@ def test_attn_fwd(case):
 
 
 # ----------------------------------------------------------------------------- attention backward
-@pytest.mark.parametrize("case", ["cross", "enc_rel", "dec_causal", "dec_full", "big_enc", "dec_wide", "dec_causal_bh8"])
+@pytest.mark.parametrize("case", ["cross", "enc_rel", "dec_causal", "dec_full", "big_enc", "dec_wide", "dec_causal_bh8",
+                                  "enc_w40", "dec_w40", "enc_w48"])
 def test_attn_bwd(case):
     from ifseg_amd import hip
     dev = _dev()
@@ -231,6 +240,13 @@ def test_attn_bwd(case):
         gh, gw, P, Lt = 8, 40, 320, 1  # so the bos key shares a 128-key tile with grid keys
         T = S = P + Lt
         causal = True
+    elif case in ("enc_w40", "dec_w40", "enc_w48"):
+        # widths that are multiples of 8 but not 32: blocks and waves that straddle grid rows in every combination
+        # (gradient of the rel-pos table by per-class sums of the rotated terms, csrc/attention.hip `rowseg`)
+        gh, gw = (16, 40) if case != "enc_w48" else (8, 48)
+        P, Lt = gh * gw, (1 if case == "dec_w40" else 37)
+        T = S = P + Lt
+        causal = case == "dec_w40"
     C = H * 64
     q, k, v = _rand((B, T, C), dev, 20, 0.35), _rand((B, S, C), dev, 21), _rand((B, S, C), dev, 22)
     pq, pk = _rand((T, C), dev, 23, 0.35), _rand((S, C), dev, 24)
@@ -305,6 +321,16 @@ def test_attn_bwd(case):
     print(case, {k_: round(v_, 5) for k_, v_ in errs.items()})
     for k_, v_ in errs.items():
         assert v_ < 2e-2, (k_, v_)
+    if rel is not None and gw >= 32 and gw % 8 == 0:
+        # bit-reproducible: no float atomics on any grid width that is a multiple of 8
+        keep = [t.clone() for t in parts] + [dq.clone(), dk.clone(), dv.clone()]
+        for _ in range(3):
+            hip.attn_bwd(q, k, v, pq, pk, out, dout, lse, delta, dq, dk, dv, dpq, dpk, B, H, T, S, rel=rel, causal=causal,
+                         gain=gain, dq_scale=0.5, dpq_scale=0.25, drel2d_part=parts[0], drel1d_part=parts[1],
+                         drelx_part=parts[2], nparts=nparts)
+            torch.cuda.synchronize()
+            for a_, b_ in zip(keep, parts + [dq, dk, dv]):
+                assert torch.equal(a_, b_)
 
 
 def _dense_rel_ad(H, T, S, P, gcode, code_bias, rel2d, rel1d, relx):
