@@ -62,16 +62,55 @@ class ArenaReducer:
         import os
         self.bucket = int(float(os.environ.get("IFSEG_BUCKET_MB", "48")) * (1 << 20)) // max(1, flat.element_size())
         self._open = None               # [lo, hi) of the bucket being filled
+        # IFSEG_REDUCE_MODE: "direct" (default on the nccl backend: ifseg_amd/rccl.py, collectives enqueued in the calling
+        # stream), "c10d" (torch.distributed's async all_reduce on its internal stream), and for measurements "none",
+        # "fake-extra-stream", "fake-same-stream"
+        self.mode = os.environ.get("IFSEG_REDUCE_MODE", "direct")
+        self.direct = None
+        if self.mode == "direct" and dist.is_initialized() and dist.get_backend() == "nccl" and flat.is_cuda:
+            from .rccl import RcclComm
+            self.direct = RcclComm(flat.device)
         # gloo (functional runs: N ranks on one GPU, CPU tests) has no bf16 device reduction: staged through fp32 host
         # memory, synchronously.  The production backend is "nccl" (= RCCL over xGMI), asynchronous on its own stream.
         self.staged = dist.is_initialized() and dist.get_backend() == "gloo" and flat.is_cuda
 
     def _reduce(self, lo, hi):
+        mode = self.mode
+        if mode == "none":                                   # (measurement only: tools/rccl_phase_probe.py)
+            return
         if self.staged:
             torch.cuda.current_stream().synchronize()       # the hook runs in weight-gradient-stream order
             cpu = self.flat[lo:hi].float().cpu()
             dist.all_reduce(cpu)
             self.flat[lo:hi].copy_(cpu)
+        elif self.direct is not None:
+            # RCCL's C API, on the CURRENT stream (the weight-gradient stream inside the backward, the main stream in
+            # finish()): stream-ordered behind the kernels that produced the slice, nothing to wait for afterwards
+            if self.fp32:
+                wide = self.flat[lo:hi].float()
+                self.direct.all_reduce_(wide)
+                self.flat[lo:hi].copy_(wide)                # one rounding, after the fp32 sum
+            else:
+                self.direct.all_reduce_(self.flat[lo:hi])
+        elif mode.startswith("fake"):
+            # the stream choreography of an async c10d collective WITHOUT any collective (measurement only): an extra
+            # stream waits for the caller's stream and records an end event that finish() makes the main stream wait for
+            if getattr(self, "_comm", None) is None:
+                self._comm = torch.cuda.current_stream() if mode == "fake-same-stream" else torch.cuda.Stream()
+                self._fake_events, self._fei = [torch.cuda.Event() for _ in range(64)], 0
+            ev, end = self._fake_events[self._fei % 64], self._fake_events[(self._fei + 1) % 64]
+            self._fei += 2
+            ev.record()
+            self._comm.wait_event(ev)
+            end.record(self._comm)
+
+            class _W:
+                def __init__(s_, e):
+                    s_.e = e
+
+                def wait(s_):
+                    torch.cuda.current_stream().wait_event(s_.e)
+            self.works.append(_W(end))
         elif self.fp32:
             wide = self.flat[lo:hi].float()
             self._wide.append((lo, hi, wide))

@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # see bench.py
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -54,16 +55,17 @@ def run(forced, nsteps=6, timed=30):
     torch.cuda.synchronize()
     ms = (time.time() - t0) / timed * 1e3
     nred = len(tr.reducer.slices)
+    mode = "direct" if tr.reducer.direct is not None else tr.reducer.mode
     del tr, model
     torch.cuda.empty_cache()
-    return losses, state, ms, nred
+    return losses, state, ms, nred, mode
 
 
-l0, s0, ms0, _ = run(False)
-l1, s1, ms1, nred = run(True)
+l0, s0, ms0, _, _ = run(False)
+l1, s1, ms1, nred, mode = run(True)
 res = {"losses_equal": l0 == l1, "g16_equal": bool(torch.equal(s0[0], s1[0])), "p16_equal": bool(torch.equal(s0[1], s1[1])),
        "p32_equal": bool(torch.equal(s0[2], s1[2])), "ms_plain": ms0, "ms_rccl": ms1, "slices": nred,
-       "backend": dist.get_backend()}
+       "backend": dist.get_backend(), "reduce_mode": mode}
 with open(outfile, "w") as f:
     json.dump(res, f)
 dist.destroy_process_group()

@@ -385,7 +385,8 @@ def test_rccl_world1_hooked_step_is_bit_equal_and_not_slower(tmp_path):
             log = p.communicate()[0]
     assert p.returncode == 0, log[-4000:]
     r = json.load(open(out))
-    print("RCCL world-1 leg: %d slices reduced per step; step %.3f ms hooked vs %.3f ms plain" % (r["slices"], r["ms_rccl"], r["ms_plain"]))
+    print("RCCL world-1 leg (%s): %d slices reduced per step; step %.3f ms hooked vs %.3f ms plain" % (r["reduce_mode"], r["slices"], r["ms_rccl"], r["ms_plain"]))
+    assert r["reduce_mode"] == "direct"           # ifseg_amd/rccl.py: collectives enqueued in the weight-gradient stream
     assert r["backend"] == "nccl" and r["losses_equal"] and r["g16_equal"] and r["p16_equal"] and r["p32_equal"], r
     assert r["ms_rccl"] <= 1.03 * r["ms_plain"] + 0.3, r
 
