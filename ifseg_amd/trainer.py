@@ -256,6 +256,8 @@ class Trainer:
             cpu = buf.cpu()
             dist.all_reduce(cpu)
             buf = cpu.to(self.device)
+        elif getattr(self.reducer, "direct", None) is not None:
+            self.reducer.direct.all_reduce_(buf)                # RCCL on the current stream: no c10d stream inside a step
         else:
             dist.all_reduce(buf)
         out, o = [dict(lg) for lg in logs], 0
