@@ -22,11 +22,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The step uses four streams of
-# its own; a process that also holds RCCL's streams then shares queues between them and kernels of DIFFERENT streams
-# serialise behind each other (measured with an initialised process group: 20.1 ms per step at 4 queues, 18.4 at 8 = the
-# single-process figure).  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -31,7 +31,6 @@ import torch
 import torch.nn.functional as F
 
 from ... import hip
-from ...streams import engine_streams
 from .config import image_rp_bucket, token_bucket_of_delta
 
 BF = torch.bfloat16
@@ -321,8 +320,7 @@ class HipEngine:
 
     def _wgrad_init(self):
         if self._side is None:
-            # process-wide streams measured NOT to share a hardware queue with the main stream or with each other
-            self._side = engine_streams(self.device)["side"]
+            self._side = torch.cuda.Stream(device=self.device)
             self._evs = [torch.cuda.Event() for _ in range(128)]
             self._evi = 0
 
@@ -368,7 +366,7 @@ class HipEngine:
     def _dq_stream_get(self):
         if getattr(self, "_dqs", None) is None:
             self._wgrad_init()
-            self._dqs = engine_streams(self.device)["dq"]
+            self._dqs = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("IFSEG_DQ_PRIO", "0")))
         return self._dqs
 
     @contextlib.contextmanager
@@ -435,7 +433,7 @@ class HipEngine:
         if self._trunk_stream is None:
             # high priority: the ~100 small convolutions must finish within the step they run under -- at normal priority
             # they were starved by the main / weight-gradient queues and the NEXT forward waited 2.6 ms for its features
-            self._trunk_stream = engine_streams(self.device)["trunk"]
+            self._trunk_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("IFSEG_TRUNK_PRIO", "-1")))
         cur = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(cur)                                   # the images were produced on the caller's stream

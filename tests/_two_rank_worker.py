@@ -8,7 +8,6 @@ rank, world, port, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # see bench.py
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
