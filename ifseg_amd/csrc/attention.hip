@@ -529,7 +529,7 @@ __device__ __forceinline__ void seg_sums(const float (&h)[16], unsigned mk, floa
 //       dK^T[c,key]   += Q_ext^T dS        (A = Q tile tr-reads,   B = dS regs)
 //     so the key stays in the lane for S, P, dS and both accumulators.
 template <bool HAS_POS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int blk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // two staging buffers of DKV_STAGE_BYTES (one 32-query block each) open the LDS image
   const int n2dp = (a.n2d + 3) & ~3, n1d = a.rel_mode ? 2 * a.Lt - 1 : 0, n1dp = (n1d + 3) & ~3;
@@ -548,10 +548,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int nkt = (a.S + 127) >> 7;
-  int bid = xcd_remap(blockIdx.x, nkt * a.H * a.B);
+  int bid = xcd_remap(blk, nkt * a.H * a.B);
   if (a.causal) {     // the tail tile (keys every query sees) and the early key tiles are the long workgroups: first
     int rank, bh;
-    causal_order(blockIdx.x, a.H * a.B, &rank, &bh);
+    causal_order(blk, a.H * a.B, &rank, &bh);
     bid = bh * nkt + (rank + nkt - 1) % nkt;
   }
   const int kt = bid % nkt, h = (bid / nkt) % a.H, b = bid / (nkt * a.H);
@@ -1062,7 +1062,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 //       S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (gain*dP^T - delta),
 //       dQ_ext^T[c,q] += K_ext^T dS^T  (A = K tile tr-reads, B = dS regs)
 template <bool HAS_POS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) { attn_bwd_dkv_body<HAS_POS>(a, blockIdx.x); }
+
+template <bool HAS_POS>
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int blk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   auto sKb = [&](int buf) { return smem + buf * (KT_BYTES + VT_BYTES); };
   auto sVb = [&](int buf) { return smem + buf * (KT_BYTES + VT_BYTES) + KT_BYTES; };
@@ -1074,10 +1077,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   int qt, h, b;
   if (a.causal) {
     int rank, bh;
-    causal_order(blockIdx.x, a.H * a.B, &rank, &bh);
+    causal_order(blk, a.H * a.B, &rank, &bh);
     qt = nq - 1 - rank; h = bh % a.H; b = bh / a.H;
   } else {
-    const int bid = xcd_remap(blockIdx.x, nq * a.H * a.B);
+    const int bid = xcd_remap(blk, nq * a.H * a.B);
     qt = bid % nq; h = (bid / nq) % a.H; b = bid / (nq * a.H);
   }
   const int q0 = qt * 128, qw = q0 + wave * 32;
@@ -1352,6 +1355,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   }
 }
 
+template <bool HAS_POS>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) { attn_bwd_dq_body<HAS_POS>(a, blockIdx.x); }
+
+// ONE launch for the whole attention backward: the dK/dV workgroups (key-stationary) followed by the dQ workgroups
+// (query-stationary) in one grid.  As two launches on two streams (round 2) the pair needed a cross-stream fork and join
+// around every attention (an event bubble on the main queue plus ~36 us of waiting for the dQ kernel, 18 x per step) and
+// a stream of its own -- and the GPU runs at most four queues concurrently, which the data-parallel step needs for RCCL.
+// The dQ workgroups are the shorter ones: dispatched last they fill the holes the last round of dK/dV workgroups leaves.
+template <bool HAS_POS>
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a, int n_dkv) {
+  if ((int)blockIdx.x < n_dkv) attn_bwd_dkv_body<HAS_POS>(a, blockIdx.x);
+  else attn_bwd_dq_body<HAS_POS>(a, (int)blockIdx.x - n_dkv);
+}
+
 // delta[b,h,t] = sum_d dO[b,t,h,d] * O[b,t,h,d]   (8 lanes per (row, head))
 __global__ void attn_delta_kernel(const bf16_t* o, const bf16_t* dO, float* delta, int B, int H, int T,
                                   long long o_bs, int ldo, long long do_bs, int lddo) {
@@ -1603,6 +1620,22 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   const size_t lds_q = 2 * (KT_BYTES + VT_BYTES) + (a.rel_mode ? n2dp * 4 + (size_t)a.P * 4 : 0);
   if (lds_kv > 160 * 1024 || lds_q > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
   const bool do_kv = ph & IFSEG_ATTN_BWD_DKV, do_q = ph & IFSEG_ATTN_BWD_DQ;
+  if (do_kv && do_q && !getenv("IFSEG_ATTN_BWD_TWO_LAUNCHES")) {
+    const size_t lds = lds_kv > lds_q ? lds_kv : lds_q;
+    const int n_dkv = nkt * a.H * a.B, n_dq = nq * a.H * a.B;
+    // (timed as the dK/dV family: 8 T S 64 flops per (b, h) = dV, dP, dK and dQ of the reference at head dim 64)
+    ifseg_prof_begin(IFSEG_K_ATTN_DKV, s, 8.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);
+    if (x->pos_q) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, dim3(n_dkv + n_dq), dim3(256), lds, s, a, n_dkv);
+    } else {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, dim3(n_dkv + n_dq), dim3(256), lds, s, a, n_dkv);
+    }
+    ifseg_prof_end(IFSEG_K_ATTN_DKV, s);
+    IFSEG_CHECK_LAUNCH();
+    return 0;
+  }
   if (x->pos_q) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);

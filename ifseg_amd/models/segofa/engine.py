@@ -1244,7 +1244,11 @@ class HipEngine:
             else:       # one event pair on the main stream around delta + dK/dV + dQ (bench.py's roofline object)
                 t0 = torch.cuda.Event(enable_timing=True)
                 t0.record()
-        if self.overlap and not os.environ.get("IFSEG_DQ_SERIAL"):
+        if os.environ.get("IFSEG_ATTN_BWD_TWO_STREAMS") is None:
+            # one launch: dK/dV workgroups followed by the dQ workgroups in one grid (csrc/attention.hip,
+            # attn_bwd_fused_kernel) -- no fork / join around the attention, no stream of its own
+            hip.attn_bwd(*args, phases=(hip.ATTN_BWD_DKV | hip.ATTN_BWD_DQ) if have_delta else 0, **kw)
+        elif self.overlap and not os.environ.get("IFSEG_DQ_SERIAL"):
             # dK/dV and dQ are independent once delta exists; each leaves its last round of workgroups partly
             # empty (864 workgroups on 512 slots), so they run on two streams and fill each other's holes
             if not have_delta:
