@@ -1363,6 +1363,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) { attn_
 // around every attention (an event bubble on the main queue plus ~36 us of waiting for the dQ kernel, 18 x per step) and
 // a stream of its own -- and the GPU runs at most four queues concurrently, which the data-parallel step needs for RCCL.
 // The dQ workgroups are the shorter ones: dispatched last they fill the holes the last round of dK/dV workgroups leaves.
+// MEASURED (round 3): slower than the two kernels on two streams -- 447 us on the encoder shape against 189 + 125 us alone,
+// 18.82 vs 17.89 ms per step: one kernel = one register allocation for both bodies (75 spilled SGPRs, scratch in the loop).
+// Off by default (IFSEG_ATTN_BWD_ONE_LAUNCH=1 selects it).
 template <bool HAS_POS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a, int n_dkv) {
   if ((int)blockIdx.x < n_dkv) attn_bwd_dkv_body<HAS_POS>(a, blockIdx.x);
@@ -1620,7 +1623,7 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   const size_t lds_q = 2 * (KT_BYTES + VT_BYTES) + (a.rel_mode ? n2dp * 4 + (size_t)a.P * 4 : 0);
   if (lds_kv > 160 * 1024 || lds_q > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
   const bool do_kv = ph & IFSEG_ATTN_BWD_DKV, do_q = ph & IFSEG_ATTN_BWD_DQ;
-  if (do_kv && do_q && !getenv("IFSEG_ATTN_BWD_TWO_LAUNCHES")) {
+  if (do_kv && do_q && getenv("IFSEG_ATTN_BWD_ONE_LAUNCH")) {      // measured slower than the two launches: see the kernel
     const size_t lds = lds_kv > lds_q ? lds_kv : lds_q;
     const int n_dkv = nkt * a.H * a.B, n_dq = nq * a.H * a.B;
     // (timed as the dK/dV family: 8 T S 64 flops per (b, h) = dV, dP, dK and dQ of the reference at head dim 64)

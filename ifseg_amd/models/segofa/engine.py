@@ -1244,9 +1244,11 @@ class HipEngine:
             else:       # one event pair on the main stream around delta + dK/dV + dQ (bench.py's roofline object)
                 t0 = torch.cuda.Event(enable_timing=True)
                 t0.record()
-        if os.environ.get("IFSEG_ATTN_BWD_TWO_STREAMS") is None:
+        if os.environ.get("IFSEG_ATTN_BWD_ONE_LAUNCH"):
             # one launch: dK/dV workgroups followed by the dQ workgroups in one grid (csrc/attention.hip,
-            # attn_bwd_fused_kernel) -- no fork / join around the attention, no stream of its own
+            # attn_bwd_fused_kernel).  Measured SLOWER than the two kernels side by side on two streams (round 3: 18.82 vs
+            # 17.89 ms per step; encoder shape alone 447 us vs 189 + 125 us): compiled as one kernel the two bodies share a
+            # register allocation (75 spilled SGPRs, 36 bytes of scratch per lane in the loop).  Kept selectable.
             hip.attn_bwd(*args, phases=(hip.ATTN_BWD_DKV | hip.ATTN_BWD_DQ) if have_delta else 0, **kw)
         elif self.overlap and not os.environ.get("IFSEG_DQ_SERIAL"):
             # dK/dV and dQ are independent once delta exists; each leaves its last round of workgroups partly

@@ -44,7 +44,7 @@ def main(kind="enc", iters=5):
     torch.cuda.synchronize()
     for kd in (4, 5, 6):
         p = hip.prof_read(kd)
-        print(kind, p["kind"], "avg us %.1f" % (p["ms"] * 1e3 / max(1, p["launches"])), "alg TF/s %.1f" % (p["flops"] / (p["ms"] * 1e-3) / 1e12))
+        print(kind, p["kind"], "avg us %.1f" % (p["ms"] * 1e3 / max(1, p["launches"])), "alg TF/s %.1f" % (p["flops"] / max(1e-9, p["ms"] * 1e-3) / 1e12))
     hip.prof_enable(0)
     def bwd(phases):
         hip.attn_bwd(q, k, v, pq, pk, out, dout, lse, delta, dqkv[:, :, :C], dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:], dpq, dpk,
