@@ -81,6 +81,9 @@ class HipEngine:
         self.dw_grouped = os.environ.get("IFSEG_NO_DW_GROUP") is None
         self.dw_split = os.environ.get("IFSEG_DW_SPLIT", "0") == "1"
         self.attn_bwd_timing = None      # {"stride": n, "seen": 0, "pairs": []} while bench.py times the attention backward
+        # where the NEXT batch's frozen-trunk pass is launched: "fwd" = at the start of this step's forward, "e<k>" = when
+        # the backward reaches encoder layer k, "end" = after the last backward kernel of the main stream
+        self.trunk_at = os.environ.get("IFSEG_TRUNK_AT", "fwd")
         self._bt = ""                    # tag of the backward block being processed (unique gradient buffers)
 
     # ------------------------------------------------------------------ packing
@@ -722,7 +725,9 @@ class HipEngine:
                 raise RuntimeError("aux_input: %d bags for a batch of %d x %dx%d patches" % (bag[1].numel(), B, h, w))
         else:
             feat, h, w = self._trunk(patch_images)
-            if self._pf_request is not None:  # the next batch's trunk starts once this batch's features are taken
+            # the next batch's trunk starts once this batch's features are taken -- or (IFSEG_TRUNK_AT=e<k> / end) later,
+            # inside this step's backward, see `_trunk_launch_point`
+            if self._pf_request is not None and (self.trunk_at == "fwd" or not need_grad):
                 req, self._pf_request = self._pf_request, None
                 self.prefetch_trunk(req)
         P = h * w
@@ -1441,6 +1446,8 @@ class HipEngine:
             p = "%slayers.%d." % (e, l)
             tg = "e%d" % l
             first = l == cfg.enc_layers - 1
+            if self.trunk_at == "e%d" % l:
+                self._trunk_launch_point()
             nx_f = self._next_drop("e%d" % (l - 1), B * T) if fuse and l > 0 else None
             dx = self._ffn_bwd(tg, p, dx, B * T, dbr_pre=dbr)
             dx = self._self_block_bwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", dx, B, T, ctx["e_pq"],
@@ -1454,8 +1461,17 @@ class HipEngine:
         # ---- encoder abs-pos operands
         self._bt = "etop"
         self._side_do(lambda: (self._dw_flush(), self._enc_tail_bwd(B, L, P, T, h, w, dx, depq, depk, pos_all, dpos_all)))
+        if self.trunk_at == "end":
+            self._trunk_launch_point()
         self._join_side()            # (flushes) the optimizer (main stream) reads the whole gradient arena next
         return self.g16
+
+    def _trunk_launch_point(self):
+        """the frozen trunk of the NEXT batch, launched from inside this step's backward: its ~90 convolutions then run
+        under the tail of the backward, the final join and the HBM-bound clip + Adam instead of under the next forward"""
+        if self._pf_request is not None and not torch.cuda.is_current_stream_capturing():
+            req, self._pf_request = self._pf_request, None
+            self.prefetch_trunk(req)
 
     def _enc_tail_bwd(self, B, L, P, T, h, w, dx, depq, depk, pos_all, dpos_all):
         """encoder abs-pos operands and embedding LayerNorms: parameter gradients only -- side stream"""
