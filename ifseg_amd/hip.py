@@ -33,7 +33,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 8:
+        if _lib.ifseg_abi_version() != 9:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -559,6 +559,24 @@ def rel_gather(table, idx, out):
     n, H = idx.numel(), table.shape[1]
     _check(lib().ifseg_rel_gather(_ptr(table), _ptr(idx), _ptr(out), c_int(n), c_int(H), _stream()), "rel_gather")
     return out
+
+
+def resized_rel_bias(out, table2d, rel1d, relx, h, w, oh, ow, Lt, causal=False):
+    """out fp32 [H, T, T] (T = h*w + Lt): the reference's doubly bilinear-resized rel-pos bias of a (h, w) grid from the delta
+    table of the trained (oh, ow) grid; tail blocks from rel1d / relx (None: zero)"""
+    H = out.shape[0]
+    _check(lib().ifseg_resized_rel_bias(_ptr(out), _ptr(table2d), _ptr(rel1d), _ptr(relx), c_int(H), c_int(h), c_int(w),
+                                        c_int(oh), c_int(ow), c_int(Lt), c_int(1 if causal else 0), _stream()), "resized_rel_bias")
+    return out
+
+
+def resize_rows_bilinear(src, dst, h, w, oh, ow, src_stride, src_off):
+    """dst bf16 [h*w, C] = bilinear resize of the oh x ow grid of rows src[y * src_stride + x + src_off]"""
+    C = dst.shape[1]
+    _check(lib().ifseg_resize_rows_bilinear(_ptr(src), _ptr(dst), c_int(C), c_int(h), c_int(w), c_int(oh), c_int(ow),
+                                            c_int(src_stride), c_int(src_off), c_int(src.stride(0)), _stream()),
+           "resize_rows_bilinear")
+    return dst
 
 
 def rel_gather_multi(tables, idx, out):

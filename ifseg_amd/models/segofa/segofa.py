@@ -332,6 +332,7 @@ class SegOFAModel(ModelBase):
                 if n in state_dict:
                     eng.Wf(n).copy_(state_dict[n].to(eng.device, torch.float32).view(eng.shapes[n]))
             eng._master_stale = False
+            eng._wver += 1                  # cached resized rel-pos biases belong to the old weights
             eng._pack_resnet()
             eng.refresh_frozen()
         return out

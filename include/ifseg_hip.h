@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 8
+#define IFSEG_ABI_VERSION 9
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -270,6 +270,22 @@ int ifseg_rel_gather(const void* table, const int* idx, float* out, int n, int H
  * tables = host array of L device pointers, out fp32 [L][H][n] */
 int ifseg_rel_gather_multi(const void* const* tables, int L, const int* idx, float* out, int n, int H, void* stream);
 int ifseg_rel_scatter_add(const float* d, const int* idx, float* acc, int n, int H, void* stream);
+
+/* Variable-aspect evaluation (criterions/seg_criterion.py:194-217 feeds images at their native aspect ratio): the reference
+ * resizes its [H, P0, P0] relative-position bias with two bilinear interpolations per layer when the feature grid (h, w)
+ * differs from the trained (oh, ow) one (encoder_module.py:802-808, decoder_module.py:603-627).  out fp32 [H, T, T],
+ * T = h*w + Lt, internal order [grid | tail]: grid x grid = the doubly resized bias, evaluated as 4 x 4 taps of the ORIGINAL
+ * delta table table2d [H, (2oh-1)(2ow-1)] (ifseg_rel_gather on the original geometry); tail x tail = rel1d [H, 2Lt-1]
+ * (NULL: 0); grid x tail / tail x grid = relx [H, 2] (NULL: 0) -- the decoder's bos column / row, which the reference's
+ * resize passes through.  causal != 0 (decoder_module.py:592-600, buffered_future_mask in the internal order with the tail =
+ * bos first): -inf where the key lies after the query. */
+int ifseg_resized_rel_bias(float* out, const float* table2d, const float* rel1d, const float* relx, int H, int h, int w,
+                           int oh, int ow, int Lt, int causal, void* stream);
+/* dst bf16 [h*w, C] = bilinear resize (align_corners = False, fp32 arithmetic, one rounding) of the oh x ow grid of rows
+ * src[(y * src_stride + x + src_off) * ld_src + c]: the position-embedding tables of encoder_module.py:360-368 and
+ * decoder_module.py:541-548 on a resized grid */
+int ifseg_resize_rows_bilinear(const void* src, void* dst, int C, int h, int w, int oh, int ow, int src_stride, int src_off,
+                               int ld_src, void* stream);
 
 /* out = [resid +] drop_path_scale[row / rows_per_batch] * keep * x / (1 - p) on [rows, C] bf16 (row addressing as above);
  * keep ~ Bernoulli(1-p) from a counter-based hash of (seed, element): calling it again with x = dy,
