@@ -96,14 +96,14 @@ struct RelCtx {
 
 // Global -> LDS copy of a small table by a 256-thread workgroup with eight loads in flight per thread (a plain
 // `for (i = tid; i < n; i += 256)` loop issues one load per round trip: 16 serial L2 latencies for a 63 x 63 table).
-template <typename T, bool REVERSE = false>
+template <typename T, bool REVERSE = false, int NT = 256>
 __device__ __forceinline__ void stage_table(T* dst, const T* __restrict__ src, int n, int tid) {
-  for (int i0 = 0; i0 < n; i0 += 8 * 256) {
+  for (int i0 = 0; i0 < n; i0 += 8 * NT) {
     T v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256 + tid; v[u] = i < n ? src[i] : T(0); }
+    for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT + tid; v[u] = i < n ? src[i] : T(0); }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256 + tid; if (i < n) dst[REVERSE ? n - 1 - i : i] = v[u]; }
+    for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT + tid; if (i < n) dst[REVERSE ? n - 1 - i : i] = v[u]; }
   }
 }
 
@@ -528,26 +528,30 @@ __device__ __forceinline__ void seg_sums(const float (&h)[16], unsigned mk, floa
 //       dV^T[d,key]   += dO^T P            (A = dO tile tr-reads,  B = P regs)
 //       dK^T[c,key]   += Q_ext^T dS        (A = Q tile tr-reads,   B = dS regs)
 //     so the key stays in the lane for S, P, dS and both accumulators.
-template <bool HAS_POS>
+// NW = waves per workgroup (4 or 8): 32 NW keys per workgroup.  8 waves when the per-head tables make one 4-wave workgroup
+// exceed half of a CU's LDS (40 x 40 grids: 112 KiB) -- the 8 waves then SHARE one copy of the tables, two waves per SIMD
+// instead of one (the staging of the query blocks is done by the first four waves).
+template <bool HAS_POS, int NW>
 __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int blk) {
+  constexpr int NT = NW * 64;                     // threads
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // two staging buffers of DKV_STAGE_BYTES (one 32-query block each) open the LDS image
   const int n2dp = (a.n2d + 3) & ~3, n1d = a.rel_mode ? 2 * a.Lt - 1 : 0, n1dp = (n1d + 3) & ~3;
-  unsigned char* sVk = smem + KT_BYTES + VT_BYTES + 512;                       // V rows of this WG's 128 keys
-  float* sTbl = reinterpret_cast<float*>(sVk + 2 * VT_BYTES);                  // rel2d[h]
+  unsigned char* sVk = smem + KT_BYTES + VT_BYTES + 512;                       // V rows of this WG's 32 NW keys
+  float* sTbl = reinterpret_cast<float*>(sVk + (NW / 2) * VT_BYTES);           // rel2d[h]
   float* sHist = sTbl + n2dp;                                                  // d rel2d[h]
   // token-offset histogram and relx0 / relx1 accumulators: ONE COPY PER WAVE, summed in wave order at the end -- waves
   // adding to shared bins with LDS float atomics do so in an order that depends on their relative timing, and float
   // addition is not associative: the gradients then differ in the last bit from run to run
-  float* sHist1 = sHist + n2dp;       // [4][n1dp]
-  float* sX = sHist1 + 4 * n1dp;      // [4][2]
-  int* sGc = reinterpret_cast<int*>(sX + 8);
+  float* sHist1 = sHist + n2dp;       // [NW][n1dp]
+  float* sX = sHist1 + NW * n1dp;     // [NW][2]
+  int* sGc = reinterpret_cast<int*>(sX + 2 * NW);
   // general grid width: per-block exchange area of the rel-pos gradient terms, [2 buffers][4 waves][header 4 | 3 x 64]
   constexpr int XW = 4 + 3 * 64;
   float* sXc = reinterpret_cast<float*>(sGc + ((a.P + 3) & ~3));
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-  const int nkt = (a.S + 127) >> 7;
+  const int nkt = (a.S + 32 * NW - 1) / (32 * NW);
   int bid = xcd_remap(blk, nkt * a.H * a.B);
   if (a.causal) {     // the tail tile (keys every query sees) and the early key tiles are the long workgroups: first
     int rank, bh;
@@ -555,7 +559,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
     bid = bh * nkt + (rank + nkt - 1) % nkt;
   }
   const int kt = bid % nkt, h = (bid / nkt) % a.H, b = bid / (nkt * a.H);
-  const int k0 = kt * 128;
+  const int k0 = kt * 32 * NW;
   const int kw = __builtin_amdgcn_readfirstlane(k0 + wave * 32);
   const int kj = kw + (lane & 31);
   const bool kvalid = kj < a.S;
@@ -571,7 +575,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
     // V rows of the workgroup's keys live in LDS (frees 16 VGPRs/lane so two workgroups fit a CU)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = (tid >> 3) + 32 * i, c = tid & 7, j = k0 + r;
+      const int r = (tid >> 3) + (NT / 8) * i, c = tid & 7, j = k0 + r;
       uint4 v4 = make_uint4(0, 0, 0, 0);
       if (j < a.S) v4 = *reinterpret_cast<const uint4*>(a.v + (long long)b * a.v_bs + (long long)j * a.ldv + h * 64 + c * 8);
       // stored as -gain * V: with the dP accumulator seeded with delta the MFMAs leave delta - gain * dP = -(dS / P)
@@ -584,11 +588,11 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
     }
   }
   if (a.rel_mode) {
-    stage_table(sTbl, a.rel2d + (long long)h * a.n2d, a.n2d, tid);
-    stage_table(sGc, a.gcode, a.P, tid);
-    for (int i = tid; i < a.n2d; i += 256) sHist[i] = 0.f;
-    for (int i = tid; i < 4 * n1dp + 8; i += 256) sHist1[i] = 0.f;
-    for (int i = tid; i < 2 * 4 * XW; i += 256) sXc[i] = 0.f;
+    stage_table<float, false, NT>(sTbl, a.rel2d + (long long)h * a.n2d, a.n2d, tid);
+    stage_table<int, false, NT>(sGc, a.gcode, a.P, tid);
+    for (int i = tid; i < a.n2d; i += NT) sHist[i] = 0.f;
+    for (int i = tid; i < NW * n1dp + 2 * NW; i += NT) sHist1[i] = 0.f;
+    for (int i = tid; i < 2 * NW * XW; i += NT) sXc[i] = 0.f;
   }
   const bool k_grid = kj < a.P;
   const bool wave_kgrid = kw + 31 < a.P;
@@ -610,8 +614,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
   const unsigned mk = rowseg ? (unsigned)__builtin_amdgcn_ballot_w64(k_grid && (cj - cj0 != (lane & 31))) : 0u;
   auto seg_duty = [&](int buf) {
 #pragma unroll 1
-    for (int w = 0; w < 4; ++w) {
-      const float* xs = sXc + (buf * 4 + w) * XW;
+    for (int w = 0; w < NW; ++w) {
+      const float* xs = sXc + (buf * NW + w) * XW;
       if (__builtin_amdgcn_readfirstlane(__float_as_int(xs[0])) == 0) continue;
       const int bq = __builtin_amdgcn_readfirstlane(__float_as_int(xs[1])) + (lane < 32 ? -lane : 64 - lane);
 #pragma unroll
@@ -629,7 +633,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
   int qs = 0, qe = nqt;
   // causal: a pure-grid key tile is visible only to grid queries at or after it; a tile holding tail
   // keys (visible to every grid query) keeps the full range and relies on the per-wave skip below
-  if (a.causal && k0 + 127 < a.P) { qs = k0 >> 6; qe = a.P >> 6; }
+  if (a.causal && k0 + 32 * NW - 1 < a.P) { qs = k0 >> 6; qe = a.P >> 6; }
   const int nsched = qe - qs;
 
   const bf16_t* qb_ = a.q + (long long)b * a.q_bs + h * 64;
@@ -646,6 +650,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   auto issue = [&](int ib, int st) {
     const unsigned base = lds0 + st * STG;
+    if (NW > 4 && wv >= 4) return;          // (8-wave workgroups: the first four waves stage the query block)
     // lane constants derived from a re-materialised lane id on every call (six VGPRs less across the loop)
     int ln = lane;
     asm volatile("" : "+v"(ln));
@@ -702,8 +707,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
     __syncthreads();              // block n has landed; everyone is done with block n-1 (and the table init)
     if (n + 1 < nblk) issue(ib + 32, (n + 1) & 1);
     if (rowseg) {
-      if (n > 0 && wv == ((n - 1) & 3)) seg_duty((n - 1) & 1);       // the terms of block n-1, by one wave
-      if (lane == 0) sXc[((n & 1) * 4 + wv) * XW] = __int_as_float(0);   // this wave's slot of block n: empty so far
+      if (n > 0 && wv == ((n - 1) & (NW - 1))) seg_duty((n - 1) & 1);       // the terms of block n-1, by one wave
+      if (lane == 0) sXc[((n & 1) * NW + wv) * XW] = __int_as_float(0);   // this wave's slot of block n: empty so far
     }
     {
       const bool skip = (kw >= a.S) || (a.causal && wave_kgrid && ((ib + 31 < kw) || (ib >= a.P)));
@@ -1010,7 +1015,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
         //   set 0: first-row keys d = 0, second-row keys d = -1;  set 1: first-row keys d = +1, second-row keys d = 0
         const float nw[3] = {c0[2] - c0[3], (c0[0] - c0[1] - c0[2] + c0[3]) + (c1[2] - c1[3]), c1[0] - c1[1] - c1[2] + c1[3]};
         const float wr[3] = {c0[3], (c0[1] - c0[3]) + c1[3], c1[1] - c1[3]};
-        float* xs = sXc + ((n & 1) * 4 + wv) * XW;
+        float* xs = sXc + ((n & 1) * NW + wv) * XW;
         const bool lo = lane < 32, in = (lane & 31) <= 27;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -1027,7 +1032,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
   }
   if (rowseg && nblk > 0) {
     __syncthreads();
-    if (wv == ((nblk - 1) & 3)) seg_duty((nblk - 1) & 1);
+    if (wv == ((nblk - 1) & (NW - 1))) seg_duty((nblk - 1) & 1);
   }
 
   // ---- write dV, dK, dpos_k partial: lane = key, reg r <-> column (r&3) + 8*(r>>2) + 4*half
@@ -1049,12 +1054,30 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
     gx0 = warp_sum(gx0); gx1 = warp_sum(gx1);
     if (lane == 0) { sX[wv * 2] = gx0; sX[wv * 2 + 1] = gx1; }
     __syncthreads();
-    const int part = b * nkt + kt;
+    // partial slots are per 128 keys (nparts = B * ceil(S / 128)): an 8-wave workgroup fills the first of its two slots
+    // and clears the second
+    const int np128 = (a.S + 127) >> 7;
+    const int part = b * np128 + kt * (NW / 4);
     float* o2 = a.drel2d_part + ((long long)h * a.nparts + part) * a.n2d;
-    for (int i = tid; i < a.n2d; i += 256) o2[i] = sHist[i];
+    for (int i = tid; i < a.n2d; i += NT) o2[i] = sHist[i];
     float* o1 = a.drel1d_part + ((long long)h * a.nparts + part) * n1d;
-    for (int i = tid; i < n1d; i += 256) o1[i] = (sHist1[i] + sHist1[n1dp + i]) + (sHist1[2 * n1dp + i] + sHist1[3 * n1dp + i]);
-    if (tid < 2) a.drelx_part[((long long)h * a.nparts + part) * 2 + tid] = (sX[tid] + sX[2 + tid]) + (sX[4 + tid] + sX[6 + tid]);
+    for (int i = tid; i < n1d; i += NT) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += sHist1[w * n1dp + i];
+      o1[i] = t;
+    }
+    if (tid < 2) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += sX[2 * w + tid];
+      a.drelx_part[((long long)h * a.nparts + part) * 2 + tid] = t;
+    }
+    if (NW == 8 && kt * 2 + 1 < np128) {
+      for (int i = tid; i < a.n2d; i += NT) o2[a.n2d + i] = 0.f;
+      for (int i = tid; i < n1d; i += NT) o1[n1d + i] = 0.f;
+      if (tid < 2) a.drelx_part[((long long)h * a.nparts + part + 1) * 2 + tid] = 0.f;
+    }
   }
 }
 
@@ -1062,7 +1085,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
 //       S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (gain*dP^T - delta),
 //       dQ_ext^T[c,q] += K_ext^T dS^T  (A = K tile tr-reads, B = dS regs)
 template <bool HAS_POS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) { attn_bwd_dkv_body<HAS_POS>(a, blockIdx.x); }
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) { attn_bwd_dkv_body<HAS_POS, 4>(a, blockIdx.x); }
+template <bool HAS_POS>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv8_kernel(AttnArgs a) { attn_bwd_dkv_body<HAS_POS, 8>(a, blockIdx.x); }
 
 template <bool HAS_POS>
 __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int blk) {
@@ -1368,7 +1393,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) { attn_
 // Off by default (IFSEG_ATTN_BWD_ONE_LAUNCH=1 selects it).
 template <bool HAS_POS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a, int n_dkv) {
-  if ((int)blockIdx.x < n_dkv) attn_bwd_dkv_body<HAS_POS>(a, blockIdx.x);
+  if ((int)blockIdx.x < n_dkv) attn_bwd_dkv_body<HAS_POS, 4>(a, blockIdx.x);
   else attn_bwd_dq_body<HAS_POS>(a, (int)blockIdx.x - n_dkv);
 }
 
@@ -1619,11 +1644,17 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   }
   const size_t n2dp = ((size_t)a.n2d + 3) & ~(size_t)3;
   const size_t n1dp = a.rel_mode ? (((size_t)(2 * a.Lt - 1) + 3) & ~(size_t)3) : 0;
-  const size_t lds_kv = (KT_BYTES + VT_BYTES + 512) + 2 * VT_BYTES + (a.rel_mode ? (2 * n2dp + 4 * n1dp + 8) * 4 + (((size_t)a.P + 3) & ~(size_t)3) * 4 + 2 * 4 * (4 + 3 * 64) * 4 : 0);
+  auto lds_kv_of = [&](int nw) {
+    return (size_t)(KT_BYTES + VT_BYTES + 512) + (nw / 2) * VT_BYTES +
+           (a.rel_mode ? (2 * n2dp + nw * n1dp + 2 * nw) * 4 + (((size_t)a.P + 3) & ~(size_t)3) * 4 + (size_t)2 * nw * (4 + 3 * 64) * 4 : 0);
+  };
+  // 8-wave workgroups (one copy of the tables for twice the waves) when a 4-wave workgroup takes more than half a CU's LDS
+  const bool dkv8 = a.rel_mode && lds_kv_of(4) > 80 * 1024 && lds_kv_of(8) <= 160 * 1024 && !getenv("IFSEG_ATTN_DKV_4WAVES");
+  const size_t lds_kv = lds_kv_of(dkv8 ? 8 : 4);
   const size_t lds_q = 2 * (KT_BYTES + VT_BYTES) + (a.rel_mode ? n2dp * 4 + (size_t)a.P * 4 : 0);
   if (lds_kv > 160 * 1024 || lds_q > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
   const bool do_kv = ph & IFSEG_ATTN_BWD_DKV, do_q = ph & IFSEG_ATTN_BWD_DQ;
-  if (do_kv && do_q && getenv("IFSEG_ATTN_BWD_ONE_LAUNCH")) {      // measured slower than the two launches: see the kernel
+  if (do_kv && do_q && !dkv8 && getenv("IFSEG_ATTN_BWD_ONE_LAUNCH")) {      // measured slower than the two launches: see the kernel
     const size_t lds = lds_kv > lds_q ? lds_kv : lds_q;
     const int n_dkv = nkt * a.H * a.B, n_dq = nq * a.H * a.B;
     // (timed as the dK/dV family: 8 T S 64 flops per (b, h) = dV, dP, dK and dQ of the reference at head dim 64)
@@ -1644,7 +1675,12 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
     if (do_kv) {
       ifseg_prof_begin(IFSEG_K_ATTN_DKV, s, 6.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);   // dV, dP, dK of the reference
-      hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(nkt * a.H * a.B), dim3(256), lds_kv, s, a);
+      if (dkv8) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+        hipLaunchKernelGGL(attn_bwd_dkv8_kernel<true>, dim3(((a.S + 255) / 256) * a.H * a.B), dim3(512), lds_kv, s, a);
+      } else {
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(nkt * a.H * a.B), dim3(256), lds_kv, s, a);
+      }
       ifseg_prof_end(IFSEG_K_ATTN_DKV, s);
     }
     if (do_q) {
@@ -1655,7 +1691,14 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   } else {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-    if (do_kv) hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(nkt * a.H * a.B), dim3(256), lds_kv, s, a);
+    if (do_kv) {
+      if (dkv8) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+        hipLaunchKernelGGL(attn_bwd_dkv8_kernel<false>, dim3(((a.S + 255) / 256) * a.H * a.B), dim3(512), lds_kv, s, a);
+      } else {
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(nkt * a.H * a.B), dim3(256), lds_kv, s, a);
+      }
+    }
     if (do_q) hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(nq * a.H * a.B), dim3(256), lds_q, s, a);
   }
   IFSEG_CHECK_LAUNCH();

@@ -210,7 +210,7 @@ def test_attn_fwd(case):
 
 # ----------------------------------------------------------------------------- attention backward
 @pytest.mark.parametrize("case", ["cross", "enc_rel", "dec_causal", "dec_full", "big_enc", "dec_wide", "dec_causal_bh8",
-                                  "enc_w40", "dec_w40", "enc_w48"])
+                                  "enc_w40", "dec_w40", "enc_w48", "enc_w40_full", "dec_w40_full"])
 def test_attn_bwd(case):
     from ifseg_amd import hip
     dev = _dev()
@@ -247,6 +247,13 @@ def test_attn_bwd(case):
         P, Lt = gh * gw, (1 if case == "dec_w40" else 37)
         T = S = P + Lt
         causal = case == "dec_w40"
+    elif case in ("enc_w40_full", "dec_w40_full"):
+        # the full 40 x 40 grid of SegOFA-Large at 640^2: the per-head tables (2 x 25 KB) push a 4-wave dK/dV workgroup
+        # past half a CU's LDS, so the 8-wave variant (256 keys per workgroup, one copy of the tables) runs
+        gh, gw, B = 40, 40, 1
+        P, Lt = 1600, (1 if case == "dec_w40_full" else 37)
+        T = S = P + Lt
+        causal = case == "dec_w40_full"
     C = H * 64
     q, k, v = _rand((B, T, C), dev, 20, 0.35), _rand((B, S, C), dev, 21), _rand((B, S, C), dev, 22)
     pq, pk = _rand((T, C), dev, 23, 0.35), _rand((S, C), dev, 24)
