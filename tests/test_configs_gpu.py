@@ -281,9 +281,9 @@ def test_large_full_depth_resnet152_vs_oracle():
     # 24 bf16 layers, 171 near-uniform classes, identical weights (measured: logits 1.0e-2, argmax 0.988 plain / 1.000 on
     # the decided positions): as for config 3
     assert e <= 2e-2 and agree >= 0.97 and decided >= 0.99 and consistent
-    # the forward is bit-deterministic; on a grid that is not 32 wide (40 x 40 here) the rel-pos table gradient is an LDS
-    # float-atomic histogram (csrc/attention.hip), so the gradient arena is reproducible to rounding, not bitwise
-    assert loss == loss2 and _rel(g1, g2) <= 1e-3 and torch.isfinite(g1.float()).all()
+    # bit-deterministic, forward and backward, on the 40 x 40 grid too: the rel-pos table gradient of grids that are not 32
+    # wide is reduced in registers and added to the table by one wave per block in a fixed order (csrc/attention.hip, `rowseg`)
+    assert loss == loss2 and torch.equal(g1, g2) and torch.isfinite(g1.float()).all()
     eng = m.engine
     dead = [n for n in eng.trainable_names() if eng.G(n).float().abs().sum().item() == 0]
     never = ("decoder.embed_positions", "decoder.embed_image_positions", "decoder.pos_ln", "decoder.image_pos_ln",
