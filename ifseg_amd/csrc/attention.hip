@@ -38,6 +38,7 @@ struct AttnArgs {
   int rel_mode, P, code_bias, n2d, Lt, causal;
   const int* gcode;
   const float *rel2d, *rel1d, *relx, *dense;
+  int dense_ld;               // row stride of `dense` [H, T, dense_ld] (>= S; a multiple of 4 enables the 16-byte seed loads)
   // backward
   const bf16_t* dO; long long do_bs; int lddo;
   const float* delta;
@@ -246,6 +247,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       // (cross attention): both take the straight-line path below.  P % 32 == 0: a wave lies on one side.
       const bool cbias = a.rel_mode && !a.dense && ((wave_grid && !tile_grid) || (qw_u >= a.P && tile_grid));
       const bool plain = cbias || (!a.rel_mode && !a.causal && !a.dense);
+      // a dense fp32 bias alone (resized-grid evaluation: the causal mask travels inside it): the lane's query row is fixed
+      // and its 16 keys are four runs of four, so the accumulator is seeded with four 16-byte loads per 32-key block
+      const bool dfast = a.dense && !a.rel_mode && !a.causal && !(a.dense_ld & 3);
       f32x16 s[2];
       auto s_mfma = [&]() {
 #pragma unroll
@@ -278,6 +282,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             const float* tp = sTbl + (ciR + sGc[j0 + kb * 32 + 8 * rg] + 4 * half);
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[kb][rg * 4 + e] = tp[e];
+          }
+        }
+        s_mfma();
+      } else if (dfast) {
+        const float* drow = a.dense + ((long long)h * a.T + qrow) * a.dense_ld;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int jb = j0 + kb * 32 + 8 * rg + 4 * half;
+            const float4 d4 = jb < a.dense_ld ? *reinterpret_cast<const float4*>(drow + jb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s[kb][rg * 4 + 0] = d4.x; s[kb][rg * 4 + 1] = d4.y; s[kb][rg * 4 + 2] = d4.z; s[kb][rg * 4 + 3] = d4.w;
           }
         }
         s_mfma();
@@ -331,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) m4[e & 3] = fmaxf(m4[e & 3], s[kb][e]);
         mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-      } else if (plain) {
+      } else if (plain || dfast) {
         if (j0 + 64 > a.S) {           // last tile: keys past S are masked
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb)
@@ -367,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 else bias = q_grid ? relx0 : ((j < a.S && qvalid) ? rel1d[ti - (j - a.P)] : 0.f);
                 sv += bias;
               }
-              if (a.dense && j < a.S) sv += a.dense[((long long)h * a.T + qrow) * a.S + j];
+              if (a.dense && j < a.S) sv += a.dense[((long long)h * a.T + qrow) * a.dense_ld + j];
               bool masked = j >= a.S;
               if (a.causal) {
                 if (tile_grid) masked |= (qi >= a.P) || (j > qi);
@@ -1575,7 +1591,7 @@ extern "C" int ifseg_attn_fwd(const void* q, const void* k, const void* v, const
                               int ldo, int ldpq, int ldpk, long long q_bs, long long k_bs, long long v_bs,
                               long long o_bs, int rel_mode, int P, const int* gcode, int code_bias, int n2d,
                               const float* rel2d, const float* rel1d, const float* relx, int causal,
-                              const float* dense_bias, const void* gain, int grid_w, void* stream) {
+                              const float* dense_bias, const void* gain, int grid_w, int dense_ld, void* stream) {
   (void)hipGetLastError();
   AttnArgs a{};
   a.grid_w = grid_w;
@@ -1585,6 +1601,8 @@ extern "C" int ifseg_attn_fwd(const void* q, const void* k, const void* v, const
   a.ldpq = ldpq; a.ldpk = ldpk; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
   a.rel_mode = rel_mode; a.P = P; a.gcode = gcode; a.code_bias = code_bias; a.n2d = rel_mode ? n2d : 0;
   a.Lt = T - P; a.rel2d = rel2d; a.rel1d = rel1d; a.relx = relx; a.causal = causal; a.dense = dense_bias; a.gain = (const float*)gain;
+  a.dense_ld = dense_bias ? (dense_ld > 0 ? dense_ld : S) : 0;
+  if (dense_bias && a.dense_ld < S) return IFSEG_ERR_BAD_ARG;
   if (!rel_mode && !causal) a.P = S;
   int rc = attn_check(a);
   if (rc) return rc;

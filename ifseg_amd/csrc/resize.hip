@@ -40,7 +40,7 @@ __device__ __forceinline__ void taps2d(int p, const TapGeo& g, int (&y)[2], int 
 // the query -- the mask travels inside the dense bias because the kernels' causal tile skipping needs P % 64 == 0
 __global__ __launch_bounds__(256) void resized_bias_kernel(float* __restrict__ out, const float* __restrict__ table2d,
                                                            const float* __restrict__ rel1d, const float* __restrict__ relx,
-                                                           int H, int P, int Lt, TapGeo g, int n2d0, int causal) {
+                                                           int H, int P, int Lt, TapGeo g, int n2d0, int causal, int ld) {
   extern __shared__ float sTab[];
   const int T = P + Lt;
   const int hd = blockIdx.z;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void resized_bias_kernel(float* __restrict__ o
   __syncthreads();
   const int i = blockIdx.y;                           // query row
   const int stride0 = 2 * g.ow - 1, bias0 = (g.oh - 1) * stride0 + (g.ow - 1);
-  float* orow = out + ((long long)hd * T + i) * T;
+  float* orow = out + ((long long)hd * T + i) * ld;
   if (i < P) {
     int ya[2], xa[2]; float wya[2], wxa[2];
     taps2d(i, g, ya, xa, wya, wxa);
@@ -107,17 +107,19 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const bf16_t* __restri
 }  // namespace
 
 extern "C" int ifseg_resized_rel_bias(float* out, const float* table2d, const float* rel1d, const float* relx, int H, int h,
-                                      int w, int oh, int ow, int Lt, int causal, void* stream) {
+                                      int w, int oh, int ow, int Lt, int causal, int ld, void* stream) {
   (void)hipGetLastError();
   if (!out || !table2d || H <= 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || Lt < 0) return IFSEG_ERR_BAD_ARG;
   const int P = h * w, T = P + Lt, n2d0 = (2 * oh - 1) * (2 * ow - 1);
+  if (ld <= 0) ld = T;
+  if (ld < T) return IFSEG_ERR_BAD_ARG;
   const size_t lds = (size_t)n2d0 * sizeof(float);
   if (lds > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)resized_bias_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   TapGeo g{h, w, oh, ow};
   const int bx = (T + 255) / 256 < 8 ? (T + 255) / 256 : 8;
   hipLaunchKernelGGL(resized_bias_kernel, dim3(bx, T, H), dim3(256), lds, (hipStream_t)stream, out, table2d, rel1d, relx, H, P,
-                     Lt, g, n2d0, causal);
+                     Lt, g, n2d0, causal, ld);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

@@ -277,7 +277,8 @@ def attn_fwd_gain(q, k, v, pos_q, pos_k, out, lse, B, H, T, S, rel=None, causal=
                           c_int(rel.rel2d.shape[1] if rel is not None else 0),
                           _ptr(rel.rel2d) if rel is not None else None, _ptr(rel.rel1d) if rel is not None else None,
                           _ptr(rel.relx) if rel is not None else None, c_int(1 if causal else 0), _ptr(dense_bias),
-                          _ptr(_f32(gain)), c_int(rel.grid_w if rel is not None else 0), _stream())
+                          _ptr(_f32(gain)), c_int(rel.grid_w if rel is not None else 0),
+                          c_int(dense_bias.stride(1) if dense_bias is not None else 0), _stream())
     _check(rc, "attn_fwd")
     return out
 
@@ -562,11 +563,13 @@ def rel_gather(table, idx, out):
 
 
 def resized_rel_bias(out, table2d, rel1d, relx, h, w, oh, ow, Lt, causal=False):
-    """out fp32 [H, T, T] (T = h*w + Lt): the reference's doubly bilinear-resized rel-pos bias of a (h, w) grid from the delta
-    table of the trained (oh, ow) grid; tail blocks from rel1d / relx (None: zero)"""
+    """out fp32 [H, T, ld >= T] (T = h*w + Lt, rows `out.stride(1)` apart): the reference's doubly bilinear-resized rel-pos
+    bias of a (h, w) grid from the delta table of the trained (oh, ow) grid; tail blocks from rel1d / relx (None: zero)"""
     H = out.shape[0]
+    assert out.stride(2) == 1 and out.stride(0) == out.shape[1] * out.stride(1)
     _check(lib().ifseg_resized_rel_bias(_ptr(out), _ptr(table2d), _ptr(rel1d), _ptr(relx), c_int(H), c_int(h), c_int(w),
-                                        c_int(oh), c_int(ow), c_int(Lt), c_int(1 if causal else 0), _stream()), "resized_rel_bias")
+                                        c_int(oh), c_int(ow), c_int(Lt), c_int(1 if causal else 0), c_int(out.stride(1)),
+                                        _stream()), "resized_rel_bias")
     return out
 
 

@@ -909,7 +909,9 @@ class HipEngine:
                                               [(True, g0["dec_idx2d"]), (True, g0["dec_idx1d"]), (True, g0["dec_idxx"])])
             nl = cfg.dec_layers
         T = h * w + Lt
-        out = torch.empty(nl, H, T, T, dtype=torch.float32, device=self.device)
+        # rows padded to a multiple of 4 floats: the attention kernel then seeds its accumulators with 16-byte loads (the pad
+        # columns are never read as keys: j < S)
+        out = torch.zeros(nl, H, T, (T + 3) // 4 * 4, dtype=torch.float32, device=self.device)[..., :T]
         for l in range(nl):
             hip.resized_rel_bias(out[l], r2[l], r1[l], rx[l] if rx is not None else None, h, w, oh, oh, Lt, causal=causal)
         while len(cache) >= 2 * 16:

@@ -100,8 +100,10 @@ int ifseg_conv2d_nhwc_bf16(const void* in, const void* w, const void* shift, con
  *   i,j >= P : rel1d[h][(i-j)+Lt-1], Lt=T-P               (text; decoder bos corner)
  *   i<P<=j   : relx[h][0]          i>=P>j : relx[h][1]    (decoder bos col / row)
  * causal=1 uses "tail-first" order: grid query i sees grid keys j<=i and all tail
- * keys; tail query i sees tail keys j<=i only.  dense_bias: optional fp32 [H,T,S]
- * (slow path for resized grids).  Requires P % 64 == 0 when rel_mode or causal. */
+ * keys; tail query i sees tail keys j<=i only.  dense_bias: optional fp32 [H,T,dense_ld]
+ * (resized grids: ifseg_resized_rel_bias; dense_ld >= S is the row stride, 0 = S; a multiple of 4 with no rel_mode / causal
+ * takes the seeded path: four 16-byte loads per 32-key block into the score accumulator, -inf entries = masked keys).
+ * Requires P % 64 == 0 when rel_mode or causal. */
 int ifseg_attn_fwd(const void* q, const void* k, const void* v, const void* pos_q, const void* pos_k,
                    void* out, float* lse, int B, int H, int T, int S, int ldq, int ldk, int ldv, int ldo,
                    int ldpq, int ldpk, long long q_bs, long long k_bs, long long v_bs, long long o_bs,
@@ -109,7 +111,8 @@ int ifseg_attn_fwd(const void* q, const void* k, const void* v, const void* pos_
                    const float* rel1d, const float* relx, int causal, const float* dense_bias,
                    const void* gain /* fp32 [H] or NULL */,
                    int grid_w /* token-grid width if gcode is the raster code y*(2w-1)+x, else 0; 32 enables
-                                 the row-aligned bias lookup */,
+                                 the row-aligned bias lookup; any other multiple of 8 >= 32: seeds per group of 8 */,
+                   int dense_ld /* row stride of dense_bias (0: S) */,
                    void* stream);
 
 /* Backward of ifseg_attn_fwd (autograd of the same reference lines).  Launches
@@ -280,7 +283,7 @@ int ifseg_rel_scatter_add(const float* d, const int* idx, float* acc, int n, int
  * resize passes through.  causal != 0 (decoder_module.py:592-600, buffered_future_mask in the internal order with the tail =
  * bos first): -inf where the key lies after the query. */
 int ifseg_resized_rel_bias(float* out, const float* table2d, const float* rel1d, const float* relx, int H, int h, int w,
-                           int oh, int ow, int Lt, int causal, void* stream);
+                           int oh, int ow, int Lt, int causal, int ld /* row stride of out, >= T (0: T) */, void* stream);
 /* dst bf16 [h*w, C] = bilinear resize (align_corners = False, fp32 arithmetic, one rounding) of the oh x ow grid of rows
  * src[(y * src_stride + x + src_off) * ld_src + c]: the position-embedding tables of encoder_module.py:360-368 and
  * decoder_module.py:541-548 on a resized grid */

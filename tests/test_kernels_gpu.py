@@ -136,7 +136,7 @@ def _grid_codes(gh, gw):
 
 
 @pytest.mark.parametrize("case", ["cross", "enc_rel", "dec_causal", "dec_full", "dense_nopos", "big_enc", "dec_causal_bh8",
-                                  "enc_w40", "dec_w40", "enc_w48"])
+                                  "enc_w40", "dec_w40", "enc_w48", "dense_pad"])
 def test_attn_fwd(case):
     from ifseg_amd import hip
     dev = _dev()
@@ -167,6 +167,8 @@ def test_attn_fwd(case):
     elif case == "dense_nopos":
         T, S = 100, 130
         use_pos = False
+    elif case == "dense_pad":          # dense bias with rows padded to a multiple of 4 floats: the seeded path (resized grids)
+        T, S = 165, 165
     elif case == "big_enc":
         gh, gw = 32, 32
         P, Lt = 1024, 36
@@ -196,6 +198,12 @@ def test_attn_fwd(case):
         g = torch.Generator().manual_seed(31)
         bias = torch.randn(H, T, S, generator=g)
         dense = bias.to(dev).contiguous()
+    if case == "dense_pad":
+        g = torch.Generator().manual_seed(32)
+        bias = torch.randn(H, T, S, generator=g)
+        bias[:, :, 1:][torch.rand(H, T, S - 1, generator=g) < 0.3] = float("-inf")      # masked keys travel inside the bias
+        dense = torch.zeros(H, T, (S + 3) // 4 * 4, device=dev)[..., :S]
+        dense.copy_(bias)
     mask = _causal_mask(T, S, P) if causal else None
     out = torch.zeros(B, T, C, dtype=torch.bfloat16, device=dev)
     lse = torch.zeros(B, H, T, dtype=torch.float32, device=dev)
