@@ -608,7 +608,6 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
     stage_table<int, false, NT>(sGc, a.gcode, a.P, tid);
     for (int i = tid; i < a.n2d; i += NT) sHist[i] = 0.f;
     for (int i = tid; i < NW * n1dp + 2 * NW; i += NT) sHist1[i] = 0.f;
-    for (int i = tid; i < 2 * NW * XW; i += NT) sXc[i] = 0.f;
   }
   const bool k_grid = kj < a.P;
   const bool wave_kgrid = kw + 31 < a.P;
@@ -628,6 +627,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, const int b
   // a fixed order: bit-reproducible, no LDS float atomics (the 4 waves share table rows here).
   const bool rowseg = a.rel_mode && !row32 && a.grid_w >= 32 && (a.grid_w & 7) == 0;
   const unsigned mk = rowseg ? (unsigned)__builtin_amdgcn_ballot_w64(k_grid && (cj - cj0 != (lane & 31))) : 0u;
+  if (rowseg) {       // (the exchange area exists only on these grids: the host sizes the LDS accordingly)
+    for (int i = tid; i < 2 * NW * XW; i += NT) sXc[i] = 0.f;
+  }
   auto seg_duty = [&](int buf) {
 #pragma unroll 1
     for (int w = 0; w < NW; ++w) {
@@ -1662,9 +1664,11 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   }
   const size_t n2dp = ((size_t)a.n2d + 3) & ~(size_t)3;
   const size_t n1dp = a.rel_mode ? (((size_t)(2 * a.Lt - 1) + 3) & ~(size_t)3) : 0;
+  const bool rowseg_h = a.rel_mode && a.grid_w != 32 && a.grid_w >= 32 && (a.grid_w & 7) == 0;   // as in the kernel
   auto lds_kv_of = [&](int nw) {
     return (size_t)(KT_BYTES + VT_BYTES + 512) + (nw / 2) * VT_BYTES +
-           (a.rel_mode ? (2 * n2dp + nw * n1dp + 2 * nw) * 4 + (((size_t)a.P + 3) & ~(size_t)3) * 4 + (size_t)2 * nw * (4 + 3 * 64) * 4 : 0);
+           (a.rel_mode ? (2 * n2dp + nw * n1dp + 2 * nw) * 4 + (((size_t)a.P + 3) & ~(size_t)3) * 4 +
+                             (rowseg_h ? (size_t)2 * nw * (4 + 3 * 64) * 4 : 0) : 0);      // exchange area: `rowseg` grids only
   };
   // 8-wave workgroups (one copy of the tables for twice the waves) when a 4-wave workgroup takes more than half a CU's LDS
   const bool dkv8 = a.rel_mode && lds_kv_of(4) > 80 * 1024 && lds_kv_of(8) <= 160 * 1024 && !getenv("IFSEG_ATTN_DKV_4WAVES");
