@@ -843,3 +843,60 @@ def test_attn_bwd_reduce_matches_the_separate_reductions():
                             nparts, again)
         torch.cuda.synchronize()
         assert all(torch.equal(x[2], y[2]) for x, y in zip(tables, again))
+
+
+# ----------------------------------------------------------------------------- torch.library ops (ifseg_amd/ops.py)
+def test_custom_ops_forward_backward_through_the_dispatcher():
+    """torch.ops.ifseg.linear / layer_norm / bias_attention: forward and autograd through the dispatcher against plain PyTorch
+    fp32 references of the same ops (the kernels behind them are the ones the engine launches through the C ABI)."""
+    import ifseg_amd.ops  # noqa: F401
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev).to(torch.bfloat16)
+    # ---- linear
+    x, w, b = r(2, 300, 256).requires_grad_(True), r(384, 256, sc=0.05).requires_grad_(True), r(384).requires_grad_(True)
+    y = torch.ops.ifseg.linear(x, w, b)
+    go = r(2, 300, 384)
+    y.backward(go)
+    xf, wf, bfl = (t.detach().float().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.linear(xf, wf, bfl)
+    yr.backward(go.float())
+    assert _rel(y, yr) < 1e-2 and _rel(x.grad, xf.grad) < 1e-2 and _rel(w.grad, wf.grad) < 1e-2 and _rel(b.grad, bfl.grad) < 1e-2
+    # ---- layer norm (with the GELU in front, as ffn_layernorm(gelu(fc1)))
+    for gelu in (False, True):
+        x = r(600, 768).requires_grad_(True)
+        gam = (1 + 0.1 * torch.randn(768, generator=g)).to(dev).requires_grad_(True)
+        bet = (0.1 * torch.randn(768, generator=g)).to(dev).requires_grad_(True)
+        y, _, _ = torch.ops.ifseg.layer_norm(x, gam, bet, 1e-5, gelu)
+        go = r(600, 768)
+        y.backward(go)
+        xf, gf, bf_ = (t.detach().float().requires_grad_(True) for t in (x, gam, bet))
+        hx = torch.nn.functional.gelu(xf) if gelu else xf
+        yr = torch.nn.functional.layer_norm(hx, (768,), gf, bf_, 1e-5)
+        yr.backward(go.float())
+        assert _rel(y, yr) < 1e-2 and _rel(x.grad, xf.grad) < 2e-2 and _rel(gam.grad, gf.grad) < 2e-2 and _rel(bet.grad, bf_.grad) < 2e-2
+    # ---- position-biased attention with a 16 x 40 grid + text tail (rel-pos tables, abs-pos operands, head gains)
+    H, B, gh, gw, Lt = 2, 2, 16, 40, 37
+    P = gh * gw
+    T, C = P + Lt, H * 64
+    q, k, v = (r(B, T, C, sc=s_).requires_grad_(True) for s_ in (0.35, 1.0, 1.0))
+    pq, pk = r(T, C, sc=0.35).requires_grad_(True), r(T, C).requires_grad_(True)
+    gain = (1.0 + 0.2 * torch.randn(H, generator=g)).to(dev).requires_grad_(True)
+    gcode, code_bias, n2d = _grid_codes(gh, gw)
+    tabs = [torch.randn(H, n, generator=g).to(dev).requires_grad_(True) for n in (n2d, 2 * Lt - 1, 2)]
+    out, lse = torch.ops.ifseg.bias_attention(q, k, v, pq, pk, gain, gcode.to(dev), tabs[0], tabs[1], tabs[2], P, code_bias, gw, False)
+    go = r(B, T, C)
+    out.backward(go)
+    qf, kf, vf, pqf, pkf, gf = (t.detach().float().requires_grad_(True) for t in (q, k, v, pq, pk, gain))
+    tl = [t.detach().cpu().clone().requires_grad_(True) for t in tabs]
+    bias = _dense_rel_ad(H, T, T, P, gcode.long(), code_bias, *tl).to(dev)
+    o_ref, _ = _attn_ref(qf, kf, vf, pqf, pkf, bias, None)
+    o_ref = (o_ref.view(B, T, H, 64) * gf.view(1, 1, H, 1)).reshape(B, T, C)
+    o_ref.backward(go.float())
+    assert _rel(out, o_ref) < 1e-2
+    for name, a_, b_ in (("dq", q.grad, qf.grad), ("dk", k.grad, kf.grad), ("dv", v.grad, vf.grad), ("dpq", pq.grad, pqf.grad),
+                         ("dpk", pk.grad, pkf.grad), ("dgain", gain.grad, gf.grad)):
+        assert _rel(a_, b_) < 3e-2, (name, _rel(a_, b_))
+    scale = max(t.grad.abs().max().item() for t in tl)
+    for name, a_, b_ in zip(("drel2d", "drel1d", "drelx"), tabs, tl):
+        assert ((a_.grad.cpu() - b_.grad).abs().max() / scale).item() < 3e-2, name
