@@ -59,7 +59,7 @@ def linear_bwd(g: torch.Tensor, x: torch.Tensor, w: torch.Tensor) -> Tuple[torch
         dw, db = buf[: N * K].view(N, K), buf[N * K:]
         if not hip.linear_dw(g2, x2, dw, bias_out=db):
             db.copy_(g2.float().sum(0))
-        return dx.view(x.shape), dw, db
+        return dx.view(x.shape), dw, db.clone()           # (returns of a custom op must not share storage)
     finally:
         hip.set_stream(prev)
 
@@ -119,7 +119,7 @@ def layer_norm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean:
         hip.ln_bwd(dy2, x2, gamma, mean, rstd, dx, part[0], part[1], gelu=gelu)
         dgb = torch.empty(2, C, dtype=gamma.dtype if gamma.dtype in (BF, torch.float32) else torch.float32, device=x.device)
         hip.reduce_parts(part, dgb, 2, hip.LN_BWD_BLOCKS, C)
-        return dx.view(x.shape), dgb[0], dgb[1]
+        return dx.view(x.shape), dgb[0].clone(), dgb[1].clone()
     finally:
         hip.set_stream(prev)
 
