@@ -69,7 +69,15 @@ class ArenaReducer:
         self.direct = None
         if self.mode == "direct" and dist.is_initialized() and dist.get_backend() == "nccl" and flat.is_cuda:
             from .rccl import RcclComm
-            self.direct = RcclComm(flat.device)
+            try:
+                self.direct = RcclComm(flat.device)
+            except (OSError, AttributeError, RuntimeError) as exc:
+                # (every rank takes the same branch: the failure modes are a missing librccl.so / symbol or a communicator
+                # that cannot be created -- not data dependent).  Still RCCL, through torch.distributed, and said loudly.
+                import sys
+                sys.stderr.write("ifseg_amd: direct RCCL communicator unavailable (%s): gradient all-reduce falls back to "
+                                 "torch.distributed's all_reduce (measured ~20 %% slower per step, DESIGN.md section 5)\n" % exc)
+                self.direct, self.mode = None, "c10d"
         # gloo (functional runs: N ranks on one GPU, CPU tests) has no bf16 device reduction: staged through fp32 host
         # memory, synchronously.  The production backend is "nccl" (= RCCL over xGMI), asynchronous on its own stream.
         self.staged = dist.is_initialized() and dist.get_backend() == "gloo" and flat.is_cuda
