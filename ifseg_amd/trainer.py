@@ -264,7 +264,7 @@ class Trainer:
             cpu = buf.cpu()
             dist.all_reduce(cpu)
             buf = cpu.to(self.device)
-        elif getattr(self.reducer, "direct", None) is not None:
+        elif getattr(getattr(self, "reducer", None), "direct", None) is not None:
             self.reducer.direct.all_reduce_(buf)                # RCCL on the current stream: no c10d stream inside a step
         else:
             dist.all_reduce(buf)
