@@ -47,6 +47,15 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// erf(x/sqrt2) by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution); e = exp(-x^2/2) is the
+// same exponential the Gaussian pdf of the GELU derivative needs, so backward costs one exp per element.
+__device__ __forceinline__ float erf_as(float x, float e) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);      // v_rcp_f32 (1 ulp); __frcp_rn is a ten-instruction IEEE divide
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.f - poly * e;
+  return x < 0.f ? -r : r;
+}
 union U128 {
   uint4 v;
   bf16x8 b;

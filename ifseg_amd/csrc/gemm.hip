@@ -44,6 +44,12 @@ struct GemmArgs {
   // sum over the 64 columns of head n/64 of C[m][n] (as stored in bf16) * dot[m][n]
   const bf16_t* dot; int ldd; float* dot_out; int dot_T;
   int xcd_groups;          // > 0: split-K slices pinned to XCDs (see the kernel), grid = tiles * splitk workgroups in x
+  // optional "GELU + LayerNorm backward" epilogue (EPI_GLN, the FFN's ffn_layernorm(gelu(fc1)) on the way back): the GEMM
+  // result is dz = d(LN output); the epilogue turns it into du = d(fc1 output) without dz ever reaching HBM:
+  //   g = gelu(u), xh = (g - mean_m) rstd_m, du = rstd_m (gamma_n dz - c1_m - xh c2_m) gelu'(u)
+  // c1 / c2 = the two row means of the LayerNorm backward, supplied by the caller (ifseg_ffn_ln_rowstats computes them from
+  // 768-wide tensors: the row sums over the 3072 columns are linear in dz = dY . W)
+  const bf16_t* gln_u; int gln_ldu; const float* gln_gamma; const float* gln_mean; const float* gln_rstd; const float* gln_c;
 };
 
 // ---- LDS tile images -------------------------------------------------------
@@ -102,7 +108,7 @@ __device__ __forceinline__ void lds_dma16(v4i32 rs, unsigned lds_base, unsigned 
 // One output tile (and, with split-K, one k-slice of it).  bx / by / bz are the workgroup's tile, batch and k-slice
 // coordinates (blockIdx of the plain kernel; the grouped kernel passes the tile index inside its problem);
 // `remapped`: bx is already an XCD-remapped tile index.
-template <int AMODE, bool B_KS, int BN, int BK, int STAGES, bool COLSUM = false>
+template <int AMODE, bool B_KS, int BN, int BK, int STAGES, bool COLSUM = false, bool EPI_GLN = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int bz_in, const bool remapped) {
   static_assert(BN == 128 || (BN == 64 && !B_KS), "64-wide tiles only for k-contiguous B");
   constexpr int NJ = BN / 64;                 // 32-column MFMA tiles per wave along N
@@ -372,6 +378,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     const bool mvalid = m < g.M;
     if (!lds_out && !mvalid) continue;
     float dsum = 0.f;
+    float gl_mu = 0.f, gl_rs = 0.f, gl_c1 = 0.f, gl_c2 = 0.f;
+    if constexpr (EPI_GLN) {
+      if (mvalid) { gl_mu = g.gln_mean[m]; gl_rs = g.gln_rstd[m]; gl_c1 = g.gln_c[2 * m]; gl_c2 = g.gln_c[2 * m + 1]; }
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int nj = n0 + wn * (BN / 2) + j * 32;
@@ -399,6 +409,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
         if (relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if constexpr (EPI_GLN) {
+          const uint2 uw = *reinterpret_cast<const uint2*>(g.gln_u + (long long)m * g.gln_ldu + n);
+          const float4 gm = *reinterpret_cast<const float4*>(g.gln_gamma + n);
+          const float uu[4] = {bflo(uw.x), bfhi(uw.x), bflo(uw.y), bfhi(uw.y)};
+          const float gg[4] = {gm.x, gm.y, gm.z, gm.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xv = uu[e], ex = __expf(-0.5f * xv * xv), er = erf_as(xv, ex);
+            const float act = 0.5f * xv * (1.f + er);
+            const float dact = 0.5f * (1.f + er) + xv * 0.39894228040143268f * ex;
+            const float xh = (act - gl_mu) * gl_rs;
+            v[e] = gl_rs * (gg[e] * v[e] - gl_c1 - xh * gl_c2) * dact;
+          }
         }
         if (out_f32) {
           float* cp = reinterpret_cast<float*>(g.C) + (long long)by * g.sC + (long long)bz * g.sCsplit +
@@ -459,6 +483,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 template <int AMODE, bool B_KS, int BN, int BK, int STAGES, bool COLSUM = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   gemm_tile<AMODE, B_KS, BN, BK, STAGES, COLSUM>(g, blockIdx.x, blockIdx.y, blockIdx.z, false);
+}
+// dX GEMM with the "GELU + LayerNorm backward" epilogue (its own instantiation: the epilogue's registers must not cost
+// the plain dX GEMMs their fourth wave per SIMD)
+template <int STAGES>
+__global__ __launch_bounds__(256, 2) void gemm_nn_gln_kernel(GemmArgs g) {
+  gemm_tile<A_KC, true, 128, GBK, STAGES, false, true>(g, blockIdx.x, blockIdx.y, blockIdx.z, false);
 }
 
 // Grouped weight-gradient GEMM: up to IFSEG_GEMM_GROUP_MAX independent TN problems (the dW = dY^T X products of one
@@ -624,6 +654,32 @@ extern "C" int ifseg_gemm_nn_rowdot(const void* A, const void* B, void* C, int M
                                     const void* dot, int ldd, float* dot_out, int rows_per_batch, void* stream) {
   return gemm_impl(IFSEG_GEMM_NN, A, B, C, M, N, K, lda, ldb, ldc, nullptr, 1.f, 0, nullptr, 0, 0, 1, 0, 0, 0, 0, 1, stream,
                    dot, ldd, dot_out, rows_per_batch);
+}
+
+extern "C" int ifseg_gemm_nn_gelu_ln_bwd(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                         const void* u, int ldu, const float* gamma, const float* mean, const float* rstd,
+                                         const float* cstats, void* stream) {
+  (void)hipGetLastError();
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (!A || !B || !C || !u || !gamma || !mean || !rstd || !cstats) return IFSEG_ERR_BAD_ARG;
+  if ((N & 7) || (K & 7) || (lda & 7) || (ldb & 7) || (ldc & 3) || (ldu & 3) || ((size_t)gamma & 15)) return IFSEG_ERR_BAD_SHAPE;
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.alpha = 1.f; g.splitk = 1;
+  g.gln_u = (const bf16_t*)u; g.gln_ldu = ldu; g.gln_gamma = gamma; g.gln_mean = mean; g.gln_rstd = rstd; g.gln_c = cstats;
+  const long long nrA = ((long long)(M - 1) * lda + K) * 2, nrB = ((long long)(K - 1) * ldb + N) * 2;
+  if (nrA >= (1ll << 31) || nrB >= (1ll << 31)) return IFSEG_ERR_BAD_SHAPE;
+  g.nrecA = (unsigned)nrA; g.nrecB = (unsigned)nrB;
+  const int tiles = ((M + BM - 1) / BM) * ((N + 127) / 128);
+  hipStream_t s = (hipStream_t)stream;
+  // (timed with the NN family; flops of the GEMM only)
+  ifseg_prof_begin(IFSEG_K_GEMM_NT + IFSEG_GEMM_NN, s, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + 2.0 * M * N));
+  if (tiles <= TWO_STAGE_MAX_WGS) hipLaunchKernelGGL(gemm_nn_gln_kernel<2>, dim3(tiles), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(gemm_nn_gln_kernel<1>, dim3(tiles), dim3(256), 0, s, g);
+  ifseg_prof_end(IFSEG_K_GEMM_NT + IFSEG_GEMM_NN, s);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
 }
 
 // Implicit-GEMM convolution on an NHWC bf16 image with folded FrozenBN:

@@ -21,15 +21,6 @@ struct RowMap {  // logical row r -> element offset  (r / rpb) * bs + (r % rpb) 
   }
 };
 
-// erf(x/sqrt2) by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution); e = exp(-x^2/2) is the
-// same exponential the Gaussian pdf of the GELU derivative needs, so backward costs one exp per element.
-__device__ __forceinline__ float erf_as(float x, float e) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);      // v_rcp_f32 (1 ulp); __frcp_rn is a ten-instruction IEEE divide
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float r = 1.f - poly * e;
-  return x < 0.f ? -r : r;
-}
 __device__ __forceinline__ float gelu_f(float x) {
   return 0.5f * x * (1.f + erf_as(x, __expf(-0.5f * x * x)));
 }
@@ -1005,6 +996,113 @@ extern "C" int ifseg_droppath_scale(float* out, const float* keep, int n, int B,
   (void)hipGetLastError();
   if (n * B <= 0) return 0;
   hipLaunchKernelGGL(droppath_scale_kernel, dim3((n * B + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, keep, n, B, seed, seed_add);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The FFN's ffn_layernorm(gelu(fc1)) on the way back WITHOUT a 3072-wide LayerNorm-backward pass
+// (unify_transformer_layer.py:279-283 under autograd).  With z = gamma * xh + beta the input of fc2 (t = z W2^T + b2 its
+// output, dY the gradient of t) the LayerNorm backward needs two row means over the N = 3072 columns of dz = dY W2:
+//     c1 = mean_k(gamma_k dz_k)        = (1/N) sum_j dY_j a_j ,            a_j  = sum_k gamma_k W2[j,k]
+//     c2 = mean_k(gamma_k xh_k dz_k)   = (1/N) sum_j dY_j (t_j - wb_j) ,   wb_j = b2_j + sum_k beta_k W2[j,k]
+// (both are linear in dz, and sum_k gamma_k xh_k W2[j,k] is the forward product minus its beta / bias part) -- row dots over
+// the 768 columns of dY and of the SAVED fc2 output.  With c1, c2 known per row, du is element-wise in dz and rides in the
+// epilogue of the dX GEMM (csrc/gemm.hip, EPI_GLN): dz is never written, the wide LayerNorm-backward kernel (97 us in the
+// step, x 12 layers) is gone.  The parameter gradients follow from the weight gradient of fc2, which is computed anyway:
+//     dbeta_k  = sum_j db2_j W2[j,k]
+//     dgamma_k = (sum_j W2[j,k] dW2[j,k] - beta_k dbeta_k) / gamma_k        (dW2[j,k] = sum_r dY[r,j] (gamma_k xh[r,k] + beta_k))
+namespace {
+
+// coef[0][j] = a_j, coef[1][j] = wb_j : one wave per row j of W2 [J, N]
+__global__ __launch_bounds__(256) void ffn_ln_coef_kernel(const bf16_t* __restrict__ w2, int ldw, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const bf16_t* __restrict__ b2,
+                                                          float* __restrict__ coef, int J, int N) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= J) return;
+  const bf16_t* row = w2 + (long long)j * ldw;
+  float sa = 0.f, sb = 0.f;
+  for (int k = lane * 8; k < N; k += 64 * 8) {
+    float w[8];
+    unpack8(*reinterpret_cast<const uint4*>(row + k), w);
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + k), g1 = *reinterpret_cast<const float4*>(gamma + k + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + k), b1 = *reinterpret_cast<const float4*>(beta + k + 4);
+    sa += w[0] * g0.x + w[1] * g0.y + w[2] * g0.z + w[3] * g0.w + w[4] * g1.x + w[5] * g1.y + w[6] * g1.z + w[7] * g1.w;
+    sb += w[0] * b0.x + w[1] * b0.y + w[2] * b0.z + w[3] * b0.w + w[4] * b1.x + w[5] * b1.y + w[6] * b1.z + w[7] * b1.w;
+  }
+  sa = warp_sum(sa); sb = warp_sum(sb);
+  if (lane == 0) { coef[j] = sa; coef[J + j] = sb + (b2 ? bf2f(b2[j]) : 0.f); }
+}
+
+// c[r][0] = (1/N) sum_j dY[r][j] a_j ; c[r][1] = (1/N) sum_j dY[r][j] (t[r][j] - wb_j) : one wave per row
+__global__ __launch_bounds__(256) void ffn_ln_rowstats_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ t,
+                                                              int ldt, const float* __restrict__ coef, float* __restrict__ c,
+                                                              int rows, int J, float inv_n) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int j = lane * 8; j < J; j += 64 * 8) {
+    float d[8], tv[8];
+    unpack8(*reinterpret_cast<const uint4*>(dy + (long long)r * lddy + j), d);
+    unpack8(*reinterpret_cast<const uint4*>(t + (long long)r * ldt + j), tv);
+    const float4 a0 = *reinterpret_cast<const float4*>(coef + j), a1 = *reinterpret_cast<const float4*>(coef + j + 4);
+    const float4 w0 = *reinterpret_cast<const float4*>(coef + J + j), w1 = *reinterpret_cast<const float4*>(coef + J + j + 4);
+    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1 += d[e] * av[e]; s2 += d[e] * (tv[e] - wv[e]); }
+  }
+  s1 = warp_sum(s1); s2 = warp_sum(s2);
+  if (lane == 0) { c[2 * r] = s1 * inv_n; c[2 * r + 1] = s2 * inv_n; }
+}
+
+// one thread per column k of W2 [J, N] / dW2 [J, N] (bf16, row-major): coalesced across k, a loop over the J rows
+__global__ __launch_bounds__(256) void ffn_ln_param_grads_kernel(const bf16_t* __restrict__ w2, const bf16_t* __restrict__ dw2,
+                                                                 const bf16_t* __restrict__ db2, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, bf16_t* __restrict__ dgamma,
+                                                                 bf16_t* __restrict__ dbeta, int J, int N) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= N) return;
+  float swd = 0.f, sdb = 0.f;
+  for (int j = 0; j < J; ++j) {
+    const float w = bf2f(w2[(long long)j * N + k]);
+    swd += w * bf2f(dw2[(long long)j * N + k]);
+    sdb += w * bf2f(db2[j]);
+  }
+  const float bk = beta[k], gk = gamma[k];
+  dbeta[k] = f2bf(sdb);
+  dgamma[k] = f2bf((swd - bk * sdb) / gk);
+}
+
+}  // namespace
+
+extern "C" int ifseg_ffn_ln_coef(const void* w2, int ldw, const float* gamma, const float* beta, const void* b2, float* coef,
+                                 int J, int N, void* stream) {
+  (void)hipGetLastError();
+  if (!w2 || !gamma || !beta || !coef || J <= 0 || N <= 0 || (N & 7) || (ldw & 7) || (((size_t)gamma | (size_t)beta) & 15))
+    return IFSEG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ffn_ln_coef_kernel, dim3((J + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w2, ldw, gamma, beta,
+                     (const bf16_t*)b2, coef, J, N);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_ffn_ln_rowstats(const void* dy, int lddy, const void* t, int ldt, const float* coef, float* c, int rows,
+                                     int J, int N, void* stream) {
+  (void)hipGetLastError();
+  if (!dy || !t || !coef || !c || rows <= 0 || J <= 0 || N <= 0 || (J & 7) || (lddy & 7) || (ldt & 7) || ((size_t)coef & 15))
+    return IFSEG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ffn_ln_rowstats_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy,
+                     (const bf16_t*)t, ldt, coef, c, rows, J, 1.f / (float)N);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_ffn_ln_param_grads(const void* w2, const void* dw2, const void* db2, const float* gamma, const float* beta,
+                                        void* dgamma, void* dbeta, int J, int N, void* stream) {
+  (void)hipGetLastError();
+  if (!w2 || !dw2 || !db2 || !gamma || !beta || !dgamma || !dbeta || J <= 0 || N <= 0) return IFSEG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ffn_ln_param_grads_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w2,
+                     (const bf16_t*)dw2, (const bf16_t*)db2, gamma, beta, (bf16_t*)dgamma, (bf16_t*)dbeta, J, N);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

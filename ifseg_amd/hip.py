@@ -33,7 +33,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 9:
+        if _lib.ifseg_abi_version() != 10:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -114,6 +114,40 @@ def linear_dx_rowdot(dy, w, out, dot, dot_out, rows_per_batch):
                                     c_int(rows_per_batch), _stream())
     _check(rc, "gemm_nn_rowdot")
     return out
+
+
+def ffn_ln_coef(w2, gamma, beta, b2, coef):
+    """coef fp32 [2, J]: row sums of W2 [J, N] against gamma / beta (+ b2) -- see include/ifseg_hip.h"""
+    J, N = w2.shape
+    _check(lib().ifseg_ffn_ln_coef(_ptr(_bf(w2)), c_int(w2.stride(0)), _ptr(gamma), _ptr(beta), _ptr(b2), _ptr(coef), c_int(J),
+                                   c_int(N), _stream()), "ffn_ln_coef")
+    return coef
+
+
+def ffn_ln_rowstats(dy, t, coef, c, N):
+    """c fp32 [rows, 2]: the two row means of the ffn_layernorm backward from dY [rows, J] and the saved fc2 output t"""
+    rows, J = dy.shape
+    _check(lib().ifseg_ffn_ln_rowstats(_ptr(_bf(dy)), c_int(dy.stride(0)), _ptr(_bf(t)), c_int(t.stride(0)), _ptr(coef), _ptr(c),
+                                       c_int(rows), c_int(J), c_int(N), _stream()), "ffn_ln_rowstats")
+    return c
+
+
+def linear_dx_gelu_ln_bwd(dy, w, out, u, gamma, mean, rstd, c):
+    """du[M, N] = LayerNorm+GELU backward of dz = dy[M, K] @ w[K, N], in the GEMM epilogue (dz is not written)"""
+    M, K = dy.shape
+    N = w.shape[1]
+    _check(lib().ifseg_gemm_nn_gelu_ln_bwd(_ptr(_bf(dy)), _ptr(_bf(w)), _ptr(out), c_int(M), c_int(N), c_int(K),
+                                           c_int(dy.stride(0)), c_int(w.stride(0)), c_int(out.stride(0)), _ptr(_bf(u)),
+                                           c_int(u.stride(0)), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(c), _stream()),
+           "gemm_nn_gelu_ln_bwd")
+    return out
+
+
+def ffn_ln_param_grads(w2, dw2, db2, gamma, beta, dgamma, dbeta):
+    J, N = w2.shape
+    assert w2.is_contiguous() and dw2.is_contiguous()
+    _check(lib().ifseg_ffn_ln_param_grads(_ptr(_bf(w2)), _ptr(_bf(dw2)), _ptr(_bf(db2)), _ptr(gamma), _ptr(beta), _ptr(dgamma),
+                                          _ptr(dbeta), c_int(J), c_int(N), _stream()), "ffn_ln_param_grads")
 
 
 _splitk_ws = {}

@@ -33,6 +33,9 @@ from ... import hip
 from .config import image_rp_bucket, token_bucket_of_delta
 
 BF = torch.bfloat16
+# TIMING EXPERIMENTS ONLY (wrong results): kernels left out of the step to bound what optimising them could return,
+# e.g. IFSEG_EXP_SKIP=lnwide,dq (tools/skip_bound.sh; DESIGN section 4 "Round 3")
+_EXP_SKIP = set(filter(None, os.environ.get("IFSEG_EXP_SKIP", "").split(",")))
 
 
 def _pad8(n):
@@ -81,6 +84,11 @@ class HipEngine:
         self.dw_split = os.environ.get("IFSEG_DW_SPLIT", "0") == "1"
         self.attn_bwd_timing = None      # {"stride": n, "seen": 0, "pairs": []} while bench.py times the attention backward
         self._rb_cache, self._wver = {}, 0   # dense resized rel-pos biases (eval on other aspect ratios), weights version
+        # ffn_layernorm(gelu(fc1)) backward folded into the fc2 dX GEMM's epilogue (csrc/rowops.hip "FFN's ffn_layernorm",
+        # csrc/gemm.hip EPI_GLN): no 3072-wide LayerNorm-backward pass.  IFSEG_NO_FFN_LN_FUSE=1: the stand-alone kernel.
+        self.ffn_ln_fused = os.environ.get("IFSEG_NO_FFN_LN_FUSE") is None
+        self._ffn_pg_tasks = []
+        self._train_fwd = False
         # where the NEXT batch's frozen-trunk pass is launched: "fwd" = at the start of this step's forward, "e<k>" = when
         # the backward reaches encoder layer k, "end" = after the last backward kernel of the main stream
         self.trunk_at = os.environ.get("IFSEG_TRUNK_AT", "fwd")
@@ -747,6 +755,7 @@ class HipEngine:
         g = self._geometry(h, w, L)
         T, Td = P + L, P + 1
         self._drop_setup(B, need_grad)
+        self._train_fwd = bool(need_grad)
         ctx = {"B": B, "L": L, "P": P, "T": T, "Td": Td, "h": h, "w": w, "full": bool(full_context_alignment),
                "src_tokens": src_tokens, "feat": feat}
         self.ctx_building = ctx
@@ -813,8 +822,12 @@ class HipEngine:
         # the K|V projections of every decoder layer's cross-attention only read the encoder output: they run on
         # the side stream underneath the first decoder blocks instead of inside each layer's dependent chain
         ctx["ckv_ready"] = None
+        if need_grad and self.ffn_ln_fused and not self.overlap:
+            self._ffn_ln_coefs()
         if self.overlap and need_grad:
             with self._wgrad():
+                if self.ffn_ln_fused:
+                    self._ffn_ln_coefs()        # weights only: needed by the backward (its first kernel waits for ckv_ready's stream)
                 for l in range(cfg.dec_layers):
                     a_ = "%slayers.%d.encoder_attn" % (d, l)
                     kv = buf("d%d_ckv" % l, (B, T, 2 * C))
@@ -1089,21 +1102,26 @@ class HipEngine:
         hip.ln_fwd(u, Wf(p + "ffn_layernorm.weight"), Wf(p + "ffn_layernorm.bias"), z, mu, rs, gelu=True)
         x2 = buf(tg + "_x2", x1.shape)
         nxt = None
-        if self.drop_on and site is not None:
-            t = buf("drop_tmp_%d" % rows, (rows, C))
+        dropping = self.drop_on and site is not None
+        keep_t = self.ffn_ln_fused and self._train_fwd and site is not None    # the backward reads the fc2 output (row means)
+        t = None
+        if dropping or keep_t:
+            t = buf(tg + "_t", (rows, C)) if keep_t else buf("drop_tmp_%d" % rows, (rows, C))
             hip.linear_fwd(z, W(p + "fc2.weight"), W(p + "fc2.bias"), out=t)
+            drop = (self.cfg.dropout, self._site_seed(self._site_id(site)), self._dp(*site), rpb) if dropping else None
             if next_ln is not None:
                 # dropout + DropPath + residual of this block and the pre-LN of the next layer in one launch
                 npname, ntag, nxt = next_ln
                 mu2, rs2 = self._ln_stats(ntag, rows)
                 hip.ln_fwd_pair(t, None, None, x2.view(rows, C), None, None, Wf(npname + ".weight"), Wf(npname + ".bias"), nxt,
-                                mu2, rs2, resid=x1.view(rows, C),
-                                drop=(self.cfg.dropout, self._site_seed(self._site_id(site)), self._dp(*site), rpb))
-            else:
+                                mu2, rs2, resid=x1.view(rows, C), drop=drop)
+            elif dropping:
                 self._drop(t, x1.view(rows, C), x2.view(rows, C), self._site_id(site), self._dp(*site), rpb)
+            else:
+                hip.dropout(t, x1.view(rows, C), x2.view(rows, C), 0.0, 0, None, None)       # x2 = x1 + t
         else:
             hip.linear_fwd(z, W(p + "fc2.weight"), W(p + "fc2.bias"), out=x2.view(rows, C), resid=x1.view(rows, C))
-        self._save(tg + "_ffn", x1=x1, xn=xn, u=u, z=z, site=site, rpb=rpb)
+        self._save(tg + "_ffn", x1=x1, xn=xn, u=u, z=z, site=site, rpb=rpb, t=t if keep_t else None)
         return x2, nxt
 
     def _save(self, key, **kw):
@@ -1200,15 +1218,27 @@ class HipEngine:
         W, Wf, G, buf = self.W, self.Wf, self.G, self.buf
         self._bt = tg + "f"
         gbuf = self.gbuf
-        dz = buf("g_dz_%d" % rows, (rows, Fd))
         dbr = dx2
         if dbr_pre is not None:
             dbr = dbr_pre
         elif self.drop_on and s["site"] is not None:      # adjoint of dropout + DropPath on the branch
             dbr = self._drop(dx2, None, gbuf("g_drop_%d" % rows, (rows, C)), self._site_id(s["site"]), self._dp(*s["site"]), s["rpb"])
-        self._linear_bwd(dbr, s["z"], W(p + "fc2.weight"), G(p + "fc2.weight"), G(p + "fc2.bias"), dx_out=dz)
         du = gbuf("g_du_%d" % rows, (rows, Fd))
-        self._ln_bwd(dz, s["u"], p + "ffn_layernorm", tg + "_fln2", du, gelu=True)
+        if self.ffn_ln_fused and s.get("t") is not None:
+            # fc2 dW / db as usual; dX with the ffn_layernorm + GELU backward in its epilogue: the two row means come from the
+            # 768-wide dbr and the saved fc2 output, dz is never written (no wide LayerNorm-backward kernel)
+            self._linear_bwd(dbr, s["z"], W(p + "fc2.weight"), G(p + "fc2.weight"), G(p + "fc2.bias"), need_dx=False)
+            mu, rs = self._ln_stats(tg + "_fln2", rows)
+            cst = buf(tg + "_fc12", (rows, 2), torch.float32)
+            hip.ffn_ln_rowstats(dbr, s["t"].view(rows, C), self.ws[tg + "_fcoef"], cst, Fd)
+            hip.linear_dx_gelu_ln_bwd(dbr, W(p + "fc2.weight"), du, s["u"], Wf(p + "ffn_layernorm.weight"), mu, rs, cst)
+            self._ffn_pg_tasks.append((W(p + "fc2.weight"), G(p + "fc2.weight"), G(p + "fc2.bias"), Wf(p + "ffn_layernorm.weight"),
+                                       Wf(p + "ffn_layernorm.bias"), G(p + "ffn_layernorm.weight"), G(p + "ffn_layernorm.bias")))
+        else:
+            dz = buf("g_dz_%d" % rows, (rows, Fd))
+            self._linear_bwd(dbr, s["z"], W(p + "fc2.weight"), G(p + "fc2.weight"), G(p + "fc2.bias"), dx_out=dz)
+            if "lnwide" not in _EXP_SKIP:
+                self._ln_bwd(dz, s["u"], p + "ffn_layernorm", tg + "_fln2", du, gelu=True)
         dxn = buf("g_dxn_%d" % rows, (rows, C))
         self._linear_bwd(du, s["xn"], W(p + "fc1.weight"), G(p + "fc1.weight"), G(p + "fc1.bias"), dx_out=dxn)
         dx1 = gbuf("g_dx1_%d" % rows, (rows, C))
@@ -1273,10 +1303,12 @@ class HipEngine:
             if not have_delta:
                 hip.attn_bwd(*args, phases=hip.ATTN_BWD_DELTA, **kw)
             with self._fork(self._dq_stream_get()):
-                hip.attn_bwd(*args, phases=hip.ATTN_BWD_DQ, **kw)
+                if "dq" not in _EXP_SKIP:
+                    hip.attn_bwd(*args, phases=hip.ATTN_BWD_DQ, **kw)
                 dq_done = self._ev()
                 dq_done.record(self._dqs)
-            hip.attn_bwd(*args, phases=hip.ATTN_BWD_DKV, **kw)
+            if "dkv" not in _EXP_SKIP:
+                hip.attn_bwd(*args, phases=hip.ATTN_BWD_DKV, **kw)
             torch.cuda.current_stream().wait_event(dq_done)
         else:
             hip.attn_bwd(*args, phases=(hip.ATTN_BWD_DKV | hip.ATTN_BWD_DQ) if have_delta else 0, **kw)
@@ -1294,7 +1326,8 @@ class HipEngine:
                         tables.append((part, idx, self._table_acc(tabname)))
             hip.attn_bwd_reduce(B, H, T, S, C, dpq_part, dpk_part, dpq_acc, dpk_acc, not first_pos, delta, gain,
                                 self.G(gain_name), nparts if rel is not None else 1, tables)
-        self._side_do(reductions)
+        if "reduce" not in _EXP_SKIP:
+            self._side_do(reductions)
 
     def _table_acc(self, tabname):
         key = "g_tabacc_" + tabname
@@ -1478,6 +1511,17 @@ class HipEngine:
         self._join_side()            # (flushes) the optimizer (main stream) reads the whole gradient arena next
         return self.g16
 
+    def _ffn_ln_coefs(self):
+        """per layer: row sums of fc2.weight against ffn_layernorm's gamma / beta (+ fc2.bias) -> ws[tag + "_fcoef"] fp32 [2, C]
+        (what `ifseg_ffn_ln_rowstats` dots the fc2 output gradient with; weights only, so it runs off the main stream)"""
+        cfg = self.cfg
+        for kind, n in (("e", cfg.enc_layers), ("d", cfg.dec_layers)):
+            for l in range(n):
+                p = "%s.layers.%d." % ("encoder" if kind == "e" else "decoder", l)
+                coef = self.buf("%s%d_fcoef" % (kind, l), (2, cfg.embed_dim), torch.float32)
+                hip.ffn_ln_coef(self.W(p + "fc2.weight"), self.Wf(p + "ffn_layernorm.weight"), self.Wf(p + "ffn_layernorm.bias"),
+                                self.W(p + "fc2.bias"), coef)
+
     def _trunk_launch_point(self):
         """the frozen trunk of the NEXT batch, launched from inside this step's backward: its ~90 convolutions then run
         under the tail of the backward, the final join and the HBM-bound clip + Adam instead of under the next forward"""
@@ -1553,8 +1597,12 @@ class HipEngine:
 
     def _dw_flush(self):
         tasks, self._dw_tasks = self._dw_tasks, []
-        if tasks:
+        if tasks and "dw" not in _EXP_SKIP:
             hip.linear_dw_group(tasks)
+        # ffn_layernorm's dgamma / dbeta from fc2's (now final) weight / bias gradient
+        pg, self._ffn_pg_tasks = self._ffn_pg_tasks, []
+        for w2, dw2, db2, gam, bet, dgam, dbet in pg:
+            hip.ffn_ln_param_grads(w2, dw2, db2, gam, bet, dgam, dbet)
         # the LayerNorm dgamma / dbeta partials collected since the last flush: one reduction launch
         for attr in ("_ln_red_tasks", "_ln_red_acc"):
             red = getattr(self, attr)

@@ -386,7 +386,7 @@ class Trainer:
         if graph and self.world == 1 and len(samples) == 1:
             logs = self._graph_step(samples[0], prefetch[0] if prefetch else None)
         else:
-            if prefetch:
+            if prefetch and "trunkpf" not in __import__("os").environ.get("IFSEG_EXP_SKIP", ""):
                 eng._pf_request = prefetch[0]["net_input"]["patch_images"]
             logs = self._step_body(samples)
         self.num_updates += 1

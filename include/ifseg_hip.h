@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 9
+#define IFSEG_ABI_VERSION 10
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -75,6 +75,26 @@ int ifseg_gemm_tn_group(int n, const ifseg_gemm_tn_problem* probs, int max_workg
  * (unify_multihead_attention.py:503-513 backward); N % 64 == 0.  Replaces phase 1 of ifseg_attn_bwd. */
 int ifseg_gemm_nn_rowdot(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                          const void* dot, int ldd, float* dot_out, int rows_per_batch, void* stream);
+
+/* The FFN's ffn_layernorm(gelu(fc1(x))) -> fc2 on the way back (unify_transformer_layer.py:279-283 under autograd) without a
+ * 3072-wide LayerNorm-backward pass.  dY [M, J] = gradient of the fc2 output t [M, J] (J = embed dim), W2 [J, N] (N = ffn
+ * dim), u [M, N] the saved fc1 output, gamma / beta fp32 [N] of ffn_layernorm, mean / rstd [M] its saved row statistics:
+ *   ifseg_ffn_ln_coef       coef[0][j] = sum_k gamma_k W2[j,k],  coef[1][j] = b2_j + sum_k beta_k W2[j,k]        (per step)
+ *   ifseg_ffn_ln_rowstats   c[m][0] = mean_k(gamma_k dz_k), c[m][1] = mean_k(gamma_k xh_k dz_k) with dz = dY W2, computed as
+ *                           row dots of dY with coef[0] and with (t - coef[1]) -- linear in dz, no 3072-wide tensor is read
+ *   ifseg_gemm_nn_gelu_ln_bwd   C = du [M, N] (bf16) = rstd (gamma dz - c1 - xh c2) gelu'(u), dz = A . B in the accumulators
+ *                           (A = dY [M, K = J], B = W2 [K, N]); dz never reaches HBM
+ *   ifseg_ffn_ln_param_grads    dbeta_k = sum_j db2_j W2[j,k], dgamma_k = (sum_j W2[j,k] dW2[j,k] - beta_k dbeta_k) / gamma_k
+ *                           from the (bf16) weight / bias gradient of fc2, written as bf16 */
+int ifseg_ffn_ln_coef(const void* w2, int ldw, const float* gamma, const float* beta, const void* b2 /* bf16 [J] or NULL */,
+                      float* coef /* [2][J] */, int J, int N, void* stream);
+int ifseg_ffn_ln_rowstats(const void* dy, int lddy, const void* t, int ldt, const float* coef, float* c /* [rows][2] */,
+                          int rows, int J, int N, void* stream);
+int ifseg_gemm_nn_gelu_ln_bwd(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                              const void* u, int ldu, const float* gamma, const float* mean, const float* rstd,
+                              const float* cstats, void* stream);
+int ifseg_ffn_ln_param_grads(const void* w2, const void* dw2, const void* db2, const float* gamma, const float* beta,
+                             void* dgamma, void* dbeta, int J, int N, void* stream);
 
 /* Implicit-GEMM conv on NHWC bf16 with folded FrozenBatchNorm (+residual, +ReLU).
  * `w` is [Cout][KH][KW][Cin] with the BN scale already folded in, `shift` the

@@ -900,3 +900,50 @@ def test_custom_ops_forward_backward_through_the_dispatcher():
     scale = max(t.grad.abs().max().item() for t in tl)
     for name, a_, b_ in zip(("drel2d", "drel1d", "drelx"), tabs, tl):
         assert ((a_.grad.cpu() - b_.grad).abs().max() / scale).item() < 3e-2, name
+
+
+def test_ffn_layernorm_backward_in_the_gemm_epilogue():
+    """ffn_layernorm(gelu(fc1)) -> fc2 on the way back without a wide LayerNorm-backward pass: the two row means from 768-wide
+    tensors (ifseg_ffn_ln_coef / _rowstats), du from the dX GEMM's epilogue (ifseg_gemm_nn_gelu_ln_bwd), dgamma / dbeta from
+    fc2's weight gradient (ifseg_ffn_ln_param_grads) -- against fp32 autograd of z = LN(gelu(u)), t = z W2^T + b2."""
+    from ifseg_amd import hip
+    dev = _dev()
+    M, J, N = 1060 * 2 + 5, 256, 1024
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    u = r(M, N).to(torch.bfloat16)
+    gamma, beta = (1 + 0.2 * r(N)).contiguous(), (0.1 * r(N)).contiguous()
+    w2, b2 = r(J, N, sc=0.05).to(torch.bfloat16), r(J, sc=0.1).to(torch.bfloat16)
+    dy = r(M, J, sc=0.1).to(torch.bfloat16)
+    # forward through the kernels (what the engine saves): z, row statistics, t
+    z = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    mu, rs = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    hip.ln_fwd(u, gamma, beta, z, mu, rs, gelu=True)
+    t = hip.linear_fwd(z, w2, b2)
+    # fp32 autograd reference on the same (bf16-valued) operands
+    uf, gf, bf_ = u.float().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    zr = torch.nn.functional.layer_norm(torch.nn.functional.gelu(uf), (N,), gf, bf_, 1e-5)
+    tr = zr @ w2.float().t() + b2.float()
+    (tr * dy.float()).sum().backward()
+    # fused backward
+    coef = torch.empty(2, J, device=dev)
+    hip.ffn_ln_coef(w2, gamma, beta, b2, coef)
+    assert _rel(coef[0], w2.float() @ gamma) < 1e-5 and _rel(coef[1], b2.float() + w2.float() @ beta) < 1e-5
+    c = torch.empty(M, 2, device=dev)
+    hip.ffn_ln_rowstats(dy, t, coef, c, N)
+    du = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    hip.linear_dx_gelu_ln_bwd(dy, w2, du, u, gamma, mu, rs, c)
+    buf = torch.empty(J * N + J, dtype=torch.bfloat16, device=dev)
+    dw2, db2 = buf[: J * N].view(J, N), buf[J * N:]
+    assert hip.linear_dw(dy, z, dw2, bias_out=db2)
+    dgam, dbet = torch.empty(N, dtype=torch.bfloat16, device=dev), torch.empty(N, dtype=torch.bfloat16, device=dev)
+    hip.ffn_ln_param_grads(w2, dw2, db2, gamma, beta, dgam, dbet)
+    torch.cuda.synchronize()
+    # the row means themselves, against their definition
+    with torch.no_grad():
+        dz = dy.float() @ w2.float()
+        xh = (torch.nn.functional.gelu(u.float()) - mu[:, None]) * rs[:, None]
+        c1, c2 = (dz * gamma).mean(1), (dz * gamma * xh).mean(1)
+    e = {"c1": _rel(c[:, 0], c1), "c2": _rel(c[:, 1], c2), "du": _rel(du, uf.grad), "dgamma": _rel(dgam, gf.grad), "dbeta": _rel(dbet, bf_.grad)}
+    print("ffn-ln fused backward", {k: round(v, 5) for k, v in e.items()})
+    assert e["c1"] < 5e-3 and e["c2"] < 2e-2 and e["du"] < 1e-2 and e["dgamma"] < 2e-2 and e["dbeta"] < 1e-2, e
