@@ -1014,12 +1014,16 @@ extern "C" int ifseg_droppath_scale(float* out, const float* keep, int n, int B,
 //     dgamma_k = (sum_j W2[j,k] dW2[j,k] - beta_k dbeta_k) / gamma_k        (dW2[j,k] = sum_r dY[r,j] (gamma_k xh[r,k] + beta_k))
 namespace {
 
-// coef[0][j] = a_j, coef[1][j] = wb_j : one wave per row j of W2 [J, N]
-__global__ __launch_bounds__(256) void ffn_ln_coef_kernel(const bf16_t* __restrict__ w2, int ldw, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const bf16_t* __restrict__ b2,
-                                                          float* __restrict__ coef, int J, int N) {
+// coef[0][j] = a_j, coef[1][j] = wb_j : one wave per row j of W2 [J, N]; blockIdx.y = layer (up to 32 layers per launch)
+struct FfnCoefPtrs { const bf16_t* w2[32]; const float* gamma[32]; const float* beta[32]; const bf16_t* b2[32]; float* coef[32]; };
+__global__ __launch_bounds__(256) void ffn_ln_coef_kernel(FfnCoefPtrs pt, int ldw, int J, int N) {
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (j >= J) return;
+  const bf16_t* __restrict__ w2 = pt.w2[blockIdx.y];
+  const float* __restrict__ gamma = pt.gamma[blockIdx.y];
+  const float* __restrict__ beta = pt.beta[blockIdx.y];
+  const bf16_t* __restrict__ b2 = pt.b2[blockIdx.y];
+  float* __restrict__ coef = pt.coef[blockIdx.y];
   const bf16_t* row = w2 + (long long)j * ldw;
   float sa = 0.f, sb = 0.f;
   for (int k = lane * 8; k < N; k += 64 * 8) {
@@ -1055,33 +1059,63 @@ __global__ __launch_bounds__(256) void ffn_ln_rowstats_kernel(const bf16_t* __re
   if (lane == 0) { c[2 * r] = s1 * inv_n; c[2 * r + 1] = s2 * inv_n; }
 }
 
-// one thread per column k of W2 [J, N] / dW2 [J, N] (bf16, row-major): coalesced across k, a loop over the J rows
-__global__ __launch_bounds__(256) void ffn_ln_param_grads_kernel(const bf16_t* __restrict__ w2, const bf16_t* __restrict__ dw2,
-                                                                 const bf16_t* __restrict__ db2, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, bf16_t* __restrict__ dgamma,
-                                                                 bf16_t* __restrict__ dbeta, int J, int N) {
+// stage 1: partial column sums over a slab of rows.  Block = 128 columns x 16 row lanes (a thread: 8 columns of every 16th
+// row of its slab), grid (N / 128, PG_SLABS): part[slab][0][k] = sum_j W2[j,k] dW2[j,k], part[slab][1][k] = sum_j W2[j,k] db2_j
+constexpr int PG_SLABS = 8;
+__global__ __launch_bounds__(256) void ffn_ln_pg_partial_kernel(const bf16_t* __restrict__ w2, const bf16_t* __restrict__ dw2,
+                                                                const bf16_t* __restrict__ db2, float* __restrict__ part, int J, int N) {
+  __shared__ float red[2][16][128 + 4];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int k0 = blockIdx.x * 128 + cx * 8;
+  const int rows_per = (J + PG_SLABS - 1) / PG_SLABS, j0 = blockIdx.y * rows_per, j1 = min(J, j0 + rows_per);
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (k0 < N) {
+    for (int j = j0 + ry; j < j1; j += 16) {
+      float w[8], d[8];
+      unpack8(*reinterpret_cast<const uint4*>(w2 + (long long)j * N + k0), w);
+      unpack8(*reinterpret_cast<const uint4*>(dw2 + (long long)j * N + k0), d);
+      const float dbj = bf2f(db2[j]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a[e] += w[e] * d[e]; b[e] += w[e] * dbj; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[0][ry][cx * 8 + e] = a[e]; red[1][ry][cx * 8 + e] = b[e]; }
+  __syncthreads();
+  const int which = threadIdx.x >> 7, col = threadIdx.x & 127, k = blockIdx.x * 128 + col;
+  if (k < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[which][r][col];          // fixed order: bit-reproducible
+    part[((long long)blockIdx.y * 2 + which) * N + k] = t;
+  }
+}
+// stage 2: dbeta_k = sum over slabs of part[.][1][k]; dgamma_k = (sum of part[.][0][k] - beta_k dbeta_k) / gamma_k
+__global__ __launch_bounds__(256) void ffn_ln_pg_final_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, bf16_t* __restrict__ dgamma,
+                                                              bf16_t* __restrict__ dbeta, int N) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= N) return;
   float swd = 0.f, sdb = 0.f;
-  for (int j = 0; j < J; ++j) {
-    const float w = bf2f(w2[(long long)j * N + k]);
-    swd += w * bf2f(dw2[(long long)j * N + k]);
-    sdb += w * bf2f(db2[j]);
-  }
-  const float bk = beta[k], gk = gamma[k];
+#pragma unroll
+  for (int sl = 0; sl < PG_SLABS; ++sl) { swd += part[((long long)sl * 2) * N + k]; sdb += part[((long long)sl * 2 + 1) * N + k]; }
   dbeta[k] = f2bf(sdb);
-  dgamma[k] = f2bf((swd - bk * sdb) / gk);
+  dgamma[k] = f2bf((swd - beta[k] * sdb) / gamma[k]);
 }
 
 }  // namespace
 
-extern "C" int ifseg_ffn_ln_coef(const void* w2, int ldw, const float* gamma, const float* beta, const void* b2, float* coef,
-                                 int J, int N, void* stream) {
+extern "C" int ifseg_ffn_ln_coef(const void* const* w2, int ldw, const float* const* gamma, const float* const* beta,
+                                 const void* const* b2, float* const* coef, int L, int J, int N, void* stream) {
   (void)hipGetLastError();
-  if (!w2 || !gamma || !beta || !coef || J <= 0 || N <= 0 || (N & 7) || (ldw & 7) || (((size_t)gamma | (size_t)beta) & 15))
-    return IFSEG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(ffn_ln_coef_kernel, dim3((J + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w2, ldw, gamma, beta,
-                     (const bf16_t*)b2, coef, J, N);
+  if (!w2 || !gamma || !beta || !coef || L <= 0 || L > 32 || J <= 0 || N <= 0 || (N & 7) || (ldw & 7)) return IFSEG_ERR_BAD_ARG;
+  FfnCoefPtrs pt{};
+  for (int l = 0; l < L; ++l) {
+    if (!w2[l] || !gamma[l] || !beta[l] || !coef[l] || (((size_t)gamma[l] | (size_t)beta[l]) & 15)) return IFSEG_ERR_BAD_ARG;
+    pt.w2[l] = (const bf16_t*)w2[l]; pt.gamma[l] = gamma[l]; pt.beta[l] = beta[l];
+    pt.b2[l] = b2 ? (const bf16_t*)b2[l] : nullptr; pt.coef[l] = coef[l];
+  }
+  hipLaunchKernelGGL(ffn_ln_coef_kernel, dim3((J + 3) / 4, L), dim3(256), 0, (hipStream_t)stream, pt, ldw, J, N);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }
@@ -1098,11 +1132,14 @@ extern "C" int ifseg_ffn_ln_rowstats(const void* dy, int lddy, const void* t, in
 }
 
 extern "C" int ifseg_ffn_ln_param_grads(const void* w2, const void* dw2, const void* db2, const float* gamma, const float* beta,
-                                        void* dgamma, void* dbeta, int J, int N, void* stream) {
+                                        void* dgamma, void* dbeta, float* workspace /* >= 16 N floats */, int J, int N,
+                                        void* stream) {
   (void)hipGetLastError();
-  if (!w2 || !dw2 || !db2 || !gamma || !beta || !dgamma || !dbeta || J <= 0 || N <= 0) return IFSEG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(ffn_ln_param_grads_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w2,
-                     (const bf16_t*)dw2, (const bf16_t*)db2, gamma, beta, (bf16_t*)dgamma, (bf16_t*)dbeta, J, N);
+  if (!w2 || !dw2 || !db2 || !gamma || !beta || !dgamma || !dbeta || !workspace || J <= 0 || N <= 0 || (N & 7)) return IFSEG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ffn_ln_pg_partial_kernel, dim3((N + 127) / 128, PG_SLABS), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)w2, (const bf16_t*)dw2, (const bf16_t*)db2, workspace, J, N);
+  hipLaunchKernelGGL(ffn_ln_pg_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, gamma, beta,
+                     (bf16_t*)dgamma, (bf16_t*)dbeta, N);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

@@ -117,10 +117,15 @@ def linear_dx_rowdot(dy, w, out, dot, dot_out, rows_per_batch):
 
 
 def ffn_ln_coef(w2, gamma, beta, b2, coef):
-    """coef fp32 [2, J]: row sums of W2 [J, N] against gamma / beta (+ b2) -- see include/ifseg_hip.h"""
-    J, N = w2.shape
-    _check(lib().ifseg_ffn_ln_coef(_ptr(_bf(w2)), c_int(w2.stride(0)), _ptr(gamma), _ptr(beta), _ptr(b2), _ptr(coef), c_int(J),
-                                   c_int(N), _stream()), "ffn_ln_coef")
+    """coef fp32 [2, J]: row sums of W2 [J, N] against gamma / beta (+ b2) -- see include/ifseg_hip.h.  Lists of equally
+    shaped tensors (one entry per layer, <= 32) go out in ONE launch."""
+    if not isinstance(w2, (list, tuple)):
+        w2, gamma, beta, b2, coef = [w2], [gamma], [beta], [b2], [coef]
+    L = len(w2)
+    J, N = w2[0].shape
+    arr = lambda ts: (c_void_p * L)(*[t.data_ptr() for t in ts])
+    _check(lib().ifseg_ffn_ln_coef(arr([_bf(t) for t in w2]), c_int(w2[0].stride(0)), arr(gamma), arr(beta), arr(b2), arr(coef),
+                                   c_int(L), c_int(J), c_int(N), _stream()), "ffn_ln_coef")
     return coef
 
 
@@ -143,11 +148,17 @@ def linear_dx_gelu_ln_bwd(dy, w, out, u, gamma, mean, rstd, c):
     return out
 
 
+_pg_ws = {}
+
+
 def ffn_ln_param_grads(w2, dw2, db2, gamma, beta, dgamma, dbeta):
     J, N = w2.shape
     assert w2.is_contiguous() and dw2.is_contiguous()
+    ws = _pg_ws.get((w2.device, N))
+    if ws is None:
+        ws = _pg_ws[(w2.device, N)] = torch.empty(16 * N, dtype=torch.float32, device=w2.device)
     _check(lib().ifseg_ffn_ln_param_grads(_ptr(_bf(w2)), _ptr(_bf(dw2)), _ptr(_bf(db2)), _ptr(gamma), _ptr(beta), _ptr(dgamma),
-                                          _ptr(dbeta), c_int(J), c_int(N), _stream()), "ffn_ln_param_grads")
+                                          _ptr(dbeta), _ptr(ws), c_int(J), c_int(N), _stream()), "ffn_ln_param_grads")
 
 
 _splitk_ws = {}

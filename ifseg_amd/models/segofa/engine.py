@@ -822,12 +822,10 @@ class HipEngine:
         # the K|V projections of every decoder layer's cross-attention only read the encoder output: they run on
         # the side stream underneath the first decoder blocks instead of inside each layer's dependent chain
         ctx["ckv_ready"] = None
-        if need_grad and self.ffn_ln_fused and not self.overlap:
-            self._ffn_ln_coefs()
+        if need_grad and self.ffn_ln_fused:
+            self._ffn_ln_coefs()        # one small launch for all layers, main stream (read again by the backward)
         if self.overlap and need_grad:
             with self._wgrad():
-                if self.ffn_ln_fused:
-                    self._ffn_ln_coefs()        # weights only: needed by the backward (its first kernel waits for ckv_ready's stream)
                 for l in range(cfg.dec_layers):
                     a_ = "%slayers.%d.encoder_attn" % (d, l)
                     kv = buf("d%d_ckv" % l, (B, T, 2 * C))
@@ -1513,14 +1511,17 @@ class HipEngine:
 
     def _ffn_ln_coefs(self):
         """per layer: row sums of fc2.weight against ffn_layernorm's gamma / beta (+ fc2.bias) -> ws[tag + "_fcoef"] fp32 [2, C]
-        (what `ifseg_ffn_ln_rowstats` dots the fc2 output gradient with; weights only, so it runs off the main stream)"""
+        (what `ifseg_ffn_ln_rowstats` dots the fc2 output gradient with): all layers in one launch"""
         cfg = self.cfg
+        w2, gam, bet, b2, coef = [], [], [], [], []
         for kind, n in (("e", cfg.enc_layers), ("d", cfg.dec_layers)):
             for l in range(n):
                 p = "%s.layers.%d." % ("encoder" if kind == "e" else "decoder", l)
-                coef = self.buf("%s%d_fcoef" % (kind, l), (2, cfg.embed_dim), torch.float32)
-                hip.ffn_ln_coef(self.W(p + "fc2.weight"), self.Wf(p + "ffn_layernorm.weight"), self.Wf(p + "ffn_layernorm.bias"),
-                                self.W(p + "fc2.bias"), coef)
+                w2.append(self.W(p + "fc2.weight")); gam.append(self.Wf(p + "ffn_layernorm.weight"))
+                bet.append(self.Wf(p + "ffn_layernorm.bias")); b2.append(self.W(p + "fc2.bias"))
+                coef.append(self.buf("%s%d_fcoef" % (kind, l), (2, cfg.embed_dim), torch.float32))
+        for i in range(0, len(w2), 32):
+            hip.ffn_ln_coef(w2[i:i + 32], gam[i:i + 32], bet[i:i + 32], b2[i:i + 32], coef[i:i + 32])
 
     def _trunk_launch_point(self):
         """the frozen trunk of the NEXT batch, launched from inside this step's backward: its ~90 convolutions then run

@@ -86,15 +86,17 @@ int ifseg_gemm_nn_rowdot(const void* A, const void* B, void* C, int M, int N, in
  *                           (A = dY [M, K = J], B = W2 [K, N]); dz never reaches HBM
  *   ifseg_ffn_ln_param_grads    dbeta_k = sum_j db2_j W2[j,k], dgamma_k = (sum_j W2[j,k] dW2[j,k] - beta_k dbeta_k) / gamma_k
  *                           from the (bf16) weight / bias gradient of fc2, written as bf16 */
-int ifseg_ffn_ln_coef(const void* w2, int ldw, const float* gamma, const float* beta, const void* b2 /* bf16 [J] or NULL */,
-                      float* coef /* [2][J] */, int J, int N, void* stream);
+int ifseg_ffn_ln_coef(const void* const* w2, int ldw, const float* const* gamma, const float* const* beta,
+                      const void* const* b2 /* bf16 [J] each, or NULL */, float* const* coef /* [2][J] each */,
+                      int L /* layers in this launch (host arrays of L device pointers), <= 32 */, int J, int N, void* stream);
 int ifseg_ffn_ln_rowstats(const void* dy, int lddy, const void* t, int ldt, const float* coef, float* c /* [rows][2] */,
                           int rows, int J, int N, void* stream);
 int ifseg_gemm_nn_gelu_ln_bwd(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                               const void* u, int ldu, const float* gamma, const float* mean, const float* rstd,
                               const float* cstats, void* stream);
 int ifseg_ffn_ln_param_grads(const void* w2, const void* dw2, const void* db2, const float* gamma, const float* beta,
-                             void* dgamma, void* dbeta, int J, int N, void* stream);
+                             void* dgamma, void* dbeta, float* workspace /* >= 16 N floats: partial column sums of 8 row slabs */,
+                             int J, int N, void* stream);
 
 /* Implicit-GEMM conv on NHWC bf16 with folded FrozenBatchNorm (+residual, +ReLU).
  * `w` is [Cout][KH][KW][Cin] with the BN scale already folded in, `shift` the
