@@ -19,6 +19,10 @@ OBJDIR = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + os.environ.get("IFSEG_EXTRA_FLAGS", "").split()
 
 
+# per-file flags on top of FLAGS (see the build note at the top of csrc/ffn_ln.hip)
+PER_FILE_FLAGS = {"ffn_ln.hip": ["-fno-slp-vectorize"]}
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -54,7 +58,7 @@ def build(force=False, verbose=True):
         o = os.path.join(OBJDIR, src[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + PER_FILE_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -902,6 +902,49 @@ def test_custom_ops_forward_backward_through_the_dispatcher():
         assert ((a_.grad.cpu() - b_.grad).abs().max() / scale).item() < 3e-2, name
 
 
+def test_ffn_ln_reductions_are_bit_exact_next_to_a_running_gemm():
+    """The small reduction kernels of the FFN-LayerNorm fold run on the main stream while GEMMs of another stream (the next
+    batch's trunk, the weight gradients) share their CUs.  In its SLP-vectorised form ifseg_ffn_ln_coef returned a few wrong
+    sum(w * gamma) entries per launch in exactly that situation (csrc/ffn_ln.hip, build note; tools/probe/) and the training
+    step stopped being reproducible -- so: 12 layers x 768 rows, 60 launches, every one next to a stream of F.linear-shaped
+    GEMMs, bit-equal to the launch that ran alone.  The row-statistics kernel rides along."""
+    from ifseg_amd import hip
+    dev = _dev()
+    L, J, N, M = 12, 768, 3072, 2120
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    w2 = [r(J, N, sc=0.02).to(torch.bfloat16) for _ in range(L)]
+    gam, bet = [(1 + 0.01 * r(N)).contiguous() for _ in range(L)], [(0.01 * r(N)).contiguous() for _ in range(L)]
+    b2 = [r(J, sc=0.01).to(torch.bfloat16) for _ in range(L)]
+    dy, t = r(M, J, sc=0.1).to(torch.bfloat16), r(M, J).to(torch.bfloat16)
+    new = lambda: [torch.empty(2, J, device=dev) for _ in range(L)]
+    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    ref, ref_c = new(), torch.empty(M, 2, device=dev)
+    hip.ffn_ln_coef(w2, gam, bet, b2, ref)
+    hip.ffn_ln_rowstats(dy, t, ref[0], ref_c, N)
+    torch.cuda.synchronize()
+    assert ((ref[0][0] - w2[0].float() @ gam[0]).abs().max() / ref[0][0].abs().max()).item() < 1e-5
+    x, w = r(4096, 768).to(torch.bfloat16), r(768, 768).to(torch.bfloat16)
+    o = torch.empty(4096, 768, device=dev, dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+    coef, c = new(), torch.empty(M, 2, device=dev)
+    for it in range(15):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            prev = hip.set_stream(side.cuda_stream)
+            for _ in range(40):
+                hip.linear_fwd(x, w, None, out=o)
+            hip.set_stream(prev)
+        for rep in range(4):
+            hip.ffn_ln_coef(w2, gam, bet, b2, coef)
+            hip.ffn_ln_rowstats(dy, t, coef[0], c, N)
+            torch.cuda.current_stream().synchronize()
+            for l in range(L):
+                assert torch.equal(coef[l], ref[l]), (it, rep, l, (coef[l] - ref[l]).abs().max().item())
+            assert torch.equal(c, ref_c), (it, rep, (c - ref_c).abs().max().item())
+        torch.cuda.synchronize()
+
+
 def test_ffn_layernorm_backward_in_the_gemm_epilogue():
     """ffn_layernorm(gelu(fc1)) -> fc2 on the way back without a wide LayerNorm-backward pass: the two row means from 768-wide
     tensors (ifseg_ffn_ln_coef / _rowstats), du from the dX GEMM's epilogue (ifseg_gemm_nn_gelu_ln_bwd), dgamma / dbeta from

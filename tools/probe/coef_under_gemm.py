@@ -1,0 +1,77 @@
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+from ifseg_amd import hip
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+L, J, N = 12, 768, 3072
+w2 = [(torch.randn(J, N, device=dev) * 0.02).to(torch.bfloat16) for _ in range(L)]
+gam = [1 + 0.01 * torch.randn(N, device=dev) for _ in range(L)]
+bet = [0.01 * torch.randn(N, device=dev) for _ in range(L)]
+b2 = [(0.01 * torch.randn(J, device=dev)).to(torch.bfloat16) for _ in range(L)]
+coef = [torch.empty(2, J, device=dev) for _ in range(L)]
+ref = [torch.empty(2, J, device=dev) for _ in range(L)]
+hip.set_stream(torch.cuda.current_stream().cuda_stream)
+import ctypes
+variant = int(os.environ.get("VARIANT", "-1"))
+vlib = ctypes.CDLL(os.path.join(os.getcwd(), "tools/probe/libcoefv.so")) if variant >= 0 else None
+def run_coef(out):
+    if variant < 0: return hip.ffn_ln_coef(w2, gam, bet, b2, out)
+    arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
+    vlib.coefv_launch(variant, arr(w2), N, arr(gam), arr(bet), arr(b2), arr(out), L, J, N, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+hip.ffn_ln_coef(w2, gam, bet, b2, ref)
+torch.cuda.synchronize()
+mode = sys.argv[1]
+M_, K_, N_ = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (4096, 768, 768)
+prio = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+s2 = torch.cuda.Stream(priority=prio)
+x = torch.randn(M_, K_, device=dev).to(torch.bfloat16)
+w = torch.randn(N_, K_, device=dev).to(torch.bfloat16)
+o = torch.empty(M_, N_, device=dev, dtype=torch.bfloat16)
+wt = torch.randn(N_, N_, device=dev).to(torch.bfloat16)
+dx = torch.empty(M_, N_, device=dev, dtype=torch.bfloat16)
+# conv operands: 1x1 on [2, 64, 64, 256] -> 64 and 3x3 64 -> 64
+B, H, W, Ci, Co = 2, 64, 64, 256, 64
+cx = torch.randn(B, H, W, Ci, device=dev).to(torch.bfloat16)
+cw1 = torch.randn(Co, 1, 1, Ci, device=dev).to(torch.bfloat16)
+cs = torch.zeros(Co, device=dev)
+co1 = torch.empty(B, H, W, Co, device=dev, dtype=torch.bfloat16)
+cw3 = torch.randn(Co, 3, 3, Co, device=dev).to(torch.bfloat16)
+co3 = torch.empty(B, H, W, Co, device=dev, dtype=torch.bfloat16)
+bad = 0
+rows = [0, 0]
+for it in range(100):
+    ev = torch.cuda.Event(); ev.record(); s2.wait_event(ev)
+    with torch.cuda.stream(s2):
+        prev = hip.set_stream(s2.cuda_stream)
+        for _ in range(40):
+            if mode == "linear": hip.linear_fwd(x, w, None, out=o)
+            elif mode == "dx": hip.linear_dx(o, wt, out=dx)
+            elif mode == "conv1": hip.conv2d_nhwc(cx, cw1, cs, None, co1, B, H, W, Ci, Co, 1, 1, 1, 0, True)
+            elif mode == "conv3": hip.conv2d_nhwc(co1, cw3, cs, None, co3, B, H, W, Co, Co, 3, 3, 1, 1, True)
+            elif mode == "torch": torch.mm(x, w.t(), out=o)
+        hip.set_stream(prev)
+    for rep in range(20):
+        run_coef(coef)
+        if rep % 4 == 3:
+            torch.cuda.current_stream().synchronize()
+            for l in range(L):
+                if not torch.allclose(coef[l], ref[l], rtol=0, atol=1e-5):
+                    d = (coef[l] - ref[l]).abs(); bad += 1
+                    rows[0] += int((d[0] > 1e-5).sum()); rows[1] += int((d[1] > 1e-5).sum())
+                    if bad < 0:
+                        for jj in (d[0] > 0).nonzero().flatten().tolist()[:2]:
+                            df = (coef[l][0, jj] - ref[l][0, jj]).item()
+                            ch = (w2[l][jj].float() * gam[l]).view(6, 64, 8)          # [it, lane, e]
+                            lane_part = ch.sum((0, 2)); it_part = ch.sum(2)
+                            k1 = (lane_part + df).abs().argmin().item(); k2 = (it_part + df).abs().argmin().item()
+                            k3 = (ch + df).abs().argmin().item()
+                            cum = it_part.cumsum(0)                                    # partial after it iterations
+                            k4 = (cum + df).abs().argmin().item()
+                            print("   j", jj, "diff %.6f" % df, "| nearest -lane_partial: lane %d (%.6f)" % (k1, -lane_part[k1].item()),
+                                  "| nearest -chunk: it %d lane %d (%.6f)" % (k2 // 64, k2 % 64, -it_part.flatten()[k2].item()),
+                                  "| nearest -cum: it %d lane %d (%.6f)" % (k4 // 64, k4 % 64, -cum.flatten()[k4].item()),
+                                  "| nearest -term: %.6f" % (-ch.flatten()[k3].item()))
+                    if bad < 4: print("iter", it, rep, "layer", l, "nonequal", (d > 0).nonzero().tolist()[:6], d.max().item())
+    torch.cuda.synchronize()
+print(mode, sys.argv[2:], "bad", bad, "wrong entries in coef[0] / coef[1]:", rows)

@@ -12,7 +12,7 @@ vdir = os.path.join(B.LIBDIR, "variants"); os.makedirs(vdir, exist_ok=True)
 odir = os.path.join(B.OBJDIR, "variants"); os.makedirs(odir, exist_ok=True)
 o = os.path.join(odir, "%s_%s.o" % (name, src[:-4]))
 hipcc = "/opt/rocm/bin/hipcc"
-subprocess.run([hipcc] + B.FLAGS + flags + ["-c", os.path.join(B.CSRC, src), "-o", o], check=True)
+subprocess.run([hipcc] + B.FLAGS + B.PER_FILE_FLAGS.get(src, []) + flags + ["-c", os.path.join(B.CSRC, src), "-o", o], check=True)
 objs = [o if s == src else os.path.join(B.OBJDIR, s[:-4] + ".o") for s in B._sources()]
 out = os.path.join(vdir, name + ".so")
 subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-no-hip-rt", "-o", out] + objs, check=True)
