@@ -241,9 +241,10 @@ def dw_groupable(dy, x, out, bias_out):
     return dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0
 
 
-def linear_dw_group(tasks):
+def linear_dw_group(tasks, wgs=None):
     """tasks: list of (dy [M,N], x [M,K], out [N,K] bf16, bias_out or None): every dW (+ db) in ONE launch
-    (ifseg_gemm_tn_group), at most GEMM_GROUP_MAX per launch"""
+    (ifseg_gemm_tn_group), at most GEMM_GROUP_MAX per launch.  `wgs`: workgroup cap (default DW_GROUP_WGS: one per CU,
+    the main stream's kernels keep half of every CU; 0 = one workgroup per tile, for a launch with the GPU to itself)"""
     for i in range(0, len(tasks), GEMM_GROUP_MAX):
         chunk = tasks[i:i + GEMM_GROUP_MAX]
         arr = (_TnProblem * len(chunk))()
@@ -252,7 +253,7 @@ def linear_dw_group(tasks):
             q.A, q.B, q.C = _p(_bf(dy)), _p(_bf(x)), _p(out)
             q.M, q.N, q.K, q.lda, q.ldb = N, x.shape[1], M, dy.stride(0), x.stride(0)
             q.colsum, q.accumulate = (1 if bias_out is not None else 0), 0
-        _check(lib().ifseg_gemm_tn_group(c_int(len(chunk)), arr, c_int(DW_GROUP_WGS), _stream()), "gemm_tn_group")
+        _check(lib().ifseg_gemm_tn_group(c_int(len(chunk)), arr, c_int(DW_GROUP_WGS if wgs is None else wgs), _stream()), "gemm_tn_group")
 
 
 def conv2d_nhwc(x, w, shift, resid, out, B, H, W, Cin, Cout, KH, KW, stride, pad, relu):

@@ -1503,10 +1503,19 @@ class HipEngine:
             self._side_flush()
         # ---- encoder abs-pos operands
         self._bt = "etop"
-        self._side_do(lambda: (self._dw_flush(), self._enc_tail_bwd(B, L, P, T, h, w, dx, depq, depk, pos_all, dpos_all)))
+        # the main stream has run out of work: the side stream gets the whole GPU for the last weight gradients (no workgroup
+        # cap) and the abs-pos half of the tail, the main stream takes the embedding half, which only reads its own dx
+        if "tailsplit" in _EXP_SKIP:     # (measurement: the whole tail on the side stream, capped grid)
+            self._side_do(lambda: (self._dw_flush(), self._enc_tail_pos_bwd(B, L, P, T, h, w, depq, depk, pos_all, dpos_all),
+                                   self._enc_tail_emb_bwd(B, L, P, T, dx)))
+        else:
+            self._side_do(lambda: (self._dw_flush(wgs=0), self._enc_tail_pos_bwd(B, L, P, T, h, w, depq, depk, pos_all, dpos_all)))
+            self._side_flush()
+            self._enc_tail_emb_bwd(B, L, P, T, dx)
         if self.trunk_at == "end":
             self._trunk_launch_point()
-        self._join_side()            # (flushes) the optimizer (main stream) reads the whole gradient arena next
+        self._join_side()            # the optimizer (main stream) reads the whole gradient arena next
+        self._notify(e)              # both halves of the tail are in: the last gradient slice may be reduced (main stream)
         return self.g16
 
     def _ffn_ln_coefs(self):
@@ -1530,8 +1539,8 @@ class HipEngine:
             req, self._pf_request = self._pf_request, None
             self.prefetch_trunk(req)
 
-    def _enc_tail_bwd(self, B, L, P, T, h, w, dx, depq, depk, pos_all, dpos_all):
-        """encoder abs-pos operands and embedding LayerNorms: parameter gradients only -- side stream"""
+    def _enc_tail_pos_bwd(self, B, L, P, T, h, w, depq, depk, pos_all, dpos_all):
+        """encoder abs-pos operands (parameter gradients only; inputs accumulated on the side stream) -- side stream"""
         cfg = self.cfg
         C = cfg.embed_dim
         W, Wf, G, buf = self.W, self.Wf, self.G, self.buf
@@ -1549,7 +1558,16 @@ class HipEngine:
         self._ln_bwd(dpos_all[:P].view(h, w, C), ipos_view, e + "image_pos_ln", "ipos_ln", ipos_grad)
         self._ln_bwd(dpos_all[P:], W(e + "embed_positions.weight")[:L], e + "pos_ln", "tpos_ln",
                      G(e + "embed_positions.weight")[:L])
-        # ---- encoder embeddings (embed_tokens / image_proj / ResNet frozen -> stop here)
+        self._dw_flush()                 # the LayerNorm partials of this half
+        assert not self._ln_red_tasks and not self._ln_red_acc and not self._dw_tasks
+
+    def _enc_tail_emb_bwd(self, B, L, P, T, dx):
+        """encoder embedding LayerNorms / type embedding (embed_tokens / image_proj / ResNet frozen -> stop here): reads only
+        the main stream's dx -- main stream, next to the side stream's last weight gradients"""
+        cfg = self.cfg
+        C = cfg.embed_dim
+        W, Wf, G, buf = self.W, self.Wf, self.G, self.buf
+        e = "encoder."
         dx3 = dx.view(B, T, C)
         dxi, dxt = dx3[:, :P], dx3[:, P:]
         dimg = buf("g_dimg_pre", (B, P, C))
@@ -1561,9 +1579,8 @@ class HipEngine:
         gt = G(e + "type_embedding.weight")
         self._bias_grad(dtok.view(B * L, C), gt[0])
         self._bias_grad(dimg.view(B * P, C), gt[1])
-        self._dw_flush()                 # the LayerNorm partials of this tail
+        self._dw_flush()                 # the LayerNorm partials of this half
         assert not self._ln_red_tasks and not self._ln_red_acc and not self._dw_tasks
-        self._notify(e)
 
     def _dec_pos_bwd(self, B, P, T, Td, dspq, dspk, dcpq, dcpk, pos_all, dpos_all):
         """gradients of the decoder's position operands (self / cross abs-pos projections, seg positions) -- side stream"""
@@ -1596,10 +1613,10 @@ class HipEngine:
         self._dw_flush()                 # the LayerNorm partials queued since the last layer
         self._side_do(lambda: self._notify(d))
 
-    def _dw_flush(self):
+    def _dw_flush(self, wgs=None):
         tasks, self._dw_tasks = self._dw_tasks, []
         if tasks and "dw" not in _EXP_SKIP:
-            hip.linear_dw_group(tasks)
+            hip.linear_dw_group(tasks, wgs)
         # ffn_layernorm's dgamma / dbeta from fc2's (now final) weight / bias gradient
         pg, self._ffn_pg_tasks = self._ffn_pg_tasks, []
         for w2, dw2, db2, gam, bet, dgam, dbet in pg:

@@ -10,4 +10,5 @@ python $GRAFT_REPO_ROOT/tools/prof_summary.py $out/trace 10 "rocprofv3 --kernel-
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 python $GRAFT_REPO_ROOT/tools/queue_kernels.py $(find $out/trace -name "*kernel_trace.csv" | head -1) 2 6 > $out/queues.txt
 python $GRAFT_REPO_ROOT/tools/queue_gaps.py $(find $out/trace -name "*kernel_trace.csv" | head -1) 2 6 > $out/gaps.txt
+python $GRAFT_REPO_ROOT/tools/step_timeline.py $(find $out/trace -name "*kernel_trace.csv" | head -1) 3 > $out/timeline.txt
 find $out/trace -name "*.csv" -size +3M -delete; find $out -name "*.db" -delete
