@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, os.getcwd())
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import torch
 from ifseg_amd import hip
 dev = torch.device("cuda:0")
@@ -14,7 +14,7 @@ ref = [torch.empty(2, J, device=dev) for _ in range(L)]
 hip.set_stream(torch.cuda.current_stream().cuda_stream)
 import ctypes
 variant = int(os.environ.get("VARIANT", "-1"))
-vlib = ctypes.CDLL(os.path.join(os.getcwd(), "tools/probe/libcoefv.so")) if variant >= 0 else None
+vlib = ctypes.CDLL(os.path.join(ROOT, "tools/probe/libcoefv.so")) if variant >= 0 else None
 def run_coef(out):
     if variant < 0: return hip.ffn_ln_coef(w2, gam, bet, b2, out)
     arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])

@@ -1,5 +1,5 @@
 import os, sys, ctypes, collections
-sys.path.insert(0, os.getcwd())
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import torch
 from ifseg_amd import hip
 dev = torch.device("cuda:0")
