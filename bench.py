@@ -215,10 +215,12 @@ def main():
     model.cfg.dropout, model.cfg.encoder_drop_path_rate, model.cfg.decoder_drop_path_rate = a.dropout, a.drop_path, a.drop_path
     crit = SegCriterion(task, unsupervised_segmentation=a.image_free, init_seg_with_text=False)
     trainer = Trainer(model, crit, task, device=dev, lazy_logs=True)
-    # two different synthetic batches, alternated: batch i+1 is handed to the trainer as `prefetch` (what a data
-    # iterator holds one step ahead), so its frozen-trunk pass runs underneath step i on a second stream
+    # RING different synthetic batches, cycled: the batches of the next calls are handed to the trainer as `prefetch` (what
+    # a buffered data iterator holds ahead), so their frozen-trunk pass runs underneath this step on a second stream -- one
+    # pass per IFSEG_TRUNK_LOOKAHEAD (default 2) batches; every batch of the timed region goes through the trunk exactly once
+    RING, AHEAD = 4, 4
     ring = []
-    for j in range(2):
+    for j in range(RING):
         sm = task.synthetic_sample(a.batch, dev, seed=1234 + rank + 7919 * j)
         sm["net_input"]["patch_images"] = sm["net_input"]["patch_images"].to(torch.bfloat16)
         if a.image_free:
@@ -232,7 +234,8 @@ def main():
     def one_step():
         i = step_no[0]
         step_no[0] += 1
-        return trainer.train_step([ring[i % 2]], prefetch=None if a.no_prefetch else [ring[(i + 1) % 2]], graph=use_graph[0])
+        nxt = None if a.no_prefetch else [ring[(i + k) % RING] for k in range(1, AHEAD + 1)]
+        return trainer.train_step([ring[i % RING]], prefetch=nxt, graph=use_graph[0])
 
     def sync():
         if world > 1:

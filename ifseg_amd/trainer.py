@@ -371,9 +371,9 @@ class Trainer:
         return logs
 
     def train_step(self, samples, prefetch=None, graph=False):
-        """One update.  `prefetch`: the samples of the NEXT call, if the data iterator already holds them:
-        their frozen-trunk features are computed on a second stream underneath this step
-        (HipEngine.prefetch_trunk).
+        """One update.  `prefetch`: the samples of the NEXT call(s), in order, as far as the data iterator already holds
+        them: their frozen-trunk features are computed on a second stream underneath this step (HipEngine.prefetch_trunk);
+        with more than one, `IFSEG_TRUNK_LOOKAHEAD` (default 2) batches go through the trunk in one pass.
         `graph=True` (one GPU, update_freq 1): the whole update -- ~800 kernel launches on four streams -- is captured
         into a HIP graph the first time a (sample, prefetch) pair of tensors is seen and REPLAYED afterwards: one graph
         launch instead of ~9 ms of host enqueue per step.  The sample tensors are the graph's static inputs: a data
@@ -387,7 +387,7 @@ class Trainer:
             logs = self._graph_step(samples[0], prefetch[0] if prefetch else None)
         else:
             if prefetch and "trunkpf" not in __import__("os").environ.get("IFSEG_EXP_SKIP", ""):
-                eng._pf_request = prefetch[0]["net_input"]["patch_images"]
+                eng._pf_request = [q["net_input"]["patch_images"] for q in prefetch]
             logs = self._step_body(samples)
         self.num_updates += 1
         self._ovf_host.copy_(self.overflow, non_blocking=True)

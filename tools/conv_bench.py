@@ -8,7 +8,7 @@ from ifseg_amd import hip
 def main():
     dev = torch.device("cuda:0")
     r = lambda *s: (torch.randn(*s, device=dev) * 0.1).to(torch.bfloat16)
-    B = 8
+    B = int(os.environ.get("CONV_BENCH_B", "8"))
     shapes = [  # (H, Cin, Cout, k, stride, count per step)
         (128, 64, 64, 1, 1, 3), (128, 64, 64, 3, 1, 3), (128, 64, 256, 1, 1, 4), (128, 256, 64, 1, 1, 2),
         (128, 256, 128, 1, 1, 1), (128, 128, 128, 3, 2, 1), (64, 128, 512, 1, 1, 4), (64, 512, 128, 1, 1, 3),
