@@ -35,6 +35,7 @@ from .config import image_rp_bucket, token_bucket_of_delta
 BF = torch.bfloat16
 # TIMING EXPERIMENTS ONLY (wrong results): kernels left out of the step to bound what optimising them could return,
 # e.g. IFSEG_EXP_SKIP=lnwide,dq (tools/skip_bound.sh; DESIGN section 4 "Round 3")
+_POISON = os.environ.get("IFSEG_POISON_WS", "") == "1"
 _EXP_SKIP = set(filter(None, os.environ.get("IFSEG_EXP_SKIP", "").split(",")))
 
 
@@ -319,6 +320,8 @@ class HipEngine:
         shape = tuple(int(s) for s in shape)
         if t is None or tuple(t.shape) != shape or t.dtype != dtype:
             t = torch.empty(shape, dtype=dtype, device=self.device)
+            if _POISON:          # (debug) a read of a workspace element nobody wrote shows up as NaN / a huge index
+                t.view(torch.uint8).fill_(0xFF) if t.numel() else None
             self.ws[name] = t
         return t
 
@@ -436,7 +439,7 @@ class HipEngine:
         return g
 
     # ------------------------------------------------------------------ ResNet
-    def prefetch_trunk(self, patch_images):
+    def prefetch_trunk(self, patch_images, append=False):
         """Start the frozen ResNet-101 trunk of FUTURE batches on its own stream.
 
         The trunk has no trainable parameter (resnet.py + frozen_bn.py, `freeze_resnet`), so its output for
@@ -480,7 +483,10 @@ class HipEngine:
             done.record(self._trunk_stream)
         ents = [{"key": self._tkey(t), "images": t, "feat": feat[i * B:(i + 1) * B], "h": h, "w": w, "done": done}
                 for i, t in enumerate(batches)]
-        self._pf, self._pf_more = ents[0], ents[1:]
+        if append and self._pf is not None:                  # behind the features that are still waiting to be used
+            self._pf_more = self._pf_more + ents
+        else:
+            self._pf, self._pf_more = ents[0], ents[1:]
 
     @staticmethod
     def _tkey(t):
@@ -761,9 +767,11 @@ class HipEngine:
             feat, h, w = self._trunk(patch_images)
             # the next batch's trunk starts once this batch's features are taken -- or (IFSEG_TRUNK_AT=e<k> / end) later,
             # inside this step's backward, see `_trunk_launch_point`
-            if self._pf_request is not None and (self.trunk_at == "fwd" or not need_grad):
-                req, self._pf_request = self._pf_request, None
-                self._prefetch_request(req)
+            if self._pf_request is not None and (self.trunk_at in ("fwd", "fwd1") or not need_grad):
+                req = self._pf_request
+                if not need_grad or not self._prefetch_request(req):
+                    self._pf_request = None
+                # (training, next batch already cached: the request stays for the end of the backward -- `_backward`)
         P = h * w
         oh = cfg.orig_patch_image_size // 16
         slow = (h, w) != (oh, oh) or (h, w) != (cfg.seg_bucket_size,) * 2 or P % 64 != 0
@@ -1537,6 +1545,9 @@ class HipEngine:
             self._enc_tail_emb_bwd(B, L, P, T, dx)
         if self.trunk_at == "end":
             self._trunk_launch_point()
+        elif self.trunk_at == "fwd" and self._pf_request is not None and not torch.cuda.is_current_stream_capturing():
+            req, self._pf_request = self._pf_request, None           # ("fwd1": passes start at a forward only -- measurement)
+            self._prefetch_request(req, at_end=True)
         self._join_side()            # the optimizer (main stream) reads the whole gradient arena next
         self._notify(e)              # both halves of the tail are in: the last gradient slice may be reduced (main stream)
         return self.g16
@@ -1555,17 +1566,33 @@ class HipEngine:
         for i in range(0, len(w2), 32):
             hip.ffn_ln_coef(w2[i:i + 32], gam[i:i + 32], bet[i:i + 32], b2[i:i + 32], coef[i:i + 32])
 
-    def _prefetch_request(self, req):
-        """`req`: the image tensors of the following forward calls, in order (or one tensor).  Nothing to do while the next
-        batch's features are already there (an earlier pass covered it); otherwise one pass over the first
-        `trunk_lookahead` of them."""
+    def _prefetch_request(self, req, at_end=False):
+        """`req`: the image tensors of the following forward calls, in order (or one tensor).  At the start of a forward
+        (`at_end` False) a pass over the first `trunk_lookahead` of them is started unless the next batch's features are
+        already there; returns True if the request should be looked at again at the end of this step's backward.  There
+        (`at_end`), with at most ONE batch left in the cache, the pass over the batches behind it starts: its convolutions
+        then run under the final join, the gradient norm and the HBM-bound Adam, where nothing else needs the MFMAs, and
+        under the next forward."""
         if not isinstance(req, (list, tuple)):
-            return self.prefetch_trunk(req)
-        if not req:
-            return
-        if self._pf is not None and self._pf["key"] == self._tkey(req[0]):
-            return
-        self.prefetch_trunk(list(req[: self.trunk_lookahead]))
+            if not at_end:
+                self.prefetch_trunk(req)
+            return False
+        cache = ([self._pf] if self._pf is not None else []) + (self._pf_more if self._pf is not None else [])
+        covered = 0
+        while covered < len(cache) and covered < len(req) and cache[covered]["key"] == self._tkey(req[covered]):
+            covered += 1
+        if covered < len(cache):                            # the cache is not a prefix of the request: start over
+            covered = 0
+            self._pf, self._pf_more = None, []
+        if not at_end:
+            if covered == 0:
+                if req:
+                    self.prefetch_trunk(list(req[: self.trunk_lookahead]))
+                return False
+            return self.trunk_lookahead > 1
+        if covered <= 1 and len(req) > covered and self.trunk_lookahead > 1:
+            self.prefetch_trunk(list(req[covered: covered + self.trunk_lookahead]), append=covered > 0)
+        return False
 
     def _trunk_launch_point(self):
         """the frozen trunk of the NEXT batch, launched from inside this step's backward: its ~90 convolutions then run

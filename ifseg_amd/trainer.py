@@ -343,7 +343,13 @@ class Trainer:
                 self._gacc = torch.empty(eng.n_train, dtype=torch.float32, device=self.device)
             self._gacc.zero_()
         try:
-            for sample in samples:
+            ahead = getattr(self, "_ahead", None)
+            for i, sample in enumerate(samples):
+                if ahead is not None:
+                    # what the forward calls after this one will be handed, in order: the remaining micro-batches of this
+                    # update, then the next call's samples (HipEngine._prefetch_request)
+                    eng._pf_request = [q["net_input"]["patch_images"] for q in list(samples[i + 1:]) + ahead
+                                       if "patch_images" in q.get("net_input", {})]
                 loss, ss, lg = self.task.train_step(sample, self.model, self.criterion, None, self.num_updates)
                 logs.append(lg)
                 sample_sizes.append(ss)
@@ -383,11 +389,12 @@ class Trainer:
         if not self.model.training:
             self.model.train()
         eng.step_seed = self.seed + self.num_updates
+        self._ahead = None
         if graph and self.world == 1 and len(samples) == 1:
             logs = self._graph_step(samples[0], prefetch[0] if prefetch else None)
         else:
             if prefetch and "trunkpf" not in __import__("os").environ.get("IFSEG_EXP_SKIP", ""):
-                eng._pf_request = [q["net_input"]["patch_images"] for q in prefetch]
+                self._ahead = list(prefetch)
             logs = self._step_body(samples)
         self.num_updates += 1
         self._ovf_host.copy_(self.overflow, non_blocking=True)
