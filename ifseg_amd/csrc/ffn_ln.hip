@@ -1,13 +1,13 @@
 // ffn_layernorm backward folded into the fc2 dX GEMM: the small reduction kernels around the GEMM epilogue (csrc/gemm.hip, EPI_GLN).
 //
-// BUILD NOTE -- this file is compiled with -fno-slp-vectorize (ifseg_amd/build.py, PER_FILE_FLAGS).  The two-accumulator loops
-// below (sum w*gamma next to sum w*beta, ...) are what clang's SLP vectoriser turns into v_pk_mov_b32 / v_pk_mul_f32 /
-// v_pk_fma_f32 chains with op_sel half-swizzles; in that form ffn_ln_coef_kernel returned a wrong LOW-half sum (sum w*gamma,
-// never sum w*beta) in a few of its 9216 waves per launch whenever an LDS-DMA + MFMA GEMM (ours or hipBLASLt's) ran next to
-// it on another stream -- bit-exact alone, bit-exact in scalar form under the same load.  Isolated with tools/probe/ (the
-// inputs are stable, all loads have landed (vmcnt(0) + s_nop) before the first packed op, plain v_pk_fma_f32 chains are
-// clean); the training step's cross-run determinism test caught it.  tests/test_kernels_gpu.py keeps the kernel under a
-// concurrent GEMM and demands bit equality.
+// BUILD NOTE -- this file is compiled with -fno-slp-vectorize (ifseg_amd/build.py, PER_FILE_FLAGS).  clang's SLP vectoriser
+// turns the two-accumulator loop of ffn_ln_coef_kernel (sum w*gamma next to sum w*beta) into packed-fp32 code that starts with
+//     v_pk_mul_f32 vD, vA, vB op_sel:[0,1] op_sel_hi:[1,0]        (low lane = A.lo * B.HI, high lane = A.hi * B.lo)
+// and with that instruction the kernel returned a wrong LOW-half sum (sum w*gamma, never sum w*beta) in a few of its 9216 waves
+// per launch whenever an LDS-DMA + MFMA GEMM (ours or hipBLASLt's) ran next to it on another stream -- bit-exact alone, and
+// bit-exact under the same load in every form without that instruction (tools/probe/README.md, DESIGN.md "Round 3" (6)).
+// tools/check_isa.py / test_library_has_no_cross_half_packed_fp32_instruction keep the form out of the built library;
+// tests/test_kernels_gpu.py keeps these kernels under a concurrent GEMM and demands bit equality.
 #include "common.h"
 #include "prof.h"
 #include "../../include/ifseg_hip.h"

@@ -77,6 +77,24 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.ifseg_abi_version() == int(re.search(r"#define IFSEG_ABI_VERSION (\d+)", hdr).group(1))
 
 
+def test_library_has_no_cross_half_packed_fp32_instruction():
+    """DESIGN.md "Round 3" (6): `v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` (the low lane reading the HIGH half of its
+    second source) returned wrong low results next to a running GEMM; clang's SLP vectoriser emitted it in exactly one kernel
+    (ffn_ln_coef_kernel), whose source is now built without that pass.  The shipped library must not contain the form
+    anywhere (tools/check_isa.py disassembles every gfx950 code object of the built .so)."""
+    import importlib.util
+    from ifseg_amd import build
+    lib = build.build(verbose=False)
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(os.path.dirname(__file__), "..", "tools", "check_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.OBJDUMP):
+        pytest.skip("no llvm-objdump")
+    nobj, hits = mod.scan(lib)
+    assert nobj >= 1, "no gfx950 code object found in %s" % lib
+    assert not hits, hits[:5]
+
+
 def test_arena_lays_every_linear_out_weight_then_bias():
     """The gradient arena keeps each (fused) Linear's bias right behind its weight(s): dW and db are then one
     contiguous range, which lets the weight-gradient GEMM's split-K reduction write both (IFSEG_GEMM_COLSUM), and

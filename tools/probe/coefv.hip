@@ -22,6 +22,36 @@ __global__ __launch_bounds__(256) void coefv_kernel(Ptrs pt, int ldw, int J, int
     unpack8(*reinterpret_cast<const uint4*>(row + k), w);
     const float4 g0 = *reinterpret_cast<const float4*>(gamma + k), g1 = *reinterpret_cast<const float4*>(gamma + k + 4);
     const float4 b0 = *reinterpret_cast<const float4*>(beta + k), b1 = *reinterpret_cast<const float4*>(beta + k + 4);
+    if (V >= 10 && V <= 17) {
+      // the SLP code's FIRST step in explicit form: (sa, sb) += (g.x w0 + g.y w1, b.x w0 + b.y w1) built from a half-swapping
+      // v_pk_mov_b32 and a cross-selecting v_pk_mul_f32; the other six terms as plain packed FMAs
+      //   V10: pk_mov op_sel + pk_mul cross op_sel (as clang emits)   V11: two v_mov instead of the pk_mov
+      //   V12: pk_mov kept, products by two scalar multiplies          V13: everything plain (control)
+      typedef float f2v __attribute__((ext_vector_type(2)));
+      const float gs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      unpack8(*reinterpret_cast<const uint4*>(row + k), w);
+      f2v acc = {sa, sb};
+      f2v gxy = {gs[0], gs[1]}, bxy = {bs[0], bs[1]}, w01 = {w[0], w[1]}, mv, t, a0 = {gs[0], bs[1]};
+      if (V == 10 || V == 12 || V >= 14) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(mv) : "v"(gxy), "v"(bxy));      // (g.y, b.x)
+      else { mv.x = gs[1]; mv.y = bs[0]; asm volatile("" : "+v"(mv)); }
+      if (V == 10 || V == 11) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(mv), "v"(w01));   // (g.y w1, b.x w0)
+      else if (V == 14) asm volatile("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(mv), "v"(w01));
+      else if (V == 15) asm volatile("s_nop 1\n\tv_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(mv), "v"(w01));
+      else if (V == 16) asm volatile("s_nop 3\n\tv_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(mv), "v"(w01));
+      else if (V == 17) asm volatile("s_nop 7\n\tv_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(mv), "v"(w01));
+      else { t.x = mv.x * w[1]; t.y = mv.y * w[0]; asm volatile("" : "+v"(t)); }
+      if (V == 13) { t.x += a0.x * w[0]; t.y += a0.y * w[1]; asm volatile("" : "+v"(t)); }
+      else asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(a0), "v"(w01));                                              // + (g.x w0, b.y w1)
+#pragma unroll
+      for (int e = 2; e < 8; ++e) {
+        f2v gb = {gs[e], bs[e]}, ww;
+        ww.x = w[e];
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(t) : "v"(gb), "v"(ww));
+      }
+      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(t));
+      sa = acc.x; sb = acc.y;
+      continue;
+    }
     if (V == 7 || V == 8 || V == 9) {
       // explicit packed math: acc = {sa, sb}; V7: src1 = {w, w} fully defined; V8: same but accumulators parked away from v[0:1]
       typedef float f2v __attribute__((ext_vector_type(2)));
@@ -89,6 +119,14 @@ extern "C" int coefv_launch(int variant, const void* const* w2, int ldw, const f
     case 7: hipLaunchKernelGGL(coefv_kernel<7>, g, b, 0, s, pt, ldw, J, N); break;
     case 8: hipLaunchKernelGGL(coefv_kernel<8>, g, b, 0, s, pt, ldw, J, N); break;
     case 9: hipLaunchKernelGGL(coefv_kernel<9>, g, b, 0, s, pt, ldw, J, N); break;
+    case 10: hipLaunchKernelGGL(coefv_kernel<10>, g, b, 0, s, pt, ldw, J, N); break;
+    case 11: hipLaunchKernelGGL(coefv_kernel<11>, g, b, 0, s, pt, ldw, J, N); break;
+    case 12: hipLaunchKernelGGL(coefv_kernel<12>, g, b, 0, s, pt, ldw, J, N); break;
+    case 13: hipLaunchKernelGGL(coefv_kernel<13>, g, b, 0, s, pt, ldw, J, N); break;
+    case 14: hipLaunchKernelGGL(coefv_kernel<14>, g, b, 0, s, pt, ldw, J, N); break;
+    case 15: hipLaunchKernelGGL(coefv_kernel<15>, g, b, 0, s, pt, ldw, J, N); break;
+    case 16: hipLaunchKernelGGL(coefv_kernel<16>, g, b, 0, s, pt, ldw, J, N); break;
+    case 17: hipLaunchKernelGGL(coefv_kernel<17>, g, b, 0, s, pt, ldw, J, N); break;
   }
   return (int)hipGetLastError();
 }
