@@ -769,7 +769,8 @@ class HipEngine:
             # inside this step's backward, see `_trunk_launch_point`
             if self._pf_request is not None and (self.trunk_at in ("fwd", "fwd1") or not need_grad):
                 req = self._pf_request
-                if not need_grad or not self._prefetch_request(req):
+                keep = self._prefetch_request(req)
+                if not need_grad or not keep:
                     self._pf_request = None
                 # (training, next batch already cached: the request stays for the end of the backward -- `_backward`)
         P = h * w
