@@ -365,6 +365,26 @@ def test_trunk_lookahead_pass_is_bit_identical_and_every_batch_passes_once():
     l3, p3 = run(3)
     assert l0 == l3 and torch.equal(p0, p3)
 
+    # update_freq 2: the second micro-batch of an update is look-ahead for the first, the next call's samples for both
+    def run2(ahead):
+        torch.manual_seed(0)
+        m = task.build_model()
+        tr = Trainer(m, SegCriterion(task, unsupervised_segmentation=False, init_seg_with_text=False), task, device=dev)
+        calls = []
+        orig = tr.eng._resnet
+        tr.eng._resnet = lambda images, tag="": (calls.append(images.shape[0]), orig(images, tag))[1]
+        losses = []
+        for i in range(3):
+            cur = [ss[(2 * i) % 3], ss[(2 * i + 1) % 3]]
+            nxt = [ss[(2 * i + 2) % 3], ss[(2 * i + 3) % 3]] if ahead else None
+            losses += [float(lg["loss"]) for lg in tr.train_step(cur, prefetch=nxt)]
+        torch.cuda.synchronize()
+        return losses, tr.p32.clone(), calls
+    la, pa, ca = run2(False)
+    lb, pb, cb = run2(True)
+    assert la == lb and torch.equal(pa, pb)
+    assert ca == [2] * 6 and sum(cb[1:]) >= 2 * 5 and cb[0] == 2 and 4 in cb, (ca, cb)   # in line once, then passes of two batches
+
 
 def test_image_free_branch_vs_reference_golden(golden_dir):
     """model(aux_input=...) (EmbeddingBag patches, no trunk, causal decoder) + the criterion's
