@@ -1,7 +1,7 @@
 """Two runs of N training steps (Base, B = 8, every stream on, trunk look-ahead): per-step loss and the final parameters must be
 bit-equal.  A long version of tests/test_model_gpu.py::test_training_step_is_deterministic_across_streams -- sporadic
 corruption of a kernel under concurrency (see tools/probe/README.md) at a rate the 3-step test would miss shows up here.
-usage: python tools/long_determinism.py [steps=40] [batch=8]"""
+usage: python tools/long_determinism.py [steps=40] [batch=8] [base|large]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,9 @@ from ifseg_amd.trainer import Trainer
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev = torch.device("cuda:0")
-task = SegmentationTask(num_seg_tokens=15, patch_image_size=512, arch="segofa_base")
+large = len(sys.argv) > 3 and sys.argv[3] == "large"
+task = (SegmentationTask(num_seg_tokens=171, patch_image_size=640, arch="segofa_large") if large
+        else SegmentationTask(num_seg_tokens=15, patch_image_size=512, arch="segofa_base"))
 ring = []
 for j in range(4):
     sm = task.synthetic_sample(B, dev, seed=100 + j)
