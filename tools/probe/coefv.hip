@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void coefv_kernel(Ptrs pt, int ldw, int J, int
     unpack8(*reinterpret_cast<const uint4*>(row + k), w);
     const float4 g0 = *reinterpret_cast<const float4*>(gamma + k), g1 = *reinterpret_cast<const float4*>(gamma + k + 4);
     const float4 b0 = *reinterpret_cast<const float4*>(beta + k), b1 = *reinterpret_cast<const float4*>(beta + k + 4);
-    if (V >= 10 && V <= 17) {
+    if (V >= 10 && V <= 19) {
       // the SLP code's FIRST step in explicit form: (sa, sb) += (g.x w0 + g.y w1, b.x w0 + b.y w1) built from a half-swapping
       // v_pk_mov_b32 and a cross-selecting v_pk_mul_f32; the other six terms as plain packed FMAs
       //   V10: pk_mov op_sel + pk_mul cross op_sel (as clang emits)   V11: two v_mov instead of the pk_mov
@@ -35,6 +35,8 @@ __global__ __launch_bounds__(256) void coefv_kernel(Ptrs pt, int ldw, int J, int
       if (V == 10 || V == 12 || V >= 14) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(mv) : "v"(gxy), "v"(bxy));      // (g.y, b.x)
       else { mv.x = gs[1]; mv.y = bs[0]; asm volatile("" : "+v"(mv)); }
       if (V == 10 || V == 11) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(mv), "v"(w01));   // (g.y w1, b.x w0)
+      else if (V == 18) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(w01), "v"(mv));   // the cross read on src0
+      else if (V == 19) { f2v w10 = {w[1], w[0]}; asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(mv), "v"(w10)); }           // plain, pre-swapped pair
       else if (V == 14) asm volatile("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(mv), "v"(w01));
       else if (V == 15) asm volatile("s_nop 1\n\tv_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(mv), "v"(w01));
       else if (V == 16) asm volatile("s_nop 3\n\tv_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(mv), "v"(w01));
@@ -127,6 +129,8 @@ extern "C" int coefv_launch(int variant, const void* const* w2, int ldw, const f
     case 15: hipLaunchKernelGGL(coefv_kernel<15>, g, b, 0, s, pt, ldw, J, N); break;
     case 16: hipLaunchKernelGGL(coefv_kernel<16>, g, b, 0, s, pt, ldw, J, N); break;
     case 17: hipLaunchKernelGGL(coefv_kernel<17>, g, b, 0, s, pt, ldw, J, N); break;
+    case 18: hipLaunchKernelGGL(coefv_kernel<18>, g, b, 0, s, pt, ldw, J, N); break;
+    case 19: hipLaunchKernelGGL(coefv_kernel<19>, g, b, 0, s, pt, ldw, J, N); break;
   }
   return (int)hipGetLastError();
 }
