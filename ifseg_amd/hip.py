@@ -228,7 +228,7 @@ class _TnProblem(ctypes.Structure):
 
 
 GEMM_GROUP_MAX = 8
-DW_GROUP_WGS = int(os.environ.get("IFSEG_DW_GROUP_WGS", "512"))     # grid cap of the grouped dW GEMM (one workgroup per CU)
+DW_GROUP_WGS = int(os.environ.get("IFSEG_DW_GROUP_WGS", "512"))     # grid cap of the grouped dW GEMM: two workgroups per CU (in-step sweep, round 3: 256: 17.49, 384: 17.46, 512: 17.23 / 17.39, 768: 17.28, uncapped: 17.36 ms)
 
 
 def dw_groupable(dy, x, out, bias_out):
@@ -243,8 +243,8 @@ def dw_groupable(dy, x, out, bias_out):
 
 def linear_dw_group(tasks, wgs=None):
     """tasks: list of (dy [M,N], x [M,K], out [N,K] bf16, bias_out or None): every dW (+ db) in ONE launch
-    (ifseg_gemm_tn_group), at most GEMM_GROUP_MAX per launch.  `wgs`: workgroup cap (default DW_GROUP_WGS: one per CU,
-    the main stream's kernels keep half of every CU; 0 = one workgroup per tile, for a launch with the GPU to itself)"""
+    (ifseg_gemm_tn_group), at most GEMM_GROUP_MAX per launch.  `wgs`: workgroup cap (default DW_GROUP_WGS; 0 = one workgroup per
+    tile, for a launch with the GPU to itself)"""
     for i in range(0, len(tasks), GEMM_GROUP_MAX):
         chunk = tasks[i:i + GEMM_GROUP_MAX]
         arr = (_TnProblem * len(chunk))()
