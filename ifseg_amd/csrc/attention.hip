@@ -1605,6 +1605,9 @@ extern "C" int ifseg_attn_fwd(const void* q, const void* k, const void* v, const
   a.Lt = T - P; a.rel2d = rel2d; a.rel1d = rel1d; a.relx = relx; a.causal = causal; a.dense = dense_bias; a.gain = (const float*)gain;
   a.dense_ld = dense_bias ? (dense_ld > 0 ? dense_ld : S) : 0;
   if (dense_bias && a.dense_ld < S) return IFSEG_ERR_BAD_ARG;
+#ifdef IFSEG_EXP_NOBIAS_FWD
+  pos_q = nullptr; a.pq = nullptr; a.pk = nullptr; a.rel_mode = 0; a.n2d = 0; rel_mode = 0;   // timing bound only
+#endif
   if (!rel_mode && !causal) a.P = S;
   int rc = attn_check(a);
   if (rc) return rc;
@@ -1645,6 +1648,11 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   a.drel2d_part = x->drel2d_part; a.drel1d_part = x->drel1d_part; a.drelx_part = x->drelx_part;
   a.nparts = x->nparts; a.gain = (const float*)x->gain; a.dq_scale = x->dq_scale; a.dpq_scale = x->dpq_scale;
   a.grid_w = x->grid_w;
+#ifdef IFSEG_EXP_NOBIAS_BWD
+  // timing bound only (tools/variant.py): the backward with every per-batch bias term compiled out -- no abs-pos columns,
+  // no rel-pos seeds, no table-gradient bins (results are wrong)
+  a.pq = nullptr; a.pk = nullptr; a.rel_mode = 0; a.n2d = 0;
+#endif
   if (!a.rel_mode && !a.causal) a.P = a.S;
   int rc = attn_check(a);
   if (rc) return rc;
@@ -1676,6 +1684,11 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   const size_t lds_q = 2 * (KT_BYTES + VT_BYTES) + (a.rel_mode ? n2dp * 4 + (size_t)a.P * 4 : 0);
   if (lds_kv > 160 * 1024 || lds_q > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
   const bool do_kv = ph & IFSEG_ATTN_BWD_DKV, do_q = ph & IFSEG_ATTN_BWD_DQ;
+#ifdef IFSEG_EXP_NOBIAS_BWD
+  const bool has_pos = false;
+#else
+  const bool has_pos = x->pos_q != nullptr;
+#endif
   if (do_kv && do_q && !dkv8 && getenv("IFSEG_ATTN_BWD_ONE_LAUNCH")) {      // measured slower than the two launches: see the kernel
     const size_t lds = lds_kv > lds_q ? lds_kv : lds_q;
     const int n_dkv = nkt * a.H * a.B, n_dq = nq * a.H * a.B;
@@ -1692,7 +1705,7 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
     IFSEG_CHECK_LAUNCH();
     return 0;
   }
-  if (x->pos_q) {
+  if (has_pos) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
     if (do_kv) {

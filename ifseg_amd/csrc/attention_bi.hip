@@ -1,0 +1,822 @@
+// Attention backward with the batch as the INNER dimension of a workgroup ("bi"), gfx950.
+//
+// Reference semantics (unify_multihead_attention.py:346,459-512 under autograd, with the bias the reference builds ONCE per
+// layer and broadcasts over the batch: encoder_module.py:757-771,790-809, decoder_module.py:553-558,603-627, expand at
+// encoder_module.py:317,791):
+//     S_b = (q_b*scaling) k_b^T + Bias,   Bias[h] = abs_pos + rel_pos (+ causal / key-padding -inf): batch invariant
+//     P_b = softmax_fp32(S_b);  O_b = gain[h] P_b v_b
+//     dV_b = gain P_b^T dO_b;  dS_b = P_b o (gain dO_b v_b^T - delta_b);  dQ_b = dS_b k_b;  dK_b = dS_b^T q_b
+//     dBias = sum_b dS_b      -> d abs-pos operands, d rel-pos tables (ifseg_attn_dbias_grads)
+//
+// MI355X formulation.  The bias is a dense fp32 operand D[h] (and its transpose Dt[h]) built once per layer and step by
+// ifseg_attn_dense_bias from parameters only (side stream, start of the step).  A workgroup of 8 waves owns
+// (head, 64 stationary rows = 2 blocks of 32, 4 batch elements): wave = (row block, batch element).  The 4 batch waves of a
+// row block read the SAME 32 x 32 bias tile from LDS (one LDS-DMA per tile instead of four regenerations by MFMA + table
+// look-ups), so the hot loop has one uniform body for every bias kind (grid of any width, text, bos, causal, cross):
+// the tile seeds the score accumulator, masked entries are -inf inside it.  In the dQ kernel the four waves leave their
+// fp32 dS tiles in LDS and each sums a quarter of the four: sum_b dS leaves the kernel once per tile (bf16, one slab per
+// group of 4 batch elements) -- no per-batch bias-gradient work, no abs-pos columns in the contractions (head dim 64
+// everywhere), no table-gradient bins in the loop.  Deterministic: fixed summation order, no atomics.
+//
+//   dQ kernel   (lane = query):  S^T = K Q^T (A = K rows from LDS, B = q regs), dP^T = V dO^T, dS^T, dQ^T += K^T dS^T
+//   dK/dV kernel (lane = key):   S = Q K^T (A = Q rows from LDS, B = k regs), dP = dO V^T (B = -gain V regs, accumulator
+//                                seeded with delta), dV^T += dO^T P, dK^T += Q^T dS
+#include <type_traits>
+#include "common.h"
+#include "prof.h"
+#include "../../include/ifseg_hip.h"
+
+namespace {
+
+constexpr float NEG_INF = -INFINITY;
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct BiArgs {
+  const bf16_t *q, *k, *v, *dO;
+  const float *lse, *delta, *D, *Dt, *gain;
+  bf16_t *dq, *dk, *dv, *dbias;
+  int B, H, T, S, Sp, Tp;
+  long long q_bs, k_bs, v_bs, do_bs, dq_bs, dk_bs, dv_bs, dbias_gs;
+  int ldq, ldk, ldv, lddo, lddq, lddk, lddv;
+  int causal, P;
+  float dq_scale;
+};
+
+// 32 x (128-byte row) tile image read BOTH row-wise (ds_read_b128: 16 rows x one 16-byte chunk per lane group) and
+// transposed (ds_read_b64_tr_b16: 4 consecutive rows x one 64-byte granule): chunk index XOR-ed with a bit-rotated row id
+// (two rows per 256-byte bank line).  Used for the bf16 operand tiles [32][64] and the fp32 bias tiles [32][32].
+__device__ __forceinline__ int vx_off(int r, int colbyte) {
+  const int u = r >> 1, hsw = ((u & 1) << 2) | ((u >> 1) & 3);
+  return r * 128 + ((((colbyte >> 4) ^ hsw) & 7) << 4) + (colbyte & 15);
+}
+__device__ __forceinline__ int vx_swz(int r) { const int u = r >> 1; return ((u & 1) << 2) | ((u >> 1) & 3); }
+
+__device__ __forceinline__ void consume_frag(const bf16x8& f) {
+  typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+  asm volatile("" :: "v"(__builtin_bit_cast(u32x4_t, f)));
+}
+
+__device__ __forceinline__ uint4 scale_bf16x8(uint4 v, float f) {
+  unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    w[i] = pack2bf(__uint_as_float(w[i] << 16) * f, __uint_as_float(w[i] & 0xffff0000u) * f);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Epilogue of a 32 x 32 accumulator tile whose row is the lane: element r of lane (half, x) is column
+// (r&3) + 8*(r>>2) + 4*half.  The two lanes of a row exchange one 8-byte run each so that every lane stores 16 bytes.
+__device__ __forceinline__ void store_tile_bf16(bf16_t* rowp, const f32x16& acc, float scale, int half, bool valid) {
+#pragma unroll
+  for (int rgp = 0; rgp < 2; ++rgp) {
+    const int e0 = rgp * 8, e1 = rgp * 8 + 4;
+    const unsigned x0 = pack2bf(acc[e0] * scale, acc[e0 + 1] * scale), x1 = pack2bf(acc[e0 + 2] * scale, acc[e0 + 3] * scale);
+    const unsigned y0 = pack2bf(acc[e1] * scale, acc[e1 + 1] * scale), y1 = pack2bf(acc[e1 + 2] * scale, acc[e1 + 3] * scale);
+    const auto p0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+    const auto p1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+    if (valid) *reinterpret_cast<uint4*>(rowp + 16 * rgp + 8 * half) = make_uint4(p0[0], p1[0], p0[1], p1[1]);
+  }
+}
+
+// LDS image of one stage (both kernels): four batch elements' two operand tiles, two bias tiles, the dK/dV kernel's
+// row statistics
+constexpr int ST_A = 0;                 // dQ: K[4][32][64]   dK/dV: Q[4][32][64]       (bf16, 4 KiB each)
+constexpr int ST_B = 16384;             // dQ: V[4][32][64]   dK/dV: dO[4][32][64]
+constexpr int ST_D = 32768;             // bias tiles [2][32][32] fp32 (4 KiB each)
+constexpr int ST_L = 40960;             // dK/dV: [4][lse 32 | delta 32] fp32
+constexpr int STG_DQ = 40960, STG_DKV = 41984;
+constexpr int SLOT = 4096;              // dQ kernel: one wave's fp32 dS tile [32][32], chunk XOR (row & 7)
+constexpr int LDS_DQ = 2 * STG_DQ + 2 * 8 * SLOT;      // 147456
+constexpr int LDS_DKV = 2 * STG_DKV;                    // 83968
+
+// Block schedule of the streamed side under the causal mask ("tail-first" order: a grid row i sees grid columns j <= i and
+// every tail column; a tail row sees tail columns j <= i only).  The dense bias already holds -inf for every masked
+// entry; the schedule only skips 32-blocks that are masked entirely.  first..g_end-1 are grid blocks, then tail blocks.
+struct Sched {
+  int g_begin, g_end, t_begin, n;
+  __device__ __forceinline__ int block(int it) const { return it < g_end - g_begin ? g_begin + it : t_begin + (it - (g_end - g_begin)); }
+};
+
+// ---------------------------------------------------------------------------------------------- dQ (+ sum_b dS)
+__global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* slots = smem + 2 * STG_DQ;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qb = wv >> 2, bl = wv & 3;
+  const int nqt = (a.T + 63) >> 6, nbg = (a.B + 3) >> 2;
+  int bid = xcd_remap(blockIdx.x, nqt * a.H * nbg);
+  int qt = bid % nqt;
+  const int h = (bid / nqt) % a.H, bg = bid / (nqt * a.H);
+  if (a.causal) qt = nqt - 1 - qt;                       // later query tiles see more keys: long workgroups first
+  const int q0 = qt * 64;
+  const int b = bg * 4 + bl;
+  const bool bact = b < a.B;
+  const int bc = bact ? b : a.B - 1;
+  const int qi = q0 + qb * 32 + (lane & 31);
+  const bool qvalid = qi < a.T;
+  const int qrow = qvalid ? qi : a.T - 1;
+  const float gain = a.gain ? a.gain[h] : 1.f;
+
+  bf16x8 qf[4], dof[4];
+  {
+    const bf16_t* qp = a.q + (long long)bc * a.q_bs + (long long)qrow * a.ldq + h * 64 + half * 8;
+    const bf16_t* op = a.dO + (long long)bc * a.do_bs + (long long)qrow * a.lddo + h * 64 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      U128 u; u.v = *reinterpret_cast<const uint4*>(qp + ks * 16); qf[ks] = u.b;
+      U128 w; w.v = *reinterpret_cast<const uint4*>(op + ks * 16); dof[ks] = w.b;
+    }
+  }
+  // an inactive wave (batch element past B) or an invalid query row has lse = +inf: P = 0, dS = 0 -- it still feeds a
+  // (zero) tile to the batch sum and helps staging
+  const float nlse = (qvalid && bact) ? -a.lse[((long long)bc * a.H + h) * a.T + qi] : NEG_INF;      // log2 units
+  const float del = (qvalid && bact) ? a.delta[((long long)bc * a.H + h) * a.T + qi] : 0.f;
+
+  Sched sc;
+  {
+    const int nkb = a.Sp >> 5;
+    if (a.causal) {
+      const int pb = a.P >> 5;
+      sc.g_begin = 0;
+      sc.g_end = q0 < a.P ? min(pb, (min(q0 + 63, a.P - 1) >> 5) + 1) : 0;
+      sc.t_begin = pb;
+      sc.n = sc.g_end + (nkb - pb);
+    } else {
+      sc.g_begin = 0; sc.g_end = nkb; sc.t_begin = nkb; sc.n = nkb;
+    }
+  }
+
+  const bf16_t* kb_ = a.k + (long long)bc * a.k_bs + h * 64;
+  const bf16_t* vb_ = a.v + (long long)bc * a.v_bs + h * 64;
+  const float* db_ = a.D + (long long)h * a.T * a.Sp;
+  const unsigned lds0 = lds_addr(smem);
+  auto issue = [&](int it, int st) {
+    const int j0 = sc.block(it) * 32;
+    const unsigned base = lds0 + st * STG_DQ;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int r8 = ln >> 3, cp = ln & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = qb * 2 + i, row = piece * 8 + r8;
+      const int c = cp ^ vx_swz(row);
+      const int jr = min(j0 + row, a.S - 1);
+      lds_dma16_gs(kb_, (jr * a.ldk + c * 8) * 2, base + ST_A + bl * 4096 + piece * 1024);
+      lds_dma16_gs(vb_, (jr * a.ldv + c * 8) * 2, base + ST_B + bl * 4096 + piece * 1024);
+    }
+    {
+      // bias tile of query block qb, rows 8 bl .. 8 bl + 7
+      const int row = bl * 8 + r8;
+      const int c = cp ^ vx_swz(row);
+      const int ir = min(q0 + qb * 32 + row, a.T - 1);
+      lds_dma16_gs(db_, (ir * a.Sp + j0 + c * 4) * 4, base + ST_D + qb * 4096 + bl * 1024);
+    }
+  };
+
+  f32x16 dq[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { consume_frag(qf[ks]); consume_frag(dof[ks]); }
+
+  // quarter bl of query block qb's tile: row 8 bl + (lane >> 3), columns 4 (lane & 7) .. + 3
+  const int rrow = bl * 8 + (lane >> 3);
+  const int rq = q0 + qb * 32 + rrow;
+  bf16_t* dbp = a.dbias + (long long)bg * a.dbias_gs + ((long long)h * a.T + (rq < a.T ? rq : a.T - 1)) * a.Sp + 4 * (lane & 7);
+  auto reduce = [&](int itp) {
+    const unsigned char* sl = slots + ((itp & 1) * 8 + qb * 4) * SLOT + rrow * 128 + ((((lane & 7) ^ (rrow & 7))) << 4);
+    const float4 x0 = *reinterpret_cast<const float4*>(sl), x1 = *reinterpret_cast<const float4*>(sl + SLOT);
+    const float4 x2 = *reinterpret_cast<const float4*>(sl + 2 * SLOT), x3 = *reinterpret_cast<const float4*>(sl + 3 * SLOT);
+    const float s0 = (x0.x + x1.x) + (x2.x + x3.x), s1 = (x0.y + x1.y) + (x2.y + x3.y);
+    const float s2 = (x0.z + x1.z) + (x2.z + x3.z), s3 = (x0.w + x1.w) + (x2.w + x3.w);
+    if (rq < a.T) *reinterpret_cast<uint2*>(dbp + sc.block(itp) * 32) = make_uint2(pack2bf(s0, s1), pack2bf(s2, s3));
+  };
+
+  if (sc.n > 0) issue(0, 0);
+  for (int it = 0; it < sc.n; ++it) {
+    const unsigned char* stg = smem + (it & 1) * STG_DQ;
+    lds_dma_wait();
+    __syncthreads();                 // stage `it` has landed; everyone is done with stage it-1 and wrote its dS tile of it-1
+    if (it + 1 < sc.n) issue(it + 1, (it + 1) & 1);
+    if (it > 0) reduce(it - 1);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int half_i = ln >> 5, i16 = ln & 15, g16 = (ln >> 4) & 1;
+    const int bR = vx_off(ln & 31, half_i * 16);               // row reads: K rows, V rows, bias rows (chunk half + 2 ks)
+    const unsigned char* sK = stg + ST_A + bl * 4096;
+    const unsigned char* sV = stg + ST_B + bl * 4096;
+    const unsigned char* sD = stg + ST_D + qb * 4096;
+    f32x16 s, dp;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 d4 = *reinterpret_cast<const float4*>(sD + (bR ^ (rg << 5)));
+      s[rg * 4] = d4.x; s[rg * 4 + 1] = d4.y; s[rg * 4 + 2] = d4.z; s[rg * 4 + 3] = d4.w;
+    }
+    {
+      bf16x8 kf[4], vf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[ks] = lds_read_b128(sK + (bR ^ (ks << 5)));
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) vf[ks] = lds_read_b128(sV + (bR ^ (ks << 5)));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], dof[ks], dp, 0, 0, 0);
+    }
+    // element r <-> key j0 + (r&3) + 8*(r>>2) + 4*half ; query = lane
+    float ds[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float p = __builtin_amdgcn_exp2f(fmaf(s[e], LOG2E, nlse));
+      ds[e] = p * fmaf(gain, dp[e], -del);
+    }
+    {
+      // this wave's fp32 dS tile for the batch sum: row = query, 16-byte chunk (half + 2 rg) XOR (row & 7)
+      unsigned char* sl = slots + ((it & 1) * 8 + wv) * SLOT;
+      const int so = (ln & 31) * 128 + ((half_i ^ (ln & 7)) << 4);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+        *reinterpret_cast<float4*>(sl + (so ^ (rg << 5))) = make_float4(ds[rg * 4], ds[rg * 4 + 1], ds[rg * 4 + 2], ds[rg * 4 + 3]);
+    }
+    U128 ud[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) ud[s2].w[e >> 1] = pack2bf(ds[s2 * 8 + e], ds[s2 * 8 + e + 1]);
+    // dQ^T += K^T dS^T ; slot (kh, e) <-> key 16*s2 + 4*kh + (e&3) + 8*(e>>2)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      U128 f[2];
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int colb = (db * 32 + g16 * 16 + (i16 & 3) * 4) * 2;
+        const int r0 = 16 * s2 + 4 * half_i + (i16 >> 2);
+        U64 x, y;
+        x.s = lds_read_tr(sK + vx_off(r0, colb));
+        y.s = lds_read_tr(sK + vx_off(r0 + 8, colb));
+        f[db].w[0] = x.w[0]; f[db].w[1] = x.w[1]; f[db].w[2] = y.w[0]; f[db].w[3] = y.w[1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[db].b, ud[s2].b, dq[db], 0, 0, 0);
+    }
+  }
+  if (sc.n > 0) {
+    __syncthreads();
+    reduce(sc.n - 1);
+  }
+  if (bact) {
+    bf16_t* dqp = a.dq + (long long)b * a.dq_bs + (long long)qrow * a.lddq + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) store_tile_bf16(dqp + db * 32, dq[db], a.dq_scale, half, qvalid);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- dK / dV
+__global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kbw = wv >> 2, bl = wv & 3;
+  const int nkt = (a.S + 63) >> 6, nbg = (a.B + 3) >> 2;
+  int bid = xcd_remap(blockIdx.x, nkt * a.H * nbg);
+  const int kt = bid % nkt, h = (bid / nkt) % a.H, bg = bid / (nkt * a.H);
+  const int k0 = kt * 64;
+  const int b = bg * 4 + bl;
+  const bool bact = b < a.B;
+  const int bc = bact ? b : a.B - 1;
+  const int kj = k0 + kbw * 32 + (lane & 31);
+  const bool kvalid = kj < a.S;
+  const int krow = kvalid ? kj : a.S - 1;
+  const float gain = a.gain ? a.gain[h] : 1.f;
+
+  bf16x8 kf[4], vfn[4];
+  {
+    const bf16_t* kp = a.k + (long long)bc * a.k_bs + (long long)krow * a.ldk + h * 64 + half * 8;
+    const bf16_t* vp = a.v + (long long)bc * a.v_bs + (long long)krow * a.ldv + h * 64 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      U128 u; u.v = *reinterpret_cast<const uint4*>(kp + ks * 16); kf[ks] = u.b;
+      // -gain * V: with the dP accumulator seeded with delta the MFMAs leave delta - gain * dP = -(dS / P)
+      U128 w; w.v = scale_bf16x8(*reinterpret_cast<const uint4*>(vp + ks * 16), -gain); vfn[ks] = w.b;
+    }
+  }
+  Sched sc;
+  {
+    const int nqb = a.Tp >> 5;
+    if (a.causal) {
+      const int pb = a.P >> 5;
+      if (k0 < a.P) {     // grid keys: visible to the grid rows at or after them, to no tail row
+        sc.g_begin = k0 >> 5; sc.g_end = pb; sc.t_begin = nqb; sc.n = sc.g_end - sc.g_begin;
+      } else {            // tail keys: every grid row, and the tail rows (masked element-wise inside the bias)
+        sc.g_begin = 0; sc.g_end = pb; sc.t_begin = pb; sc.n = nqb;
+      }
+    } else {
+      sc.g_begin = 0; sc.g_end = nqb; sc.t_begin = nqb; sc.n = nqb;
+    }
+  }
+  const bf16_t* qb_ = a.q + (long long)bc * a.q_bs + h * 64;
+  const bf16_t* ob_ = a.dO + (long long)bc * a.do_bs + h * 64;
+  const float* lb_ = a.lse + ((long long)bc * a.H + h) * a.T;
+  const float* eb_ = a.delta + ((long long)bc * a.H + h) * a.T;
+  const float* db_ = a.Dt + (long long)h * a.S * a.Tp;
+  const unsigned lds0 = lds_addr(smem);
+  auto issue = [&](int it, int st) {
+    const int i0 = sc.block(it) * 32;
+    const unsigned base = lds0 + st * STG_DKV;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int r8 = ln >> 3, cp = ln & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = kbw * 2 + i, row = piece * 8 + r8;
+      const int c = cp ^ vx_swz(row);
+      const int ir = min(i0 + row, a.T - 1);
+      lds_dma16_gs(qb_, (ir * a.ldq + c * 8) * 2, base + ST_A + bl * 4096 + piece * 1024);
+      lds_dma16_gs(ob_, (ir * a.lddo + c * 8) * 2, base + ST_B + bl * 4096 + piece * 1024);
+    }
+    {
+      // bias tile (transposed bias: row = key) of key block kbw, rows 8 bl .. 8 bl + 7
+      const int row = bl * 8 + r8;
+      const int c = cp ^ vx_swz(row);
+      const int jr = min(k0 + kbw * 32 + row, a.S - 1);
+      lds_dma16_gs(db_, (jr * a.Tp + i0 + c * 4) * 4, base + ST_D + kbw * 4096 + bl * 1024);
+    }
+    if (kbw == 0) {
+      // lanes 0..31: lse, lanes 32..63: delta of this wave's batch element (LDS-DMA places lane i at base + 4 i)
+      const int ir = min(i0 + (ln & 31), a.T - 1);
+      if (ln < 32) lds_dma4_gs(lb_, ir * 4, base + ST_L + bl * 256);
+      else lds_dma4_gs(eb_, ir * 4, base + ST_L + bl * 256);
+    }
+  };
+
+  f32x16 dv[2], dk[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dv[0][e] = 0.f; dv[1][e] = 0.f; dk[0][e] = 0.f; dk[1][e] = 0.f; }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { consume_frag(kf[ks]); consume_frag(vfn[ks]); }
+
+  if (sc.n > 0) issue(0, 0);
+  for (int it = 0; it < sc.n; ++it) {
+    const unsigned char* stg = smem + (it & 1) * STG_DKV;
+    lds_dma_wait();
+    __syncthreads();
+    if (it + 1 < sc.n) issue(it + 1, (it + 1) & 1);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int half_i = ln >> 5, i16 = ln & 15, g16 = (ln >> 4) & 1;
+    const int bR = vx_off(ln & 31, half_i * 16);
+    const unsigned char* sQ = stg + ST_A + bl * 4096;
+    const unsigned char* sO = stg + ST_B + bl * 4096;
+    const unsigned char* sD = stg + ST_D + kbw * 4096;
+    const float* sL = reinterpret_cast<const float*>(stg + ST_L + bl * 256);
+    f32x16 s, dp;
+    float ls[16];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 d4 = *reinterpret_cast<const float4*>(sD + (bR ^ (rg << 5)));
+      s[rg * 4] = d4.x; s[rg * 4 + 1] = d4.y; s[rg * 4 + 2] = d4.z; s[rg * 4 + 3] = d4.w;
+      const float4 e4 = *reinterpret_cast<const float4*>(sL + 32 + 8 * rg + 4 * half_i);
+      dp[rg * 4] = e4.x; dp[rg * 4 + 1] = e4.y; dp[rg * 4 + 2] = e4.z; dp[rg * 4 + 3] = e4.w;
+      const float4 l4 = *reinterpret_cast<const float4*>(sL + 8 * rg + 4 * half_i);
+      ls[rg * 4] = l4.x; ls[rg * 4 + 1] = l4.y; ls[rg * 4 + 2] = l4.z; ls[rg * 4 + 3] = l4.w;
+    }
+    {
+      bf16x8 qf[4], of[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf[ks] = lds_read_b128(sQ + (bR ^ (ks << 5)));
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) of[ks] = lds_read_b128(sO + (bR ^ (ks << 5)));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s, 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[ks], vfn[ks], dp, 0, 0, 0);
+    }
+    // element r <-> query i0 + (r&3) + 8*(r>>2) + 4*half ; key = lane
+    U128 up[2], ud[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const int r = s2 * 8 + e;
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -ls[r]));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], LOG2E, -ls[r + 1]));
+        up[s2].w[e >> 1] = pack2bf(p0, p1);
+        ud[s2].w[e >> 1] = pack2bf(-p0 * dp[r], -p1 * dp[r + 1]);
+      }
+    // dV^T += dO^T P ; dK^T += Q^T dS ; slot (kh, e) <-> query 16*s2 + 4*kh + (e&3) + 8*(e>>2)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      U128 fo[2], fq[2];
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int colb = (db * 32 + g16 * 16 + (i16 & 3) * 4) * 2;
+        const int r0 = 16 * s2 + 4 * half_i + (i16 >> 2);
+        U64 x, y;
+        x.s = lds_read_tr(sO + vx_off(r0, colb));
+        y.s = lds_read_tr(sO + vx_off(r0 + 8, colb));
+        fo[db].w[0] = x.w[0]; fo[db].w[1] = x.w[1]; fo[db].w[2] = y.w[0]; fo[db].w[3] = y.w[1];
+        x.s = lds_read_tr(sQ + vx_off(r0, colb));
+        y.s = lds_read_tr(sQ + vx_off(r0 + 8, colb));
+        fq[db].w[0] = x.w[0]; fq[db].w[1] = x.w[1]; fq[db].w[2] = y.w[0]; fq[db].w[3] = y.w[1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[db].b, up[s2].b, dv[db], 0, 0, 0);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[db].b, ud[s2].b, dk[db], 0, 0, 0);
+    }
+  }
+  if (bact && kvalid) {
+    bf16_t* dvp = a.dv + (long long)b * a.dv_bs + (long long)kj * a.lddv + h * 64;
+    bf16_t* dkp = a.dk + (long long)b * a.dk_bs + (long long)kj * a.lddk + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      store_tile_bf16(dvp + db * 32, dv[db], gain, half, true);
+      store_tile_bf16(dkp + db * 32, dk[db], 1.f, half, true);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- dense bias
+struct DenseArgs {
+  const bf16_t *pq, *pk;
+  int ldpq, ldpk, H, T, S, Sp, Tp;
+  int rel_mode, P, code_bias, n2d, Lt, causal;
+  const int* gcode;
+  const float *rel2d, *rel1d, *relx;
+  float *D, *Dt;
+};
+
+// D[h][i][j] = pos_q[i] . pos_k[j] + rel(i, j), -inf where (i, j) is masked (causal, "tail-first" order) or j >= S;
+// Dt[h][j][i] the transpose, -inf where masked or i >= T.  One wave per 32 x 32 tile, computed in both orientations (the
+// accumulator row is the lane either way, so both outputs leave as 16-byte row segments without a transposition).
+__device__ __forceinline__ float dense_entry(const DenseArgs& a, int h, int i, int j, float abs_ij) {
+  if (i >= a.T || j >= a.S) return NEG_INF;
+  if (a.causal) {
+    const bool masked = (j < a.P) ? ((i >= a.P) || (j > i)) : ((i >= a.P) && (j > i));
+    if (masked) return NEG_INF;
+  }
+  float r = 0.f;
+  if (a.rel_mode) {
+    if (i < a.P) r = (j < a.P) ? a.rel2d[(long long)h * a.n2d + (a.gcode[i] - a.gcode[j] + a.code_bias)] : a.relx[h * 2];
+    else r = (j < a.P) ? a.relx[h * 2 + 1] : a.rel1d[(long long)h * (2 * a.Lt - 1) + (i - j) + a.Lt - 1];
+  }
+  return abs_ij + r;
+}
+
+__global__ __launch_bounds__(256) void attn_dense_bias_kernel(DenseArgs a) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, x = lane & 31;
+  const int ntq = a.Tp >> 5, ntk = a.Sp >> 5;
+  const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= (long long)a.H * ntq * ntk) return;
+  const int tj = (int)(tile % ntk), ti = (int)((tile / ntk) % ntq), h = (int)(tile / ((long long)ntk * ntq));
+  const int i0 = ti * 32, j0 = tj * 32;
+  bf16x8 fq[4], fk[4];
+  if (a.pq) {
+    const bf16_t* qp = a.pq + (long long)min(i0 + x, a.T - 1) * a.ldpq + h * 64 + half * 8;
+    const bf16_t* kp = a.pk + (long long)min(j0 + x, a.S - 1) * a.ldpk + h * 64 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      U128 u; u.v = *reinterpret_cast<const uint4*>(qp + ks * 16); fq[ks] = u.b;
+      U128 w; w.v = *reinterpret_cast<const uint4*>(kp + ks * 16); fk[ks] = w.b;
+    }
+  }
+  f32x16 acc;
+  // (1) lane = query i0 + x, element r <-> key j0 + (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  if (a.pq) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[ks], fq[ks], acc, 0, 0, 0);
+  }
+  if (i0 + x < a.T) {
+    float* dp = a.D + ((long long)h * a.T + i0 + x) * a.Sp + j0 + 4 * half;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = dense_entry(a, h, i0 + x, j0 + 8 * rg + 4 * half + e, acc[rg * 4 + e]);
+      *reinterpret_cast<float4*>(dp + 8 * rg) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  // (2) lane = key j0 + x, element r <-> query i0 + (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  if (a.pq) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[ks], fk[ks], acc, 0, 0, 0);
+  }
+  if (j0 + x < a.S) {
+    float* dp = a.Dt + ((long long)h * a.S + j0 + x) * a.Tp + i0 + 4 * half;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = dense_entry(a, h, i0 + 8 * rg + 4 * half + e, j0 + x, acc[rg * 4 + e]);
+      *reinterpret_cast<float4*>(dp + 8 * rg) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- gradients of the bias
+struct DbArgs {
+  const bf16_t* dbias;        // [ng][H][T][Sp]
+  long long gs;               // elements per group slab
+  int ng, H, T, S, Sp, C;
+  const bf16_t *pq, *pk;      // [T, ldpq], [S, ldpk]
+  int ldpq, ldpk;
+  float *dpq, *dpk;           // fp32 [T, C], [S, C]
+  int accumulate;
+  float dpq_scale;
+  int P, gh, gw, Lt;
+  float *drel2d, *drel1d, *drelx;     // [H][(2gh-1)(2gw-1)], [H][2Lt-1], [H][2]
+  int nb_q, nb_k, nb_2d;
+};
+
+// 32 x (256-byte row) tile image (kx layout of csrc/attention.hip): row-wise and transposed reads
+__device__ __forceinline__ int kx_off(int r, int c) {
+  const int f = ((r & 3) << 2) | ((r >> 2) & 3);
+  return r * 256 + ((c ^ f) << 4);
+}
+
+// A / B fragment of a transposed read: tile rows = contraction index (16 of them from row `rbase`), columns `cb*32..+31`
+// = the fragment's lane index; slot (kh, e) <-> row rbase + 4*kh + (e&3) + 8*(e>>2)
+template <bool WIDE>
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int rbase, int cb, int lane) {
+  const int half = lane >> 5, i16 = lane & 15, g16 = (lane >> 4) & 1;
+  const int col = cb * 32 + g16 * 16 + (i16 & 3) * 4;          // element column
+  const int r0 = rbase + 4 * half + (i16 >> 2);
+  U64 x, y;
+  if (WIDE) {
+    x.s = lds_read_tr(tile + kx_off(r0, col >> 3) + (col & 7) * 2);
+    y.s = lds_read_tr(tile + kx_off(r0 + 8, col >> 3) + (col & 7) * 2);
+  } else {
+    x.s = lds_read_tr(tile + vx_off(r0, col * 2));
+    y.s = lds_read_tr(tile + vx_off(r0 + 8, col * 2));
+  }
+  U128 f; f.w[0] = x.w[0]; f.w[1] = x.w[1]; f.w[2] = y.w[0]; f.w[3] = y.w[1];
+  return f.b;
+}
+
+__global__ __launch_bounds__(256) void attn_dbias_grads_kernel(DbArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[4096 + 8192 * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  int blk = blockIdx.x;
+  if (blk < a.nb_q) {
+    // ---- d pos_q[i][h*64 + c] (+)= scale * sum_j dB[h][i][j] pos_k[j][h*64 + c]:  out^T[c][i], A = pos_k^T (tr), B = dB rows
+    const int nit = (a.T + 127) >> 7;
+    const int h = blk / nit, i0 = (blk % nit) * 128 + wave * 32;
+    const int i = i0 + (lane & 31);
+    const int ir = i < a.T ? i : a.T - 1;
+    f32x16 acc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+    for (int j0 = 0; j0 < a.Sp; j0 += 32) {
+      __syncthreads();
+      {   // pos_k tile [32 j][64 c] -> LDS (vx layout), rows past S are zero
+        const int r = tid >> 3, c = tid & 7;
+        uint4 v4 = make_uint4(0, 0, 0, 0);
+        if (j0 + r < a.S) v4 = *reinterpret_cast<const uint4*>(a.pk + (long long)(j0 + r) * a.ldpk + h * 64 + c * 8);
+        *reinterpret_cast<uint4*>(sm + vx_off(r, c * 16)) = v4;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 a0 = tr_frag<false>(sm, 16 * s2, 0, lane), a1 = tr_frag<false>(sm, 16 * s2, 1, lane);
+        for (int g = 0; g < a.ng; ++g) {
+          const bf16_t* rp = a.dbias + g * a.gs + ((long long)h * a.T + ir) * a.Sp + j0 + 16 * s2 + 4 * half;
+          U128 bfr;
+          const uint2 lo = *reinterpret_cast<const uint2*>(rp), hi = *reinterpret_cast<const uint2*>(rp + 8);
+          bfr.w[0] = lo.x; bfr.w[1] = lo.y; bfr.w[2] = hi.x; bfr.w[3] = hi.y;
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr.b, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr.b, acc[1], 0, 0, 0);
+        }
+      }
+    }
+    if (i < a.T) {
+      float* op = a.dpq + (long long)i * a.C + h * 64 + 4 * half;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          float4* p = reinterpret_cast<float4*>(op + cb * 32 + 8 * rg);
+          float4 o = make_float4(acc[cb][rg * 4] * a.dpq_scale, acc[cb][rg * 4 + 1] * a.dpq_scale,
+                                 acc[cb][rg * 4 + 2] * a.dpq_scale, acc[cb][rg * 4 + 3] * a.dpq_scale);
+          if (a.accumulate) { const float4 t = *p; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+          *p = o;
+        }
+    }
+    return;
+  }
+  blk -= a.nb_q;
+  if (blk < a.nb_k) {
+    // ---- d pos_k[j][h*64 + c] (+)= sum_i dB[h][i][j] pos_q[i][h*64 + c]:  out^T[c][j], A = pos_q^T (tr), B = dB^T (tr)
+    const int njt = (a.Sp + 127) >> 7;
+    const int h = blk / njt, jw0 = (blk % njt) * 128;
+    const int j = jw0 + wave * 32 + (lane & 31);
+    unsigned char* sQ = sm;            // pos_q tile [32 i][64 c], vx layout
+    unsigned char* sB = sm + 4096;     // dB tiles [ng <= 2][32 i][128 j], kx layout (256-byte rows)
+    f32x16 acc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+    for (int i0 = 0; i0 < a.T; i0 += 32) {
+      __syncthreads();
+      {
+        const int r = tid >> 3, c = tid & 7;
+        uint4 v4 = make_uint4(0, 0, 0, 0);
+        if (i0 + r < a.T) v4 = *reinterpret_cast<const uint4*>(a.pq + (long long)(i0 + r) * a.ldpq + h * 64 + c * 8);
+        *reinterpret_cast<uint4*>(sQ + vx_off(r, c * 16)) = v4;
+        for (int g = 0; g < a.ng; ++g)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int rr = (tid >> 4) + 16 * u, cc = tid & 15;         // 32 rows x 16 chunks of 8 columns
+            uint4 w4 = make_uint4(0, 0, 0, 0);
+            if (i0 + rr < a.T && jw0 + cc * 8 < a.Sp)
+              w4 = *reinterpret_cast<const uint4*>(a.dbias + g * a.gs + ((long long)h * a.T + i0 + rr) * a.Sp + jw0 + cc * 8);
+            *reinterpret_cast<uint4*>(sB + g * 8192 + kx_off(rr, cc)) = w4;
+          }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 a0 = tr_frag<false>(sQ, 16 * s2, 0, lane), a1 = tr_frag<false>(sQ, 16 * s2, 1, lane);
+        for (int g = 0; g < a.ng; ++g) {
+          const bf16x8 bfr = tr_frag<true>(sB + g * 8192, 16 * s2, wave, lane);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr, acc[1], 0, 0, 0);
+        }
+      }
+    }
+    if (j < a.S) {
+      float* op = a.dpk + (long long)j * a.C + h * 64 + 4 * half;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          float4* p = reinterpret_cast<float4*>(op + cb * 32 + 8 * rg);
+          float4 o = make_float4(acc[cb][rg * 4], acc[cb][rg * 4 + 1], acc[cb][rg * 4 + 2], acc[cb][rg * 4 + 3]);
+          if (a.accumulate) { const float4 t = *p; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+          *p = o;
+        }
+    }
+    return;
+  }
+  blk -= a.nb_k;
+  float* sf = reinterpret_cast<float*>(sm);
+  auto dB = [&](int h, int i, int j) {
+    float t = 0.f;
+    for (int g = 0; g < a.ng; ++g) t += bf2f(a.dbias[g * a.gs + ((long long)h * a.T + i) * a.Sp + j]);
+    return t;
+  };
+  if (blk < a.nb_2d) {
+    // ---- d rel2d[h][(dy + gh-1)(2gw-1) + dx + gw-1] = sum over the grid pairs (i, j) with y_i - y_j = dy, x_i - x_j = dx
+    const int ndy = 2 * a.gh - 1, h = blk / ndy, dy = blk % ndy - (a.gh - 1);
+    const int w = a.gw, ylo = dy > 0 ? dy : 0, yhi = dy < 0 ? a.gh + dy : a.gh;
+    float* out = a.drel2d + (long long)h * ndy * (2 * w - 1) + (long long)(dy + a.gh - 1) * (2 * w - 1);
+    // pair sums over y for every (x_i, x_j), w*w <= 4096 floats of LDS (gw <= 64)
+    for (int p = tid; p < w * w; p += 256) {
+      const int xi = p / w, xj = p - xi * w;
+      float t = 0.f;
+      for (int yi = ylo; yi < yhi; ++yi) t += dB(h, yi * w + xi, (yi - dy) * w + xj);
+      sf[p] = t;
+    }
+    __syncthreads();
+    for (int d = tid; d < 2 * w - 1; d += 256) {
+      const int dx = d - (w - 1);
+      float t = 0.f;
+      for (int xi = (dx > 0 ? dx : 0); xi < (dx < 0 ? w + dx : w); ++xi) t += sf[xi * w + (xi - dx)];
+      out[d] = t;
+    }
+    return;
+  }
+  blk -= a.nb_2d;
+  {
+    // ---- head `blk`: the two scalar bias entries (grid row x tail column, tail row x grid column) and the tail x tail
+    // Toeplitz table; fixed summation order
+    const int h = blk, P = a.P, Lt = a.Lt;
+    float t0 = 0.f, t1 = 0.f;
+    for (long long e = tid; e < (long long)P * Lt; e += 256) {
+      const int i = (int)(e / Lt), tj = (int)(e - (long long)i * Lt);
+      t0 += dB(h, i, P + tj);
+    }
+    for (long long e = tid; e < (long long)P * Lt; e += 256) {
+      const int ti = (int)(e / P), jj = (int)(e - (long long)ti * P);
+      t1 += dB(h, P + ti, jj);
+    }
+    sf[tid] = t0; sf[256 + tid] = t1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) { sf[tid] += sf[tid + o]; sf[256 + tid] += sf[256 + tid + o]; }
+      __syncthreads();
+    }
+    if (tid == 0) { a.drelx[h * 2] = sf[0]; a.drelx[h * 2 + 1] = sf[256]; }
+    for (int d = tid; d < 2 * Lt - 1; d += 256) {
+      const int off = d - (Lt - 1);          // i - j
+      float t = 0.f;
+      for (int ti = (off > 0 ? off : 0); ti < (off < 0 ? Lt + off : Lt); ++ti) t += dB(h, P + ti, P + ti - off);
+      a.drel1d[(long long)h * (2 * Lt - 1) + d] = t;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ifseg_attn_dense_bias(const void* pos_q, const void* pos_k, int ldpq, int ldpk, int H, int T, int S,
+                                     int rel_mode, int P, const int* gcode, int code_bias, int n2d, const float* rel2d,
+                                     const float* rel1d, const float* relx, int causal, float* D, int Sp, float* Dt,
+                                     int Tp, void* stream) {
+  (void)hipGetLastError();
+  if (!D || !Dt || H <= 0 || T <= 0 || S <= 0 || (Sp & 31) || (Tp & 31) || Sp < S || Tp < T) return IFSEG_ERR_BAD_ARG;
+  if ((pos_q == nullptr) != (pos_k == nullptr) || ((ldpq | ldpk) & 7)) return IFSEG_ERR_BAD_ARG;
+  if (rel_mode && (!gcode || !rel2d || !rel1d || !relx)) return IFSEG_ERR_BAD_ARG;
+  if ((rel_mode || causal) && (P > T || P > S || P < 0)) return IFSEG_ERR_BAD_SHAPE;
+  DenseArgs a{};
+  a.pq = (const bf16_t*)pos_q; a.pk = (const bf16_t*)pos_k; a.ldpq = ldpq; a.ldpk = ldpk;
+  a.H = H; a.T = T; a.S = S; a.Sp = Sp; a.Tp = Tp;
+  a.rel_mode = rel_mode; a.P = (rel_mode || causal) ? P : S; a.code_bias = code_bias; a.n2d = n2d; a.Lt = T - P; a.causal = causal;
+  a.gcode = gcode; a.rel2d = rel2d; a.rel1d = rel1d; a.relx = relx; a.D = D; a.Dt = Dt;
+  const long long tiles = (long long)H * (Tp / 32) * (Sp / 32);
+  hipLaunchKernelGGL(attn_dense_bias_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* x, void* stream) {
+  (void)hipGetLastError();
+  if (!x || x->B <= 0 || x->H <= 0 || x->T <= 0 || x->S <= 0) return IFSEG_ERR_BAD_ARG;
+  if ((x->Sp & 31) || (x->Tp & 31) || x->Sp < x->S || x->Tp < x->T || !x->D || !x->Dt) return IFSEG_ERR_BAD_ARG;
+  BiArgs a{};
+  a.q = (const bf16_t*)x->q; a.k = (const bf16_t*)x->k; a.v = (const bf16_t*)x->v; a.dO = (const bf16_t*)x->dout;
+  a.lse = x->lse; a.delta = x->delta; a.D = x->D; a.Dt = x->Dt; a.gain = (const float*)x->gain;
+  a.dq = (bf16_t*)x->dq; a.dk = (bf16_t*)x->dk; a.dv = (bf16_t*)x->dv; a.dbias = (bf16_t*)x->dbias;
+  a.B = x->B; a.H = x->H; a.T = x->T; a.S = x->S; a.Sp = x->Sp; a.Tp = x->Tp;
+  a.q_bs = x->q_bs; a.k_bs = x->k_bs; a.v_bs = x->v_bs; a.do_bs = x->do_bs; a.dq_bs = x->dq_bs; a.dk_bs = x->dk_bs; a.dv_bs = x->dv_bs;
+  a.dbias_gs = (long long)x->H * x->T * x->Sp;
+  a.ldq = x->ldq; a.ldk = x->ldk; a.ldv = x->ldv; a.lddo = x->lddo; a.lddq = x->lddq; a.lddk = x->lddk; a.lddv = x->lddv;
+  a.causal = x->causal; a.P = x->causal ? x->P : x->S; a.dq_scale = x->dq_scale;
+  if ((a.ldq | a.ldk | a.ldv | a.lddo | a.lddq | a.lddk | a.lddv) & 7) return IFSEG_ERR_BAD_SHAPE;
+  if (((size_t)a.q | (size_t)a.k | (size_t)a.v | (size_t)a.dO | (size_t)a.dq | (size_t)a.dk | (size_t)a.dv | (size_t)a.dbias) & 15)
+    return IFSEG_ERR_BAD_ARG;
+  if ((a.q_bs | a.k_bs | a.v_bs | a.do_bs | a.dq_bs | a.dk_bs | a.dv_bs) & 7) return IFSEG_ERR_BAD_SHAPE;
+  if (a.causal && ((a.P & 63) || a.P > a.T || a.P > a.S)) return IFSEG_ERR_BAD_SHAPE;
+  {   // rows are addressed by 32-bit byte offsets from a per-(batch, head) or per-head base
+    long long ldmax = a.ldq;
+    for (long long l : {(long long)a.lddo, (long long)a.ldk, (long long)a.ldv}) ldmax = l > ldmax ? l : ldmax;
+    const long long rows = a.T > a.S ? a.T : a.S;
+    if (rows * ldmax * 2 >= (1ll << 31) || (long long)a.T * a.Sp * 4 >= (1ll << 31) || (long long)a.S * a.Tp * 4 >= (1ll << 31))
+      return IFSEG_ERR_BAD_SHAPE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int nbg = (a.B + 3) / 4;
+  const int ph = x->phases ? x->phases : (IFSEG_ATTN_BWD_DKV | IFSEG_ATTN_BWD_DQ);
+  if (ph & IFSEG_ATTN_BWD_DKV) {
+    if (!a.dk || !a.dv) return IFSEG_ERR_BAD_ARG;
+    (void)hipFuncSetAttribute((const void*)attn_bi_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
+    ifseg_prof_begin(IFSEG_K_ATTN_DKV, s, 6.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);
+    hipLaunchKernelGGL(attn_bi_dkv_kernel, dim3(((a.S + 63) / 64) * a.H * nbg), dim3(512), LDS_DKV, s, a);
+    ifseg_prof_end(IFSEG_K_ATTN_DKV, s);
+  }
+  if (ph & IFSEG_ATTN_BWD_DQ) {
+    if (!a.dq || !a.dbias) return IFSEG_ERR_BAD_ARG;
+    (void)hipFuncSetAttribute((const void*)attn_bi_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
+    ifseg_prof_begin(IFSEG_K_ATTN_DQ, s, 2.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);
+    hipLaunchKernelGGL(attn_bi_dq_kernel, dim3(((a.T + 63) / 64) * a.H * nbg), dim3(512), LDS_DQ, s, a);
+    ifseg_prof_end(IFSEG_K_ATTN_DQ, s);
+  }
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_attn_dbias_grads(const ifseg_attn_dbias_args* x, void* stream) {
+  (void)hipGetLastError();
+  if (!x || !x->dbias || x->ng <= 0 || x->ng > 2 || x->H <= 0 || x->T <= 0 || x->S <= 0 || (x->Sp & 31) || x->Sp < x->S)
+    return IFSEG_ERR_BAD_ARG;
+  DbArgs a{};
+  a.dbias = (const bf16_t*)x->dbias; a.gs = (long long)x->H * x->T * x->Sp; a.ng = x->ng;
+  a.H = x->H; a.T = x->T; a.S = x->S; a.Sp = x->Sp; a.C = x->C;
+  a.pq = (const bf16_t*)x->pos_q; a.pk = (const bf16_t*)x->pos_k; a.ldpq = x->ldpq; a.ldpk = x->ldpk;
+  a.dpq = x->dpos_q_acc; a.dpk = x->dpos_k_acc; a.accumulate = x->accumulate_pos; a.dpq_scale = x->dpq_scale;
+  a.P = x->P; a.gh = x->grid_h; a.gw = x->grid_w; a.Lt = x->T - x->P;
+  a.drel2d = x->drel2d; a.drel1d = x->drel1d; a.drelx = x->drelx;
+  const bool pos = a.pq != nullptr;
+  if (pos && (!a.pk || !a.dpq || !a.dpk || ((a.ldpq | a.ldpk) & 7) || (a.C & 3) || a.C < a.H * 64)) return IFSEG_ERR_BAD_ARG;
+  const bool rel = a.drel2d != nullptr;
+  if (rel) {
+    if (!a.drel1d || !a.drelx || a.gh <= 0 || a.gw <= 0 || a.gw > 64 || a.gh * a.gw != a.P || a.P > a.T || a.P > a.S || a.T != a.S)
+      return IFSEG_ERR_BAD_SHAPE;
+  }
+  a.nb_q = pos ? a.H * ((a.T + 127) / 128) : 0;
+  a.nb_k = pos ? a.H * ((a.Sp + 127) / 128) : 0;
+  a.nb_2d = rel ? a.H * (2 * a.gh - 1) : 0;
+  const int total = a.nb_q + a.nb_k + a.nb_2d + (rel ? a.H : 0);
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(attn_dbias_grads_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, a);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}

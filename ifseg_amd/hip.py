@@ -33,7 +33,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 10:
+        if _lib.ifseg_abi_version() != 11:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -363,6 +363,89 @@ def attn_bwd(q, k, v, pos_q, pos_k, out, dout, lse, delta, dq, dk, dv, dpq_part,
     a.phases = phases
     rc = lib().ifseg_attn_bwd(ctypes.byref(a), _stream())
     _check(rc, "attn_bwd")
+
+
+# ---- attention backward with the batch as a workgroup's inner dimension (csrc/attention_bi.hip)
+def _pad32(n):
+    return (n + 31) // 32 * 32
+
+
+class DenseBias:
+    """The batch-invariant attention bias of one layer as dense fp32 operands: D [H, T, Sp] and its transpose Dt [H, S, Tp]
+    (-inf = masked), built from parameters only by ifseg_attn_dense_bias."""
+
+    def __init__(self, H, T, S, device):
+        self.H, self.T, self.S, self.Sp, self.Tp = H, T, S, _pad32(S), _pad32(T)
+        self.D = torch.empty(H, T, self.Sp, dtype=torch.float32, device=device)
+        self.Dt = torch.empty(H, S, self.Tp, dtype=torch.float32, device=device)
+
+
+def attn_dense_bias(dense, pos_q, pos_k, rel=None, causal=False, P=None):
+    if rel is not None:
+        P = rel.P
+    if P is None:
+        P = dense.S
+    rc = lib().ifseg_attn_dense_bias(
+        _ptr(pos_q), _ptr(pos_k), c_int(pos_q.stride(0) if pos_q is not None else 0),
+        c_int(pos_k.stride(0) if pos_k is not None else 0), c_int(dense.H), c_int(dense.T), c_int(dense.S),
+        c_int(1 if rel is not None else 0), c_int(P), _ptr(rel.gcode) if rel is not None else None,
+        c_int(rel.code_bias if rel is not None else 0), c_int(rel.rel2d.shape[1] if rel is not None else 0),
+        _ptr(rel.rel2d) if rel is not None else None, _ptr(rel.rel1d) if rel is not None else None,
+        _ptr(rel.relx) if rel is not None else None, c_int(1 if causal else 0), _ptr(dense.D), c_int(dense.Sp),
+        _ptr(dense.Dt), c_int(dense.Tp), _stream())
+    _check(rc, "attn_dense_bias")
+    return dense
+
+
+class _AttnBiArgs(ctypes.Structure):
+    _fields_ = ([(n, c_void_p) for n in ("q", "k", "v", "dout", "lse", "delta", "D", "Dt", "gain", "dq", "dk", "dv", "dbias")]
+                + [(n, c_int) for n in ("B", "H", "T", "S", "Sp", "Tp", "ldq", "ldk", "ldv", "lddo", "lddq", "lddk", "lddv")]
+                + [(n, c_ll) for n in ("q_bs", "k_bs", "v_bs", "do_bs", "dq_bs", "dk_bs", "dv_bs")]
+                + [("causal", c_int), ("P", c_int), ("dq_scale", c_float), ("phases", c_int)])   # == ifseg_attn_bi_args
+
+
+def attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=False, P=None, gain=None,
+                dq_scale=1.0, phases=0):
+    """dbias: bf16 [ceil(B/4), H, T, dense.Sp] -- zero-filled once by the caller when causal (skipped blocks are not written)"""
+    a = _AttnBiArgs()
+    for name, t in (("q", q), ("k", k), ("v", v), ("dout", dout), ("lse", lse), ("delta", delta), ("D", dense.D),
+                    ("Dt", dense.Dt), ("gain", _f32(gain)), ("dq", dq), ("dk", dk), ("dv", dv), ("dbias", dbias)):
+        setattr(a, name, _p(t))
+    assert dbias.dtype == torch.bfloat16 and tuple(dbias.shape) == ((B + 3) // 4, H, T, dense.Sp) and dbias.is_contiguous()
+    a.B, a.H, a.T, a.S, a.Sp, a.Tp = B, H, T, S, dense.Sp, dense.Tp
+    a.ldq, a.ldk, a.ldv, a.lddo = q.stride(1), k.stride(1), v.stride(1), dout.stride(1)
+    a.lddq, a.lddk, a.lddv = dq.stride(1), dk.stride(1), dv.stride(1)
+    a.q_bs, a.k_bs, a.v_bs, a.do_bs = q.stride(0), k.stride(0), v.stride(0), dout.stride(0)
+    a.dq_bs, a.dk_bs, a.dv_bs = dq.stride(0), dk.stride(0), dv.stride(0)
+    a.causal, a.P = (1 if causal else 0), (P if P is not None else S)
+    a.dq_scale, a.phases = dq_scale, phases
+    _check(lib().ifseg_attn_bwd_bi(ctypes.byref(a), _stream()), "attn_bwd_bi")
+
+
+class _AttnDbiasArgs(ctypes.Structure):
+    _fields_ = [("dbias", c_void_p), ("ng", c_int), ("H", c_int), ("T", c_int), ("S", c_int), ("Sp", c_int), ("C", c_int),
+                ("pos_q", c_void_p), ("pos_k", c_void_p), ("ldpq", c_int), ("ldpk", c_int),
+                ("dpos_q_acc", c_void_p), ("dpos_k_acc", c_void_p), ("accumulate_pos", c_int), ("dpq_scale", c_float),
+                ("P", c_int), ("grid_h", c_int), ("grid_w", c_int),
+                ("drel2d", c_void_p), ("drel1d", c_void_p), ("drelx", c_void_p)]     # == ifseg_attn_dbias_args
+
+
+def attn_dbias_grads(dbias, S, pos_q=None, pos_k=None, dpq_acc=None, dpk_acc=None, accumulate_pos=False, dpq_scale=1.0,
+                     P=0, grid_h=0, grid_w=0, drel2d=None, drel1d=None, drelx=None):
+    """dbias [ng, H, T, Sp] bf16 -> abs-pos operand gradients (fp32 [T, C] / [S, C]) and delta-table gradients (fp32
+    [H, (2gh-1)(2gw-1)], [H, 2Lt-1], [H, 2]) in one launch"""
+    a = _AttnDbiasArgs()
+    ng, H, T, Sp = dbias.shape
+    a.dbias, a.ng, a.H, a.T, a.S, a.Sp = _p(dbias), ng, H, T, S, Sp
+    a.C = dpq_acc.shape[1] if dpq_acc is not None else 0
+    a.pos_q, a.pos_k = _p(pos_q), _p(pos_k)
+    a.ldpq = pos_q.stride(0) if pos_q is not None else 0
+    a.ldpk = pos_k.stride(0) if pos_k is not None else 0
+    a.dpos_q_acc, a.dpos_k_acc = _p(dpq_acc), _p(dpk_acc)
+    a.accumulate_pos, a.dpq_scale = (1 if accumulate_pos else 0), dpq_scale
+    a.P, a.grid_h, a.grid_w = P, grid_h, grid_w
+    a.drel2d, a.drel1d, a.drelx = _p(drel2d), _p(drel1d), _p(drelx)
+    _check(lib().ifseg_attn_dbias_grads(ctypes.byref(a), _stream()), "attn_dbias_grads")
 
 
 # ------------------------------------------------------------------------ row ops

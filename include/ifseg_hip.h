@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 10
+#define IFSEG_ABI_VERSION 11
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -197,6 +197,60 @@ typedef struct ifseg_attn_reduce_args {
   int tab_nbucket[3];                       /* rows of tab_acc_i */
 } ifseg_attn_reduce_args;
 int ifseg_attn_bwd_reduce(const ifseg_attn_reduce_args* args, void* stream);
+
+/* ---- attention backward with the batch as a workgroup's inner dimension (csrc/attention_bi.hip) ----
+ * The reference builds abs-pos + rel-pos bias ONCE per layer and broadcasts it over the batch
+ * (encoder_module.py:757-771,790-809 with the expand at :317,791; decoder_module.py:553-558,603-627;
+ * unify_multihead_attention.py:459-465).  These three entry points keep that structure:
+ *
+ * ifseg_attn_dense_bias: D[h][i][j] = pos_q[i].pos_k[j] + rel(i,j) as fp32 [H,T,Sp] and its transpose Dt [H,S,Tp]
+ *   (Sp / Tp = S / T rounded up to 32); -inf where the causal mask ("tail-first" order of ifseg_attn_fwd) hides (i,j),
+ *   for padded columns j >= S and, in Dt, padded columns i >= T.  Parameters only: built once per layer and step.
+ *   rel(i,j) as documented at ifseg_attn_fwd (rel_mode = 1), pos_q / pos_k may be NULL (no abs-pos term). */
+int ifseg_attn_dense_bias(const void* pos_q, const void* pos_k, int ldpq, int ldpk, int H, int T, int S, int rel_mode,
+                          int P, const int* gcode, int code_bias, int n2d, const float* rel2d, const float* rel1d,
+                          const float* relx, int causal, float* D, int Sp, float* Dt, int Tp, void* stream);
+
+/* ifseg_attn_bwd_bi: dq (x dq_scale), dk, dv of S_b = q_b k_b^T + D (autograd of unify_multihead_attention.py:459-512)
+ *   and dbias[g][h][i][j] = sum over the batch elements 4g .. 4g+3 of dS_b[h][i][j] (bf16 [ceil(B/4), H, T, Sp]).
+ *   One workgroup = (head, 64 rows, 4 batch elements): the bias tile is fetched once for the four, sum_b dS leaves the
+ *   kernel once per tile.  delta [B,H,T] = rowsum(dout * out) must exist (ifseg_attn_bwd phase 1 or
+ *   ifseg_gemm_nn_rowdot).  Causal launches skip 32-blocks above the diagonal: those entries of dbias are NOT written --
+ *   the caller zero-fills the buffer once (the set of skipped blocks depends only on the shape).  No atomics. */
+typedef struct ifseg_attn_bi_args {
+  const void *q, *k, *v, *dout;
+  const float *lse, *delta, *D, *Dt;
+  const void* gain;            /* fp32 [H] or NULL */
+  void *dq, *dk, *dv, *dbias;
+  int B, H, T, S, Sp, Tp;
+  int ldq, ldk, ldv, lddo, lddq, lddk, lddv;
+  long long q_bs, k_bs, v_bs, do_bs, dq_bs, dk_bs, dv_bs;
+  int causal, P;               /* P: grid tokens (multiple of 64) when causal */
+  float dq_scale;
+  int phases;                  /* 0 = both; IFSEG_ATTN_BWD_DKV | IFSEG_ATTN_BWD_DQ */
+} ifseg_attn_bi_args;
+int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* args, void* stream);
+
+/* ifseg_attn_dbias_grads: everything downstream of dbias in ONE launch (the autograd of the bias construction,
+ *   encoder_module.py:757-771,790-809 / decoder_module.py:553-558,603-627), with dB = sum_g dbias[g]:
+ *     dpos_q_acc[i][h*64+c] (=|+=) dpq_scale * sum_j dB[h][i][j] pos_k[j][h*64+c]       (fp32 [T,C])
+ *     dpos_k_acc[j][h*64+c] (=|+=)             sum_i dB[h][i][j] pos_q[i][h*64+c]       (fp32 [S,C])
+ *     drel2d[h][(dy+gh-1)(2gw-1) + dx+gw-1] = sum of dB over grid pairs with (y_i-y_j, x_i-x_j) = (dy, dx)  (raster grid gh x gw = P)
+ *     drel1d[h][(i-j)+Lt-1] = sum over tail pairs;  drelx[h][0] = sum_{i<P<=j<S} dB,  drelx[h][1] = sum_{j<P<=i<T} dB
+ *   (the delta-table gradients feed ifseg_attn_bwd_reduce with nparts = 1).  pos_q == NULL skips the operand gradients,
+ *   drel2d == NULL the tables.  Fixed summation order. */
+typedef struct ifseg_attn_dbias_args {
+  const void* dbias;           /* bf16 [ng][H][T][Sp] */
+  int ng, H, T, S, Sp, C;
+  const void *pos_q, *pos_k;   /* bf16 [T,ldpq], [S,ldpk] */
+  int ldpq, ldpk;
+  float *dpos_q_acc, *dpos_k_acc;
+  int accumulate_pos;
+  float dpq_scale;
+  int P, grid_h, grid_w;
+  float *drel2d, *drel1d, *drelx;
+} ifseg_attn_dbias_args;
+int ifseg_attn_dbias_grads(const ifseg_attn_dbias_args* args, void* stream);
 
 /* -------------------------------------------------------------- row ops */
 /* Row addressing used below: logical row r lives at element offset

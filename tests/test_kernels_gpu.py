@@ -348,6 +348,153 @@ def test_attn_bwd(case):
                 assert torch.equal(a_, b_)
 
 
+def _attn_case(case):
+    """geometry of an attention parity case: (H, B, T, S, P, Lt, gh, gw, causal); P is None without a rel-pos bias"""
+    H, B, causal, P, Lt, gh, gw = 2, 2, False, None, 0, 0, 0
+    if case == "cross":
+        T, S = 193, 292
+    elif case == "enc_rel":
+        gh, gw, P, Lt = 8, 16, 128, 36
+    elif case in ("dec_causal", "dec_full"):
+        gh, gw, P, Lt = 8, 8, 64, 1
+        causal = case == "dec_causal"
+    elif case == "big_enc":
+        gh, gw, P, Lt = 32, 32, 1024, 36
+        H, B = 3, 2
+    elif case == "big_enc_b8":            # the bench geometry's batch: two groups of four batch elements
+        gh, gw, P, Lt = 32, 32, 1024, 36
+        H, B = 2, 8
+    elif case == "enc_b5":                # a partly filled second group of batch elements
+        gh, gw, P, Lt = 8, 16, 128, 36
+        H, B = 2, 5
+    elif case == "dec_causal_bh8":
+        gh, gw, P, Lt = 32, 32, 1024, 1
+        H, B, causal = 4, 2, True
+    elif case == "dec_wide":
+        gh, gw, P, Lt = 8, 40, 320, 1
+        causal = True
+    elif case in ("enc_w40", "dec_w40", "enc_w48"):
+        gh, gw = (16, 40) if case != "enc_w48" else (8, 48)
+        P, Lt = gh * gw, (1 if case == "dec_w40" else 37)
+        causal = case == "dec_w40"
+    elif case in ("enc_w40_full", "dec_w40_full"):
+        gh, gw, B = 40, 40, 1
+        P, Lt = 1600, (1 if case == "dec_w40_full" else 37)
+        causal = case == "dec_w40_full"
+    elif case == "enc_long_text":         # BASELINE configs[2]: 150 class names, L = 215
+        gh, gw, P, Lt = 32, 32, 1024, 215
+        H, B = 2, 4
+    if P is not None:
+        T = S = P + Lt
+    return H, B, T, S, P, Lt, gh, gw, causal
+
+
+@pytest.mark.parametrize("case", ["cross", "enc_rel", "dec_causal", "dec_full", "big_enc", "big_enc_b8", "enc_b5",
+                                  "dec_causal_bh8", "enc_w40", "dec_w40", "enc_w48", "enc_w40_full", "dec_w40_full",
+                                  "enc_long_text"])
+def test_attn_bwd_batch_inner(case):
+    """csrc/attention_bi.hip: dense batch-invariant bias (ifseg_attn_dense_bias), the backward whose workgroups hold four
+    batch elements and emit sum_b dS once per tile (ifseg_attn_bwd_bi), and the gradients behind that sum
+    (ifseg_attn_dbias_grads) -- against fp32 autograd of the reference formulation (bias built once, broadcast over B)."""
+    from ifseg_amd import hip
+    dev = _dev()
+    H, B, T, S, P, Lt, gh, gw, causal = _attn_case(case)
+    C = H * 64
+    q, k, v = _rand((B, T, C), dev, 20, 0.35), _rand((B, S, C), dev, 21), _rand((B, S, C), dev, 22)
+    pq, pk = _rand((T, C), dev, 23, 0.35), _rand((S, C), dev, 24)
+    dout = _rand((B, T, C), dev, 25)
+    gain = (1.0 + 0.2 * torch.randn(H, generator=torch.Generator().manual_seed(5))).to(dev)
+    rel, tabs = None, None
+    if P is not None:
+        gcode, code_bias, n2d = _grid_codes(gh, gw)
+        g = torch.Generator().manual_seed(30)
+        tabs = [torch.randn(H, n2d, generator=g), torch.randn(H, 2 * Lt - 1, generator=g), torch.randn(H, 2, generator=g)]
+        rel = hip.RelBias(P, gcode.to(dev), code_bias, tabs[0].to(dev), tabs[1].to(dev), tabs[2].to(dev), grid_w=gw)
+    # ---- fp32 autograd reference (the bias is ONE [H, T, S] tensor broadcast over the batch)
+    qf, kf, vf, pqf, pkf = [t.float().clone().requires_grad_(True) for t in (q, k, v, pq, pk)]
+    gf = gain.clone().requires_grad_(True)
+    tl = [t.clone().requires_grad_(True) for t in tabs] if tabs is not None else None
+    bias_ref = _dense_rel_ad(H, T, S, P, gcode.long(), code_bias, *tl).to(dev) if tabs is not None else None
+    mask = _causal_mask(T, S, P).to(dev) if causal else None
+    o_ref, _ = _attn_ref(qf, kf, vf, pqf, pkf, bias_ref, mask)
+    o_ref = (o_ref.view(B, T, H, 64) * gf.view(1, 1, H, 1)).reshape(B, T, C)
+    (o_ref * dout.float()).sum().backward()
+    # ---- dense bias operands
+    dense = hip.DenseBias(H, T, S, dev)
+    dense.D.fill_(7.0); dense.Dt.fill_(7.0)
+    hip.attn_dense_bias(dense, pq, pk, rel=rel, causal=causal, P=P)
+    with torch.no_grad():
+        want = pq.float().view(T, H, 64).transpose(0, 1) @ pk.float().view(S, H, 64).permute(1, 2, 0)
+        if tabs is not None:
+            want = want + _dense_rel(H, T, S, P, gcode.long(), code_bias, *tabs).to(dev)
+        if mask is not None:
+            want = want.masked_fill(mask, float("-inf"))
+    got = dense.D[:, :, :S]
+    fin = torch.isfinite(want)
+    assert torch.equal(torch.isfinite(got), fin)
+    assert (got[fin] - want[fin]).abs().max().item() < 2e-5 * max(1.0, want[fin].abs().max().item())
+    assert torch.isinf(dense.D[:, :, S:]).all() and torch.isinf(dense.Dt[:, :, T:]).all()
+    assert torch.equal(dense.Dt[:, :, :T], got.transpose(1, 2))          # the same MFMA chain in both orientations
+    # ---- forward (unchanged kernel) for out / lse, then the batch-inner backward
+    out = torch.zeros(B, T, C, dtype=torch.bfloat16, device=dev)
+    lse = torch.zeros(B, H, T, dtype=torch.float32, device=dev)
+    hip.attn_fwd(q, k, v, pq, pk, out, lse, B, H, T, S, rel=rel, causal=causal, gain=gain)
+    delta = (dout.float() * out.float()).view(B, T, H, 64).sum(-1).permute(0, 2, 1).contiguous()
+    dq, dk, dv = torch.full_like(q, 3.0), torch.full_like(k, 3.0), torch.full_like(v, 3.0)
+    ng = (B + 3) // 4
+    dbias = torch.zeros(ng, H, T, dense.Sp, dtype=torch.bfloat16, device=dev)
+    hip.attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain, dq_scale=0.5)
+    torch.cuda.synchronize()
+    errs = {"dq": _rel(dq, qf.grad * 0.5), "dk": _rel(dk, kf.grad), "dv": _rel(dv, vf.grad)}
+    # sum_b dS against a manual fp32 backward that uses the same delta / lse (isolates the kernel from bf16 `out`)
+    with torch.no_grad():
+        qh = q.float().view(B, T, H, 64).transpose(1, 2); kh = k.float().view(B, S, H, 64).transpose(1, 2)
+        vh = v.float().view(B, S, H, 64).transpose(1, 2)
+        sc = qh @ kh.transpose(2, 3) + want
+        pr = torch.softmax(sc, -1)
+        doh = dout.float().view(B, T, H, 64).transpose(1, 2) * gain.view(1, H, 1, 1)
+        dS = pr * (doh @ vh.transpose(2, 3) - delta.unsqueeze(-1))
+        dSb = dS.sum(0)                                                    # [H, T, S]
+    errs["dbias"] = _rel(dbias.float().sum(0)[:, :, :S], dSb)
+    assert dbias.float()[:, :, :, S:].abs().max().item() == 0.0
+    # ---- everything downstream of sum_b dS in one launch
+    dpq = torch.full((T, C), 5.0, device=dev); dpk = torch.full((S, C), 5.0, device=dev)
+    kw = {}
+    if rel is not None:
+        g2 = torch.full((H, n2d), 7.0, device=dev); g1 = torch.full((H, 2 * Lt - 1), 7.0, device=dev)
+        gx = torch.full((H, 2), 7.0, device=dev)
+        kw = dict(P=P, grid_h=gh, grid_w=gw, drel2d=g2, drel1d=g1, drelx=gx)
+    hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, accumulate_pos=False, dpq_scale=0.25, **kw)
+    torch.cuda.synchronize()
+    errs["dpq"] = _rel(dpq, pqf.grad * 0.25); errs["dpk"] = _rel(dpk, pkf.grad)
+    if rel is not None:
+        with torch.no_grad():
+            dSc = dSb.cpu()
+            r2 = torch.zeros(H, n2d); r1 = torch.zeros(H, 2 * Lt - 1)
+            idx = (gcode.long()[:, None] - gcode.long()[None, :] + code_bias).reshape(-1)
+            r2.index_add_(1, idx, dSc[:, :P, :P].reshape(H, -1))
+            tt = torch.arange(Lt)
+            r1.index_add_(1, (tt[:, None] - tt[None, :] + Lt - 1).reshape(-1), dSc[:, P:, P:].reshape(H, -1))
+            rx = torch.stack([dSc[:, :P, P:].sum((1, 2)), dSc[:, P:, :P].sum((1, 2))], 1)
+        scale = max(r2.abs().max().item(), r1.abs().max().item(), rx.abs().max().item())
+        for name, gt, ref in zip(("drel2d", "drel1d", "drelx"), (g2, g1, gx), (r2, r1, rx)):
+            errs[name] = ((gt.cpu() - ref).abs().max() / scale).item()
+    # accumulate flag: a second call adds onto the first
+    hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, accumulate_pos=True, dpq_scale=0.25, **kw)
+    torch.cuda.synchronize()
+    errs["dpq_acc"] = _rel(dpq, pqf.grad * 0.5)
+    print(case, {k_: round(v_, 5) for k_, v_ in errs.items()})
+    for k_, v_ in errs.items():
+        assert v_ < 2e-2, (k_, v_)
+    # bit-reproducible: fixed summation order, no atomics
+    keep = [t.clone() for t in (dq, dk, dv, dbias)]
+    for _ in range(3):
+        hip.attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain, dq_scale=0.5)
+        torch.cuda.synchronize()
+        for a_, b_ in zip(keep, (dq, dk, dv, dbias)):
+            assert torch.equal(a_, b_)
+
+
 def _dense_rel_ad(H, T, S, P, gcode, code_bias, rel2d, rel1d, relx):
     """autograd-friendly version of _dense_rel"""
     Lt = T - P
