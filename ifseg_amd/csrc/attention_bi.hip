@@ -87,7 +87,7 @@ constexpr int ST_L = 40960;             // dK/dV: [4][lse 32 | delta 32] fp32
 constexpr int STG_DQ = 40960, STG_DKV = 41984;
 constexpr int SLOT = 4096;              // dQ kernel: one wave's fp32 dS tile [32][32], chunk XOR (row & 7)
 constexpr int LDS_DQ = 2 * STG_DQ + 2 * 8 * SLOT;      // 147456
-constexpr int LDS_DKV = 2 * STG_DKV;                    // 83968
+constexpr int LDS_DKV = 3 * STG_DKV;                    // 125952: a ring of three stages
 
 // Block schedule of the streamed side under the causal mask ("tail-first" order: a grid row i sees grid columns j <= i and
 // every tail column; a tail row sees tail columns j <= i only).  The dense bias already holds -inf for every masked
@@ -97,6 +97,16 @@ struct Sched {
   __device__ __forceinline__ int block(int it) const { return it < g_end - g_begin ? g_begin + it : t_begin + (it - (g_end - g_begin)); }
 };
 
+// Both kernels: 8 waves = two GROUPS of four (one wave of each group per SIMD).  The groups run the same iteration with
+// a phase shift, separated by ONE s_barrier per 32-row block of the streamed side:
+//     group 0:  [load-side reads + S / dP MFMAs][exp, dS (VALU)][transposed reads + gradient MFMAs]
+//     group 1:  [gradient MFMAs of the PREVIOUS block][reads + S / dP MFMAs][exp, dS (VALU)]
+// so the VALU segment of one wave of a SIMD always lies beside an MFMA segment of the other (in lock step both waves of a
+// SIMD would want the matrix pipe, then the VALU, at the same time: v1 of these kernels, 122 / 116 us on the encoder shape).
+// Group 1's gradient MFMAs read the previous block's operand tiles: the dK/dV kernel keeps a ring of three stages, the dQ
+// kernel (whose LDS also holds the batch-sum slots) has each group-1 wave issue the next K tile of ITS batch element only
+// after its own last read of the previous one.
+
 // ---------------------------------------------------------------------------------------------- dQ (+ sum_b dS)
 __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -105,9 +115,10 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qb = wv >> 2, bl = wv & 3;
   const int nqt = (a.T + 63) >> 6, nbg = (a.B + 3) >> 2;
-  int bid = xcd_remap(blockIdx.x, nqt * a.H * nbg);
-  int qt = bid % nqt;
-  const int h = (bid / nqt) % a.H, bg = bid / (nqt * a.H);
+  // batch group fastest: the workgroups that read the same bias rows run side by side on one XCD (second fetch = L2 hit)
+  const int bid = xcd_remap(blockIdx.x, nqt * a.H * nbg);
+  const int bg = bid % nbg, h = (bid / nbg) / nqt;
+  int qt = (bid / nbg) % nqt;
   if (a.causal) qt = nqt - 1 - qt;                       // later query tiles see more keys: long workgroups first
   const int q0 = qt * 64;
   const int b = bg * 4 + bl;
@@ -151,22 +162,24 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
   const bf16_t* vb_ = a.v + (long long)bc * a.v_bs + h * 64;
   const float* db_ = a.D + (long long)h * a.T * a.Sp;
   const unsigned lds0 = lds_addr(smem);
+  // staging of block `it` into stage st: the four 1-KiB pieces of ONE operand tile of this wave's batch element (group 0:
+  // V, group 1: K) and a quarter of this group's bias tile.  Lane l of a piece = row 8 p + (l >> 3), 16-byte position
+  // l & 7, which holds source chunk (l & 7) ^ swizzle(row).
+  const int r8 = lane >> 3, cp = lane & 7;
   auto issue = [&](int it, int st) {
     const int j0 = sc.block(it) * 32;
     const unsigned base = lds0 + st * STG_DQ;
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int r8 = ln >> 3, cp = ln & 7;
+    const bf16_t* src = qb ? kb_ : vb_;
+    const int ld = qb ? a.ldk : a.ldv;
+    const unsigned dst = base + (qb ? ST_A : ST_B) + bl * 4096;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int piece = qb * 2 + i, row = piece * 8 + r8;
+    for (int piece = 0; piece < 4; ++piece) {
+      const int row = piece * 8 + r8;
       const int c = cp ^ vx_swz(row);
       const int jr = min(j0 + row, a.S - 1);
-      lds_dma16_gs(kb_, (jr * a.ldk + c * 8) * 2, base + ST_A + bl * 4096 + piece * 1024);
-      lds_dma16_gs(vb_, (jr * a.ldv + c * 8) * 2, base + ST_B + bl * 4096 + piece * 1024);
+      lds_dma16_gs(src, (jr * ld + c * 8) * 2, dst + piece * 1024);
     }
     {
-      // bias tile of query block qb, rows 8 bl .. 8 bl + 7
       const int row = bl * 8 + r8;
       const int c = cp ^ vx_swz(row);
       const int ir = min(q0 + qb * 32 + row, a.T - 1);
@@ -180,12 +193,27 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) { consume_frag(qf[ks]); consume_frag(dof[ks]); }
 
+  // per-lane LDS offsets (loop invariant): row reads at chunk half + 2 ks, transposed reads of the K tile
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+  int oR[4], oT[2][2][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) oR[ks] = vx_off(lane & 31, half * 16) ^ (ks << 5);
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int colb = (db * 32 + g16 * 16 + (i16 & 3) * 4) * 2, r0 = 16 * s2 + 4 * half + (i16 >> 2);
+      oT[s2][db][0] = vx_off(r0, colb); oT[s2][db][1] = vx_off(r0 + 8, colb);
+    }
+  const int oS = (lane & 31) * 128 + ((half ^ (lane & 7)) << 4);       // this wave's dS tile: row = query, chunk (half + 2 rg) ^ (row & 7)
+
   // quarter bl of query block qb's tile: row 8 bl + (lane >> 3), columns 4 (lane & 7) .. + 3
   const int rrow = bl * 8 + (lane >> 3);
   const int rq = q0 + qb * 32 + rrow;
   bf16_t* dbp = a.dbias + (long long)bg * a.dbias_gs + ((long long)h * a.T + (rq < a.T ? rq : a.T - 1)) * a.Sp + 4 * (lane & 7);
+  const int oQ = qb * 4 * SLOT + rrow * 128 + ((((lane & 7) ^ (rrow & 7))) << 4);
   auto reduce = [&](int itp) {
-    const unsigned char* sl = slots + ((itp & 1) * 8 + qb * 4) * SLOT + rrow * 128 + ((((lane & 7) ^ (rrow & 7))) << 4);
+    const unsigned char* sl = slots + (itp & 1) * 8 * SLOT + oQ;
     const float4 x0 = *reinterpret_cast<const float4*>(sl), x1 = *reinterpret_cast<const float4*>(sl + SLOT);
     const float4 x2 = *reinterpret_cast<const float4*>(sl + 2 * SLOT), x3 = *reinterpret_cast<const float4*>(sl + 3 * SLOT);
     const float s0 = (x0.x + x1.x) + (x2.x + x3.x), s1 = (x0.y + x1.y) + (x2.y + x3.y);
@@ -193,32 +221,25 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
     if (rq < a.T) *reinterpret_cast<uint2*>(dbp + sc.block(itp) * 32) = make_uint2(pack2bf(s0, s1), pack2bf(s2, s3));
   };
 
-  if (sc.n > 0) issue(0, 0);
-  for (int it = 0; it < sc.n; ++it) {
+  U128 ud[2];
+  // S^T = bias tile + K Q^T, dP^T = V dO^T, dS^T -> this wave's slot of the batch sum and ud (bf16, the B operand of dQ)
+  auto scores = [&](int it) {
     const unsigned char* stg = smem + (it & 1) * STG_DQ;
-    lds_dma_wait();
-    __syncthreads();                 // stage `it` has landed; everyone is done with stage it-1 and wrote its dS tile of it-1
-    if (it + 1 < sc.n) issue(it + 1, (it + 1) & 1);
-    if (it > 0) reduce(it - 1);
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int half_i = ln >> 5, i16 = ln & 15, g16 = (ln >> 4) & 1;
-    const int bR = vx_off(ln & 31, half_i * 16);               // row reads: K rows, V rows, bias rows (chunk half + 2 ks)
     const unsigned char* sK = stg + ST_A + bl * 4096;
     const unsigned char* sV = stg + ST_B + bl * 4096;
     const unsigned char* sD = stg + ST_D + qb * 4096;
     f32x16 s, dp;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      const float4 d4 = *reinterpret_cast<const float4*>(sD + (bR ^ (rg << 5)));
+      const float4 d4 = *reinterpret_cast<const float4*>(sD + oR[rg]);
       s[rg * 4] = d4.x; s[rg * 4 + 1] = d4.y; s[rg * 4 + 2] = d4.z; s[rg * 4 + 3] = d4.w;
     }
     {
       bf16x8 kf[4], vf[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) kf[ks] = lds_read_b128(sK + (bR ^ (ks << 5)));
+      for (int ks = 0; ks < 4; ++ks) kf[ks] = lds_read_b128(sK + oR[ks]);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) vf[ks] = lds_read_b128(sV + (bR ^ (ks << 5)));
+      for (int ks = 0; ks < 4; ++ks) vf[ks] = lds_read_b128(sV + oR[ks]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
@@ -234,38 +255,61 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
       const float p = __builtin_amdgcn_exp2f(fmaf(s[e], LOG2E, nlse));
       ds[e] = p * fmaf(gain, dp[e], -del);
     }
-    {
-      // this wave's fp32 dS tile for the batch sum: row = query, 16-byte chunk (half + 2 rg) XOR (row & 7)
-      unsigned char* sl = slots + ((it & 1) * 8 + wv) * SLOT;
-      const int so = (ln & 31) * 128 + ((half_i ^ (ln & 7)) << 4);
+    unsigned char* sl = slots + ((it & 1) * 8 + wv) * SLOT;
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg)
-        *reinterpret_cast<float4*>(sl + (so ^ (rg << 5))) = make_float4(ds[rg * 4], ds[rg * 4 + 1], ds[rg * 4 + 2], ds[rg * 4 + 3]);
-    }
-    U128 ud[2];
+    for (int rg = 0; rg < 4; ++rg)
+      *reinterpret_cast<float4*>(sl + (oS ^ (rg << 5))) = make_float4(ds[rg * 4], ds[rg * 4 + 1], ds[rg * 4 + 2], ds[rg * 4 + 3]);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int e = 0; e < 8; e += 2) ud[s2].w[e >> 1] = pack2bf(ds[s2 * 8 + e], ds[s2 * 8 + e + 1]);
-    // dQ^T += K^T dS^T ; slot (kh, e) <-> key 16*s2 + 4*kh + (e&3) + 8*(e>>2)
+  };
+  // dQ^T += K^T dS^T ; slot (kh, e) <-> key 16*s2 + 4*kh + (e&3) + 8*(e>>2)
+  auto grads = [&](int it) {
+    const unsigned char* sK = smem + (it & 1) * STG_DQ + ST_A + bl * 4096;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       U128 f[2];
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        const int colb = (db * 32 + g16 * 16 + (i16 & 3) * 4) * 2;
-        const int r0 = 16 * s2 + 4 * half_i + (i16 >> 2);
         U64 x, y;
-        x.s = lds_read_tr(sK + vx_off(r0, colb));
-        y.s = lds_read_tr(sK + vx_off(r0 + 8, colb));
+        x.s = lds_read_tr(sK + oT[s2][db][0]);
+        y.s = lds_read_tr(sK + oT[s2][db][1]);
         f[db].w[0] = x.w[0]; f[db].w[1] = x.w[1]; f[db].w[2] = y.w[0]; f[db].w[3] = y.w[1];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[db].b, ud[s2].b, dq[db], 0, 0, 0);
     }
+  };
+
+  if (sc.n > 0) issue(0, 0);
+  for (int it = 0; it < sc.n; ++it) {
+    lds_dma_wait();
+    __syncthreads();                 // stage `it` has landed; every dS tile of block it-1 is in its slot
+#if defined(BI_EXP_NODMA)
+#define BI_ISSUE(...)
+#else
+#define BI_ISSUE(...) issue(__VA_ARGS__)
+#endif
+#ifndef BI_EXP_NOCOMPUTE
+    if (qb == 0) {
+      if (it + 1 < sc.n) BI_ISSUE(it + 1, (it + 1) & 1);
+      if (it > 0) reduce(it - 1);
+      scores(it);
+      grads(it);
+    } else {
+      if (it > 0) grads(it - 1);
+      if (it + 1 < sc.n) BI_ISSUE(it + 1, (it + 1) & 1);      // (this wave's K tile of block it-1 is free now)
+      if (it > 0) reduce(it - 1);
+      scores(it);
+    }
+#else
+    if (it + 1 < sc.n) BI_ISSUE(it + 1, (it + 1) & 1);
+#endif
   }
   if (sc.n > 0) {
+    if (qb == 1) grads(sc.n - 1);
     __syncthreads();
     reduce(sc.n - 1);
   }
@@ -283,8 +327,8 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kbw = wv >> 2, bl = wv & 3;
   const int nkt = (a.S + 63) >> 6, nbg = (a.B + 3) >> 2;
-  int bid = xcd_remap(blockIdx.x, nkt * a.H * nbg);
-  const int kt = bid % nkt, h = (bid / nkt) % a.H, bg = bid / (nkt * a.H);
+  const int bid = xcd_remap(blockIdx.x, nkt * a.H * nbg);
+  const int bg = bid % nbg, kt = (bid / nbg) % nkt, h = (bid / nbg) / nkt;
   const int k0 = kt * 64;
   const int b = bg * 4 + bl;
   const bool bact = b < a.B;
@@ -325,19 +369,20 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
   const float* eb_ = a.delta + ((long long)bc * a.H + h) * a.T;
   const float* db_ = a.Dt + (long long)h * a.S * a.Tp;
   const unsigned lds0 = lds_addr(smem);
+  const int r8 = lane >> 3, cp = lane & 7;
   auto issue = [&](int it, int st) {
     const int i0 = sc.block(it) * 32;
     const unsigned base = lds0 + st * STG_DKV;
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int r8 = ln >> 3, cp = ln & 7;
+    // group 0: the Q tile, group 1: the dO tile of this wave's batch element; a quarter of this group's bias tile
+    const bf16_t* src = kbw ? ob_ : qb_;
+    const int ld = kbw ? a.lddo : a.ldq;
+    const unsigned dst = base + (kbw ? ST_B : ST_A) + bl * 4096;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int piece = kbw * 2 + i, row = piece * 8 + r8;
+    for (int piece = 0; piece < 4; ++piece) {
+      const int row = piece * 8 + r8;
       const int c = cp ^ vx_swz(row);
       const int ir = min(i0 + row, a.T - 1);
-      lds_dma16_gs(qb_, (ir * a.ldq + c * 8) * 2, base + ST_A + bl * 4096 + piece * 1024);
-      lds_dma16_gs(ob_, (ir * a.lddo + c * 8) * 2, base + ST_B + bl * 4096 + piece * 1024);
+      lds_dma16_gs(src, (ir * ld + c * 8) * 2, dst + piece * 1024);
     }
     {
       // bias tile (transposed bias: row = key) of key block kbw, rows 8 bl .. 8 bl + 7
@@ -348,8 +393,8 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
     }
     if (kbw == 0) {
       // lanes 0..31: lse, lanes 32..63: delta of this wave's batch element (LDS-DMA places lane i at base + 4 i)
-      const int ir = min(i0 + (ln & 31), a.T - 1);
-      if (ln < 32) lds_dma4_gs(lb_, ir * 4, base + ST_L + bl * 256);
+      const int ir = min(i0 + (lane & 31), a.T - 1);
+      if (lane < 32) lds_dma4_gs(lb_, ir * 4, base + ST_L + bl * 256);
       else lds_dma4_gs(eb_, ir * 4, base + ST_L + bl * 256);
     }
   };
@@ -360,37 +405,39 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) { consume_frag(kf[ks]); consume_frag(vfn[ks]); }
 
-  if (sc.n > 0) issue(0, 0);
-  for (int it = 0; it < sc.n; ++it) {
-    const unsigned char* stg = smem + (it & 1) * STG_DKV;
-    lds_dma_wait();
-    __syncthreads();
-    if (it + 1 < sc.n) issue(it + 1, (it + 1) & 1);
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int half_i = ln >> 5, i16 = ln & 15, g16 = (ln >> 4) & 1;
-    const int bR = vx_off(ln & 31, half_i * 16);
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+  int oR[4], oT[2][2][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) oR[ks] = vx_off(lane & 31, half * 16) ^ (ks << 5);
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int colb = (db * 32 + g16 * 16 + (i16 & 3) * 4) * 2, r0 = 16 * s2 + 4 * half + (i16 >> 2);
+      oT[s2][db][0] = vx_off(r0, colb); oT[s2][db][1] = vx_off(r0 + 8, colb);
+    }
+
+  U128 up[2], ud[2];
+  auto scores = [&](int st) {
+    const unsigned char* stg = smem + st * STG_DKV;
     const unsigned char* sQ = stg + ST_A + bl * 4096;
     const unsigned char* sO = stg + ST_B + bl * 4096;
     const unsigned char* sD = stg + ST_D + kbw * 4096;
     const float* sL = reinterpret_cast<const float*>(stg + ST_L + bl * 256);
     f32x16 s, dp;
-    float ls[16];
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      const float4 d4 = *reinterpret_cast<const float4*>(sD + (bR ^ (rg << 5)));
+      const float4 d4 = *reinterpret_cast<const float4*>(sD + oR[rg]);
       s[rg * 4] = d4.x; s[rg * 4 + 1] = d4.y; s[rg * 4 + 2] = d4.z; s[rg * 4 + 3] = d4.w;
-      const float4 e4 = *reinterpret_cast<const float4*>(sL + 32 + 8 * rg + 4 * half_i);
+      const float4 e4 = *reinterpret_cast<const float4*>(sL + 32 + 8 * rg + 4 * half);
       dp[rg * 4] = e4.x; dp[rg * 4 + 1] = e4.y; dp[rg * 4 + 2] = e4.z; dp[rg * 4 + 3] = e4.w;
-      const float4 l4 = *reinterpret_cast<const float4*>(sL + 8 * rg + 4 * half_i);
-      ls[rg * 4] = l4.x; ls[rg * 4 + 1] = l4.y; ls[rg * 4 + 2] = l4.z; ls[rg * 4 + 3] = l4.w;
     }
     {
       bf16x8 qf[4], of[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) qf[ks] = lds_read_b128(sQ + (bR ^ (ks << 5)));
+      for (int ks = 0; ks < 4; ++ks) qf[ks] = lds_read_b128(sQ + oR[ks]);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) of[ks] = lds_read_b128(sO + (bR ^ (ks << 5)));
+      for (int ks = 0; ks < 4; ++ks) of[ks] = lds_read_b128(sO + oR[ks]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s, 0, 0, 0);
@@ -398,31 +445,36 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
       for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[ks], vfn[ks], dp, 0, 0, 0);
     }
     // element r <-> query i0 + (r&3) + 8*(r>>2) + 4*half ; key = lane
-    U128 up[2], ud[2];
+    __builtin_amdgcn_sched_barrier(0);        // (the row statistics are read here, not held across the MFMAs)
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 l4 = *reinterpret_cast<const float4*>(sL + 8 * rg + 4 * half);
+      const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
 #pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        const int r = s2 * 8 + e;
-        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -ls[r]));
-        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], LOG2E, -ls[r + 1]));
-        up[s2].w[e >> 1] = pack2bf(p0, p1);
-        ud[s2].w[e >> 1] = pack2bf(-p0 * dp[r], -p1 * dp[r + 1]);
+      for (int e = 0; e < 4; e += 2) {
+        const int r = rg * 4 + e;
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -ls[e]));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], LOG2E, -ls[e + 1]));
+        up[rg >> 1].w[(rg & 1) * 2 + (e >> 1)] = pack2bf(p0, p1);
+        ud[rg >> 1].w[(rg & 1) * 2 + (e >> 1)] = pack2bf(-p0 * dp[r], -p1 * dp[r + 1]);
       }
-    // dV^T += dO^T P ; dK^T += Q^T dS ; slot (kh, e) <-> query 16*s2 + 4*kh + (e&3) + 8*(e>>2)
+    }
+  };
+  // dV^T += dO^T P ; dK^T += Q^T dS ; slot (kh, e) <-> query 16*s2 + 4*kh + (e&3) + 8*(e>>2)
+  auto grads = [&](int st) {
+    const unsigned char* sQ = smem + st * STG_DKV + ST_A + bl * 4096;
+    const unsigned char* sO = smem + st * STG_DKV + ST_B + bl * 4096;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       U128 fo[2], fq[2];
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        const int colb = (db * 32 + g16 * 16 + (i16 & 3) * 4) * 2;
-        const int r0 = 16 * s2 + 4 * half_i + (i16 >> 2);
         U64 x, y;
-        x.s = lds_read_tr(sO + vx_off(r0, colb));
-        y.s = lds_read_tr(sO + vx_off(r0 + 8, colb));
+        x.s = lds_read_tr(sO + oT[s2][db][0]);
+        y.s = lds_read_tr(sO + oT[s2][db][1]);
         fo[db].w[0] = x.w[0]; fo[db].w[1] = x.w[1]; fo[db].w[2] = y.w[0]; fo[db].w[3] = y.w[1];
-        x.s = lds_read_tr(sQ + vx_off(r0, colb));
-        y.s = lds_read_tr(sQ + vx_off(r0 + 8, colb));
+        x.s = lds_read_tr(sQ + oT[s2][db][0]);
+        y.s = lds_read_tr(sQ + oT[s2][db][1]);
         fq[db].w[0] = x.w[0]; fq[db].w[1] = x.w[1]; fq[db].w[2] = y.w[0]; fq[db].w[3] = y.w[1];
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -431,7 +483,29 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
 #pragma unroll
       for (int db = 0; db < 2; ++db) dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[db].b, ud[s2].b, dk[db], 0, 0, 0);
     }
+  };
+
+  if (sc.n > 0) issue(0, 0);
+  int st = 0;                          // stage of block `it` in the ring of three
+  for (int it = 0; it < sc.n; ++it) {
+    lds_dma_wait();
+    __syncthreads();                   // block `it` has landed; group 1 is done with block it-2's tiles
+    const int stn = st == 2 ? 0 : st + 1, stp = st == 0 ? 2 : st - 1;
+#ifndef BI_EXP_NODMA
+    if (it + 1 < sc.n) issue(it + 1, stn);
+#endif
+#ifndef BI_EXP_NOCOMPUTE
+    if (kbw == 0) {
+      scores(st);
+      grads(st);
+    } else {
+      if (it > 0) grads(stp);
+      scores(st);
+    }
+#endif
+    st = stn;
   }
+  if (sc.n > 0 && kbw == 1) grads(st == 0 ? 2 : st - 1);
   if (bact && kvalid) {
     bf16_t* dvp = a.dv + (long long)b * a.dv_bs + (long long)kj * a.lddv + h * 64;
     bf16_t* dkp = a.dk + (long long)b * a.dk_bs + (long long)kj * a.lddk + h * 64;
