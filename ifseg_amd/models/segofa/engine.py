@@ -90,6 +90,10 @@ class HipEngine:
         # ffn_layernorm(gelu(fc1)) backward folded into the fc2 dX GEMM's epilogue (csrc/rowops.hip "FFN's ffn_layernorm",
         # csrc/gemm.hip EPI_GLN): no 3072-wide LayerNorm-backward pass.  IFSEG_NO_FFN_LN_FUSE=1: the stand-alone kernel.
         self.ffn_ln_fused = os.environ.get("IFSEG_NO_FFN_LN_FUSE") is None
+        # attention backward with the batch inside the workgroup (csrc/attention_bi.hip): the bias is a dense batch-invariant
+        # operand built once per layer from parameters, sum_b dS leaves the dQ kernel once per tile.  IFSEG_ATTN_BI=0: the
+        # round-3 kernels (one workgroup per (batch, head, tile), bias regenerated per batch element).
+        self.attn_bi = os.environ.get("IFSEG_ATTN_BI", "1") != "0"
         self._ffn_pg_tasks = []
         self._train_fwd = False
         # where the NEXT batch's frozen-trunk pass is launched: "fwd" = at the start of this step's forward, "e<k>" = when
@@ -406,6 +410,16 @@ class HipEngine:
             e = self._ev()
             e.record(self._side)
             torch.cuda.current_stream().wait_event(e)
+
+    def _dense_bias(self, tag, H, T, S, pq, pk, rel, causal, P):
+        """dense batch-invariant bias operands of one attention (hip.DenseBias), built on the CURRENT stream"""
+        key = "dense_" + tag
+        d = self.ws.get(key)
+        if d is None or (d.H, d.T, d.S) != (H, T, S):
+            d = hip.DenseBias(H, T, S, self.device)
+            self.ws[key] = d
+        hip.attn_dense_bias(d, pq, pk, rel=rel, causal=causal, P=P)
+        return d
 
     def _geometry(self, h, w, L):
         """index tables for a (h, w) feature grid and L text tokens (device tensors, cached)."""
@@ -830,6 +844,14 @@ class HipEngine:
                                        [(True, g["enc_idx1d"])])
         (e_rx,) = self._rel_tables_all("e_x", [None] * cfg.enc_layers, [(False, g["enc_idxx"])])
         x_pre = None
+        bi = self.attn_bi and need_grad and w <= 64
+        ctx["dense"] = {}
+        if bi:
+            # parameters only: every layer's dense bias on the side stream, under the first blocks of the forward
+            with self._wgrad():
+                for l in range(cfg.enc_layers):
+                    rel = hip.RelBias(P, g["gcode"], g["code_bias"], e_r2[l], e_r1[l], e_rx[l], grid_w=w)
+                    ctx["dense"]["e%d" % l] = self._dense_bias("e%d" % l, H, T, T, ctx["e_pq"], ctx["e_pk"], rel, False, P)
         for l in range(cfg.enc_layers):
             p = "%slayers.%d." % (e, l)
             tg = "e%d" % l
@@ -897,6 +919,18 @@ class HipEngine:
             "d_seg", ["%sseg_rel_pos_table_list.%d.weight" % (d, l) for l in range(cfg.dec_layers)],
             [(True, g["dec_idx2d"]), (True, g["dec_idx1d"]), (True, g["dec_idxx"])])
         y_pre = None
+        if bi:
+            with self._wgrad():
+                for l in range(cfg.dec_layers):
+                    rel = hip.RelBias(P, g["gcode"], g["code_bias"], d_r2[l], d_r1[l], d_rx[l], grid_w=w)
+                    ctx["dense"]["d%d" % l] = self._dense_bias("d%d" % l, H, Td, Td, ctx["d_spq"], ctx["d_spk"], rel, causal, P)
+                # the cross-attention bias has no per-layer part (decoder_module.py:556-558): one operand for all layers
+                ctx["dense"]["dc"] = self._dense_bias("dc", H, Td, T, cpq, cpk, None, False, None)
+                if self.overlap:        # (a dedicated event: the ring of `_ev` wraps around long before the backward waits for it)
+                    if getattr(self, "_dense_ev", None) is None:
+                        self._dense_ev = torch.cuda.Event()
+                    self._dense_ev.record(self._side)
+                    ctx["dense_ready"] = self._dense_ev
         for l in range(cfg.dec_layers):
             p = "%slayers.%d." % (d, l)
             tg = "d%d" % l
@@ -1295,7 +1329,7 @@ class HipEngine:
         return delta
 
     def _attn_core_bwd(self, tag, q, k, v, pq, pk, o, lse, do, dq, dk, dv, B, T, S, rel, causal, gain, gain_name,
-                       scaling, dpq_acc, dpk_acc, first_pos, rel_grads, delta=None):
+                       scaling, dpq_acc, dpk_acc, first_pos, rel_grads, delta=None, dense=None):
         cfg = self.cfg
         C, H = cfg.embed_dim, cfg.heads
         buf = self.buf
@@ -1303,6 +1337,9 @@ class HipEngine:
         have_delta = delta is not None
         if not have_delta:
             delta = gbuf("g_delta_%d" % T, (B, H, T), torch.float32)
+        if dense is not None:
+            return self._attn_core_bwd_bi(q, k, v, pq, pk, o, lse, do, dq, dk, dv, B, T, S, rel, causal, gain, gain_name,
+                                          scaling, dpq_acc, dpk_acc, first_pos, rel_grads, delta, have_delta, dense)
         dpq_part = gbuf("g_dpq_part_%d" % T, (B, T, C))        # bf16 per-batch partials, summed by attn_bwd_reduce
         dpk_part = gbuf("g_dpk_part_%d" % S, (B, S, C))
         nparts = B * ((S + 127) // 128)
@@ -1359,6 +1396,63 @@ class HipEngine:
         if "reduce" not in _EXP_SKIP:
             self._side_do(reductions)
 
+    def _attn_core_bwd_bi(self, q, k, v, pq, pk, o, lse, do, dq, dk, dv, B, T, S, rel, causal, gain, gain_name, scaling,
+                          dpq_acc, dpk_acc, first_pos, rel_grads, delta, have_delta, dense):
+        """csrc/attention_bi.hip: the bias is the dense operand `dense` (built once per layer by the forward's side stream),
+        a workgroup holds four batch elements, sum_b dS leaves the dQ kernel once per tile; everything behind that sum --
+        abs-pos operand gradients, rel-pos tables, c_attn -- is two launches on the weight-gradient stream."""
+        C, H = self.cfg.embed_dim, self.cfg.heads
+        gbuf = self.gbuf
+        ng = (B + 3) // 4
+        key = "g_dbias_%dx%d" % (T, dense.Sp) + ("@" + self._bt if self.overlap else "")
+        fresh = key not in self.ws
+        dbias = gbuf("g_dbias_%dx%d" % (T, dense.Sp), (ng, H, T, dense.Sp))
+        if fresh:
+            dbias.zero_()          # causal launches never write the blocks above the diagonal (the same blocks every step)
+        if not have_delta:
+            hip.attn_bwd(q, k, v, None, None, o, do, lse, delta, dq, dk, dv, None, None, B, H, T, S, phases=hip.ATTN_BWD_DELTA)
+        timing = self.attn_bwd_timing
+        if timing is not None:
+            timing["seen"] += 1
+            if (timing["seen"] - 1) % timing["stride"]:
+                timing = None
+            else:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record()
+        P = rel.P if rel is not None else None
+        ph = 0
+        if "dq" in _EXP_SKIP:
+            ph = hip.ATTN_BWD_DKV
+        if "dkv" in _EXP_SKIP:
+            ph = hip.ATTN_BWD_DQ if not ph else -1
+        if ph >= 0:
+            hip.attn_bwd_bi(q, k, v, do, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain,
+                            dq_scale=scaling, phases=ph)
+        if timing is not None:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record()
+            timing["pairs"].append((t0, t1, 8.0 * 64 * T * S * B * H))
+        parts = [None, None, None]
+        if rel is not None:
+            parts = [gbuf("g_relg%d_%d" % (i, t.shape[1]), (H, 1, t.shape[1]), torch.float32)
+                     for i, t in enumerate((rel.rel2d, rel.rel1d, rel.relx))]
+
+        def reductions():
+            kw = {}
+            if rel is not None:
+                kw = dict(P=rel.P, grid_h=rel.P // rel.grid_w, grid_w=rel.grid_w, drel2d=parts[0], drel1d=parts[1], drelx=parts[2])
+            hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq_acc, dpk_acc=dpk_acc, accumulate_pos=not first_pos,
+                                 dpq_scale=scaling, **kw)
+            tables = []
+            if rel is not None:
+                for (tabname, idx), part in zip(rel_grads, parts):
+                    if tabname is not None:
+                        tables.append((part, idx, self._table_acc(tabname)))
+            # bucket scatter of the delta-table gradients and d c_attn (no abs-pos partials: nothing to sum over the batch)
+            hip.attn_bwd_reduce(B, H, T, S, C, None, None, dpq_acc, dpk_acc, True, delta, gain, self.G(gain_name), 1, tables)
+        if "reduce" not in _EXP_SKIP:
+            self._side_do(reductions)
+
     def _table_acc(self, tabname):
         key = "g_tabacc_" + tabname
         if key not in self._tab_touched:
@@ -1390,7 +1484,8 @@ class HipEngine:
         qkv = s["qkv"]
         self._attn_core_bwd(tg, qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], pq, pk, s["o"], s["lse"], do,
                             dqkv[:, :, :C], dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:], B, T, T, s["rel"], s["causal"],
-                            s["gain"], a_ + ".c_attn", scaling, dpq_acc, dpk_acc, first_pos, rel_grads, delta=delta)
+                            s["gain"], a_ + ".c_attn", scaling, dpq_acc, dpk_acc, first_pos, rel_grads, delta=delta,
+                            dense=self.ctx.get("dense", {}).get(tg))
         dxn = buf("g_dxn_%d" % rows, (rows, C))
         self._linear_bwd(dqkv.view(rows, 3 * C), s["xn"], self._fused(self.p16, a_ + ".q_proj.weight", 3 * C, C),
                          self._fused(self.g16, a_ + ".q_proj.weight", 3 * C, C),
@@ -1422,7 +1517,7 @@ class HipEngine:
         kv = s["kv"]
         self._attn_core_bwd(tg + "c", s["q"], kv[:, :, :C], kv[:, :, C:], cpq, cpk, s["o"], s["lse"], do, dq,
                             dkv[:, :, :C], dkv[:, :, C:], B, Td, Te, None, False, s["gain"], a_ + ".c_attn", scaling,
-                            dcpq_acc, dcpk_acc, first_cross, None, delta=delta)
+                            dcpq_acc, dcpk_acc, first_cross, None, delta=delta, dense=self.ctx.get("dense", {}).get("dc"))
         dyn = buf("g_dxn_%d" % rows, (rows, C))
         self._linear_bwd(dq.view(rows, C), s["xn"], W(a_ + ".q_proj.weight"), G(a_ + ".q_proj.weight"),
                          G(a_ + ".q_proj.bias"), dx_out=dyn)
@@ -1460,6 +1555,8 @@ class HipEngine:
         self.g16.zero_()
         self._tab_touched = {}
         self._bt = "top"
+        if ctx.get("dense_ready") is not None:      # the dense biases were built on the side stream during the forward
+            torch.cuda.current_stream().wait_event(ctx["dense_ready"])
         e, d = "encoder.", "decoder."
         # ---- seg projection (frozen, tied to seg_embed_tokens: no weight grad)
         dl = buf("g_dlogits", (B * Td, self.npad))
