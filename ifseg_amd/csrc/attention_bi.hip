@@ -528,77 +528,95 @@ struct DenseArgs {
 };
 
 // D[h][i][j] = pos_q[i] . pos_k[j] + rel(i, j), -inf where (i, j) is masked (causal, "tail-first" order) or j >= S;
-// Dt[h][j][i] the transpose, -inf where masked or i >= T.  One wave per 32 x 32 tile, computed in both orientations (the
+// Dt[h][j][i] the transpose, -inf where masked or i >= T.  One workgroup per (head, 32-row strip): the head's delta table
+// and the grid codes sit in LDS, each wave walks 32 x 32 tiles of the strip and computes them in both orientations (the
 // accumulator row is the lane either way, so both outputs leave as 16-byte row segments without a transposition).
-__device__ __forceinline__ float dense_entry(const DenseArgs& a, int h, int i, int j, float abs_ij) {
-  if (i >= a.T || j >= a.S) return NEG_INF;
-  if (a.causal) {
-    const bool masked = (j < a.P) ? ((i >= a.P) || (j > i)) : ((i >= a.P) && (j > i));
-    if (masked) return NEG_INF;
-  }
-  float r = 0.f;
-  if (a.rel_mode) {
-    if (i < a.P) r = (j < a.P) ? a.rel2d[(long long)h * a.n2d + (a.gcode[i] - a.gcode[j] + a.code_bias)] : a.relx[h * 2];
-    else r = (j < a.P) ? a.relx[h * 2 + 1] : a.rel1d[(long long)h * (2 * a.Lt - 1) + (i - j) + a.Lt - 1];
-  }
-  return abs_ij + r;
-}
-
-__global__ __launch_bounds__(256) void attn_dense_bias_kernel(DenseArgs a) {
-  const int lane = threadIdx.x & 63, half = lane >> 5, x = lane & 31;
+__global__ __launch_bounds__(512) void attn_dense_bias_kernel(DenseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sT = reinterpret_cast<float*>(smem);                       // rel2d[h]
+  float* s1 = sT + ((a.n2d + 3) & ~3);                              // rel1d[h]
+  int* sG = reinterpret_cast<int*>(s1 + ((2 * a.Lt + 2) & ~3));     // gcode
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, x = lane & 31;
   const int ntq = a.Tp >> 5, ntk = a.Sp >> 5;
-  const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tile >= (long long)a.H * ntq * ntk) return;
-  const int tj = (int)(tile % ntk), ti = (int)((tile / ntk) % ntq), h = (int)(tile / ((long long)ntk * ntq));
-  const int i0 = ti * 32, j0 = tj * 32;
-  bf16x8 fq[4], fk[4];
+  const int h = blockIdx.x / ntq, ti = blockIdx.x % ntq, i0 = ti * 32;
+  float rx0 = 0.f, rx1 = 0.f;
+  if (a.rel_mode) {
+    for (int i = tid; i < a.n2d; i += 512) sT[i] = a.rel2d[(long long)h * a.n2d + i];
+    for (int i = tid; i < 2 * a.Lt - 1; i += 512) s1[i] = a.rel1d[(long long)h * (2 * a.Lt - 1) + i];
+    for (int i = tid; i < a.P; i += 512) sG[i] = a.gcode[i];
+    rx0 = a.relx[h * 2]; rx1 = a.relx[h * 2 + 1];
+  }
+  __syncthreads();
+  auto entry = [&](int i, int j, float abs_ij) -> float {
+    if (i >= a.T || j >= a.S) return NEG_INF;
+    if (a.causal) {
+      const bool masked = (j < a.P) ? ((i >= a.P) || (j > i)) : ((i >= a.P) && (j > i));
+      if (masked) return NEG_INF;
+    }
+    float r = 0.f;
+    if (a.rel_mode) {
+      if (i < a.P) r = (j < a.P) ? sT[sG[i] - sG[j] + a.code_bias] : rx0;
+      else r = (j < a.P) ? rx1 : s1[(i - j) + a.Lt - 1];
+    }
+    return abs_ij + r;
+  };
+  bf16x8 fq[4];
   if (a.pq) {
     const bf16_t* qp = a.pq + (long long)min(i0 + x, a.T - 1) * a.ldpq + h * 64 + half * 8;
-    const bf16_t* kp = a.pk + (long long)min(j0 + x, a.S - 1) * a.ldpk + h * 64 + half * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      U128 u; u.v = *reinterpret_cast<const uint4*>(qp + ks * 16); fq[ks] = u.b;
-      U128 w; w.v = *reinterpret_cast<const uint4*>(kp + ks * 16); fk[ks] = w.b;
+    for (int ks = 0; ks < 4; ++ks) { U128 u; u.v = *reinterpret_cast<const uint4*>(qp + ks * 16); fq[ks] = u.b; }
+  }
+  for (int tj = wave; tj < ntk; tj += 8) {
+    const int j0 = tj * 32;
+    // (causal) a tile entirely above the diagonal: -inf without any look-up
+    const bool dead = a.causal && j0 < a.P && (i0 >= a.P || j0 > i0 + 31);
+    bf16x8 fk[4];
+    if (a.pq && !dead) {
+      const bf16_t* kp = a.pk + (long long)min(j0 + x, a.S - 1) * a.ldpk + h * 64 + half * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { U128 w; w.v = *reinterpret_cast<const uint4*>(kp + ks * 16); fk[ks] = w.b; }
     }
-  }
-  f32x16 acc;
-  // (1) lane = query i0 + x, element r <-> key j0 + (r&3) + 8*(r>>2) + 4*half
+    f32x16 acc;
+    // (1) lane = query i0 + x, element r <-> key j0 + (r&3) + 8*(r>>2) + 4*half
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  if (a.pq) {
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    if (a.pq && !dead) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[ks], fq[ks], acc, 0, 0, 0);
-  }
-  if (i0 + x < a.T) {
-    float* dp = a.D + ((long long)h * a.T + i0 + x) * a.Sp + j0 + 4 * half;
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      float o[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = dense_entry(a, h, i0 + x, j0 + 8 * rg + 4 * half + e, acc[rg * 4 + e]);
-      *reinterpret_cast<float4*>(dp + 8 * rg) = make_float4(o[0], o[1], o[2], o[3]);
+      for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[ks], fq[ks], acc, 0, 0, 0);
     }
-  }
-  // (2) lane = key j0 + x, element r <-> query i0 + (r&3) + 8*(r>>2) + 4*half
+    if (i0 + x < a.T) {
+      float* dp = a.D + ((long long)h * a.T + i0 + x) * a.Sp + j0 + 4 * half;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  if (a.pq) {
+      for (int rg = 0; rg < 4; ++rg) {
+        float o[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[ks], fk[ks], acc, 0, 0, 0);
-  }
-  if (j0 + x < a.S) {
-    float* dp = a.Dt + ((long long)h * a.S + j0 + x) * a.Tp + i0 + 4 * half;
+        for (int e = 0; e < 4; ++e) o[e] = dead ? NEG_INF : entry(i0 + x, j0 + 8 * rg + 4 * half + e, acc[rg * 4 + e]);
+        *reinterpret_cast<float4*>(dp + 8 * rg) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    // (2) lane = key j0 + x, element r <-> query i0 + (r&3) + 8*(r>>2) + 4*half
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      float o[4];
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    if (a.pq && !dead) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = dense_entry(a, h, i0 + 8 * rg + 4 * half + e, j0 + x, acc[rg * 4 + e]);
-      *reinterpret_cast<float4*>(dp + 8 * rg) = make_float4(o[0], o[1], o[2], o[3]);
+      for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[ks], fk[ks], acc, 0, 0, 0);
+    }
+    if (j0 + x < a.S) {
+      float* dp = a.Dt + ((long long)h * a.S + j0 + x) * a.Tp + i0 + 4 * half;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = dead ? NEG_INF : entry(i0 + 8 * rg + 4 * half + e, j0 + x, acc[rg * 4 + e]);
+        *reinterpret_cast<float4*>(dp + 8 * rg) = make_float4(o[0], o[1], o[2], o[3]);
+      }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------- gradients of the bias
+constexpr int DB_NSUB = 8;            // Toeplitz-table blocks per (head, part)
+constexpr int DB_NPARTS = 4;          // partial delta tables per head (summed by ifseg_attn_bwd_reduce in a fixed order)
 struct DbArgs {
   const bf16_t* dbias;        // [ng][H][T][Sp]
   long long gs;               // elements per group slab
@@ -608,180 +626,294 @@ struct DbArgs {
   float *dpq, *dpk;           // fp32 [T, C], [S, C]
   int accumulate;
   float dpq_scale;
-  int P, gh, gw, Lt;
-  float *drel2d, *drel1d, *drelx;     // [H][(2gh-1)(2gw-1)], [H][2Lt-1], [H][2]
+  int P, gh, gw, Lt, causal;
+  float *drel2d, *drel1d, *drelx;     // [H][DB_NPARTS][(2gh-1)(2gw-1)], [H][DB_NPARTS][2Lt-1], [H][DB_NPARTS][2]
   int nb_q, nb_k, nb_2d;
 };
 
-// 32 x (256-byte row) tile image (kx layout of csrc/attention.hip): row-wise and transposed reads
-__device__ __forceinline__ int kx_off(int r, int c) {
-  const int f = ((r & 3) << 2) | ((r >> 2) & 3);
-  return r * 256 + ((c ^ f) << 4);
-}
-
-// A / B fragment of a transposed read: tile rows = contraction index (16 of them from row `rbase`), columns `cb*32..+31`
-// = the fragment's lane index; slot (kh, e) <-> row rbase + 4*kh + (e&3) + 8*(e>>2)
-template <bool WIDE>
+// A / B fragment of a transposed read of a [rows = contraction index][128-byte row] tile (vx layout): 16 rows from
+// `rbase`, columns cb*32 .. +31 = the fragment's lane index; slot (kh, e) <-> row rbase + 4*kh + (e&3) + 8*(e>>2)
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int rbase, int cb, int lane) {
   const int half = lane >> 5, i16 = lane & 15, g16 = (lane >> 4) & 1;
-  const int col = cb * 32 + g16 * 16 + (i16 & 3) * 4;          // element column
+  const int col = cb * 32 + g16 * 16 + (i16 & 3) * 4;
   const int r0 = rbase + 4 * half + (i16 >> 2);
   U64 x, y;
-  if (WIDE) {
-    x.s = lds_read_tr(tile + kx_off(r0, col >> 3) + (col & 7) * 2);
-    y.s = lds_read_tr(tile + kx_off(r0 + 8, col >> 3) + (col & 7) * 2);
-  } else {
-    x.s = lds_read_tr(tile + vx_off(r0, col * 2));
-    y.s = lds_read_tr(tile + vx_off(r0 + 8, col * 2));
-  }
+  x.s = lds_read_tr(tile + vx_off(r0, col * 2));
+  y.s = lds_read_tr(tile + vx_off(r0 + 8, col * 2));
   U128 f; f.w[0] = x.w[0]; f.w[1] = x.w[1]; f.w[2] = y.w[0]; f.w[3] = y.w[1];
   return f.b;
 }
 
+// Two block ranges (d pos_q | d pos_k): small GEMMs with the contraction split over the four waves of a workgroup
+// (each wave stages its own tiles in its own LDS region: no block barrier inside the loop; the next step's global loads
+// are in flight under the current step's MFMAs) and a fixed-order sum of the four accumulators at the end.
 __global__ __launch_bounds__(256) void attn_dbias_grads_kernel(DbArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char sm[4096 + 8192 * 2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+  __shared__ __attribute__((aligned(16))) unsigned char sm[32768];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int blk = blockIdx.x;
+  const int lr = lane >> 3, lc = lane & 7;        // tile staging: rows lr + 8 u, 16-byte chunk lc
   if (blk < a.nb_q) {
     // ---- d pos_q[i][h*64 + c] (+)= scale * sum_j dB[h][i][j] pos_k[j][h*64 + c]:  out^T[c][i], A = pos_k^T (tr), B = dB rows
-    const int nit = (a.T + 127) >> 7;
-    const int h = blk / nit, i0 = (blk % nit) * 128 + wave * 32;
+    const int nit = (a.T + 31) >> 5;
+    const int h = blk / nit, i0 = (blk % nit) * 32;
     const int i = i0 + (lane & 31);
     const int ir = i < a.T ? i : a.T - 1;
+    unsigned char* tile = sm + wave * 4096;
     f32x16 acc[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
-    for (int j0 = 0; j0 < a.Sp; j0 += 32) {
-      __syncthreads();
-      {   // pos_k tile [32 j][64 c] -> LDS (vx layout), rows past S are zero
-        const int r = tid >> 3, c = tid & 7;
-        uint4 v4 = make_uint4(0, 0, 0, 0);
-        if (j0 + r < a.S) v4 = *reinterpret_cast<const uint4*>(a.pk + (long long)(j0 + r) * a.ldpk + h * 64 + c * 8);
-        *reinterpret_cast<uint4*>(sm + vx_off(r, c * 16)) = v4;
+    uint4 t4[4];
+    uint2 lo[2][2], hi[2][2];
+    auto fetch = [&](int j0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {          // pos_k tile [32 j][64 c], rows past S are zero
+        t4[u] = make_uint4(0, 0, 0, 0);
+        if (j0 + lr + 8 * u < a.S) t4[u] = *reinterpret_cast<const uint4*>(a.pk + (long long)(j0 + lr + 8 * u) * a.ldpk + h * 64 + lc * 8);
       }
-      __syncthreads();
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          lo[s2][g] = make_uint2(0, 0); hi[s2][g] = make_uint2(0, 0);
+          if (g < a.ng) {
+            const bf16_t* rp = a.dbias + g * a.gs + ((long long)h * a.T + ir) * a.Sp + j0 + 16 * s2 + 4 * half;
+            lo[s2][g] = *reinterpret_cast<const uint2*>(rp); hi[s2][g] = *reinterpret_cast<const uint2*>(rp + 8);
+          }
+        }
+    };
+    // (causal: sum_b dS is zero -- and was never written -- for the grid columns beyond the block's last row, and for every
+    // grid column when the rows are tail rows; the schedule of the dQ kernel, step by step)
+    auto live = [&](int j) { return !(a.causal && j < a.P && (i0 >= a.P || j > i0 + 31)); };
+    int j0 = wave * 32;
+    if (j0 < a.Sp) fetch(j0);
+    for (; j0 < a.Sp; j0 += 128) {
+      if (!live(j0)) { if (j0 + 128 < a.Sp) fetch(j0 + 128); continue; }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4*>(tile + vx_off(lr + 8 * u, lc * 16)) = t4[u];
+      U128 bfr[2][2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) { bfr[s2][g].w[0] = lo[s2][g].x; bfr[s2][g].w[1] = lo[s2][g].y; bfr[s2][g].w[2] = hi[s2][g].x; bfr[s2][g].w[3] = hi[s2][g].y; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (j0 + 128 < a.Sp) fetch(j0 + 128);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 a0 = tr_frag<false>(sm, 16 * s2, 0, lane), a1 = tr_frag<false>(sm, 16 * s2, 1, lane);
-        for (int g = 0; g < a.ng; ++g) {
-          const bf16_t* rp = a.dbias + g * a.gs + ((long long)h * a.T + ir) * a.Sp + j0 + 16 * s2 + 4 * half;
-          U128 bfr;
-          const uint2 lo = *reinterpret_cast<const uint2*>(rp), hi = *reinterpret_cast<const uint2*>(rp + 8);
-          bfr.w[0] = lo.x; bfr.w[1] = lo.y; bfr.w[2] = hi.x; bfr.w[3] = hi.y;
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr.b, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr.b, acc[1], 0, 0, 0);
+        const bf16x8 a0 = tr_frag(tile, 16 * s2, 0, lane), a1 = tr_frag(tile, 16 * s2, 1, lane);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          if (g < a.ng) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr[s2][g].b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr[s2][g].b, acc[1], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // fixed-order sum of the four waves' accumulators, one column block at a time: [wave][r][lane]
+    float* red = reinterpret_cast<float*>(sm + 16384);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[cb][r];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int v = tid + 256 * k, r = v >> 6, ln = v & 63;
+        const float t = (red[r * 64 + ln] + red[(16 + r) * 64 + ln]) + (red[(32 + r) * 64 + ln] + red[(48 + r) * 64 + ln]);
+        const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), ii = i0 + (ln & 31);
+        if (ii < a.T) {
+          float* p = a.dpq + (long long)ii * a.C + h * 64 + c;
+          *p = (a.accumulate ? *p : 0.f) + t * a.dpq_scale;
         }
       }
-    }
-    if (i < a.T) {
-      float* op = a.dpq + (long long)i * a.C + h * 64 + 4 * half;
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          float4* p = reinterpret_cast<float4*>(op + cb * 32 + 8 * rg);
-          float4 o = make_float4(acc[cb][rg * 4] * a.dpq_scale, acc[cb][rg * 4 + 1] * a.dpq_scale,
-                                 acc[cb][rg * 4 + 2] * a.dpq_scale, acc[cb][rg * 4 + 3] * a.dpq_scale);
-          if (a.accumulate) { const float4 t = *p; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
-          *p = o;
-        }
     }
     return;
   }
   blk -= a.nb_q;
-  if (blk < a.nb_k) {
+  {
     // ---- d pos_k[j][h*64 + c] (+)= sum_i dB[h][i][j] pos_q[i][h*64 + c]:  out^T[c][j], A = pos_q^T (tr), B = dB^T (tr)
-    const int njt = (a.Sp + 127) >> 7;
-    const int h = blk / njt, jw0 = (blk % njt) * 128;
-    const int j = jw0 + wave * 32 + (lane & 31);
-    unsigned char* sQ = sm;            // pos_q tile [32 i][64 c], vx layout
-    unsigned char* sB = sm + 4096;     // dB tiles [ng <= 2][32 i][128 j], kx layout (256-byte rows)
+    // 32 columns j per workgroup
+    const int njt = a.Sp >> 5;
+    const int h = blk / njt, jw0 = (blk % njt) * 32;
+    unsigned char* sQ = sm + wave * 8192;       // pos_q tile [32 i][64 c]; behind it the dB tile [32 i][ng x 32 j] (64-byte halves)
     f32x16 acc[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
-    for (int i0 = 0; i0 < a.T; i0 += 32) {
-      __syncthreads();
-      {
-        const int r = tid >> 3, c = tid & 7;
-        uint4 v4 = make_uint4(0, 0, 0, 0);
-        if (i0 + r < a.T) v4 = *reinterpret_cast<const uint4*>(a.pq + (long long)(i0 + r) * a.ldpq + h * 64 + c * 8);
-        *reinterpret_cast<uint4*>(sQ + vx_off(r, c * 16)) = v4;
-        for (int g = 0; g < a.ng; ++g)
+    uint4 t4[4], d4[4];
+    auto fetch = [&](int i0) {
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int rr = (tid >> 4) + 16 * u, cc = tid & 15;         // 32 rows x 16 chunks of 8 columns
-            uint4 w4 = make_uint4(0, 0, 0, 0);
-            if (i0 + rr < a.T && jw0 + cc * 8 < a.Sp)
-              w4 = *reinterpret_cast<const uint4*>(a.dbias + g * a.gs + ((long long)h * a.T + i0 + rr) * a.Sp + jw0 + cc * 8);
-            *reinterpret_cast<uint4*>(sB + g * 8192 + kx_off(rr, cc)) = w4;
-          }
+      for (int u = 0; u < 4; ++u) {
+        const int r = lr + 8 * u;
+        t4[u] = make_uint4(0, 0, 0, 0); d4[u] = make_uint4(0, 0, 0, 0);
+        if (i0 + r < a.T) {
+          t4[u] = *reinterpret_cast<const uint4*>(a.pq + (long long)(i0 + r) * a.ldpq + h * 64 + lc * 8);
+          // chunks 0..3: group 0's 32 columns, chunks 4..7: group 1's
+          const int g = lc >> 2;
+          if (g < a.ng) d4[u] = *reinterpret_cast<const uint4*>(a.dbias + g * a.gs + ((long long)h * a.T + i0 + r) * a.Sp + jw0 + (lc & 3) * 8);
+        }
       }
-      __syncthreads();
+    };
+    auto live = [&](int i) { return !(a.causal && jw0 < a.P && (i >= a.P || jw0 > i + 31)); };
+    int i0 = wave * 32;
+    if (i0 < a.T) fetch(i0);
+    for (; i0 < a.T; i0 += 128) {
+      if (!live(i0)) { if (i0 + 128 < a.T) fetch(i0 + 128); continue; }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int o = vx_off(lr + 8 * u, lc * 16);
+        *reinterpret_cast<uint4*>(sQ + o) = t4[u];
+        *reinterpret_cast<uint4*>(sQ + 4096 + o) = d4[u];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (i0 + 128 < a.T) fetch(i0 + 128);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 a0 = tr_frag<false>(sQ, 16 * s2, 0, lane), a1 = tr_frag<false>(sQ, 16 * s2, 1, lane);
-        for (int g = 0; g < a.ng; ++g) {
-          const bf16x8 bfr = tr_frag<true>(sB + g * 8192, 16 * s2, wave, lane);
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr, acc[1], 0, 0, 0);
+        const bf16x8 a0 = tr_frag(sQ, 16 * s2, 0, lane), a1 = tr_frag(sQ, 16 * s2, 1, lane);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          if (g < a.ng) {
+            const bf16x8 bfr = tr_frag(sQ + 4096, 16 * s2, g, lane);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr, acc[1], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();                                   // (the tiles are dead: the sum reuses their LDS)
+    float* red = reinterpret_cast<float*>(sm);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      if (cb) __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[cb][r];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int v = tid + 256 * k, r = v >> 6, ln = v & 63;
+        const float t = (red[r * 64 + ln] + red[(16 + r) * 64 + ln]) + (red[(32 + r) * 64 + ln] + red[(48 + r) * 64 + ln]);
+        const int c = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), j = jw0 + (ln & 31);
+        if (j < a.S) {
+          float* p = a.dpk + (long long)j * a.C + h * 64 + c;
+          *p = (a.accumulate ? *p : 0.f) + t;
         }
       }
     }
-    if (j < a.S) {
-      float* op = a.dpk + (long long)j * a.C + h * 64 + 4 * half;
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          float4* p = reinterpret_cast<float4*>(op + cb * 32 + 8 * rg);
-          float4 o = make_float4(acc[cb][rg * 4], acc[cb][rg * 4 + 1], acc[cb][rg * 4 + 2], acc[cb][rg * 4 + 3]);
-          if (a.accumulate) { const float4 t = *p; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
-          *p = o;
-        }
-    }
-    return;
   }
-  blk -= a.nb_k;
-  float* sf = reinterpret_cast<float*>(sm);
-  auto dB = [&](int h, int i, int j) {
-    float t = 0.f;
-    for (int g = 0; g < a.ng; ++g) t += bf2f(a.dbias[g * a.gs + ((long long)h * a.T + i) * a.Sp + j]);
-    return t;
+}
+
+// delta-table gradients from sum_b dS: block ranges [2-D grid table | scalar entries + Toeplitz table]
+__global__ __launch_bounds__(256) void attn_dbias_tables_kernel(DbArgs a) {
+  __shared__ __attribute__((aligned(16))) float sf[2 * 4096];
+  const int tid = threadIdx.x;
+  int blk = blockIdx.x;
+  auto add8 = [](float* t, const uint4& v) {
+    t[0] += bflo(v.x); t[1] += bfhi(v.x); t[2] += bflo(v.y); t[3] += bfhi(v.y);
+    t[4] += bflo(v.z); t[5] += bfhi(v.z); t[6] += bflo(v.w); t[7] += bfhi(v.w);
   };
   if (blk < a.nb_2d) {
-    // ---- d rel2d[h][(dy + gh-1)(2gw-1) + dx + gw-1] = sum over the grid pairs (i, j) with y_i - y_j = dy, x_i - x_j = dx
-    const int ndy = 2 * a.gh - 1, h = blk / ndy, dy = blk % ndy - (a.gh - 1);
-    const int w = a.gw, ylo = dy > 0 ? dy : 0, yhi = dy < 0 ? a.gh + dy : a.gh;
-    float* out = a.drel2d + (long long)h * ndy * (2 * w - 1) + (long long)(dy + a.gh - 1) * (2 * w - 1);
-    // pair sums over y for every (x_i, x_j), w*w <= 4096 floats of LDS (gw <= 64)
-    for (int p = tid; p < w * w; p += 256) {
-      const int xi = p / w, xj = p - xi * w;
-      float t = 0.f;
-      for (int yi = ylo; yi < yhi; ++yi) t += dB(h, yi * w + xi, (yi - dy) * w + xj);
-      sf[p] = t;
+    // ---- d rel2d[h][part][(dy + gh-1)(2gw-1) + dx + gw-1] = sum over the grid pairs (i, j) with y_i - y_j = dy,
+    // x_i - x_j = dx and y_i = part (mod DB_NPARTS).  A thread owns (x_i, 8 consecutive x_j) of every second row: 16-byte loads,
+    // all of a thread's loads in flight together.
+    const int ndy = 2 * a.gh - 1, w = a.gw, nch = w >> 3, npair = w * nch;
+    const int part = blk % DB_NPARTS, dy = (blk / DB_NPARTS) % ndy - (a.gh - 1), h = blk / (DB_NPARTS * ndy);
+    const int ylo = dy > 0 ? dy : 0, yhi = dy < 0 ? a.gh + dy : a.gh;
+    const int y0 = ylo + ((part - ylo) % DB_NPARTS + DB_NPARTS) % DB_NPARTS;
+    float* out = a.drel2d + ((long long)h * DB_NPARTS + part) * ndy * (2 * w - 1) + (long long)(dy + a.gh - 1) * (2 * w - 1);
+    if (a.causal && dy < 0) {           // pairs with y_j > y_i are masked: nothing was written there
+      for (int d = tid; d < 2 * w - 1; d += 256) out[d] = 0.f;
+      return;
     }
-    __syncthreads();
+    const int nyp = npair <= 128 ? 2 : 1;                       // row phases handled side by side
+    const int yp = tid / npair, p = tid - yp * npair;
+    for (int p0 = 0; p0 < npair; p0 += 256) {                   // (one pass unless the grid is wider than 40)
+      const int pp = p0 + p;
+      float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const bool on = yp < nyp && pp < npair;
+      const int xi = on ? pp / nch : 0, xc = on ? pp - xi * nch : 0;
+      if (on) {
+        const bf16_t* base = a.dbias + ((long long)h * a.T + xi) * a.Sp + xc * 8 - (long long)dy * w;
+        const long long ystep = (long long)w * a.Sp + w;        // one grid row down in i and in j
+#pragma unroll 4
+        for (int yi = y0 + yp * DB_NPARTS; yi < yhi; yi += nyp * DB_NPARTS) {
+          add8(t, *reinterpret_cast<const uint4*>(base + yi * ystep));
+          if (a.ng > 1) add8(t, *reinterpret_cast<const uint4*>(base + a.gs + yi * ystep));
+        }
+      }
+      if (p0) __syncthreads();
+      if (on) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sf[yp * 4096 + xi * w + xc * 8 + e] = t[e];
+      }
+      __syncthreads();
+      // (a grid of more than 256 pairs per phase takes several passes; the diagonal sums below run after the last)
+    }
     for (int d = tid; d < 2 * w - 1; d += 256) {
       const int dx = d - (w - 1);
       float t = 0.f;
-      for (int xi = (dx > 0 ? dx : 0); xi < (dx < 0 ? w + dx : w); ++xi) t += sf[xi * w + (xi - dx)];
+      for (int xi = (dx > 0 ? dx : 0); xi < (dx < 0 ? w + dx : w); ++xi) {
+        t += sf[xi * w + (xi - dx)];
+        if (nyp > 1) t += sf[4096 + xi * w + (xi - dx)];
+      }
       out[d] = t;
     }
     return;
   }
   blk -= a.nb_2d;
-  {
-    // ---- head `blk`: the two scalar bias entries (grid row x tail column, tail row x grid column) and the tail x tail
-    // Toeplitz table; fixed summation order
-    const int h = blk, P = a.P, Lt = a.Lt;
-    float t0 = 0.f, t1 = 0.f;
-    for (long long e = tid; e < (long long)P * Lt; e += 256) {
-      const int i = (int)(e / Lt), tj = (int)(e - (long long)i * Lt);
-      t0 += dB(h, i, P + tj);
+  if (blk >= a.H * DB_NPARTS) {
+    // ---- (head, part, sub): the tail x tail Toeplitz table, rows i = part (mod DB_NPARTS), diagonals d = sub (mod DB_NSUB);
+    // a thread owns a diagonal (i - j = off) and walks its rows in order
+    blk -= a.H * DB_NPARTS;
+    const int sub = blk % DB_NSUB, part = (blk / DB_NSUB) % DB_NPARTS, h = blk / (DB_NSUB * DB_NPARTS), P = a.P, Lt = a.Lt;
+    const bf16_t* hb = a.dbias + (long long)h * a.T * a.Sp;
+    float* o1 = a.drel1d + ((long long)h * DB_NPARTS + part) * (2 * Lt - 1);
+    for (int d = sub + DB_NSUB * tid; d < 2 * Lt - 1; d += DB_NSUB * 256) {
+      const int off = d - (Lt - 1);          // i - j
+      float t = 0.f;
+      const int lo = off > 0 ? off : 0, hi = off < 0 ? Lt + off : Lt;
+#pragma unroll 4
+      for (int ti = lo + ((part - lo) % DB_NPARTS + DB_NPARTS) % DB_NPARTS; ti < hi; ti += DB_NPARTS) {
+        const long long o = (long long)(P + ti) * a.Sp + P + ti - off;
+        t += bf2f(hb[o]);
+        if (a.ng > 1) t += bf2f(hb[a.gs + o]);
+      }
+      o1[d] = t;
     }
-    for (long long e = tid; e < (long long)P * Lt; e += 256) {
-      const int ti = (int)(e / P), jj = (int)(e - (long long)ti * P);
-      t1 += dB(h, P + ti, jj);
+    return;
+  }
+  {
+    // ---- (head, part): the two scalar bias entries (grid row x tail column, tail row x grid column) and the tail x tail
+    // Toeplitz table, over the rows i = part (mod DB_NPARTS); fixed summation order
+    const int h = blk / DB_NPARTS, part = blk % DB_NPARTS, P = a.P, Lt = a.Lt;
+    const bf16_t* hb = a.dbias + (long long)h * a.T * a.Sp;
+    auto dB = [&](int i, int j) {
+      float t = bf2f(hb[(long long)i * a.Sp + j]);
+      if (a.ng > 1) t += bf2f(hb[a.gs + (long long)i * a.Sp + j]);
+      return t;
+    };
+    // grid rows x tail columns: a thread takes whole rows, the tail columns in 16-byte chunks (P is a multiple of 8)
+    float t0 = 0.f, t1 = 0.f;
+    for (int i = part + DB_NPARTS * tid; i < P; i += DB_NPARTS * 256) {
+      float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int tj = 0;
+#pragma unroll 4
+      for (; tj + 8 <= Lt; tj += 8)
+        for (int g = 0; g < a.ng; ++g) add8(t, *reinterpret_cast<const uint4*>(hb + g * a.gs + (long long)i * a.Sp + P + tj));
+      float tail = 0.f;
+      for (; tj < Lt; ++tj) tail += dB(i, P + tj);
+      t0 += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])) + tail;
+    }
+    // tail rows x grid columns: coalesced 16-byte chunks along the row
+    for (int ti = part; ti < Lt; ti += DB_NPARTS) {
+      float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int c = tid; c < (P >> 3); c += 256)
+        for (int g = 0; g < a.ng; ++g) add8(t, *reinterpret_cast<const uint4*>(hb + g * a.gs + (long long)(P + ti) * a.Sp + c * 8));
+      t1 += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     }
     sf[tid] = t0; sf[256 + tid] = t1;
     __syncthreads();
@@ -789,13 +921,9 @@ __global__ __launch_bounds__(256) void attn_dbias_grads_kernel(DbArgs a) {
       if (tid < o) { sf[tid] += sf[tid + o]; sf[256 + tid] += sf[256 + tid + o]; }
       __syncthreads();
     }
-    if (tid == 0) { a.drelx[h * 2] = sf[0]; a.drelx[h * 2 + 1] = sf[256]; }
-    for (int d = tid; d < 2 * Lt - 1; d += 256) {
-      const int off = d - (Lt - 1);          // i - j
-      float t = 0.f;
-      for (int ti = (off > 0 ? off : 0); ti < (off < 0 ? Lt + off : Lt); ++ti) t += dB(h, P + ti, P + ti - off);
-      a.drel1d[(long long)h * (2 * Lt - 1) + d] = t;
-    }
+    float* ox = a.drelx + ((long long)h * DB_NPARTS + part) * 2;
+    if (tid == 0) { ox[0] = sf[0]; ox[1] = sf[256]; }
+    return;
   }
 }
 
@@ -813,10 +941,12 @@ extern "C" int ifseg_attn_dense_bias(const void* pos_q, const void* pos_k, int l
   DenseArgs a{};
   a.pq = (const bf16_t*)pos_q; a.pk = (const bf16_t*)pos_k; a.ldpq = ldpq; a.ldpk = ldpk;
   a.H = H; a.T = T; a.S = S; a.Sp = Sp; a.Tp = Tp;
-  a.rel_mode = rel_mode; a.P = (rel_mode || causal) ? P : S; a.code_bias = code_bias; a.n2d = n2d; a.Lt = T - P; a.causal = causal;
+  a.rel_mode = rel_mode; a.P = (rel_mode || causal) ? P : S; a.code_bias = code_bias; a.n2d = rel_mode ? n2d : 0; a.Lt = rel_mode ? T - P : 0; a.causal = causal;
   a.gcode = gcode; a.rel2d = rel2d; a.rel1d = rel1d; a.relx = relx; a.D = D; a.Dt = Dt;
-  const long long tiles = (long long)H * (Tp / 32) * (Sp / 32);
-  hipLaunchKernelGGL(attn_dense_bias_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  const size_t lds = rel_mode ? ((((size_t)n2d + 3) & ~(size_t)3) + (((size_t)2 * a.Lt + 2) & ~(size_t)3) + (size_t)P) * 4 : 16;
+  if (lds > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_dense_bias_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(attn_dense_bias_kernel, dim3((unsigned)(H * (Tp / 32))), dim3(512), lds, (hipStream_t)stream, a);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }
@@ -876,21 +1006,25 @@ extern "C" int ifseg_attn_dbias_grads(const ifseg_attn_dbias_args* x, void* stre
   a.H = x->H; a.T = x->T; a.S = x->S; a.Sp = x->Sp; a.C = x->C;
   a.pq = (const bf16_t*)x->pos_q; a.pk = (const bf16_t*)x->pos_k; a.ldpq = x->ldpq; a.ldpk = x->ldpk;
   a.dpq = x->dpos_q_acc; a.dpk = x->dpos_k_acc; a.accumulate = x->accumulate_pos; a.dpq_scale = x->dpq_scale;
-  a.P = x->P; a.gh = x->grid_h; a.gw = x->grid_w; a.Lt = x->T - x->P;
+  a.P = x->P; a.gh = x->grid_h; a.gw = x->grid_w; a.Lt = x->T - x->P; a.causal = x->causal;
+  if (a.causal && (a.P <= 0 || (a.P & 31))) return IFSEG_ERR_BAD_SHAPE;
   a.drel2d = x->drel2d; a.drel1d = x->drel1d; a.drelx = x->drelx;
   const bool pos = a.pq != nullptr;
   if (pos && (!a.pk || !a.dpq || !a.dpk || ((a.ldpq | a.ldpk) & 7) || (a.C & 3) || a.C < a.H * 64)) return IFSEG_ERR_BAD_ARG;
   const bool rel = a.drel2d != nullptr;
   if (rel) {
-    if (!a.drel1d || !a.drelx || a.gh <= 0 || a.gw <= 0 || a.gw > 64 || a.gh * a.gw != a.P || a.P > a.T || a.P > a.S || a.T != a.S)
+    if (!a.drel1d || !a.drelx || a.gh <= 0 || a.gw <= 0 || a.gw > 64 || (a.gw & 7) || a.gh * a.gw != a.P || a.P > a.T || a.P > a.S || a.T != a.S)
       return IFSEG_ERR_BAD_SHAPE;
   }
-  a.nb_q = pos ? a.H * ((a.T + 127) / 128) : 0;
-  a.nb_k = pos ? a.H * ((a.Sp + 127) / 128) : 0;
-  a.nb_2d = rel ? a.H * (2 * a.gh - 1) : 0;
-  const int total = a.nb_q + a.nb_k + a.nb_2d + (rel ? a.H : 0);
-  if (total <= 0) return 0;
-  hipLaunchKernelGGL(attn_dbias_grads_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, a);
+  a.nb_q = pos ? a.H * ((a.T + 31) / 32) : 0;
+  a.nb_k = pos ? a.H * (a.Sp / 32) : 0;
+  a.nb_2d = rel ? a.H * (2 * a.gh - 1) * DB_NPARTS : 0;
+  if (pos) {
+    hipLaunchKernelGGL(attn_dbias_grads_kernel, dim3(a.nb_q + a.nb_k), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  if (rel) hipLaunchKernelGGL(attn_dbias_tables_kernel, dim3(a.nb_2d + a.H * DB_NPARTS * (1 + DB_NSUB)), dim3(256), 0, (hipStream_t)stream, a);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }
+
+extern "C" int ifseg_attn_dbias_nparts(void) { return DB_NPARTS; }

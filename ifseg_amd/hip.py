@@ -422,18 +422,24 @@ def attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S,
     _check(lib().ifseg_attn_bwd_bi(ctypes.byref(a), _stream()), "attn_bwd_bi")
 
 
+def dbias_nparts():
+    return lib().ifseg_attn_dbias_nparts()
+
+
 class _AttnDbiasArgs(ctypes.Structure):
     _fields_ = [("dbias", c_void_p), ("ng", c_int), ("H", c_int), ("T", c_int), ("S", c_int), ("Sp", c_int), ("C", c_int),
                 ("pos_q", c_void_p), ("pos_k", c_void_p), ("ldpq", c_int), ("ldpk", c_int),
                 ("dpos_q_acc", c_void_p), ("dpos_k_acc", c_void_p), ("accumulate_pos", c_int), ("dpq_scale", c_float),
                 ("P", c_int), ("grid_h", c_int), ("grid_w", c_int),
-                ("drel2d", c_void_p), ("drel1d", c_void_p), ("drelx", c_void_p)]     # == ifseg_attn_dbias_args
+                ("drel2d", c_void_p), ("drel1d", c_void_p), ("drelx", c_void_p), ("causal", c_int)]     # == ifseg_attn_dbias_args
 
 
 def attn_dbias_grads(dbias, S, pos_q=None, pos_k=None, dpq_acc=None, dpk_acc=None, accumulate_pos=False, dpq_scale=1.0,
-                     P=0, grid_h=0, grid_w=0, drel2d=None, drel1d=None, drelx=None):
-    """dbias [ng, H, T, Sp] bf16 -> abs-pos operand gradients (fp32 [T, C] / [S, C]) and delta-table gradients (fp32
-    [H, (2gh-1)(2gw-1)], [H, 2Lt-1], [H, 2]) in one launch"""
+                     P=0, grid_h=0, grid_w=0, drel2d=None, drel1d=None, drelx=None, causal=False):
+    """dbias [ng, H, T, Sp] bf16 -> abs-pos operand gradients (fp32 [T, C] / [S, C]) and delta-table gradients as
+    NP = dbias_nparts() partial tables per head (fp32 [H, NP, (2gh-1)(2gw-1)], [H, NP, 2Lt-1], [H, NP, 2]) in one launch"""
+    if drel2d is not None:
+        assert all(t.shape[1] == dbias_nparts() and t.is_contiguous() for t in (drel2d, drel1d, drelx))
     a = _AttnDbiasArgs()
     ng, H, T, Sp = dbias.shape
     a.dbias, a.ng, a.H, a.T, a.S, a.Sp = _p(dbias), ng, H, T, S, Sp
@@ -445,6 +451,7 @@ def attn_dbias_grads(dbias, S, pos_q=None, pos_k=None, dpq_acc=None, dpk_acc=Non
     a.accumulate_pos, a.dpq_scale = (1 if accumulate_pos else 0), dpq_scale
     a.P, a.grid_h, a.grid_w = P, grid_h, grid_w
     a.drel2d, a.drel1d, a.drelx = _p(drel2d), _p(drel1d), _p(drelx)
+    a.causal = 1 if causal else 0
     _check(lib().ifseg_attn_dbias_grads(ctypes.byref(a), _stream()), "attn_dbias_grads")
 
 

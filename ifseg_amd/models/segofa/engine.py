@@ -1434,7 +1434,7 @@ class HipEngine:
             timing["pairs"].append((t0, t1, 8.0 * 64 * T * S * B * H))
         parts = [None, None, None]
         if rel is not None:
-            parts = [gbuf("g_relg%d_%d" % (i, t.shape[1]), (H, 1, t.shape[1]), torch.float32)
+            parts = [gbuf("g_relg%d_%d" % (i, t.shape[1]), (H, hip.dbias_nparts(), t.shape[1]), torch.float32)
                      for i, t in enumerate((rel.rel2d, rel.rel1d, rel.relx))]
 
         def reductions():
@@ -1442,14 +1442,15 @@ class HipEngine:
             if rel is not None:
                 kw = dict(P=rel.P, grid_h=rel.P // rel.grid_w, grid_w=rel.grid_w, drel2d=parts[0], drel1d=parts[1], drelx=parts[2])
             hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq_acc, dpk_acc=dpk_acc, accumulate_pos=not first_pos,
-                                 dpq_scale=scaling, **kw)
+                                 dpq_scale=scaling, causal=causal, **kw)
             tables = []
             if rel is not None:
                 for (tabname, idx), part in zip(rel_grads, parts):
                     if tabname is not None:
                         tables.append((part, idx, self._table_acc(tabname)))
             # bucket scatter of the delta-table gradients and d c_attn (no abs-pos partials: nothing to sum over the batch)
-            hip.attn_bwd_reduce(B, H, T, S, C, None, None, dpq_acc, dpk_acc, True, delta, gain, self.G(gain_name), 1, tables)
+            hip.attn_bwd_reduce(B, H, T, S, C, None, None, dpq_acc, dpk_acc, True, delta, gain, self.G(gain_name),
+                                hip.dbias_nparts(), tables)
         if "reduce" not in _EXP_SKIP:
             self._side_do(reductions)
 

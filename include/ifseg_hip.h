@@ -231,14 +231,15 @@ typedef struct ifseg_attn_bi_args {
 } ifseg_attn_bi_args;
 int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* args, void* stream);
 
-/* ifseg_attn_dbias_grads: everything downstream of dbias in ONE launch (the autograd of the bias construction,
+/* ifseg_attn_dbias_grads: everything downstream of dbias (two launches: operand gradients, tables) (the autograd of the bias construction,
  *   encoder_module.py:757-771,790-809 / decoder_module.py:553-558,603-627), with dB = sum_g dbias[g]:
  *     dpos_q_acc[i][h*64+c] (=|+=) dpq_scale * sum_j dB[h][i][j] pos_k[j][h*64+c]       (fp32 [T,C])
  *     dpos_k_acc[j][h*64+c] (=|+=)             sum_i dB[h][i][j] pos_q[i][h*64+c]       (fp32 [S,C])
- *     drel2d[h][(dy+gh-1)(2gw-1) + dx+gw-1] = sum of dB over grid pairs with (y_i-y_j, x_i-x_j) = (dy, dx)  (raster grid gh x gw = P)
- *     drel1d[h][(i-j)+Lt-1] = sum over tail pairs;  drelx[h][0] = sum_{i<P<=j<S} dB,  drelx[h][1] = sum_{j<P<=i<T} dB
- *   (the delta-table gradients feed ifseg_attn_bwd_reduce with nparts = 1).  pos_q == NULL skips the operand gradients,
- *   drel2d == NULL the tables.  Fixed summation order. */
+ *     drel2d[h][p][(dy+gh-1)(2gw-1) + dx+gw-1] = sum of dB over grid pairs with (y_i-y_j, x_i-x_j) = (dy, dx)  (raster grid gh x gw = P, gw % 8 == 0)
+ *     drel1d[h][p][(i-j)+Lt-1] = sum over tail pairs;  drelx[h][p][0] = sum_{i<P<=j<S} dB,  drelx[h][p][1] = sum_{j<P<=i<T} dB
+ *   as NP = ifseg_attn_dbias_nparts() partial tables per head (part p = the rows i = p mod NP): they feed
+ *   ifseg_attn_bwd_reduce with nparts = NP.  pos_q == NULL skips the operand gradients, drel2d == NULL the tables.
+ *   Fixed summation order. */
 typedef struct ifseg_attn_dbias_args {
   const void* dbias;           /* bf16 [ng][H][T][Sp] */
   int ng, H, T, S, Sp, C;
@@ -249,8 +250,10 @@ typedef struct ifseg_attn_dbias_args {
   float dpq_scale;
   int P, grid_h, grid_w;
   float *drel2d, *drel1d, *drelx;
+  int causal;                  /* dbias comes from a causal launch of ifseg_attn_bwd_bi: the blocks it skipped are not read */
 } ifseg_attn_dbias_args;
 int ifseg_attn_dbias_grads(const ifseg_attn_dbias_args* args, void* stream);
+int ifseg_attn_dbias_nparts(void);
 
 /* -------------------------------------------------------------- row ops */
 /* Row addressing used below: logical row r lives at element offset

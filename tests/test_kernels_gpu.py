@@ -461,10 +461,11 @@ def test_attn_bwd_batch_inner(case):
     dpq = torch.full((T, C), 5.0, device=dev); dpk = torch.full((S, C), 5.0, device=dev)
     kw = {}
     if rel is not None:
-        g2 = torch.full((H, n2d), 7.0, device=dev); g1 = torch.full((H, 2 * Lt - 1), 7.0, device=dev)
-        gx = torch.full((H, 2), 7.0, device=dev)
+        NP = hip.dbias_nparts()       # partial tables per head, summed (in a fixed order) by ifseg_attn_bwd_reduce
+        g2 = torch.full((H, NP, n2d), 7.0, device=dev); g1 = torch.full((H, NP, 2 * Lt - 1), 7.0, device=dev)
+        gx = torch.full((H, NP, 2), 7.0, device=dev)
         kw = dict(P=P, grid_h=gh, grid_w=gw, drel2d=g2, drel1d=g1, drelx=gx)
-    hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, accumulate_pos=False, dpq_scale=0.25, **kw)
+    hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, accumulate_pos=False, dpq_scale=0.25, causal=causal, **kw)
     torch.cuda.synchronize()
     errs["dpq"] = _rel(dpq, pqf.grad * 0.25); errs["dpk"] = _rel(dpk, pkf.grad)
     if rel is not None:
@@ -478,9 +479,9 @@ def test_attn_bwd_batch_inner(case):
             rx = torch.stack([dSc[:, :P, P:].sum((1, 2)), dSc[:, P:, :P].sum((1, 2))], 1)
         scale = max(r2.abs().max().item(), r1.abs().max().item(), rx.abs().max().item())
         for name, gt, ref in zip(("drel2d", "drel1d", "drelx"), (g2, g1, gx), (r2, r1, rx)):
-            errs[name] = ((gt.cpu() - ref).abs().max() / scale).item()
+            errs[name] = ((gt.sum(1).cpu() - ref).abs().max() / scale).item()
     # accumulate flag: a second call adds onto the first
-    hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, accumulate_pos=True, dpq_scale=0.25, **kw)
+    hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, accumulate_pos=True, dpq_scale=0.25, causal=causal, **kw)
     torch.cuda.synchronize()
     errs["dpq_acc"] = _rel(dpq, pqf.grad * 0.5)
     print(case, {k_: round(v_, 5) for k_, v_ in errs.items()})

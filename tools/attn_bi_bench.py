@@ -51,15 +51,16 @@ def main(kind="enc"):
     dpq = torch.zeros(T, C, device=dev); dpk = torch.zeros(S, C, device=dev)
     kw = {}
     if rel is not None:
-        kw = dict(P=P, grid_h=gh, grid_w=gw, drel2d=torch.zeros(H, n2d, device=dev),
-                  drel1d=torch.zeros(H, 2 * Lt - 1, device=dev), drelx=torch.zeros(H, 2, device=dev))
+        NP = hip.dbias_nparts()
+        kw = dict(P=P, grid_h=gh, grid_w=gw, drel2d=torch.zeros(H, NP, n2d, device=dev),
+                  drel1d=torch.zeros(H, NP, 2 * Lt - 1, device=dev), drelx=torch.zeros(H, NP, 2, device=dev))
     bi = lambda ph: hip.attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal,
                                     P=P if (rel is not None or causal) else None, gain=gain, phases=ph)
     print(kind, "dense bias build        us %.1f" % timeit(lambda: hip.attn_dense_bias(dense, pq, pk, rel=rel, causal=causal, P=P)))
     print(kind, "bi dkv                  us %.1f" % timeit(lambda: bi(hip.ATTN_BWD_DKV)))
     print(kind, "bi dq (+ sum_b dS)      us %.1f" % timeit(lambda: bi(hip.ATTN_BWD_DQ)))
     print(kind, "bi dkv + dq             us %.1f" % timeit(lambda: bi(0)))
-    print(kind, "dbias grads             us %.1f" % timeit(lambda: hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, **kw)))
+    print(kind, "dbias grads             us %.1f" % timeit(lambda: hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, causal=causal, **kw)))
     # round-3 kernels
     dpqp = torch.zeros(B, T, C, device=dev, dtype=torch.bfloat16); dpkp = torch.zeros(B, S, C, device=dev, dtype=torch.bfloat16)
     nparts = B * ((S + 127) // 128)
