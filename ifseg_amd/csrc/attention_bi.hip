@@ -34,6 +34,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 struct BiArgs {
   const bf16_t *q, *k, *v, *dO;
   const float *lse, *delta, *D, *Dt, *gain;
+  float* dgain_rows;
   bf16_t *dq, *dk, *dv, *dbias;
   int B, H, T, S, Sp, Tp;
   long long q_bs, k_bs, v_bs, do_bs, dq_bs, dk_bs, dv_bs, dbias_gs;
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
   };
 
   U128 ud[2];
+  float pdp = 0.f;
   // S^T = bias tile + K Q^T, dP^T = V dO^T, dS^T -> this wave's slot of the batch sum and ud (bf16, the B operand of dQ)
   auto scores = [&](int it) {
     const unsigned char* stg = smem + (it & 1) * STG_DQ;
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
     for (int e = 0; e < 16; ++e) {
       const float p = __builtin_amdgcn_exp2f(fmaf(s[e], LOG2E, nlse));
       ds[e] = p * fmaf(gain, dp[e], -del);
+      pdp = fmaf(p, dp[e], pdp);          // sum_j P_ij dP_ij = dO_i . (P V)_i : the c_attn gradient without dividing by c_attn
     }
     unsigned char* sl = slots + ((it & 1) * 8 + wv) * SLOT;
 #pragma unroll
@@ -312,6 +315,12 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
     if (qb == 1) grads(sc.n - 1);
     __syncthreads();
     reduce(sc.n - 1);
+  }
+  if (a.dgain_rows) {
+    // d c_attn[h] = sum_{b,t} dO[b,t,h,:] . O_pre[b,t,h,:], O_pre = P V (before the gain): the row sums leave here, exact for
+    // every value of c_attn (delta / c_attn is 0 / 0 at c_attn = 0)
+    const float tot = pdp + __shfl_xor(pdp, 32);
+    if (bact && qvalid && half == 0) a.dgain_rows[((long long)b * a.H + h) * a.T + qi] = tot;
   }
   if (bact) {
     bf16_t* dqp = a.dq + (long long)b * a.dq_bs + (long long)qrow * a.lddq + h * 64;
@@ -418,6 +427,9 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
     }
 
   U128 up[2], ud[2];
+#ifdef BI_DS_SPLIT
+  U128 ul[2];        // (experiment) dS = hi + lo in two bf16 terms: 16 mantissa bits into the dK MFMA
+#endif
   auto scores = [&](int st) {
     const unsigned char* stg = smem + st * STG_DKV;
     const unsigned char* sQ = stg + ST_A + bl * 4096;
@@ -456,7 +468,12 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
         const float p0 = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -ls[e]));
         const float p1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], LOG2E, -ls[e + 1]));
         up[rg >> 1].w[(rg & 1) * 2 + (e >> 1)] = pack2bf(p0, p1);
-        ud[rg >> 1].w[(rg & 1) * 2 + (e >> 1)] = pack2bf(-p0 * dp[r], -p1 * dp[r + 1]);
+        const float d0 = -p0 * dp[r], d1 = -p1 * dp[r + 1];
+        const unsigned hi = pack2bf(d0, d1);
+        ud[rg >> 1].w[(rg & 1) * 2 + (e >> 1)] = hi;
+#ifdef BI_DS_SPLIT
+        ul[rg >> 1].w[(rg & 1) * 2 + (e >> 1)] = pack2bf(d0 - bflo(hi), d1 - bfhi(hi));
+#endif
       }
     }
   };
@@ -482,6 +499,10 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
       for (int db = 0; db < 2; ++db) dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[db].b, up[s2].b, dv[db], 0, 0, 0);
 #pragma unroll
       for (int db = 0; db < 2; ++db) dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[db].b, ud[s2].b, dk[db], 0, 0, 0);
+#ifdef BI_DS_SPLIT
+#pragma unroll
+      for (int db = 0; db < 2; ++db) dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[db].b, ul[s2].b, dk[db], 0, 0, 0);
+#endif
     }
   };
 
@@ -958,7 +979,7 @@ extern "C" int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* x, void* stream) {
   BiArgs a{};
   a.q = (const bf16_t*)x->q; a.k = (const bf16_t*)x->k; a.v = (const bf16_t*)x->v; a.dO = (const bf16_t*)x->dout;
   a.lse = x->lse; a.delta = x->delta; a.D = x->D; a.Dt = x->Dt; a.gain = (const float*)x->gain;
-  a.dq = (bf16_t*)x->dq; a.dk = (bf16_t*)x->dk; a.dv = (bf16_t*)x->dv; a.dbias = (bf16_t*)x->dbias;
+  a.dq = (bf16_t*)x->dq; a.dk = (bf16_t*)x->dk; a.dv = (bf16_t*)x->dv; a.dbias = (bf16_t*)x->dbias; a.dgain_rows = x->dgain_rows;
   a.B = x->B; a.H = x->H; a.T = x->T; a.S = x->S; a.Sp = x->Sp; a.Tp = x->Tp;
   a.q_bs = x->q_bs; a.k_bs = x->k_bs; a.v_bs = x->v_bs; a.do_bs = x->do_bs; a.dq_bs = x->dq_bs; a.dk_bs = x->dk_bs; a.dv_bs = x->dv_bs;
   a.dbias_gs = (long long)x->H * x->T * x->Sp;

@@ -119,7 +119,53 @@ __global__ __launch_bounds__(256) void ffn_ln_pg_final_kernel(const float* __res
 #pragma unroll
   for (int sl = 0; sl < PG_SLABS; ++sl) { swd += part[((long long)sl * 2) * N + k]; sdb += part[((long long)sl * 2 + 1) * N + k]; }
   dbeta[k] = f2bf(sdb);
-  dgamma[k] = f2bf((swd - beta[k] * sdb) / gamma[k]);
+  // (a gain too small for this division -- see ffn_ln_gain_is_small -- is overwritten by ffn_ln_dgamma_exact_kernel; without
+  // the operands of that rescue the result is kept finite)
+  const float g = gamma[k];
+  dgamma[k] = f2bf(g != 0.f ? (swd - beta[k] * sdb) / g : 0.f);
+}
+
+// Columns whose gain is too small for the division above (gamma_k = 0 gives 0 / 0; for |gamma_k| << |beta_k| the 2^-9
+// rounding of dW2 is amplified by 1 / gamma_k): dgamma_k from its definition,
+//     dgamma_k = sum_m dz[m][k] xhat[m][k],   dz[m][k] = sum_j dY[m][j] W2[j][k],  xhat = (gelu(u[m][k]) - mean_m) rstd_m,
+// one column at a time by the block that owns it (13 MB of dY per column: a rescue path -- with no flagged column the
+// launch is a dozen blocks that read their gammas and leave).  Same criterion on every run: deterministic.
+__device__ __forceinline__ bool ffn_ln_gain_is_small(float g, float b) { return fabsf(g) < 0.05f * fmaxf(1.f, fabsf(b)); }
+__global__ __launch_bounds__(256) void ffn_ln_dgamma_exact_kernel(const bf16_t* __restrict__ w2, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, const bf16_t* __restrict__ dy,
+                                                                  int lddy, const bf16_t* __restrict__ u, int ldu,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  bf16_t* __restrict__ dgamma, int M, int J, int N) {
+  __shared__ float sw[1024];
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  for (int k = blockIdx.x * 256; k < min(N, (int)blockIdx.x * 256 + 256); ++k) {
+    if (!ffn_ln_gain_is_small(gamma[k], beta[k])) continue;          // (block-uniform)
+    __syncthreads();
+    for (int j = tid; j < J; j += 256) sw[j] = bf2f(w2[(long long)j * N + k]);
+    __syncthreads();
+    float acc = 0.f;
+    for (int m = tid; m < M; m += 256) {
+      float dz = 0.f;
+      const bf16_t* dp = dy + (long long)m * lddy;
+      for (int j = 0; j < J; j += 8) {
+        float d[8];
+        unpack8(*reinterpret_cast<const uint4*>(dp + j), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dz += d[e] * sw[j + e];
+      }
+      const float uv = bf2f(u[(long long)m * ldu + k]);
+      const float g = 0.5f * uv * (1.f + erf_as(uv, __expf(-0.5f * uv * uv)));
+      acc += dz * (g - mean[m]) * rstd[m];
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) dgamma[k] = f2bf(red[0]);
+  }
 }
 
 }  // namespace
@@ -152,13 +198,18 @@ extern "C" int ifseg_ffn_ln_rowstats(const void* dy, int lddy, const void* t, in
 
 extern "C" int ifseg_ffn_ln_param_grads(const void* w2, const void* dw2, const void* db2, const float* gamma, const float* beta,
                                         void* dgamma, void* dbeta, float* workspace /* >= 16 N floats */, int J, int N,
-                                        void* stream) {
+                                        const void* dy, int lddy, const void* u, int ldu, const float* mean, const float* rstd,
+                                        int M, void* stream) {
   (void)hipGetLastError();
   if (!w2 || !dw2 || !db2 || !gamma || !beta || !dgamma || !dbeta || !workspace || J <= 0 || N <= 0 || (N & 7)) return IFSEG_ERR_BAD_ARG;
+  if (dy && (!u || !mean || !rstd || M <= 0 || (J & 7) || J > 1024 || (lddy & 7))) return IFSEG_ERR_BAD_ARG;
   hipLaunchKernelGGL(ffn_ln_pg_partial_kernel, dim3((N + 127) / 128, PG_SLABS), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)w2, (const bf16_t*)dw2, (const bf16_t*)db2, workspace, J, N);
   hipLaunchKernelGGL(ffn_ln_pg_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, gamma, beta,
                      (bf16_t*)dgamma, (bf16_t*)dbeta, N);
+  if (dy)
+    hipLaunchKernelGGL(ffn_ln_dgamma_exact_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w2, gamma,
+                       beta, (const bf16_t*)dy, lddy, (const bf16_t*)u, ldu, mean, rstd, (bf16_t*)dgamma, M, J, N);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

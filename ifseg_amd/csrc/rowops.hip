@@ -794,6 +794,46 @@ extern "C" int ifseg_colsum_bf16(const void* x, float* part, int nblk_rows, int 
   return 0;
 }
 
+namespace {
+// gw[n][c] -= db[n] * mean_rows(x)[c]  (x's column sums arrive as nblk partial rows: ifseg_colsum_bf16)
+__global__ __launch_bounds__(256) void kproj_common_mode_kernel(bf16_t* gw, const bf16_t* db, const float* part, int nblk, int N,
+                                                                int C, float inv_rows) {
+  __shared__ float sm[1024];
+  const int c0 = blockIdx.x * 1024;
+  for (int c = threadIdx.x; c < 1024 && c0 + c < C; c += 256) {
+    float t = 0.f;
+    for (int b = 0; b < nblk; ++b) t += part[(long long)b * C + c0 + c];
+    sm[c] = t * inv_rows;
+  }
+  __syncthreads();
+  for (int n = blockIdx.y; n < N; n += gridDim.y) {
+    const float d = bf2f(db[n]);
+    for (int c = threadIdx.x; c < 1024 && c0 + c < C; c += 256) {
+      bf16_t* g = gw + (long long)n * C + c0 + c;
+      *g = f2bf(bf2f(*g) - d * sm[c]);
+    }
+  }
+}
+}  // namespace
+
+// The weight gradient of a KEY projection with the token-common component of its input removed:
+//     gw <- gw - db (x) mean_rows(x),      gw [N, C] = dK^T x (bf16), db [N] = sum over all rows of dK (the bias gradient).
+// Exact identity: softmax is invariant to adding one vector to every key of a (batch, head), so sum_j dK_j = 0 and
+// dK^T x = dK^T (x - 1 c^T) for every c -- the reference's k_proj.bias gradient is float noise for the same reason
+// (unify_multihead_attention.py:327-346 under autograd).  In bf16 arithmetic sum_j dK_j is NOT zero (delta = rowsum(dO * O)
+// uses the bf16-rounded O, so the rows of dS do not sum to zero exactly), and that spurious sum multiplies the mean of x, which
+// is 4-8 x larger than x's token-dependent part after a LayerNorm with a bias: measured on SegOFA-Base (tools/kproj_err.py,
+// encoder layer 5) k_proj.weight rel-L2 against the fp32 reference 0.119 as computed, 0.017 with this rank-1 term removed.
+extern "C" int ifseg_kproj_common_mode(void* gw, const void* db, const float* xsum_part, int nblk, int N, int C, int rows,
+                                       void* stream) {
+  (void)hipGetLastError();
+  if (!gw || !db || !xsum_part || nblk <= 0 || N <= 0 || C <= 0 || rows <= 0) return IFSEG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(kproj_common_mode_kernel, dim3((C + 1023) / 1024, N < 256 ? N : 256), dim3(256), 0, (hipStream_t)stream,
+                     (bf16_t*)gw, (const bf16_t*)db, xsum_part, nblk, N, C, 1.f / (float)rows);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int ifseg_embed_rows(const void* table, const long long* ids, const void* add, void* out, int n, int C,
                                 int rpb, long long o_bs, int ldo, void* stream) {
   (void)hipGetLastError();

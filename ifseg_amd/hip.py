@@ -151,14 +151,19 @@ def linear_dx_gelu_ln_bwd(dy, w, out, u, gamma, mean, rstd, c):
 _pg_ws = {}
 
 
-def ffn_ln_param_grads(w2, dw2, db2, gamma, beta, dgamma, dbeta):
+def ffn_ln_param_grads(w2, dw2, db2, gamma, beta, dgamma, dbeta, dy=None, u=None, mean=None, rstd=None):
+    """dy [M, J], u [M, N], mean / rstd [M]: the operands of the rescue path for gains too small to divide by (csrc/ffn_ln.hip)"""
     J, N = w2.shape
     assert w2.is_contiguous() and dw2.is_contiguous()
     ws = _pg_ws.get((w2.device, N))
     if ws is None:
         ws = _pg_ws[(w2.device, N)] = torch.empty(16 * N, dtype=torch.float32, device=w2.device)
     _check(lib().ifseg_ffn_ln_param_grads(_ptr(_bf(w2)), _ptr(_bf(dw2)), _ptr(_bf(db2)), _ptr(gamma), _ptr(beta), _ptr(dgamma),
-                                          _ptr(dbeta), _ptr(ws), c_int(J), c_int(N), _stream()), "ffn_ln_param_grads")
+                                          _ptr(dbeta), _ptr(ws), c_int(J), c_int(N),
+                                          _ptr(_bf(dy)) if dy is not None else None, c_int(dy.stride(0) if dy is not None else 0),
+                                          _ptr(_bf(u)) if u is not None else None, c_int(u.stride(0) if u is not None else 0),
+                                          _ptr(mean), _ptr(rstd), c_int(dy.shape[0] if dy is not None else 0), _stream()),
+           "ffn_ln_param_grads")
 
 
 _splitk_ws = {}
@@ -401,11 +406,11 @@ class _AttnBiArgs(ctypes.Structure):
     _fields_ = ([(n, c_void_p) for n in ("q", "k", "v", "dout", "lse", "delta", "D", "Dt", "gain", "dq", "dk", "dv", "dbias")]
                 + [(n, c_int) for n in ("B", "H", "T", "S", "Sp", "Tp", "ldq", "ldk", "ldv", "lddo", "lddq", "lddk", "lddv")]
                 + [(n, c_ll) for n in ("q_bs", "k_bs", "v_bs", "do_bs", "dq_bs", "dk_bs", "dv_bs")]
-                + [("causal", c_int), ("P", c_int), ("dq_scale", c_float), ("phases", c_int)])   # == ifseg_attn_bi_args
+                + [("causal", c_int), ("P", c_int), ("dq_scale", c_float), ("phases", c_int), ("dgain_rows", c_void_p)])   # == ifseg_attn_bi_args
 
 
 def attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=False, P=None, gain=None,
-                dq_scale=1.0, phases=0):
+                dq_scale=1.0, phases=0, dgain_rows=None):
     """dbias: bf16 [ceil(B/4), H, T, dense.Sp] -- zero-filled once by the caller when causal (skipped blocks are not written)"""
     a = _AttnBiArgs()
     for name, t in (("q", q), ("k", k), ("v", v), ("dout", dout), ("lse", lse), ("delta", delta), ("D", dense.D),
@@ -419,6 +424,7 @@ def attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S,
     a.dq_bs, a.dk_bs, a.dv_bs = dq.stride(0), dk.stride(0), dv.stride(0)
     a.causal, a.P = (1 if causal else 0), (P if P is not None else S)
     a.dq_scale, a.phases = dq_scale, phases
+    a.dgain_rows = _p(dgain_rows)
     _check(lib().ifseg_attn_bwd_bi(ctypes.byref(a), _stream()), "attn_bwd_bi")
 
 
@@ -612,6 +618,21 @@ def colsum(x, part):
     rc = lib().ifseg_colsum_bf16(_ptr(x), _ptr(part), c_int(COLSUM_BLOCKS), c_int(M), c_int(N), c_int(rpb), c_ll(xb),
                                  c_int(xl), _stream())
     _check(rc, "colsum")
+    return part
+
+
+def kproj_common_mode(gw, db, x, part=None):
+    """gw [N, C] -= db [N] (x) mean_rows(x): the key-projection weight gradient without the product of dK's spurious column sum
+    and the token-common component of its input (csrc/rowops.hip: ifseg_kproj_common_mode).  x [rows, C] bf16; `part`: a
+    [COLSUM_BLOCKS, C] fp32 workspace that already holds x's partial column sums (several projections of the same x), else
+    computed here."""
+    N, C = gw.shape
+    assert gw.is_contiguous() and gw.dtype == torch.bfloat16 and db.dtype == torch.bfloat16 and db.is_contiguous()
+    if part is None:
+        part = colsum(x, torch.empty(COLSUM_BLOCKS, C, dtype=torch.float32, device=gw.device))
+    rows = x.numel() // C
+    _check(lib().ifseg_kproj_common_mode(_ptr(gw), _ptr(db), _ptr(part), c_int(COLSUM_BLOCKS), c_int(N), c_int(C), c_int(rows),
+                                         _stream()), "kproj_common_mode")
     return part
 
 

@@ -82,6 +82,7 @@ class HipEngine:
         # weight-gradient GEMMs of a layer are collected and launched as ONE grouped GEMM at the end of the layer's
         # backward (no split-K slabs / reduction launches: hip.linear_dw_group); IFSEG_NO_DW_GROUP=1: one GEMM each
         self._dw_tasks = []
+        self._kfix_tasks = []       # (k_proj dW [C, C], k_proj db [C], projection input x [rows, C], tag of a shared column-sum workspace or None)
         self._ln_red_tasks, self._ln_red_acc = [], []    # (partials, [2, C] gradient view, ...) of LayerNorm backward launches
         self.dw_grouped = os.environ.get("IFSEG_NO_DW_GROUP") is None
         self.dw_split = os.environ.get("IFSEG_DW_SPLIT", "0") == "1"
@@ -94,6 +95,9 @@ class HipEngine:
         # operand built once per layer from parameters, sum_b dS leaves the dQ kernel once per tile.  IFSEG_ATTN_BI=0: the
         # round-3 kernels (one workgroup per (batch, head, tile), bias regenerated per batch element).
         self.attn_bi = os.environ.get("IFSEG_ATTN_BI", "1") != "0"
+        # k_proj.weight gradients without the product of dK's spurious column sum and the token mean of the projection's input
+        # (an exact identity: sum_j dK_j = 0; csrc/rowops.hip ifseg_kproj_common_mode).  IFSEG_NO_KPROJ_FIX=1: as computed.
+        self.kproj_fix = os.environ.get("IFSEG_NO_KPROJ_FIX") is None
         self._ffn_pg_tasks = []
         self._train_fwd = False
         # where the NEXT batch's frozen-trunk pass is launched: "fwd" = at the start of this step's forward, "e<k>" = when
@@ -1297,7 +1301,8 @@ class HipEngine:
             hip.ffn_ln_rowstats(dbr, s["t"].view(rows, C), self.ws[tg + "_fcoef"], cst, Fd)
             hip.linear_dx_gelu_ln_bwd(dbr, W(p + "fc2.weight"), du, s["u"], Wf(p + "ffn_layernorm.weight"), mu, rs, cst)
             self._ffn_pg_tasks.append((W(p + "fc2.weight"), G(p + "fc2.weight"), G(p + "fc2.bias"), Wf(p + "ffn_layernorm.weight"),
-                                       Wf(p + "ffn_layernorm.bias"), G(p + "ffn_layernorm.weight"), G(p + "ffn_layernorm.bias")))
+                                       Wf(p + "ffn_layernorm.bias"), G(p + "ffn_layernorm.weight"), G(p + "ffn_layernorm.bias"),
+                                       dbr, s["u"], mu, rs))
         else:
             dz = buf("g_dz_%d" % rows, (rows, Fd))
             self._linear_bwd(dbr, s["z"], W(p + "fc2.weight"), G(p + "fc2.weight"), G(p + "fc2.bias"), dx_out=dz)
@@ -1420,14 +1425,30 @@ class HipEngine:
                 t0 = torch.cuda.Event(enable_timing=True)
                 t0.record()
         P = rel.P if rel is not None else None
+        # per-row terms of d c_attn (sum_j P dP = dO . O_pre) from the dQ kernel: no division by c_attn anywhere
+        dgr = gbuf("g_dgain_rows_%d" % T, (B, H, T), torch.float32)
+        ones = self.ws.get("ones_h")
+        if ones is None or ones.numel() != H:
+            ones = self.ws["ones_h"] = torch.ones(H, dtype=torch.float32, device=self.device)
         ph = 0
         if "dq" in _EXP_SKIP:
             ph = hip.ATTN_BWD_DKV
         if "dkv" in _EXP_SKIP:
             ph = hip.ATTN_BWD_DQ if not ph else -1
-        if ph >= 0:
+        if ph == 0 and self.overlap and os.environ.get("IFSEG_BI_DQ_STREAM"):
+            # (experiment) the dQ kernel on its own stream beside the dK/dV kernel: neither fits a CU next to the other, but
+            # the second, partly filled round of workgroups of one leaves CUs to the other
+            with self._fork(self._dq_stream_get()):
+                hip.attn_bwd_bi(q, k, v, do, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain,
+                                dq_scale=scaling, phases=hip.ATTN_BWD_DQ, dgain_rows=dgr)
+                dq_done = self._ev()
+                dq_done.record(self._dqs)
             hip.attn_bwd_bi(q, k, v, do, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain,
-                            dq_scale=scaling, phases=ph)
+                            dq_scale=scaling, phases=hip.ATTN_BWD_DKV)
+            torch.cuda.current_stream().wait_event(dq_done)
+        elif ph >= 0:
+            hip.attn_bwd_bi(q, k, v, do, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain,
+                            dq_scale=scaling, phases=ph, dgain_rows=dgr)
         if timing is not None:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record()
@@ -1449,7 +1470,8 @@ class HipEngine:
                     if tabname is not None:
                         tables.append((part, idx, self._table_acc(tabname)))
             # bucket scatter of the delta-table gradients and d c_attn (no abs-pos partials: nothing to sum over the batch)
-            hip.attn_bwd_reduce(B, H, T, S, C, None, None, dpq_acc, dpk_acc, True, delta, gain, self.G(gain_name),
+            # (d c_attn[h] = sum of the dQ kernel's row terms: `ones` stands in for the gain the round-3 formula divides by)
+            hip.attn_bwd_reduce(B, H, T, S, C, None, None, dpq_acc, dpk_acc, True, dgr, ones, self.G(gain_name),
                                 hip.dbias_nparts(), tables)
         if "reduce" not in _EXP_SKIP:
             self._side_do(reductions)
@@ -1491,6 +1513,8 @@ class HipEngine:
         self._linear_bwd(dqkv.view(rows, 3 * C), s["xn"], self._fused(self.p16, a_ + ".q_proj.weight", 3 * C, C),
                          self._fused(self.g16, a_ + ".q_proj.weight", 3 * C, C),
                          self._fused(self.g16, a_ + ".q_proj.bias", 3 * C), dx_out=dxn)
+        if self.kproj_fix:
+            self._kfix_tasks.append((G(a_ + ".k_proj.weight"), G(a_ + ".k_proj.bias"), s["xn"], None))
         dx = gbuf("g_dx0_%d" % rows, (rows, C))
         self._ln_bwd_fused(dxn, s["x"].view(rows, C), p + ln1, tg + "_ln1", dx, dx1, nxt)
         return dx                # the caller flushes the side queue together with the layer's hook
@@ -1540,6 +1564,8 @@ class HipEngine:
             self._linear_bwd(dkv.view(B * Te, 2 * C), enc2d, wkv, self._fused(self.g16, a_ + ".k_proj.weight", 2 * C, C),
                              self._fused(self.g16, a_ + ".k_proj.bias", 2 * C), dx_out=d_enc_out.view(B * Te, C),
                              dx_accumulate=not first_cross)
+        if self.kproj_fix:       # (every layer's K|V projection reads the same encoder output: one column sum per step)
+            self._kfix_tasks.append((G(a_ + ".k_proj.weight"), G(a_ + ".k_proj.bias"), enc2d, "enc_out"))
         dy1 = gbuf("g_dy1c_%d" % rows, (rows, C))
         self._ln_bwd_fused(dyn, s["x"].view(rows, C), p + "encoder_attn_layer_norm", tg + "_cln1", dy1, dy2, nxt)
         self._side_flush()
@@ -1555,6 +1581,7 @@ class HipEngine:
         g = self._geometry(h, w, L)
         self.g16.zero_()
         self._tab_touched = {}
+        self._xsum_done = set()
         self._bt = "top"
         if ctx.get("dense_ready") is not None:      # the dense biases were built on the side stream during the forward
             torch.cuda.current_stream().wait_event(ctx["dense_ready"])
@@ -1779,9 +1806,21 @@ class HipEngine:
         if tasks and "dw" not in _EXP_SKIP:
             hip.linear_dw_group(tasks, wgs)
         # ffn_layernorm's dgamma / dbeta from fc2's (now final) weight / bias gradient
+        # key projections: the weight gradient without (spurious column sum of dK) x (token-common component of the input)
+        kf, self._kfix_tasks = self._kfix_tasks, []
+        for gw, gb, x, shared in kf:
+            if shared is None:
+                hip.kproj_common_mode(gw, gb, x)
+            else:
+                key = "g_xsum_" + shared
+                part = self.ws.get(key) if key in self._xsum_done else None
+                if part is None:
+                    part = hip.colsum(x, self.buf(key, (hip.COLSUM_BLOCKS, x.shape[-1]), torch.float32))
+                    self._xsum_done.add(key)
+                hip.kproj_common_mode(gw, gb, x, part)
         pg, self._ffn_pg_tasks = self._ffn_pg_tasks, []
-        for w2, dw2, db2, gam, bet, dgam, dbet in pg:
-            hip.ffn_ln_param_grads(w2, dw2, db2, gam, bet, dgam, dbet)
+        for w2, dw2, db2, gam, bet, dgam, dbet, dy_, u_, mu_, rs_ in pg:
+            hip.ffn_ln_param_grads(w2, dw2, db2, gam, bet, dgam, dbet, dy=dy_, u=u_, mean=mu_, rstd=rs_)
         # the LayerNorm dgamma / dbeta partials collected since the last flush: one reduction launch
         for attr in ("_ln_red_tasks", "_ln_red_acc"):
             red = getattr(self, attr)

@@ -96,7 +96,12 @@ int ifseg_gemm_nn_gelu_ln_bwd(const void* A, const void* B, void* C, int M, int 
                               const float* cstats, void* stream);
 int ifseg_ffn_ln_param_grads(const void* w2, const void* dw2, const void* db2, const float* gamma, const float* beta,
                              void* dgamma, void* dbeta, float* workspace /* >= 16 N floats: partial column sums of 8 row slabs */,
-                             int J, int N, void* stream);
+                             int J, int N,
+                             /* rescue of the columns whose gain is too small to divide by (|gamma_k| < 0.05 max(1, |beta_k|), 0 included):
+                              * dgamma_k = sum_m (dY W2)[m][k] xhat[m][k] from its definition.  dy [M, J] (the gradient of fc2's output), u [M, N]
+                              * (fc1's output), mean / rstd [M] of ffn_layernorm; dy == NULL: no rescue (a zero gain then yields 0, not NaN) */
+                             const void* dy, int lddy, const void* u, int ldu, const float* mean, const float* rstd, int M,
+                             void* stream);
 
 /* Implicit-GEMM conv on NHWC bf16 with folded FrozenBatchNorm (+residual, +ReLU).
  * `w` is [Cout][KH][KW][Cin] with the BN scale already folded in, `shift` the
@@ -228,6 +233,8 @@ typedef struct ifseg_attn_bi_args {
   int causal, P;               /* P: grid tokens (multiple of 64) when causal */
   float dq_scale;
   int phases;                  /* 0 = both; IFSEG_ATTN_BWD_DKV | IFSEG_ATTN_BWD_DQ */
+  float* dgain_rows;           /* optional fp32 [B,H,T]: sum_j P_ij dP_ij = dout_i . (P v)_i, the per-row terms of d c_attn[h]
+                                  (unify_multihead_attention.py:509-512) computed WITHOUT dividing delta by c_attn: exact at c_attn = 0 */
 } ifseg_attn_bi_args;
 int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* args, void* stream);
 
@@ -328,6 +335,11 @@ int ifseg_reduce_parts_multi(int ntask, const ifseg_reduce_task* tasks, void* st
 int ifseg_colsum_bf16(const void* x, float* part, int nblk_rows, int M, int N, int rpb, long long x_bs, int ldx,
                       void* stream);
 /* out[r] = table[ids[r]] + add  (embed_tokens + type_embedding, encoder_module.py:400-406) */
+/* gw [N, C] (bf16, a key projection's weight gradient dK^T x) -= db [N] (x) mean_rows(x) [C]: sum_j dK_j = 0 in exact arithmetic
+ * (softmax shift invariance; the reference's k_proj.bias gradient is float noise), so this removes only the product of the
+ * spurious bf16 column sum of dK with the token-common component of x.  xsum_part [nblk, C]: partial column sums of x
+ * (ifseg_colsum_bf16), rows = the number of rows of x.  Autograd of unify_multihead_attention.py:327-346. */
+int ifseg_kproj_common_mode(void* gw, const void* db, const float* xsum_part, int nblk, int N, int C, int rows, void* stream);
 int ifseg_embed_rows(const void* table, const long long* ids, const void* add, void* out, int n, int C, int rpb,
                      long long o_bs, int ldo, void* stream);
 /* Image-free patch embeddings: out[b,p,:] = mean of table rows ids[b, ends[b,p-1]:ends[b,p]] + add

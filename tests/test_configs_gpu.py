@@ -96,11 +96,11 @@ def _check_grad_subsamples(g, grad_of, what):
         if r > worst[1]:
             worst = (name, r)
         # (rel-pos tables: most sampled entries are exact zeros -- buckets the geometry never reaches -- on both sides)
-        # k_proj.weight: dK = dS^T q is a sum of terms that cancel (each row of dS sums to zero -- the softmax is invariant to
-        # a per-query shift, which is also why k_proj.bias gets no gradient), so the bf16 rounding of dS shows up 2-3 x
-        # larger in this one tensor per attention (measured 0.06 - 0.15 on identical weights; a sign or permutation
-        # error would read ~1.4)
-        if r > (0.2 if name.endswith("k_proj.weight") else 6e-2):
+        # (k_proj.weight included: round 3 measured 0.06 - 0.15 there and allowed 0.2.  The cause was not the bf16 rounding of
+        # dS -- feeding the dK MFMA dS as hi + lo bf16 terms changed nothing (tools/kproj_err.py) -- but the product of dK's
+        # spurious column sum, sum_j dK_j = 0 in exact arithmetic, with the token mean of the projection's input; the engine
+        # removes that rank-1 term, csrc/rowops.hip ifseg_kproj_common_mode: 0.119 -> 0.017 on encoder layer 5)
+        if r > 6e-2:
             bad.append((round(r, 4), name))
     assert not bad, "%s: %d of %d gradient tensors beyond rel-L2 6e-2 on the sampled elements: %s" % (what, len(bad), n, sorted(bad)[-12:])
     assert n >= 300, n

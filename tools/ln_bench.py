@@ -31,6 +31,14 @@ def main():
         bench("ln_bwd C%d gelu%d add%d" % (C, gelu, add),
               lambda: hip.ln_bwd(dy, x, g, mean, rstd, dx, part[0], part[1], dx_add=res if add else None, gelu=gelu),
               M * C * (8.0 if add else 6.0))
+        if C <= 1024:
+            y2 = torch.empty_like(x); m2, r2 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+            gf, bf = g.float(), b.float()
+            bench("ln_fwd_pair C%d resid (fp32 params)" % C,
+                  lambda: hip.ln_fwd_pair(x, gf, bf, y, mean, rstd, gf, bf, y2, m2, r2, resid=res), M * C * 8.0)
+            dx2 = torch.empty_like(x)
+            bench("ln_bwd_drop C%d add (fp32 params)" % C,
+                  lambda: hip.ln_bwd_drop(dy, x, gf, mean, rstd, dx, part[0], part[1], dx2, dx_add=res), M * C * 10.0)
         gw = torch.empty(2, C, device=dev)
         bench("reduce_parts 2x%dx%d" % (hip.LN_BWD_BLOCKS, C), lambda: hip.reduce_parts(part, gw, 2, hip.LN_BWD_BLOCKS, C), 2 * hip.LN_BWD_BLOCKS * C * 4.0)
         cs = torch.empty(hip.COLSUM_BLOCKS, C, device=dev)
