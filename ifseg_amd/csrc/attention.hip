@@ -47,6 +47,7 @@ struct AttnArgs {
   float *drel2d_part, *drel1d_part, *drelx_part;  // [H][nparts][n]
   int nparts;
   const float* gain;          // [H] per-head output gain c_attn (fp32: the optimizer's master copy; may be null)
+  float* dgain_rows;          // optional [B,H,T]: sum_j P_ij dP_ij = dO_i . (P V)_i, the per-row terms of d c_attn (no division by c_attn)
   float dq_scale, dpq_scale;
   int grid_w;                 // width of the token grid (row-aligned diagonal reduction when 32)
 };
@@ -1208,6 +1209,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bl
   for (int e = 0; e < 16; ++e)
 #pragma unroll
     for (int c = 0; c < NKS / 2; ++c) dq[c][e] = 0.f;
+  float pdp = 0.f;        // sum_j P_ij dP_ij (dP before the gain): d c_attn[h] = sum_{b,i} of it, exact for every c_attn
 
   if (nsched > 0) { load_kv(tile_of(0) * 64); store_kv(0); }
 #pragma unroll
@@ -1301,6 +1303,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bl
               if (FLAGS & 1) p = (dj + e > 0) ? 0.f : p;
               if (FLAGS & 2) p = (e < jl) ? p : 0.f;
               dsv[e] = p * fmaf(gain, dp[rg * 4 + e], -del_q);
+              pdp = fmaf(p, dp[rg * 4 + e], pdp);
             }
             ud[rg >> 1].w[(rg & 1) * 2] = pack2bf(dsv[0], dsv[1]);
             ud[rg >> 1].w[(rg & 1) * 2 + 1] = pack2bf(dsv[2], dsv[3]);
@@ -1340,6 +1343,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bl
                 float p = __builtin_amdgcn_exp2f(fmaf(sv[e], LOG2E, nlse_q));
                 if (a.causal) p = (dj + e > 0) ? 0.f : p;
                 dsv[e] = p * (gain * dp[rg * 4 + e] - del_q);
+                pdp = fmaf(p, dp[rg * 4 + e], pdp);
               }
             } else {
               int4 cj = make_int4(0, 0, 0, 0);
@@ -1362,6 +1366,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bl
                 }
                 const float p = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(sv, LOG2E, nlse_q));
                 dsv[e] = p * (gain * dp[rg * 4 + e] - del_q);
+                pdp = fmaf(p, dp[rg * 4 + e], pdp);
               }
             }
             ud.w[rg2 * 2] = pack2bf(dsv[0], dsv[1]); ud.w[rg2 * 2 + 1] = pack2bf(dsv[2], dsv[3]);
@@ -1386,6 +1391,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bl
     __syncthreads();
   }
 
+  if (a.dgain_rows) {
+    const float tot = pdp + __shfl_xor(pdp, 32);
+    if (qvalid && half == 0) a.dgain_rows[((long long)b * a.H + h) * a.T + qi] = tot;
+  }
   if (qvalid) {
     bf16_t* dqp = a.dq + (long long)b * a.dq_bs + (long long)qi * a.lddq + h * 64;
 #pragma unroll
@@ -1648,6 +1657,7 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   a.drel2d_part = x->drel2d_part; a.drel1d_part = x->drel1d_part; a.drelx_part = x->drelx_part;
   a.nparts = x->nparts; a.gain = (const float*)x->gain; a.dq_scale = x->dq_scale; a.dpq_scale = x->dpq_scale;
   a.grid_w = x->grid_w;
+  a.dgain_rows = x->dgain_rows;
 #ifdef IFSEG_EXP_NOBIAS_BWD
   // timing bound only (tools/variant.py): the backward with every per-batch bias term compiled out -- no abs-pos columns,
   // no rel-pos seeds, no table-gradient bins (results are wrong)

@@ -795,24 +795,18 @@ extern "C" int ifseg_colsum_bf16(const void* x, float* part, int nblk_rows, int 
 }
 
 namespace {
-// gw[n][c] -= db[n] * mean_rows(x)[c]  (x's column sums arrive as nblk partial rows: ifseg_colsum_bf16)
-__global__ __launch_bounds__(256) void kproj_common_mode_kernel(bf16_t* gw, const bf16_t* db, const float* part, int nblk, int N,
-                                                                int C, float inv_rows) {
-  __shared__ float sm[1024];
-  const int c0 = blockIdx.x * 1024;
-  for (int c = threadIdx.x; c < 1024 && c0 + c < C; c += 256) {
-    float t = 0.f;
-    for (int b = 0; b < nblk; ++b) t += part[(long long)b * C + c0 + c];
-    sm[c] = t * inv_rows;
-  }
-  __syncthreads();
-  for (int n = blockIdx.y; n < N; n += gridDim.y) {
-    const float d = bf2f(db[n]);
-    for (int c = threadIdx.x; c < 1024 && c0 + c < C; c += 256) {
-      bf16_t* g = gw + (long long)n * C + c0 + c;
-      *g = f2bf(bf2f(*g) - d * sm[c]);
-    }
-  }
+// gw[n][c] -= db[n] * xmean[c]
+__global__ __launch_bounds__(256) void kproj_common_mode_kernel(bf16_t* gw, const bf16_t* db, const float* xmean, int N, int C) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;       // C % 8 == 0: eight columns of one row
+  if (i >= (long long)N * C) return;
+  const int n = (int)(i / C), c = (int)(i - (long long)n * C);
+  const float d = bf2f(db[n]);
+  float g[8];
+  unpack8(*reinterpret_cast<const uint4*>(gw + i), g);
+  const float4 m0 = *reinterpret_cast<const float4*>(xmean + c), m1 = *reinterpret_cast<const float4*>(xmean + c + 4);
+  g[0] -= d * m0.x; g[1] -= d * m0.y; g[2] -= d * m0.z; g[3] -= d * m0.w;
+  g[4] -= d * m1.x; g[5] -= d * m1.y; g[6] -= d * m1.z; g[7] -= d * m1.w;
+  *reinterpret_cast<uint4*>(gw + i) = pack8(g);
 }
 }  // namespace
 
@@ -824,12 +818,12 @@ __global__ __launch_bounds__(256) void kproj_common_mode_kernel(bf16_t* gw, cons
 // uses the bf16-rounded O, so the rows of dS do not sum to zero exactly), and that spurious sum multiplies the mean of x, which
 // is 4-8 x larger than x's token-dependent part after a LayerNorm with a bias: measured on SegOFA-Base (tools/kproj_err.py,
 // encoder layer 5) k_proj.weight rel-L2 against the fp32 reference 0.119 as computed, 0.017 with this rank-1 term removed.
-extern "C" int ifseg_kproj_common_mode(void* gw, const void* db, const float* xsum_part, int nblk, int N, int C, int rows,
-                                       void* stream) {
+extern "C" int ifseg_kproj_common_mode(void* gw, const void* db, const float* xmean, int N, int C, void* stream) {
   (void)hipGetLastError();
-  if (!gw || !db || !xsum_part || nblk <= 0 || N <= 0 || C <= 0 || rows <= 0) return IFSEG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(kproj_common_mode_kernel, dim3((C + 1023) / 1024, N < 256 ? N : 256), dim3(256), 0, (hipStream_t)stream,
-                     (bf16_t*)gw, (const bf16_t*)db, xsum_part, nblk, N, C, 1.f / (float)rows);
+  if (!gw || !db || !xmean || N <= 0 || C <= 0 || (C & 7) || ((size_t)gw & 15) || ((size_t)xmean & 15)) return IFSEG_ERR_BAD_ARG;
+  const long long threads = (long long)N * C / 8;
+  hipLaunchKernelGGL(kproj_common_mode_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (bf16_t*)gw, (const bf16_t*)db, xmean, N, C);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

@@ -305,7 +305,7 @@ class _AttnBwdArgs(ctypes.Structure):
                 + [(n, c_int) for n in ("rel_mode", "P", "code_bias", "n2d", "causal", "nparts")]
                 + [(n, c_void_p) for n in ("gcode", "rel2d", "rel1d", "relx", "gain", "drel2d_part", "drel1d_part",
                                            "drelx_part")]   # field order == ifseg_attn_bwd_args
-                + [("dq_scale", c_float), ("dpq_scale", c_float), ("grid_w", c_int), ("phases", c_int)])
+                + [("dq_scale", c_float), ("dpq_scale", c_float), ("grid_w", c_int), ("phases", c_int), ("dgain_rows", c_void_p)])
 
 
 def _p(t):
@@ -339,8 +339,9 @@ ATTN_BWD_DELTA, ATTN_BWD_DKV, ATTN_BWD_DQ = 1, 2, 4
 
 def attn_bwd(q, k, v, pos_q, pos_k, out, dout, lse, delta, dq, dk, dv, dpq_part, dpk_part, B, H, T, S, rel=None,
              causal=False, P=None, gain=None, dq_scale=1.0, dpq_scale=1.0, drel2d_part=None, drel1d_part=None,
-             drelx_part=None, nparts=0, phases=0):
+             drelx_part=None, nparts=0, phases=0, dgain_rows=None):
     a = _AttnBwdArgs()
+    a.dgain_rows = _p(dgain_rows)
     assert all(t is None or t.dtype == torch.bfloat16 for t in (dpq_part, dpk_part)), "abs-pos partials are bf16"
     if rel is not None:
         P = rel.P
@@ -621,19 +622,24 @@ def colsum(x, part):
     return part
 
 
-def kproj_common_mode(gw, db, x, part=None):
-    """gw [N, C] -= db [N] (x) mean_rows(x): the key-projection weight gradient without the product of dK's spurious column sum
-    and the token-common component of its input (csrc/rowops.hip: ifseg_kproj_common_mode).  x [rows, C] bf16; `part`: a
-    [COLSUM_BLOCKS, C] fp32 workspace that already holds x's partial column sums (several projections of the same x), else
-    computed here."""
+def col_mean(x, ws=None):
+    """fp32 [C] column means of x [rows, C] bf16 (two launches: partial column sums, their sum); ws: a
+    [COLSUM_BLOCKS + 1, C] fp32 workspace whose last row receives the result"""
+    C = x.shape[-1]
+    if ws is None:
+        ws = torch.empty(COLSUM_BLOCKS + 1, C, dtype=torch.float32, device=x.device)
+    colsum(x, ws[:COLSUM_BLOCKS])
+    reduce_parts(ws[:COLSUM_BLOCKS], ws[COLSUM_BLOCKS], 1, COLSUM_BLOCKS, C, scale=1.0 / (x.numel() // C))
+    return ws[COLSUM_BLOCKS]
+
+
+def kproj_common_mode(gw, db, xmean):
+    """gw [N, C] -= db [N] (x) xmean [C]: the key-projection weight gradient without the product of dK's spurious column sum
+    and the token-common component of its input (csrc/rowops.hip: ifseg_kproj_common_mode; xmean = col_mean(x))"""
     N, C = gw.shape
     assert gw.is_contiguous() and gw.dtype == torch.bfloat16 and db.dtype == torch.bfloat16 and db.is_contiguous()
-    if part is None:
-        part = colsum(x, torch.empty(COLSUM_BLOCKS, C, dtype=torch.float32, device=gw.device))
-    rows = x.numel() // C
-    _check(lib().ifseg_kproj_common_mode(_ptr(gw), _ptr(db), _ptr(part), c_int(COLSUM_BLOCKS), c_int(N), c_int(C), c_int(rows),
-                                         _stream()), "kproj_common_mode")
-    return part
+    assert xmean.dtype == torch.float32 and xmean.numel() == C
+    _check(lib().ifseg_kproj_common_mode(_ptr(gw), _ptr(db), _ptr(xmean), c_int(N), c_int(C), _stream()), "kproj_common_mode")
 
 
 def embed_bag_mean(table, ids, ends, add, out):

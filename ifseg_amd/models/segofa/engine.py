@@ -94,7 +94,10 @@ class HipEngine:
         # attention backward with the batch inside the workgroup (csrc/attention_bi.hip): the bias is a dense batch-invariant
         # operand built once per layer from parameters, sum_b dS leaves the dQ kernel once per tile.  IFSEG_ATTN_BI=0: the
         # round-3 kernels (one workgroup per (batch, head, tile), bias regenerated per batch element).
-        self.attn_bi = os.environ.get("IFSEG_ATTN_BI", "1") != "0"
+        # Default "auto": measured in the step (DESIGN, round 4) the batch-inner pair is ahead on grids that are not 32 wide
+        # (SegOFA-Large at 640^2: 90.7 vs 99.5 ms per step) and behind on the 32-wide Base grid (17.7 vs 17.2 ms), where the
+        # round-3 pair runs two workgroups per CU side by side with the weight-gradient GEMMs.
+        self.attn_bi = os.environ.get("IFSEG_ATTN_BI", "auto")
         # k_proj.weight gradients without the product of dK's spurious column sum and the token mean of the projection's input
         # (an exact identity: sum_j dK_j = 0; csrc/rowops.hip ifseg_kproj_common_mode).  IFSEG_NO_KPROJ_FIX=1: as computed.
         self.kproj_fix = os.environ.get("IFSEG_NO_KPROJ_FIX") is None
@@ -848,7 +851,7 @@ class HipEngine:
                                        [(True, g["enc_idx1d"])])
         (e_rx,) = self._rel_tables_all("e_x", [None] * cfg.enc_layers, [(False, g["enc_idxx"])])
         x_pre = None
-        bi = self.attn_bi and need_grad and w <= 64
+        bi = need_grad and w <= 64 and w % 8 == 0 and (self.attn_bi == "1" or (self.attn_bi == "auto" and w != 32))
         ctx["dense"] = {}
         if bi:
             # parameters only: every layer's dense bias on the side stream, under the first blocks of the forward
@@ -1352,8 +1355,13 @@ class HipEngine:
         if rel is not None:
             parts = [gbuf("g_relp%d_%d" % (i, t.shape[1]), (H, nparts, t.shape[1]), torch.float32)
                      for i, t in enumerate((rel.rel2d, rel.rel1d, rel.relx))]
+        # per-row terms of d c_attn (sum_j P dP = dO . O_pre) from the dQ kernel: no division by c_attn anywhere
+        dgr = gbuf("g_dgain_rows_%d" % T, (B, H, T), torch.float32)
+        ones = self.ws.get("ones_h")
+        if ones is None or ones.numel() != H:
+            ones = self.ws["ones_h"] = torch.ones(H, dtype=torch.float32, device=self.device)
         kw = dict(rel=rel, causal=causal, gain=gain, dq_scale=scaling, dpq_scale=scaling, drel2d_part=parts[0],
-                  drel1d_part=parts[1], drelx_part=parts[2], nparts=nparts)
+                  drel1d_part=parts[1], drelx_part=parts[2], nparts=nparts, dgain_rows=dgr)
         args = (q, k, v, pq, pk, o, do, lse, delta, dq, dk, dv, dpq_part, dpk_part, B, H, T, S)
         timing = self.attn_bwd_timing
         if timing is not None:
@@ -1396,7 +1404,8 @@ class HipEngine:
                 for (tabname, idx), part in zip(rel_grads, parts):
                     if tabname is not None:
                         tables.append((part, idx, self._table_acc(tabname)))
-            hip.attn_bwd_reduce(B, H, T, S, C, dpq_part, dpk_part, dpq_acc, dpk_acc, not first_pos, delta, gain,
+            # (d c_attn[h] = sum of the dQ kernel's row terms: `ones` stands in for the gain the round-3 formula divided delta by)
+            hip.attn_bwd_reduce(B, H, T, S, C, dpq_part, dpk_part, dpq_acc, dpk_acc, not first_pos, dgr, ones,
                                 self.G(gain_name), nparts if rel is not None else 1, tables)
         if "reduce" not in _EXP_SKIP:
             self._side_do(reductions)
@@ -1514,7 +1523,7 @@ class HipEngine:
                          self._fused(self.g16, a_ + ".q_proj.weight", 3 * C, C),
                          self._fused(self.g16, a_ + ".q_proj.bias", 3 * C), dx_out=dxn)
         if self.kproj_fix:
-            self._kfix_tasks.append((G(a_ + ".k_proj.weight"), G(a_ + ".k_proj.bias"), s["xn"], None))
+            self._kfix_tasks.append((G(a_ + ".k_proj.weight"), G(a_ + ".k_proj.bias"), s["xn"], tg))
         dx = gbuf("g_dx0_%d" % rows, (rows, C))
         self._ln_bwd_fused(dxn, s["x"].view(rows, C), p + ln1, tg + "_ln1", dx, dx1, nxt)
         return dx                # the caller flushes the side queue together with the layer's hook
@@ -1808,16 +1817,12 @@ class HipEngine:
         # ffn_layernorm's dgamma / dbeta from fc2's (now final) weight / bias gradient
         # key projections: the weight gradient without (spurious column sum of dK) x (token-common component of the input)
         kf, self._kfix_tasks = self._kfix_tasks, []
-        for gw, gb, x, shared in kf:
-            if shared is None:
-                hip.kproj_common_mode(gw, gb, x)
-            else:
-                key = "g_xsum_" + shared
-                part = self.ws.get(key) if key in self._xsum_done else None
-                if part is None:
-                    part = hip.colsum(x, self.buf(key, (hip.COLSUM_BLOCKS, x.shape[-1]), torch.float32))
-                    self._xsum_done.add(key)
-                hip.kproj_common_mode(gw, gb, x, part)
+        for gw, gb, x, tag in kf:
+            key = "g_xmean_" + tag
+            if key not in self._xsum_done:       # (the decoder's cross-attention key projections all read the encoder output)
+                hip.col_mean(x, self.buf(key, (hip.COLSUM_BLOCKS + 1, x.shape[-1]), torch.float32))
+                self._xsum_done.add(key)
+            hip.kproj_common_mode(gw, gb, self.ws[key][hip.COLSUM_BLOCKS])
         pg, self._ffn_pg_tasks = self._ffn_pg_tasks, []
         for w2, dw2, db2, gam, bet, dgam, dbet, dy_, u_, mu_, rs_ in pg:
             hip.ffn_ln_param_grads(w2, dw2, db2, gam, bet, dgam, dbet, dy=dy_, u=u_, mean=mu_, rstd=rs_)

@@ -171,6 +171,8 @@ typedef struct ifseg_attn_bwd_args {
   int phases; /* 0 = everything; else a mask: 1 = delta, 2 = dK/dV kernel, 4 = dQ kernel.  The dQ kernel only needs
                  delta, so a caller may launch {1|2} and {4} on two streams (ordered by an event after delta): the two
                  kernels then fill each other's partially occupied last round of workgroups. */
+  float* dgain_rows; /* optional fp32 [B,H,T], written by the dQ kernel: sum_j P_ij dP_ij = dout_i . (P v)_i -- the per-row terms of
+                 d c_attn[h] without the division of delta by c_attn (0 / 0 at c_attn = 0): sum them instead of delta / gain */
 } ifseg_attn_bwd_args;
 #define IFSEG_ATTN_BWD_DELTA 1
 #define IFSEG_ATTN_BWD_DKV 2
@@ -337,9 +339,9 @@ int ifseg_colsum_bf16(const void* x, float* part, int nblk_rows, int M, int N, i
 /* out[r] = table[ids[r]] + add  (embed_tokens + type_embedding, encoder_module.py:400-406) */
 /* gw [N, C] (bf16, a key projection's weight gradient dK^T x) -= db [N] (x) mean_rows(x) [C]: sum_j dK_j = 0 in exact arithmetic
  * (softmax shift invariance; the reference's k_proj.bias gradient is float noise), so this removes only the product of the
- * spurious bf16 column sum of dK with the token-common component of x.  xsum_part [nblk, C]: partial column sums of x
- * (ifseg_colsum_bf16), rows = the number of rows of x.  Autograd of unify_multihead_attention.py:327-346. */
-int ifseg_kproj_common_mode(void* gw, const void* db, const float* xsum_part, int nblk, int N, int C, int rows, void* stream);
+ * spurious bf16 column sum of dK with the token-common component of x.  xmean [C] fp32: the column means of x
+ * (ifseg_colsum_bf16 + ifseg_reduce_parts).  Autograd of unify_multihead_attention.py:327-346. */
+int ifseg_kproj_common_mode(void* gw, const void* db, const float* xmean, int N, int C, void* stream);
 int ifseg_embed_rows(const void* table, const long long* ids, const void* add, void* out, int n, int C, int rpb,
                      long long o_bs, int ldo, void* stream);
 /* Image-free patch embeddings: out[b,p,:] = mean of table rows ids[b, ends[b,p-1]:ends[b,p]] + add

@@ -267,6 +267,7 @@ def test_attn_bwd(case):
     pq, pk = _rand((T, C), dev, 23, 0.35), _rand((S, C), dev, 24)
     dout = _rand((B, T, C), dev, 25)
     gain = (1.0 + 0.2 * torch.randn(H, generator=torch.Generator().manual_seed(5))).to(dev).to(torch.bfloat16)
+    gain[0] = 0.0          # a head gain of exactly zero: d c_attn must not be computed as delta / c_attn
     tabs = None
     if P is not None:
         gcode, code_bias, n2d = _grid_codes(gh, gw)
@@ -298,14 +299,16 @@ def test_attn_bwd(case):
     parts = [None, None, None]
     if rel is not None:
         parts = [torch.full((H, nparts, n), 7.0, device=dev) for n in (n2d, 2 * Lt - 1, 2)]
+    dgr = torch.full((B, H, T), 9.0, device=dev)
     hip.attn_bwd(q, k, v, pq, pk, out, dout, lse, delta, dq, dk, dv, dpq, dpk, B, H, T, S, rel=rel, causal=causal,
                  gain=gain, dq_scale=0.5, dpq_scale=0.25, drel2d_part=parts[0], drel1d_part=parts[1],
-                 drelx_part=parts[2], nparts=nparts)
+                 drelx_part=parts[2], nparts=nparts, dgain_rows=dgr)
     torch.cuda.synchronize()
     errs = {"dq": _rel(dq, qf.grad * 0.5), "dk": _rel(dk, kf.grad), "dv": _rel(dv, vf.grad),
             "dpq": _rel(dpq.float().sum(0), pqf.grad * 0.25), "dpk": _rel(dpk.float().sum(0), pkf.grad)}
-    dgain = (delta.sum((0, 2)) / gain.float())
-    errs["dgain"] = _rel(dgain, gf.grad)
+    # d c_attn[h] = sum over (b, t) of the dQ kernel's row terms sum_j P dP: exact at c_attn = 0, where delta / c_attn is 0 / 0
+    assert torch.isfinite(dgr).all() and gf.grad[0].abs().item() > 0
+    errs["dgain"] = _rel(dgr.sum((0, 2)), gf.grad)
     info = {}
     if rel is not None:
         # table grads are sums of dS = P*(dP - delta) with heavy cancellation; the kernel's delta is
