@@ -170,6 +170,15 @@ def test_base_config1_batch2_vs_reference_golden(golden_dir):
     _golden_case(golden_dir, "base_c1_b2.npz", O.base_config(), 2)
 
 
+def test_base_config1_with_the_batch_inner_attention_backward(golden_dir, monkeypatch):
+    """The same golden through csrc/attention_bi.hip (IFSEG_ATTN_BI=1; the default `auto` takes that path only on grids that are
+    not 32 wide, where it is the faster one): dense batch-invariant biases built on the side stream, workgroups of four
+    batch elements, sum_b dS -> operand / table gradients -- all 359 gradient tensors element-wise, both autograd modes."""
+    monkeypatch.setenv("IFSEG_ATTN_BI", "1")
+    m, _, _, _ = _golden_case(golden_dir, "base_c1_b2.npz", O.base_config(), 2)
+    assert m.engine.attn_bi == "1" and len(m.engine.ctx.get("dense", {})) == 13      # 6 + 6 self-attention biases, one cross
+
+
 def test_base_config3_geometry_vs_reference_golden(golden_dir):
     """BASELINE configs[2] per-GPU geometry: Base width, 150 ADE20K classes, L = 215 prompt tokens, T_enc = 1239 (a T
     that is a multiple of nothing), log-spaced token buckets beyond |i-j| = 128 (reference outputs: base_c3.npz, generated
