@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       const bool plain = cbias || (!a.rel_mode && !a.causal && !a.dense);
       // a dense fp32 bias alone (resized-grid evaluation: the causal mask travels inside it): the lane's query row is fixed
       // and its 16 keys are four runs of four, so the accumulator is seeded with four 16-byte loads per 32-key block
-      const bool dfast = a.dense && !a.rel_mode && !a.causal && !(a.dense_ld & 3);
+      // (with `causal` the mask travels inside the dense bias as -inf; the flag then only drives the tile schedule)
+      const bool dfast = a.dense && !a.rel_mode && !(a.dense_ld & 3);
       f32x16 s[2];
       auto s_mfma = [&]() {
 #pragma unroll

@@ -101,6 +101,7 @@ class HipEngine:
         # k_proj.weight gradients without the product of dK's spurious column sum and the token mean of the projection's input
         # (an exact identity: sum_j dK_j = 0; csrc/rowops.hip ifseg_kproj_common_mode).  IFSEG_NO_KPROJ_FIX=1: as computed.
         self.kproj_fix = os.environ.get("IFSEG_NO_KPROJ_FIX") is None
+        self.fwd_dense = os.environ.get("IFSEG_ATTN_FWD_DENSE") == "1"
         self._ffn_pg_tasks = []
         self._train_fwd = False
         # where the NEXT batch's frozen-trunk pass is launched: "fwd" = at the start of this step's forward, "e<k>" = when
@@ -427,6 +428,12 @@ class HipEngine:
             self.ws[key] = d
         hip.attn_dense_bias(d, pq, pk, rel=rel, causal=causal, P=P)
         return d
+
+    def _dense_wait(self):
+        """(forward seeded from the dense biases) the main stream waits once per stack for the side stream's builds"""
+        ev = self.ctx_building.pop("dense_pending", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def _geometry(self, h, w, L):
         """index tables for a (h, w) feature grid and L text tokens (device tensors, cached)."""
@@ -852,13 +859,19 @@ class HipEngine:
         (e_rx,) = self._rel_tables_all("e_x", [None] * cfg.enc_layers, [(False, g["enc_idxx"])])
         x_pre = None
         bi = need_grad and w <= 64 and w % 8 == 0 and (self.attn_bi == "1" or (self.attn_bi == "auto" and w != 32))
+        bi_which = os.environ.get("IFSEG_ATTN_BI_WHICH", "e+d+c").split("+") if bi else []      # (experiment) subset of {e, d, c}
         ctx["dense"] = {}
-        if bi:
+        if bi and "e" in bi_which:
             # parameters only: every layer's dense bias on the side stream, under the first blocks of the forward
             with self._wgrad():
                 for l in range(cfg.enc_layers):
                     rel = hip.RelBias(P, g["gcode"], g["code_bias"], e_r2[l], e_r1[l], e_rx[l], grid_w=w)
                     ctx["dense"]["e%d" % l] = self._dense_bias("e%d" % l, H, T, T, ctx["e_pq"], ctx["e_pk"], rel, False, P)
+                if self.fwd_dense and self.overlap:
+                    if getattr(self, "_dense_ev_e", None) is None:
+                        self._dense_ev_e = torch.cuda.Event()
+                    self._dense_ev_e.record(self._side)
+                    ctx["dense_pending"] = self._dense_ev_e
         for l in range(cfg.enc_layers):
             p = "%slayers.%d." % (e, l)
             tg = "e%d" % l
@@ -928,16 +941,19 @@ class HipEngine:
         y_pre = None
         if bi:
             with self._wgrad():
-                for l in range(cfg.dec_layers):
+                for l in range(cfg.dec_layers if "d" in bi_which else 0):
                     rel = hip.RelBias(P, g["gcode"], g["code_bias"], d_r2[l], d_r1[l], d_rx[l], grid_w=w)
                     ctx["dense"]["d%d" % l] = self._dense_bias("d%d" % l, H, Td, Td, ctx["d_spq"], ctx["d_spk"], rel, causal, P)
                 # the cross-attention bias has no per-layer part (decoder_module.py:556-558): one operand for all layers
-                ctx["dense"]["dc"] = self._dense_bias("dc", H, Td, T, cpq, cpk, None, False, None)
+                if "c" in bi_which:
+                    ctx["dense"]["dc"] = self._dense_bias("dc", H, Td, T, cpq, cpk, None, False, None)
                 if self.overlap:        # (a dedicated event: the ring of `_ev` wraps around long before the backward waits for it)
                     if getattr(self, "_dense_ev", None) is None:
                         self._dense_ev = torch.cuda.Event()
                     self._dense_ev.record(self._side)
                     ctx["dense_ready"] = self._dense_ev
+                    if self.fwd_dense:
+                        ctx["dense_pending"] = self._dense_ev
         for l in range(cfg.dec_layers):
             p = "%slayers.%d." % (d, l)
             tg = "d%d" % l
@@ -1114,8 +1130,16 @@ class HipEngine:
         o = buf(tg + "_o", (B, T, C))
         lse = buf(tg + "_lse", (B, H, T), torch.float32)
         gain = self._gain32(tg + "_sa", a_ + ".c_attn")
-        hip.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], pq, pk, o, lse, B, H, T, T, rel=rel,
-                     causal=causal, gain=gain, dense_bias=dense)
+        dd = self.ctx_building.get("dense", {}).get(tg) if (self.fwd_dense and self.ctx_building is not None) else None
+        if dd is not None:
+            # (experiment, IFSEG_ATTN_FWD_DENSE=1) the forward seeded from the layer's dense bias too: no abs-pos columns, no
+            # table look-ups, one bias path for every grid width; the causal flag only drives the tile schedule
+            self._dense_wait()
+            hip.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], None, None, o, lse, B, H, T, T, rel=None,
+                         causal=causal, P=rel.P, gain=gain, dense_bias=dd.D)
+        else:
+            hip.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], pq, pk, o, lse, B, H, T, T, rel=rel,
+                         causal=causal, gain=gain, dense_bias=dense)
         a = buf(tg + "_a", (B * T, C))
         hip.linear_fwd(o.view(B * T, C), W(a_ + ".out_proj.weight"), W(a_ + ".out_proj.bias"), out=a)
         x1 = buf(tg + "_x1", (B, T, C))
@@ -1147,7 +1171,12 @@ class HipEngine:
         o = buf(tg + "_co", (B, Td, C))
         lse = buf(tg + "_clse", (B, H, Td), torch.float32)
         gain = self._gain32(tg + "_ca", a_ + ".c_attn")
-        hip.attn_fwd(q, kv[:, :, :C], kv[:, :, C:], cpq, cpk, o, lse, B, H, Td, Te, gain=gain)
+        dd = self.ctx_building.get("dense", {}).get("dc") if (self.fwd_dense and self.ctx_building is not None) else None
+        if dd is not None:
+            self._dense_wait()
+            hip.attn_fwd(q, kv[:, :, :C], kv[:, :, C:], None, None, o, lse, B, H, Td, Te, gain=gain, dense_bias=dd.D)
+        else:
+            hip.attn_fwd(q, kv[:, :, :C], kv[:, :, C:], cpq, cpk, o, lse, B, H, Td, Te, gain=gain)
         a = buf(tg + "_ca_a", (B * Td, C))
         hip.linear_fwd(o.view(B * Td, C), W(a_ + ".out_proj.weight"), W(a_ + ".out_proj.bias"), out=a)
         y2 = buf(tg + "_y2", (B, Td, C))
