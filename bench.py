@@ -238,6 +238,7 @@ def main():
         return trainer.train_step([ring[i % RING]], prefetch=nxt, graph=use_graph[0])
 
     def sync():
+        torch.cuda.synchronize()        # (the direct RCCL collectives of a step are stream-ordered: drained before the c10d barrier)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -346,6 +347,12 @@ def main():
     torch.cuda.synchronize()
     ors = [hip.prof_read(k) for k in ok_]
     hip.prof_enable(0)
+    rccl_stats = trainer.reducer.stats()
+    if world > 1 and rccl_stats["mode"] != "direct" and os.environ.get("IFSEG_REDUCE_MODE") is None:
+        raise RuntimeError("bench.py: %d ranks but the gradient all-reduce did not run through the direct RCCL communicator (%r)"
+                           % (world, rccl_stats))
+    if world > 1 and rccl_stats["ranks"] != world:
+        raise RuntimeError("bench.py: the RCCL communicator spans %d ranks, WORLD_SIZE is %d" % (rccl_stats["ranks"], world))
     if rank == 0:
         imgs = a.batch * world * a.steps
         value = imgs / dt
@@ -358,7 +365,7 @@ def main():
             "config": {"workload": ("IMAGE-FREE step (not the headline config) -- " if a.image_free else "") + C["tag"] + ", batch %d/GPU, %dx%d, %d classes (L=%d), "
                                    "frozen %s trunk%s, dropout %.2f / drop-path %.2f; step = fwd + upsample/CE loss + bwd + clip + Adam%s"
                                    % (a.batch, size, size, a.nseg, task.src_len, C["trunk"],
-                                      "" if a.no_prefetch else " (run one batch ahead on a second stream; two alternating batches)",
+                                      "" if a.no_prefetch else " (one pass per %d future batches on a second stream; a ring of %d synthetic batches, every batch through the trunk exactly once)" % (trainer.eng.trunk_lookahead, RING),
                                       a.dropout, a.drop_path,
                                       "; every step is one replay of the HIP-graph-captured update" if graphed else "; steps enqueued from the host"),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "loss": round(loss, 4)},
@@ -374,11 +381,15 @@ def main():
             "roofline_other_kernels": {r["kind"]: _one_roofline(r, extra) for r in ors},
             "kernel_families_ms_per_step": {f["kind"]: round(f["ms"], 3) for f in fam},
         }
+        # the data-parallel leg as it actually ran (live from the reducer): N ranks in ONE RCCL communicator, how many
+        # collectives and bytes per step.  Any N > 1 run that did not go through the direct communicator fails loudly below.
+        out["rccl"] = rccl_stats
         if steady is not None:
             out["steady_state"] = steady
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.nseg, task.src_len, arch, size)
         print(json.dumps(out))
+    trainer.close()
     if world > 1:
         dist.destroy_process_group()
 

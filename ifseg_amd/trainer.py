@@ -27,6 +27,13 @@ def layer_slices(eng):
     for n in eng.trainable_names():
         parts = n.split(".")
         key = ".".join(parts[:3]) + "." if parts[1] == "layers" else parts[0] + "."
+        if (parts[0], parts[1]) in (("encoder", "token_rel_pos_table_list"), ("encoder", "image_rel_pos_table_list"),
+                                    ("decoder", "seg_rel_pos_table_list")):
+            # a layer's rel-pos tables sit right behind it in the arena and are final when its hook fires (the engine casts
+            # their accumulators into the gradient arena before `_notify`): part of the layer's slice -- as top-level tensors
+            # they split every pair of neighbouring layers, and no two layer slices ever merged into one bucket.  (The decoder's
+            # token / image tables never receive a gradient and live at the end of the arena: top-level.)
+            key = "%s.layers.%s." % (parts[0], parts[2])
         lo, hi = eng.offs[n], eng.offs[n] + math.prod(eng.shapes[n])
         a, b = sl.get(key, (lo, hi))
         sl[key] = (min(a, lo), max(b, hi))
@@ -45,6 +52,7 @@ class ArenaReducer:
     def __init__(self, flat, slices, n, fp32_accumulate=None):
         self.flat, self.slices, self.n = flat, slices, n
         self.works, self.done = [], []
+        self._cnt, self._last = [0, 0], (0, 0)      # collectives / bytes of the step in flight, of the last finished step
         # fp32_accumulate (IFSEG_REDUCE_FP32=1): a bf16 ring sum over 8 ranks rounds after every hop (~3 bits of the sum);
         # with this option every slice travels and is summed in fp32 (twice the bytes on the links: 427 MB instead of
         # 213 MB for SegOFA-Base, ~0.7 ms over the full xGMI mesh) and is rounded to bf16 ONCE, after the sum.  The
@@ -69,21 +77,46 @@ class ArenaReducer:
         self.direct = None
         if self.mode == "direct" and dist.is_initialized() and dist.get_backend() == "nccl" and flat.is_cuda:
             from .rccl import RcclComm
+            import sys
+            err = None
             try:
                 self.direct = RcclComm(flat.device)
             except (OSError, AttributeError, RuntimeError) as exc:
-                # (every rank takes the same branch: the failure modes are a missing librccl.so / symbol or a communicator
-                # that cannot be created -- not data dependent).  Still RCCL, through torch.distributed, and said loudly.
-                import sys
-                sys.stderr.write("ifseg_amd: direct RCCL communicator unavailable (%s): gradient all-reduce falls back to "
-                                 "torch.distributed's all_reduce (measured ~20 %% slower per step, DESIGN.md section 5)\n" % exc)
+                err = exc
+            # the ranks AGREE on the outcome: a communicator that came up on some ranks only would leave them in
+            # ncclAllReduce while the others sit in a c10d collective -- the job hangs.  One MIN over a success flag through
+            # the process group that exists anyway; any failure anywhere sends every rank to torch.distributed's all_reduce.
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=flat.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            torch.cuda.synchronize(flat.device)
+            if int(ok.item()) == 0:
+                if self.direct is not None:
+                    self.direct.destroy()
+                sys.stderr.write("ifseg_amd: direct RCCL communicator unavailable on %s (%s): every rank falls back to "
+                                 "torch.distributed's all_reduce (measured ~20 %% slower per step, DESIGN.md section 5)\n"
+                                 % ("this rank" if err is not None else "another rank", err))
                 self.direct, self.mode = None, "c10d"
         # gloo (functional runs: N ranks on one GPU, CPU tests) has no bf16 device reduction: staged through fp32 host
         # memory, synchronously.  The production backend is "nccl" (= RCCL over xGMI), asynchronous on its own stream.
         self.staged = dist.is_initialized() and dist.get_backend() == "gloo" and flat.is_cuda
 
+    def stats(self):
+        """what the last finished step put on the links: {"ranks", "mode", "buckets", "bytes"} (bench.py's `rccl` object)"""
+        return {"ranks": self.direct.world if self.direct is not None else (dist.get_world_size() if dist.is_initialized() else 1),
+                "mode": self.mode if not self.staged else "gloo-staged", "buckets": self._last[0], "bytes": self._last[1],
+                "fp32_accumulate": self.fp32}
+
+    def close(self):
+        """destroy the direct communicator (after the last step: nothing of it may still be queued)"""
+        if self.direct is not None:
+            torch.cuda.synchronize(self.flat.device)
+            self.direct.destroy()
+            self.direct = None
+
     def _reduce(self, lo, hi):
         mode = self.mode
+        self._cnt[0] += 1
+        self._cnt[1] += (hi - lo) * (4 if self.fp32 else self.flat.element_size())
         if mode == "none":                                   # (measurement only: tools/rccl_phase_probe.py)
             return
         if self.staged:
@@ -121,6 +154,9 @@ class ArenaReducer:
             self.works.append(_W(end))
         elif self.fp32:
             wide = self.flat[lo:hi].float()
+            if wide.is_cuda:
+                # allocated on the calling (weight-gradient) stream, read back by finish() on the main stream
+                wide.record_stream(torch.cuda.default_stream(wide.device))
             self._wide.append((lo, hi, wide))
             self.works.append(dist.all_reduce(wide, async_op=True))
         else:
@@ -157,6 +193,7 @@ class ArenaReducer:
         for lo, hi, wide in self._wide:
             self.flat[lo:hi].copy_(wide)            # one rounding, after the fp32 sum
         self.works, self.done, self._wide = [], [], []
+        self._last, self._cnt = (self._cnt[0], self._cnt[1]), [0, 0]
 
 
 class Trainer:
@@ -256,8 +293,19 @@ class Trainer:
                     pin = self._log_pin = pin.pin_memory()
                 self._log_pin_i = 0
             r = self._log_pin_i = (self._log_pin_i + 1) % pin.shape[0]
+            #  with lazy logs nothing in a step synchronises the host: a row of the ring is reused only after the
+            # asynchronous copy that last read it has executed (one event per row)
+            evs = getattr(self, "_log_pin_ev", None)
+            if evs is None or len(evs) != pin.shape[0]:
+                evs = self._log_pin_ev = [None] * pin.shape[0]
+            if evs[r] is not None:
+                evs[r].synchronize()
             pin[r, :len(scalars)] = torch.tensor(scalars, dtype=torch.float64)
             flat.append(pin[r, :len(scalars)].to(self.device, non_blocking=True))
+            if torch.device(self.device).type == "cuda":
+                if evs[r] is None:
+                    evs[r] = torch.cuda.Event()
+                evs[r].record()
         order = [(i, k, n, shape, (None if si is None else nt + si)) for i, k, n, shape, si in keys]
         buf = torch.cat(flat)
         if dist.get_backend() == "gloo" and buf.is_cuda:        # functional runs of N ranks on one GPU
@@ -434,6 +482,19 @@ class Trainer:
         # the captured log tensors are the graph's static outputs, rewritten by every replay: hand out copies, so that a
         # caller aggregating logs over an interval (fairseq's reduce_metrics) keeps each step's values
         return [{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in lg.items()} for lg in ent[1]]
+
+    def close(self):
+        """end of training: nothing of the direct RCCL communicator may still be queued when it is destroyed, and no c10d
+        collective (a checkpoint barrier, destroy_process_group) may be issued beside queued direct ones"""
+        if torch.device(self.device).type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self.reducer.close()
+
+    def quiesce(self):
+        """before a torch.distributed collective OUTSIDE the step (validation, checkpoint barrier): the direct communicator's
+        collectives are stream-ordered on this rank's streams, c10d's on its own -- drain the device first"""
+        if torch.device(self.device).type == "cuda":
+            torch.cuda.synchronize(self.device)
 
     def grad_norm(self):
         """global gradient norm of the last update, after the world/sample_size scaling (host sync: logging only)"""

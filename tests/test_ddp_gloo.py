@@ -139,3 +139,55 @@ def test_logging_outputs_and_histograms_are_summed_over_ranks():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+@pytest.mark.parametrize("arch,nseg,size", [("segofa_base", 150, 512), ("segofa_large", 171, 640)])
+def test_bucket_plan_covers_the_gradient_arena_exactly_once(arch, nseg, size, monkeypatch):
+    """the reducer's bucket plan on the REAL arena layouts of BASELINE configs[2] / [3] (built on the meta
+    device: no weights are allocated).  Hooks fire in the engine's backward order (decoder layers last-to-first, `decoder.`,
+    encoder layers last-to-first, `encoder.`); the collectives issued by on_ready() + finish() must tile [0, n_train) with no
+    gap and no overlap, and merge layers into few buckets (48 MB default; torch DDP: 25 MB,
+    custom_fairseq/fairseq/models/distributed_fairseq_model.py:57-67)."""
+    from ifseg_amd.models.segofa import SegOFAModel, make_config
+    from ifseg_amd.models.segofa.engine import _pad8
+    from ifseg_amd.trainer import ArenaReducer, layer_slices
+    with torch.device("meta"):
+        m = SegOFAModel(make_config(arch, num_seg_tokens=nseg, vocab_size=59458, patch_image_size=size))
+    eng = m.engine
+    order, ntn = eng._arena_order()
+    names = dict(m.named_parameters())
+
+    class Layout:            # what Trainer reads from a packed engine
+        offs, shapes = {}, {n: tuple(names[n].shape) for n in order}
+
+        @staticmethod
+        def trainable_names():
+            return order[:ntn]
+    off = 0
+    for n in order:
+        Layout.offs[n] = off
+        off += _pad8(names[n].numel())
+    n_train = Layout.offs[order[ntn]] if ntn < len(order) else off
+    monkeypatch.setenv("IFSEG_REDUCE_MODE", "none")
+    flat = torch.empty(n_train, dtype=torch.bfloat16, device="meta")
+    red = ArenaReducer(flat, layer_slices(Layout), n_train)
+    calls = []
+    red._reduce = lambda lo, hi: calls.append((lo, hi))
+    cfg = eng.cfg
+    for l in reversed(range(cfg.dec_layers)):
+        red.on_ready("decoder.layers.%d." % l)
+    red.on_ready("decoder.")
+    for l in reversed(range(cfg.enc_layers)):
+        red.on_ready("encoder.layers.%d." % l)
+    red.on_ready("encoder.")
+    in_backward = len(calls)
+    red.finish()
+    cur = 0
+    for lo, hi in sorted(calls):
+        assert lo == cur and hi > lo, (lo, hi, cur)          # no gap, no overlap
+        cur = hi
+    assert cur == n_train
+    nbytes = n_train * 2
+    # few, large collectives: the layers merge into ~48 MB buckets inside the backward, the rest (top-level tensors) in finish()
+    assert in_backward <= nbytes // (48 << 20) + 2 and len(calls) <= in_backward + 4, (in_backward, len(calls))
+    print(arch, "arena %.1f MB bf16 -> %d collectives (%d issued inside the backward)" % (nbytes / 2 ** 20, len(calls), in_backward))
