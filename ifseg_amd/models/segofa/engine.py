@@ -678,6 +678,14 @@ class HipEngine:
     def _gain32(self, tag, name):
         return self.Wf(name)       # fp32 [H] from the master copy
 
+    def weights_changed(self):
+        """Tell the engine that the bf16 parameters were edited behind its back in a way no version counter sees (an EMA swap or
+        a checkpoint restore through `p.data.copy_`): the next forward re-derives the fp32 copy of the LayerNorm / c_attn
+        operands and the cached resized rel-pos biases are retired.  (Optimizer steps after a backward, in-place edits of the
+        parameters themselves and load_state_dict are detected without this call.)"""
+        self._master_stale = True
+        self._wver += 1
+
     # ----------------------------------------------------------------- forward
     def forward(self, *args, **kw):
         prev = hip.set_stream(torch.cuda.current_stream().cuda_stream)    # one stream lookup per pass, not per launch
@@ -692,10 +700,18 @@ class HipEngine:
             if self.packed and not self.master_owned and not torch.cuda.is_current_stream_capturing():
                 # an external owner of the bf16 parameters (fairseq's optimizer, an EMA swap, a manual p.data.copy_) may
                 # have edited them since the last forward: the fp32 copy the LayerNorm / c_attn operands are read from
-                # follows on EVERY forward (one pass over the arena; entries whose bf16 rounding still matches keep
-                # their fp32 value).  With the bundled Trainer (`master_owned`) both copies are written by one kernel.
-                hip.sync_master(self.master, self.p16[: self.n_train])
-                self._master_stale = False
+                # follows (one pass over the arena; entries whose bf16 rounding still matches keep their fp32 value) -- on
+                # every TRAINING forward, and at evaluation only when a parameter's version counter has moved (ADVICE r3:
+                # a validation pass does not pay a full-arena sweep per batch).  A detected edit also retires the cached
+                # resized rel-pos biases, which were built from the old tables.
+                ver = sum(p._version for p in self.trainable_params())
+                changed = ver != getattr(self, "_pver_seen", None)
+                if need_grad or self._master_stale or changed:
+                    hip.sync_master(self.master, self.p16[: self.n_train])
+                    self._master_stale = False
+                if changed:
+                    self._pver_seen = ver
+                    self._wver += 1
             out = self._forward(*args, **kw)
             if need_grad:
                 self._gctx = self.ctx
@@ -1016,6 +1032,8 @@ class HipEngine:
             hip.resized_rel_bias(out[l], r2[l], r1[l], rx[l] if rx is not None else None, h, w, oh, oh, Lt, causal=causal)
         while len(cache) >= 2 * 16:
             cache.pop(next(iter(cache)))                  # least recently used
+        for k in [k for k in cache if k[-1] != self._wver]:      # entries of older weights can never be hit again (~0.5 GB each)
+            del cache[k]
         cache[key] = out
         return out
 
