@@ -88,7 +88,7 @@ constexpr int ST_L = 40960;             // dK/dV: [4][lse 32 | delta 32] fp32
 constexpr int STG_DQ = 40960, STG_DKV = 41984;
 constexpr int SLOT = 4096;              // dQ kernel: one wave's fp32 dS tile [32][32], chunk XOR (row & 7)
 constexpr int LDS_DQ = 2 * STG_DQ + 2 * 8 * SLOT;      // 147456
-constexpr int LDS_DKV = 3 * STG_DKV;                    // 125952: a ring of three stages
+constexpr int LDS_DKV = 2 * STG_DKV;                    // 83968
 
 // Block schedule of the streamed side under the causal mask ("tail-first" order: a grid row i sees grid columns j <= i and
 // every tail column; a tail row sees tail columns j <= i only).  The dense bias already holds -inf for every masked
@@ -98,15 +98,17 @@ struct Sched {
   __device__ __forceinline__ int block(int it) const { return it < g_end - g_begin ? g_begin + it : t_begin + (it - (g_end - g_begin)); }
 };
 
-// Both kernels: 8 waves = two GROUPS of four (one wave of each group per SIMD).  The groups run the same iteration with
-// a phase shift, separated by ONE s_barrier per 32-row block of the streamed side:
-//     group 0:  [load-side reads + S / dP MFMAs][exp, dS (VALU)][transposed reads + gradient MFMAs]
-//     group 1:  [gradient MFMAs of the PREVIOUS block][reads + S / dP MFMAs][exp, dS (VALU)]
-// so the VALU segment of one wave of a SIMD always lies beside an MFMA segment of the other (in lock step both waves of a
-// SIMD would want the matrix pipe, then the VALU, at the same time: v1 of these kernels, 122 / 116 us on the encoder shape).
-// Group 1's gradient MFMAs read the previous block's operand tiles: the dK/dV kernel keeps a ring of three stages, the dQ
-// kernel (whose LDS also holds the batch-sum slots) has each group-1 wave issue the next K tile of ITS batch element only
-// after its own last read of the previous one.
+// Loop structure of both kernels: one s_barrier per 32-row block of the streamed side; the stage of block n+1 is in flight
+// (LDS-DMA, issued right after the barrier) while block n is computed; every LDS read of a block is requested before its first
+// MFMA.  What was measured on the way (encoder shape, B = 8, dK/dV kernel alone; profiles/round4_attention_bi.md):
+//   v1  lock-step waves, reads next to their MFMAs ................................ 122.6 us
+//   v2  the two wave groups of a SIMD phase-shifted inside the barrier interval ..... 121.6 us  (no gain: dropped)
+//   v3  all LDS reads of a block up front ......................................... 106.2 us  (kept)
+//   v4  + gradient MFMAs of block n-1 under the row reads of block n .................. 110.7 us  (dropped)
+//   v5  + staging two blocks ahead, ring of three stages ............................ 112.2 us  (dropped)
+// Ablation of v2 (tools/r4_bi_exp2.sh): without the S/dP MFMAs 109.8, without exp 115.8, without the gradient MFMAs 96.0,
+// without any MFMA 88.2, without any MFMA and without staging 67.8, staging + barriers alone 67.3 us: two waves per SIMD do
+// not hide the block's dependent LDS round trips, and no single pipe is the bound.
 
 // ---------------------------------------------------------------------------------------------- dQ (+ sum_b dS)
 __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
@@ -222,33 +224,47 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
     if (rq < a.T) *reinterpret_cast<uint2*>(dbp + sc.block(itp) * 32) = make_uint2(pack2bf(s0, s1), pack2bf(s2, s3));
   };
 
-  U128 ud[2];
   float pdp = 0.f;
-  // S^T = bias tile + K Q^T, dP^T = V dO^T, dS^T -> this wave's slot of the batch sum and ud (bf16, the B operand of dQ)
-  auto scores = [&](int it) {
+  // One 32-key block: every LDS read of the block is requested up front (bias seeds, K rows, V rows, the transposed K
+  // fragments of the dQ MFMAs: 20 requests), then S^T = bias + K Q^T and dP^T = V dO^T, the exp / dS segment, this wave's dS
+  // tile into its slot of the batch sum, dQ^T += K^T dS^T.
+  auto block = [&](int it) {
     const unsigned char* stg = smem + (it & 1) * STG_DQ;
     const unsigned char* sK = stg + ST_A + bl * 4096;
     const unsigned char* sV = stg + ST_B + bl * 4096;
     const unsigned char* sD = stg + ST_D + qb * 4096;
     f32x16 s, dp;
+    bf16x8 kf[4], vf[4];
+    U128 f[2][2];
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const float4 d4 = *reinterpret_cast<const float4*>(sD + oR[rg]);
       s[rg * 4] = d4.x; s[rg * 4 + 1] = d4.y; s[rg * 4 + 2] = d4.z; s[rg * 4 + 3] = d4.w;
     }
-    {
-      bf16x8 kf[4], vf[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) kf[ks] = lds_read_b128(sK + oR[ks]);
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = lds_read_b128(sK + oR[ks]);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) vf[ks] = lds_read_b128(sV + oR[ks]);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int ks = 0; ks < 4; ++ks) vf[ks] = lds_read_b128(sV + oR[ks]);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+      for (int db = 0; db < 2; ++db) {
+        U64 x, y;
+        x.s = lds_read_tr(sK + oT[s2][db][0]);
+        y.s = lds_read_tr(sK + oT[s2][db][1]);
+        f[s2][db].w[0] = x.w[0]; f[s2][db].w[1] = x.w[1]; f[s2][db].w[2] = y.w[0]; f[s2][db].w[3] = y.w[1];
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next block's staging is issued HERE: the ~5 LDS-DMA pieces of a wave cost several hundred issue cycles, which now
+    // pass while this block's LDS reads return (the other stage is free since the barrier)
+    if (it + 1 < sc.n) issue(it + 1, (it + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], dof[ks], dp, 0, 0, 0);
+    for (int e = 0; e < 16; ++e) dp[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], dof[ks], dp, 0, 0, 0);
     }
     // element r <-> key j0 + (r&3) + 8*(r>>2) + 4*half ; query = lane
     float ds[16];
@@ -262,57 +278,26 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg)
       *reinterpret_cast<float4*>(sl + (oS ^ (rg << 5))) = make_float4(ds[rg * 4], ds[rg * 4 + 1], ds[rg * 4 + 2], ds[rg * 4 + 3]);
+    U128 ud[2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int e = 0; e < 8; e += 2) ud[s2].w[e >> 1] = pack2bf(ds[s2 * 8 + e], ds[s2 * 8 + e + 1]);
-  };
-  // dQ^T += K^T dS^T ; slot (kh, e) <-> key 16*s2 + 4*kh + (e&3) + 8*(e>>2)
-  auto grads = [&](int it) {
-    const unsigned char* sK = smem + (it & 1) * STG_DQ + ST_A + bl * 4096;
+    // dQ^T += K^T dS^T ; slot (kh, e) <-> key 16*s2 + 4*kh + (e&3) + 8*(e>>2)
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      U128 f[2];
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        U64 x, y;
-        x.s = lds_read_tr(sK + oT[s2][db][0]);
-        y.s = lds_read_tr(sK + oT[s2][db][1]);
-        f[db].w[0] = x.w[0]; f[db].w[1] = x.w[1]; f[db].w[2] = y.w[0]; f[db].w[3] = y.w[1];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[db].b, ud[s2].b, dq[db], 0, 0, 0);
-    }
+      for (int db = 0; db < 2; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[s2][db].b, ud[s2].b, dq[db], 0, 0, 0);
   };
 
   if (sc.n > 0) issue(0, 0);
   for (int it = 0; it < sc.n; ++it) {
     lds_dma_wait();
     __syncthreads();                 // stage `it` has landed; every dS tile of block it-1 is in its slot
-#if defined(BI_EXP_NODMA)
-#define BI_ISSUE(...)
-#else
-#define BI_ISSUE(...) issue(__VA_ARGS__)
-#endif
-#ifndef BI_EXP_NOCOMPUTE
-    if (qb == 0) {
-      if (it + 1 < sc.n) BI_ISSUE(it + 1, (it + 1) & 1);
-      if (it > 0) reduce(it - 1);
-      scores(it);
-      grads(it);
-    } else {
-      if (it > 0) grads(it - 1);
-      if (it + 1 < sc.n) BI_ISSUE(it + 1, (it + 1) & 1);      // (this wave's K tile of block it-1 is free now)
-      if (it > 0) reduce(it - 1);
-      scores(it);
-    }
-#else
-    if (it + 1 < sc.n) BI_ISSUE(it + 1, (it + 1) & 1);
-#endif
+    if (it > 0) reduce(it - 1);
+    block(it);
   }
   if (sc.n > 0) {
-    if (qb == 1) grads(sc.n - 1);
     __syncthreads();
     reduce(sc.n - 1);
   }
@@ -426,17 +411,23 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
       oT[s2][db][0] = vx_off(r0, colb); oT[s2][db][1] = vx_off(r0 + 8, colb);
     }
 
-  U128 up[2], ud[2];
-#ifdef BI_DS_SPLIT
-  U128 ul[2];        // (experiment) dS = hi + lo in two bf16 terms: 16 mantissa bits into the dK MFMA
-#endif
-  auto scores = [&](int st) {
+  // One 32-row block of the streamed side.  EVERY LDS read of the block is requested up front -- bias seeds, delta seeds,
+  // Q / dO rows, row statistics and the transposed Q / dO fragments of the gradient MFMAs, 40 requests -- so a wave sleeps on
+  // LDS latency once per block instead of at five dependent points (ablation, tools/r4_bi_exp2.sh: with every MFMA and the
+  // staging removed the v2 loop still took 68 of its 121 us: two waves per SIMD do not hide ~5 x 150 cycles of dependent LDS
+  // round trips per block).  (Measured and dropped: the gradient MFMAs of block n-1 under the row reads of block n, 110.7 vs
+  // 106.2 us.)
+  auto block = [&](int it) {
+    const int st = it & 1;
     const unsigned char* stg = smem + st * STG_DKV;
     const unsigned char* sQ = stg + ST_A + bl * 4096;
     const unsigned char* sO = stg + ST_B + bl * 4096;
     const unsigned char* sD = stg + ST_D + kbw * 4096;
     const float* sL = reinterpret_cast<const float*>(stg + ST_L + bl * 256);
     f32x16 s, dp;
+    float ls[16];
+    bf16x8 qf[4], of[4];
+    U128 fo[2][2], fq[2][2];
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const float4 d4 = *reinterpret_cast<const float4*>(sD + oR[rg]);
@@ -444,89 +435,65 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
       const float4 e4 = *reinterpret_cast<const float4*>(sL + 32 + 8 * rg + 4 * half);
       dp[rg * 4] = e4.x; dp[rg * 4 + 1] = e4.y; dp[rg * 4 + 2] = e4.z; dp[rg * 4 + 3] = e4.w;
     }
-    {
-      bf16x8 qf[4], of[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) qf[ks] = lds_read_b128(sQ + oR[ks]);
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = lds_read_b128(sQ + oR[ks]);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) of[ks] = lds_read_b128(sO + oR[ks]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s, 0, 0, 0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[ks], vfn[ks], dp, 0, 0, 0);
-    }
-    // element r <-> query i0 + (r&3) + 8*(r>>2) + 4*half ; key = lane
-    __builtin_amdgcn_sched_barrier(0);        // (the row statistics are read here, not held across the MFMAs)
+    for (int ks = 0; ks < 4; ++ks) of[ks] = lds_read_b128(sO + oR[ks]);
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const float4 l4 = *reinterpret_cast<const float4*>(sL + 8 * rg + 4 * half);
-      const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
-#pragma unroll
-      for (int e = 0; e < 4; e += 2) {
-        const int r = rg * 4 + e;
-        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -ls[e]));
-        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], LOG2E, -ls[e + 1]));
-        up[rg >> 1].w[(rg & 1) * 2 + (e >> 1)] = pack2bf(p0, p1);
-        const float d0 = -p0 * dp[r], d1 = -p1 * dp[r + 1];
-        const unsigned hi = pack2bf(d0, d1);
-        ud[rg >> 1].w[(rg & 1) * 2 + (e >> 1)] = hi;
-#ifdef BI_DS_SPLIT
-        ul[rg >> 1].w[(rg & 1) * 2 + (e >> 1)] = pack2bf(d0 - bflo(hi), d1 - bfhi(hi));
-#endif
-      }
+      ls[rg * 4] = l4.x; ls[rg * 4 + 1] = l4.y; ls[rg * 4 + 2] = l4.z; ls[rg * 4 + 3] = l4.w;
     }
-  };
-  // dV^T += dO^T P ; dK^T += Q^T dS ; slot (kh, e) <-> query 16*s2 + 4*kh + (e&3) + 8*(e>>2)
-  auto grads = [&](int st) {
-    const unsigned char* sQ = smem + st * STG_DKV + ST_A + bl * 4096;
-    const unsigned char* sO = smem + st * STG_DKV + ST_B + bl * 4096;
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      U128 fo[2], fq[2];
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
         U64 x, y;
         x.s = lds_read_tr(sO + oT[s2][db][0]);
         y.s = lds_read_tr(sO + oT[s2][db][1]);
-        fo[db].w[0] = x.w[0]; fo[db].w[1] = x.w[1]; fo[db].w[2] = y.w[0]; fo[db].w[3] = y.w[1];
+        fo[s2][db].w[0] = x.w[0]; fo[s2][db].w[1] = x.w[1]; fo[s2][db].w[2] = y.w[0]; fo[s2][db].w[3] = y.w[1];
         x.s = lds_read_tr(sQ + oT[s2][db][0]);
         y.s = lds_read_tr(sQ + oT[s2][db][1]);
-        fq[db].w[0] = x.w[0]; fq[db].w[1] = x.w[1]; fq[db].w[2] = y.w[0]; fq[db].w[3] = y.w[1];
+        fq[s2][db].w[0] = x.w[0]; fq[s2][db].w[1] = x.w[1]; fq[s2][db].w[2] = y.w[0]; fq[s2][db].w[3] = y.w[1];
       }
-      __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // (the next block's staging is issued while this block's LDS reads return: see the dQ kernel)
+    if (it + 1 < sc.n) issue(it + 1, (it + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int db = 0; db < 2; ++db) dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[db].b, up[s2].b, dv[db], 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[ks], vfn[ks], dp, 0, 0, 0);
+    }
+    // element r <-> query i0 + (r&3) + 8*(r>>2) + 4*half ; key = lane
+    U128 up[2], ud[2];
 #pragma unroll
-      for (int db = 0; db < 2; ++db) dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[db].b, ud[s2].b, dk[db], 0, 0, 0);
-#ifdef BI_DS_SPLIT
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int db = 0; db < 2; ++db) dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[db].b, ul[s2].b, dk[db], 0, 0, 0);
-#endif
+      for (int e = 0; e < 8; e += 2) {
+        const int r = s2 * 8 + e;
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -ls[r]));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], LOG2E, -ls[r + 1]));
+        up[s2].w[e >> 1] = pack2bf(p0, p1);
+        ud[s2].w[e >> 1] = pack2bf(-p0 * dp[r], -p1 * dp[r + 1]);
+      }
+    // dV^T += dO^T P ; dK^T += Q^T dS ; slot (kh, e) <-> query 16*s2 + 4*kh + (e&3) + 8*(e>>2)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db) dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[s2][db].b, up[s2].b, dv[db], 0, 0, 0);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[s2][db].b, ud[s2].b, dk[db], 0, 0, 0);
     }
   };
 
+  // (Measured and dropped: staging two blocks ahead through a ring of three stages -- 112.2 vs 106.2 us.)
   if (sc.n > 0) issue(0, 0);
-  int st = 0;                          // stage of block `it` in the ring of three
   for (int it = 0; it < sc.n; ++it) {
     lds_dma_wait();
-    __syncthreads();                   // block `it` has landed; group 1 is done with block it-2's tiles
-    const int stn = st == 2 ? 0 : st + 1, stp = st == 0 ? 2 : st - 1;
-#ifndef BI_EXP_NODMA
-    if (it + 1 < sc.n) issue(it + 1, stn);
-#endif
-#ifndef BI_EXP_NOCOMPUTE
-    if (kbw == 0) {
-      scores(st);
-      grads(st);
-    } else {
-      if (it > 0) grads(stp);
-      scores(st);
-    }
-#endif
-    st = stn;
+    __syncthreads();                   // block `it` has landed; everyone is done with block it-1's tiles
+    block(it);
   }
-  if (sc.n > 0 && kbw == 1) grads(st == 0 ? 2 : st - 1);
   if (bact && kvalid) {
     bf16_t* dvp = a.dv + (long long)b * a.dv_bs + (long long)kj * a.lddv + h * 64;
     bf16_t* dkp = a.dk + (long long)b * a.dk_bs + (long long)kj * a.lddk + h * 64;

@@ -874,6 +874,13 @@ class HipEngine:
                                        [(True, g["enc_idx1d"])])
         (e_rx,) = self._rel_tables_all("e_x", [None] * cfg.enc_layers, [(False, g["enc_idxx"])])
         x_pre = None
+        if need_grad and self.overlap and not torch.cuda.is_current_stream_capturing() and "g16fwd" not in _EXP_SKIP:
+            with self._wgrad():          # (after everything the main stream has enqueued: the previous step's Adam read g16)
+                self.g16.zero_()
+                if getattr(self, "_g16_ev", None) is None:
+                    self._g16_ev = torch.cuda.Event()
+                self._g16_ev.record(self._side)
+                ctx["g16_zeroed"] = self._g16_ev
         bi = need_grad and w <= 64 and w % 8 == 0 and (self.attn_bi == "1" or (self.attn_bi == "auto" and w != 32))
         bi_which = os.environ.get("IFSEG_ATTN_BI_WHICH", "e+d+c").split("+") if bi else []      # (experiment) subset of {e, d, c}
         ctx["dense"] = {}
@@ -1635,7 +1642,12 @@ class HipEngine:
         scaling = float(cfg.head_dim * cfg.attn_scale_factor) ** -0.5
         W, Wf, G, buf = self.W, self.Wf, self.G, self.buf
         g = self._geometry(h, w, L)
-        self.g16.zero_()
+        if ctx.get("g16_zeroed") is not None:
+            # the gradient arena (218 MB for SegOFA-Base) was cleared on the side stream during the forward: the main stream only
+            # orders itself behind that fill instead of running it (50 us) at the head of the backward
+            torch.cuda.current_stream().wait_event(ctx.pop("g16_zeroed"))
+        else:
+            self.g16.zero_()
         self._tab_touched = {}
         self._xsum_done = set()
         self._bt = "top"
