@@ -556,8 +556,11 @@ __global__ __launch_bounds__(512) void attn_dense_bias_kernel(DenseArgs a) {
   }
   for (int tj = wave; tj < ntk; tj += 8) {
     const int j0 = tj * 32;
-    // (causal) a tile entirely above the diagonal: -inf without any look-up
+    // (causal) a tile entirely above the diagonal: -inf without any look-up; one that neither backward kernel's block schedule
+    // ever reaches (they walk 64-row tiles: a 32-row block reads at most one 32-column block beyond its own diagonal block)
+    // is not written at all
     const bool dead = a.causal && j0 < a.P && (i0 >= a.P || j0 > i0 + 31);
+    if (dead && (i0 >= a.P || j0 > i0 + 63)) continue;
     bf16x8 fk[4];
     if (a.pq && !dead) {
       const bf16_t* kp = a.pk + (long long)min(j0 + x, a.S - 1) * a.ldpk + h * 64 + half * 8;
