@@ -36,6 +36,7 @@ struct BiArgs {
   const float *lse, *delta, *D, *Dt, *gain;
   float* dgain_rows;
   bf16_t *dq, *dk, *dv, *dbias;
+  bf16_t* out; float* lse_out; long long o_bs; int ldo;      // forward
   int B, H, T, S, Sp, Tp;
   long long q_bs, k_bs, v_bs, do_bs, dq_bs, dk_bs, dv_bs, dbias_gs;
   int ldq, ldk, ldv, lddo, lddq, lddk, lddv;
@@ -109,6 +110,167 @@ struct Sched {
 // Ablation of v2 (tools/r4_bi_exp2.sh): without the S/dP MFMAs 109.8, without exp 115.8, without the gradient MFMAs 96.0,
 // without any MFMA 88.2, without any MFMA and without staging 67.8, staging + barriers alone 67.3 us: two waves per SIMD do
 // not hide the block's dependent LDS round trips, and no single pipe is the bound.
+
+// ---------------------------------------------------------------------------------------------- forward
+// O_b = gain softmax(q_b k_b^T + D) v_b for four batch elements per workgroup (wave = (32-query block, batch element)): the
+// 32 x 32 bias tile is staged once for the four, no abs-pos columns in the contraction, no table look-ups, one path for every
+// bias kind (unify_multihead_attention.py:459-512; the bias of encoder_module.py:757-809 / decoder_module.py:553-627 is the
+// dense operand D).  Flash-style online softmax in the exp2 domain with a lazily raised reference maximum (as csrc/attention.hip);
+// computed swapped (S^T = K Q^T, O^T = V^T P^T) so a query is a lane.
+constexpr float LAZY_MAX_SLACK = 8.f;
+__global__ __launch_bounds__(512, 2) void attn_bi_fwd_kernel(BiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qb = wv >> 2, bl = wv & 3;
+  const int nqt = (a.T + 63) >> 6, nbg = (a.B + 3) >> 2;
+  const int bid = xcd_remap(blockIdx.x, nqt * a.H * nbg);
+  const int bg = bid % nbg, h = (bid / nbg) / nqt;
+  int qt = (bid / nbg) % nqt;
+  if (a.causal) qt = nqt - 1 - qt;
+  const int q0 = qt * 64;
+  const int b = bg * 4 + bl;
+  const bool bact = b < a.B;
+  const int bc = bact ? b : a.B - 1;
+  const int qi = q0 + qb * 32 + (lane & 31);
+  const bool qvalid = qi < a.T;
+  const int qrow = qvalid ? qi : a.T - 1;
+  bf16x8 qf[4];
+  {
+    const bf16_t* qp = a.q + (long long)bc * a.q_bs + (long long)qrow * a.ldq + h * 64 + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { U128 u; u.v = *reinterpret_cast<const uint4*>(qp + ks * 16); qf[ks] = u.b; }
+  }
+  Sched sc;
+  {
+    const int nkb = a.Sp >> 5;
+    if (a.causal) {
+      const int pb = a.P >> 5;
+      sc.g_begin = 0;
+      sc.g_end = q0 < a.P ? min(pb, (min(q0 + 63, a.P - 1) >> 5) + 1) : 0;
+      sc.t_begin = pb;
+      sc.n = sc.g_end + (nkb - pb);
+    } else {
+      sc.g_begin = 0; sc.g_end = nkb; sc.t_begin = nkb; sc.n = nkb;
+    }
+  }
+  const bf16_t* kb_ = a.k + (long long)bc * a.k_bs + h * 64;
+  const bf16_t* vb_ = a.v + (long long)bc * a.v_bs + h * 64;
+  const float* db_ = a.D + (long long)h * a.T * a.Sp;
+  const unsigned lds0 = lds_addr(smem);
+  const int r8 = lane >> 3, cp = lane & 7;
+  auto issue = [&](int it, int st) {
+    const int j0 = sc.block(it) * 32;
+    const unsigned base = lds0 + st * STG_DQ;
+    const bf16_t* src = qb ? kb_ : vb_;
+    const int ld = qb ? a.ldk : a.ldv;
+    const unsigned dst = base + (qb ? ST_A : ST_B) + bl * 4096;
+#pragma unroll
+    for (int piece = 0; piece < 4; ++piece) {
+      const int row = piece * 8 + r8;
+      const int c = cp ^ vx_swz(row);
+      const int jr = min(j0 + row, a.S - 1);
+      lds_dma16_gs(src, (jr * ld + c * 8) * 2, dst + piece * 1024);
+    }
+    {
+      const int row = bl * 8 + r8;
+      const int c = cp ^ vx_swz(row);
+      const int ir = min(q0 + qb * 32 + row, a.T - 1);
+      lds_dma16_gs(db_, (ir * a.Sp + j0 + c * 4) * 4, base + ST_D + qb * 4096 + bl * 1024);
+    }
+  };
+  f32x16 oacc[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
+  float m_run = NEG_INF, l_run = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) consume_frag(qf[ks]);
+  const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+  int oR[4], oT[2][2][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) oR[ks] = vx_off(lane & 31, half * 16) ^ (ks << 5);
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int colb = (db * 32 + g16 * 16 + (i16 & 3) * 4) * 2, r0 = 16 * s2 + 4 * half + (i16 >> 2);
+      oT[s2][db][0] = vx_off(r0, colb); oT[s2][db][1] = vx_off(r0 + 8, colb);
+    }
+
+  if (sc.n > 0) issue(0, 0);
+  for (int it = 0; it < sc.n; ++it) {
+    lds_dma_wait();
+    __syncthreads();
+    const unsigned char* stg = smem + (it & 1) * STG_DQ;
+    const unsigned char* sK = stg + ST_A + bl * 4096;
+    const unsigned char* sV = stg + ST_B + bl * 4096;
+    const unsigned char* sD = stg + ST_D + qb * 4096;
+    f32x16 s;
+    bf16x8 kf[4];
+    U128 vt[2][2];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 d4 = *reinterpret_cast<const float4*>(sD + oR[rg]);
+      s[rg * 4] = d4.x; s[rg * 4 + 1] = d4.y; s[rg * 4 + 2] = d4.z; s[rg * 4 + 3] = d4.w;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = lds_read_b128(sK + oR[ks]);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        U64 x, y;
+        x.s = lds_read_tr(sV + oT[s2][db][0]);
+        y.s = lds_read_tr(sV + oT[s2][db][1]);
+        vt[s2][db].w[0] = x.w[0]; vt[s2][db].w[1] = x.w[1]; vt[s2][db].w[2] = y.w[0]; vt[s2][db].w[3] = y.w[1];
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 1 < sc.n) issue(it + 1, (it + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+    // element r <-> key j0 + (r&3) + 8*(r>>2) + 4*half ; query = lane.  Masked / padded entries are -inf in the bias.
+    float m4[4] = {NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) m4[e & 3] = fmaxf(m4[e & 3], s[e]);
+    float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * LOG2E;
+    if (__builtin_amdgcn_ballot_w64(mx > m_run + LAZY_MAX_SLACK)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == NEG_INF) ? 0.f : m_new));
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
+    }
+    const float m_use = (m_run == NEG_INF) ? 0.f : m_run;
+    float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+    U128 pf[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[s2 * 8 + e], LOG2E, -m_use));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[s2 * 8 + e + 1], LOG2E, -m_use));
+        ps4[(e >> 1) & 3] += p0 + p1;
+        pf[s2].w[e >> 1] = pack2bf(p0, p1);
+      }
+    l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+    // O^T += V^T P^T ; slot (kh, e) <-> key 16*s2 + 4*kh + (e&3) + 8*(e>>2)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt[s2][db].b, pf[s2].b, oacc[db], 0, 0, 0);
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = (l_tot > 0.f ? 1.f / l_tot : 0.f) * (a.gain ? a.gain[h] : 1.f);
+  if (bact) {
+    bf16_t* op = a.out + (long long)b * a.o_bs + (long long)qrow * a.ldo + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) store_tile_bf16(op + db * 32, oacc[db], inv, half, qvalid);
+    if (qvalid && half == 0) a.lse_out[((long long)b * a.H + h) * a.T + qi] = m_run + __log2f(l_tot);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------- dQ (+ sum_b dS)
 __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
@@ -984,6 +1146,34 @@ extern "C" int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* x, void* stream) {
     hipLaunchKernelGGL(attn_bi_dq_kernel, dim3(((a.T + 63) / 64) * a.H * nbg), dim3(512), LDS_DQ, s, a);
     ifseg_prof_end(IFSEG_K_ATTN_DQ, s);
   }
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_attn_fwd_bi(const ifseg_attn_bi_args* x, void* stream) {
+  (void)hipGetLastError();
+  if (!x || x->B <= 0 || x->H <= 0 || x->T <= 0 || x->S <= 0 || !x->q || !x->k || !x->v || !x->out || !x->lse || !x->D) return IFSEG_ERR_BAD_ARG;
+  if ((x->Sp & 31) || x->Sp < x->S) return IFSEG_ERR_BAD_ARG;
+  BiArgs a{};
+  a.q = (const bf16_t*)x->q; a.k = (const bf16_t*)x->k; a.v = (const bf16_t*)x->v; a.D = x->D; a.gain = (const float*)x->gain;
+  a.out = (bf16_t*)x->out; a.lse_out = const_cast<float*>(x->lse); a.o_bs = x->out_bs; a.ldo = x->ldout;
+  a.B = x->B; a.H = x->H; a.T = x->T; a.S = x->S; a.Sp = x->Sp; a.Tp = x->Tp;
+  a.q_bs = x->q_bs; a.k_bs = x->k_bs; a.v_bs = x->v_bs; a.ldq = x->ldq; a.ldk = x->ldk; a.ldv = x->ldv;
+  a.causal = x->causal; a.P = x->causal ? x->P : x->S;
+  if ((a.ldq | a.ldk | a.ldv | a.ldo) & 7) return IFSEG_ERR_BAD_SHAPE;
+  if (((size_t)a.q | (size_t)a.k | (size_t)a.v | (size_t)a.out) & 15) return IFSEG_ERR_BAD_ARG;
+  if ((a.q_bs | a.k_bs | a.v_bs | a.o_bs) & 7) return IFSEG_ERR_BAD_SHAPE;
+  if (a.causal && ((a.P & 63) || a.P > a.T || a.P > a.S)) return IFSEG_ERR_BAD_SHAPE;
+  {
+    const long long ldmax = a.ldk > a.ldv ? a.ldk : a.ldv;
+    if ((long long)a.S * ldmax * 2 >= (1ll << 31) || (long long)a.T * a.Sp * 4 >= (1ll << 31)) return IFSEG_ERR_BAD_SHAPE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int lds = 2 * STG_DQ;
+  (void)hipFuncSetAttribute((const void*)attn_bi_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  ifseg_prof_begin(IFSEG_K_ATTN_FWD, s, 4.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);
+  hipLaunchKernelGGL(attn_bi_fwd_kernel, dim3(((a.T + 63) / 64) * a.H * ((a.B + 3) / 4)), dim3(512), lds, s, a);
+  ifseg_prof_end(IFSEG_K_ATTN_FWD, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

@@ -407,7 +407,8 @@ class _AttnBiArgs(ctypes.Structure):
     _fields_ = ([(n, c_void_p) for n in ("q", "k", "v", "dout", "lse", "delta", "D", "Dt", "gain", "dq", "dk", "dv", "dbias")]
                 + [(n, c_int) for n in ("B", "H", "T", "S", "Sp", "Tp", "ldq", "ldk", "ldv", "lddo", "lddq", "lddk", "lddv")]
                 + [(n, c_ll) for n in ("q_bs", "k_bs", "v_bs", "do_bs", "dq_bs", "dk_bs", "dv_bs")]
-                + [("causal", c_int), ("P", c_int), ("dq_scale", c_float), ("phases", c_int), ("dgain_rows", c_void_p)])   # == ifseg_attn_bi_args
+                + [("causal", c_int), ("P", c_int), ("dq_scale", c_float), ("phases", c_int), ("dgain_rows", c_void_p),
+                   ("out", c_void_p), ("ldout", c_int), ("out_bs", c_ll)])   # == ifseg_attn_bi_args
 
 
 def attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=False, P=None, gain=None,
@@ -431,6 +432,19 @@ def attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S,
 
 def dbias_nparts():
     return lib().ifseg_attn_dbias_nparts()
+
+
+def attn_fwd_bi(q, k, v, dense, out, lse, B, H, T, S, causal=False, P=None, gain=None):
+    """out = gain softmax(q k^T + dense.D) v, four batch elements per workgroup (csrc/attention_bi.hip)"""
+    a = _AttnBiArgs()
+    for name, t in (("q", q), ("k", k), ("v", v), ("lse", lse), ("D", dense.D), ("Dt", dense.Dt), ("gain", _f32(gain)), ("out", out)):
+        setattr(a, name, _p(t))
+    a.B, a.H, a.T, a.S, a.Sp, a.Tp = B, H, T, S, dense.Sp, dense.Tp
+    a.ldq, a.ldk, a.ldv, a.ldout = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
+    a.q_bs, a.k_bs, a.v_bs, a.out_bs = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.causal, a.P = (1 if causal else 0), (P if P is not None else S)
+    _check(lib().ifseg_attn_fwd_bi(ctypes.byref(a), _stream()), "attn_fwd_bi")
+    return out
 
 
 class _AttnDbiasArgs(ctypes.Structure):

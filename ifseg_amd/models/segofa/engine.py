@@ -102,6 +102,8 @@ class HipEngine:
         # (an exact identity: sum_j dK_j = 0; csrc/rowops.hip ifseg_kproj_common_mode).  IFSEG_NO_KPROJ_FIX=1: as computed.
         self.kproj_fix = os.environ.get("IFSEG_NO_KPROJ_FIX") is None
         self.fwd_dense = os.environ.get("IFSEG_ATTN_FWD_DENSE") == "1"
+        # the forward through the batch-inner kernel wherever the layer's dense bias exists (IFSEG_ATTN_BI_FWD=0: round-3 forward)
+        self.bi_fwd = os.environ.get("IFSEG_ATTN_BI_FWD", "1") != "0"
         self._ffn_pg_tasks = []
         self._train_fwd = False
         # where the NEXT batch's frozen-trunk pass is launched: "fwd" = at the start of this step's forward, "e<k>" = when
@@ -429,9 +431,19 @@ class HipEngine:
         hip.attn_dense_bias(d, pq, pk, rel=rel, causal=causal, P=P)
         return d
 
-    def _dense_wait(self):
-        """(forward seeded from the dense biases) the main stream waits once per stack for the side stream's builds"""
-        ev = self.ctx_building.pop("dense_pending", None)
+    def _dense_built(self, ctx, tag):
+        """(side stream) one event per dense bias: the forward attention of that layer waits for ITS operand only"""
+        if not self.overlap:
+            return
+        evs = self.__dict__.setdefault("_dense_evs", {})
+        ev = evs.get(tag)
+        if ev is None:
+            ev = evs[tag] = torch.cuda.Event()
+        ev.record(self._side)
+        ctx.setdefault("dense_ev", {})[tag] = ev
+
+    def _dense_wait(self, tag):
+        ev = self.ctx_building.get("dense_ev", {}).pop(tag, None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
@@ -890,11 +902,7 @@ class HipEngine:
                 for l in range(cfg.enc_layers):
                     rel = hip.RelBias(P, g["gcode"], g["code_bias"], e_r2[l], e_r1[l], e_rx[l], grid_w=w)
                     ctx["dense"]["e%d" % l] = self._dense_bias("e%d" % l, H, T, T, ctx["e_pq"], ctx["e_pk"], rel, False, P)
-                if self.fwd_dense and self.overlap:
-                    if getattr(self, "_dense_ev_e", None) is None:
-                        self._dense_ev_e = torch.cuda.Event()
-                    self._dense_ev_e.record(self._side)
-                    ctx["dense_pending"] = self._dense_ev_e
+                    self._dense_built(ctx, "e%d" % l)
         for l in range(cfg.enc_layers):
             p = "%slayers.%d." % (e, l)
             tg = "e%d" % l
@@ -967,16 +975,19 @@ class HipEngine:
                 for l in range(cfg.dec_layers if "d" in bi_which else 0):
                     rel = hip.RelBias(P, g["gcode"], g["code_bias"], d_r2[l], d_r1[l], d_rx[l], grid_w=w)
                     ctx["dense"]["d%d" % l] = self._dense_bias("d%d" % l, H, Td, Td, ctx["d_spq"], ctx["d_spk"], rel, causal, P)
+                    self._dense_built(ctx, "d%d" % l)
+                    if l == 0 and "c" in bi_which:      # (the first decoder layer's cross attention follows its self attention)
+                        ctx["dense"]["dc"] = self._dense_bias("dc", H, Td, T, cpq, cpk, None, False, None)
+                        self._dense_built(ctx, "dc")
                 # the cross-attention bias has no per-layer part (decoder_module.py:556-558): one operand for all layers
-                if "c" in bi_which:
+                if "c" in bi_which and "dc" not in ctx["dense"]:
                     ctx["dense"]["dc"] = self._dense_bias("dc", H, Td, T, cpq, cpk, None, False, None)
+                    self._dense_built(ctx, "dc")
                 if self.overlap:        # (a dedicated event: the ring of `_ev` wraps around long before the backward waits for it)
                     if getattr(self, "_dense_ev", None) is None:
                         self._dense_ev = torch.cuda.Event()
                     self._dense_ev.record(self._side)
                     ctx["dense_ready"] = self._dense_ev
-                    if self.fwd_dense:
-                        ctx["dense_pending"] = self._dense_ev
         for l in range(cfg.dec_layers):
             p = "%slayers.%d." % (d, l)
             tg = "d%d" % l
@@ -1155,13 +1166,17 @@ class HipEngine:
         o = buf(tg + "_o", (B, T, C))
         lse = buf(tg + "_lse", (B, H, T), torch.float32)
         gain = self._gain32(tg + "_sa", a_ + ".c_attn")
-        dd = self.ctx_building.get("dense", {}).get(tg) if (self.fwd_dense and self.ctx_building is not None) else None
+        dd = self.ctx_building.get("dense", {}).get(tg) if (self.bi_fwd and self.ctx_building is not None) else None
         if dd is not None:
-            # (experiment, IFSEG_ATTN_FWD_DENSE=1) the forward seeded from the layer's dense bias too: no abs-pos columns, no
-            # table look-ups, one bias path for every grid width; the causal flag only drives the tile schedule
-            self._dense_wait()
-            hip.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], None, None, o, lse, B, H, T, T, rel=None,
-                         causal=causal, P=rel.P, gain=gain, dense_bias=dd.D)
+            # the forward of the batch-inner formulation: dense bias tile shared by four batch elements, no abs-pos columns in
+            # the contraction, no table look-ups, one path for every grid width (csrc/attention_bi.hip: attn_bi_fwd_kernel)
+            self._dense_wait(tg)
+            if self.fwd_dense:       # (experiment: the round-3 kernel seeded from the dense bias by global loads -- slower)
+                hip.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], None, None, o, lse, B, H, T, T, rel=None,
+                             causal=causal, P=rel.P, gain=gain, dense_bias=dd.D)
+            else:
+                hip.attn_fwd_bi(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], dd, o, lse, B, H, T, T, causal=causal,
+                                P=rel.P, gain=gain)
         else:
             hip.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], pq, pk, o, lse, B, H, T, T, rel=rel,
                          causal=causal, gain=gain, dense_bias=dense)
@@ -1196,10 +1211,13 @@ class HipEngine:
         o = buf(tg + "_co", (B, Td, C))
         lse = buf(tg + "_clse", (B, H, Td), torch.float32)
         gain = self._gain32(tg + "_ca", a_ + ".c_attn")
-        dd = self.ctx_building.get("dense", {}).get("dc") if (self.fwd_dense and self.ctx_building is not None) else None
+        dd = self.ctx_building.get("dense", {}).get("dc") if (self.bi_fwd and self.ctx_building is not None) else None
         if dd is not None:
-            self._dense_wait()
-            hip.attn_fwd(q, kv[:, :, :C], kv[:, :, C:], None, None, o, lse, B, H, Td, Te, gain=gain, dense_bias=dd.D)
+            self._dense_wait("dc")
+            if self.fwd_dense:
+                hip.attn_fwd(q, kv[:, :, :C], kv[:, :, C:], None, None, o, lse, B, H, Td, Te, gain=gain, dense_bias=dd.D)
+            else:
+                hip.attn_fwd_bi(q, kv[:, :, :C], kv[:, :, C:], dd, o, lse, B, H, Td, Te, gain=gain)
         else:
             hip.attn_fwd(q, kv[:, :, :C], kv[:, :, C:], cpq, cpk, o, lse, B, H, Td, Te, gain=gain)
         a = buf(tg + "_ca_a", (B * Td, C))

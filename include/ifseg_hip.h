@@ -237,8 +237,14 @@ typedef struct ifseg_attn_bi_args {
   int phases;                  /* 0 = both; IFSEG_ATTN_BWD_DKV | IFSEG_ATTN_BWD_DQ */
   float* dgain_rows;           /* optional fp32 [B,H,T]: sum_j P_ij dP_ij = dout_i . (P v)_i, the per-row terms of d c_attn[h]
                                   (unify_multihead_attention.py:509-512) computed WITHOUT dividing delta by c_attn: exact at c_attn = 0 */
+  void* out;                   /* ifseg_attn_fwd_bi: O [B,T,ldout] bf16 (x gain) */
+  int ldout; long long out_bs;
 } ifseg_attn_bi_args;
 int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* args, void* stream);
+/* ifseg_attn_fwd_bi: the forward of the same formulation -- out = gain softmax_fp32(q k^T + D) v, `lse` (written) as
+ * ifseg_attn_fwd's (log2 units); reads q, k, v, D, gain, causal / P (tile schedule only: the mask is inside D).  A workgroup
+ * holds four batch elements and fetches each 32 x 32 bias tile once for them (unify_multihead_attention.py:459-512). */
+int ifseg_attn_fwd_bi(const ifseg_attn_bi_args* args, void* stream);
 
 /* ifseg_attn_dbias_grads: everything downstream of dbias (two launches: operand gradients, tables) (the autograd of the bias construction,
  *   encoder_module.py:757-771,790-809 / decoder_module.py:553-558,603-627), with dB = sum_g dbias[g]:

@@ -451,10 +451,20 @@ def test_attn_bwd_batch_inner(case):
     # padding: -inf (causal: the padded query columns of GRID keys belong to tail-row tiles no schedule reads)
     assert torch.isinf(dense.D[:, :, S:]).all() and torch.isinf(dense.Dt[:, (P if causal else 0):, T:]).all()
     assert torch.equal(dense.Dt[:, :, :T], got.transpose(1, 2))          # the same MFMA chain in both orientations
-    # ---- forward (unchanged kernel) for out / lse, then the batch-inner backward
-    out = torch.zeros(B, T, C, dtype=torch.bfloat16, device=dev)
-    lse = torch.zeros(B, H, T, dtype=torch.float32, device=dev)
-    hip.attn_fwd(q, k, v, pq, pk, out, lse, B, H, T, S, rel=rel, causal=causal, gain=gain)
+    # ---- forward: the round-3 kernel (bias regenerated per batch element) and the batch-inner one (dense bias tile shared by
+    # four batch elements) against the fp32 reference and against each other; the backward below consumes the latter's out / lse
+    out3 = torch.zeros(B, T, C, dtype=torch.bfloat16, device=dev)
+    lse3 = torch.zeros(B, H, T, dtype=torch.float32, device=dev)
+    hip.attn_fwd(q, k, v, pq, pk, out3, lse3, B, H, T, S, rel=rel, causal=causal, gain=gain)
+    out = torch.full((B, T, C), 3.0, dtype=torch.bfloat16, device=dev)
+    lse = torch.full((B, H, T), 3.0, dtype=torch.float32, device=dev)
+    hip.attn_fwd_bi(q, k, v, dense, out, lse, B, H, T, S, causal=causal, P=P, gain=gain)
+    torch.cuda.synchronize()
+    assert _rel(out, o_ref) < 1e-2 and _rel(out, out3) < 1e-2, (_rel(out, o_ref), _rel(out, out3))
+    with torch.no_grad():
+        sref = (q.float().view(B, T, H, 64).transpose(1, 2) @ k.float().view(B, S, H, 64).transpose(1, 2).transpose(2, 3)) + want
+        lse_ref = torch.logsumexp(sref, -1) * 1.4426950408889634          # log2 units
+    assert (lse - lse_ref).abs().max().item() < 2e-3 and (lse - lse3).abs().max().item() < 2e-3
     delta = (dout.float() * out.float()).view(B, T, H, 64).sum(-1).permute(0, 2, 1).contiguous()
     dq, dk, dv = torch.full_like(q, 3.0), torch.full_like(k, 3.0), torch.full_like(v, 3.0)
     ng = (B + 3) // 4

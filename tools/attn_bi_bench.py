@@ -56,7 +56,10 @@ def main(kind="enc"):
                   drel1d=torch.zeros(H, NP, 2 * Lt - 1, device=dev), drelx=torch.zeros(H, NP, 2, device=dev))
     bi = lambda ph: hip.attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal,
                                     P=P if (rel is not None or causal) else None, gain=gain, phases=ph)
+    out2, lse2 = torch.zeros_like(out), torch.zeros_like(lse)
+    print(kind, "round-3 fwd             us %.1f" % timeit(lambda: hip.attn_fwd(q, k, v, pq, pk, out, lse, B, H, T, S, rel=rel, causal=causal, gain=gain)))
     print(kind, "dense bias build        us %.1f" % timeit(lambda: hip.attn_dense_bias(dense, pq, pk, rel=rel, causal=causal, P=P)))
+    print(kind, "bi fwd                  us %.1f" % timeit(lambda: hip.attn_fwd_bi(q, k, v, dense, out2, lse2, B, H, T, S, causal=causal, P=P if (rel is not None or causal) else None, gain=gain)))
     print(kind, "bi dkv                  us %.1f" % timeit(lambda: bi(hip.ATTN_BWD_DKV)))
     print(kind, "bi dq (+ sum_b dS)      us %.1f" % timeit(lambda: bi(hip.ATTN_BWD_DQ)))
     print(kind, "bi dkv + dq             us %.1f" % timeit(lambda: bi(0)))
