@@ -94,9 +94,10 @@ class HipEngine:
         # attention backward with the batch inside the workgroup (csrc/attention_bi.hip): the bias is a dense batch-invariant
         # operand built once per layer from parameters, sum_b dS leaves the dQ kernel once per tile.  IFSEG_ATTN_BI=0: the
         # round-3 kernels (one workgroup per (batch, head, tile), bias regenerated per batch element).
-        # Default "auto": measured in the step (DESIGN, round 4) the batch-inner pair is ahead on grids that are not 32 wide
-        # (SegOFA-Large at 640^2: 90.7 vs 99.5 ms per step) and behind on the 32-wide Base grid (17.7 vs 17.2 ms), where the
-        # round-3 pair runs two workgroups per CU side by side with the weight-gradient GEMMs.
+        # Default "auto" (measured in the step, DESIGN round 4): on a 32-wide grid the encoder self-attention and the decoder
+        # cross-attention take this path (Base C2 17.52 vs 17.90 ms, C3 20.06 vs 20.66 ms) and the causal decoder self-attention
+        # keeps the round-3 kernels (its row-aligned 32-wide fast path is ahead by 0.1 ms); on every other grid width all
+        # three do (SegOFA-Large at 640^2: 87.3 vs 101.7 ms per step).  "1": everywhere, "0": nowhere.
         self.attn_bi = os.environ.get("IFSEG_ATTN_BI", "auto")
         # k_proj.weight gradients without the product of dK's spurious column sum and the token mean of the projection's input
         # (an exact identity: sum_j dK_j = 0; csrc/rowops.hip ifseg_kproj_common_mode).  IFSEG_NO_KPROJ_FIX=1: as computed.
@@ -893,8 +894,9 @@ class HipEngine:
                     self._g16_ev = torch.cuda.Event()
                 self._g16_ev.record(self._side)
                 ctx["g16_zeroed"] = self._g16_ev
-        bi = need_grad and w <= 64 and w % 8 == 0 and (self.attn_bi == "1" or (self.attn_bi == "auto" and w != 32))
-        bi_which = os.environ.get("IFSEG_ATTN_BI_WHICH", "e+d+c").split("+") if bi else []      # (experiment) subset of {e, d, c}
+        bi = need_grad and w <= 64 and w % 8 == 0 and self.attn_bi in ("1", "auto")
+        # which attentions: e(ncoder self), d(ecoder self), c(ross); IFSEG_ATTN_BI_WHICH overrides
+        bi_which = os.environ.get("IFSEG_ATTN_BI_WHICH", "e+c" if (self.attn_bi == "auto" and w == 32) else "e+d+c").split("+") if bi else []
         ctx["dense"] = {}
         if bi and "e" in bi_which:
             # parameters only: every layer's dense bias on the side stream, under the first blocks of the forward
