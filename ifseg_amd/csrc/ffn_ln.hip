@@ -138,9 +138,23 @@ __global__ __launch_bounds__(256) void ffn_ln_dgamma_exact_kernel(const bf16_t* 
                                                                   bf16_t* __restrict__ dgamma, int M, int J, int N) {
   __shared__ float sw[1024];
   __shared__ float red[256];
+  __shared__ int flagged[256];
+  __shared__ int nflag;
   const int tid = threadIdx.x;
-  for (int k = blockIdx.x * 256; k < min(N, (int)blockIdx.x * 256 + 256); ++k) {
-    if (!ffn_ln_gain_is_small(gamma[k], beta[k])) continue;          // (block-uniform)
+  // every thread tests one column; the (normally empty) list of flagged columns is walked in column order
+  if (tid == 0) nflag = 0;
+  __syncthreads();
+  {
+    const int k = blockIdx.x * 256 + tid;
+    const bool f = k < N && ffn_ln_gain_is_small(gamma[k], beta[k]);
+    flagged[tid] = f ? 1 : 0;
+    if (f) atomicAdd(&nflag, 1);
+  }
+  __syncthreads();
+  if (nflag == 0) return;
+  for (int kk = 0; kk < 256; ++kk) {
+    if (!flagged[kk]) continue;          // (block-uniform)
+    const int k = blockIdx.x * 256 + kk;
     __syncthreads();
     for (int j = tid; j < J; j += 256) sw[j] = bf2f(w2[(long long)j * N + k]);
     __syncthreads();

@@ -636,14 +636,18 @@ def colsum(x, part):
     return part
 
 
-def col_mean(x, ws=None):
+def col_mean(x, ws=None, every=1):
     """fp32 [C] column means of x [rows, C] bf16 (two launches: partial column sums, their sum); ws: a
-    [COLSUM_BLOCKS + 1, C] fp32 workspace whose last row receives the result"""
+    [COLSUM_BLOCKS + 1, C] fp32 workspace whose last row receives the result; every > 1: the mean over every `every`-th row"""
     C = x.shape[-1]
     if ws is None:
         ws = torch.empty(COLSUM_BLOCKS + 1, C, dtype=torch.float32, device=x.device)
+    rows = x.numel() // C
+    if every > 1 and x.dim() == 2 and x.is_contiguous() and rows >= 64 * every:
+        x = x[: rows // every * every].view(rows // every, every * C)[:, :C]       # every `every`-th row (row stride every * C)
+        rows = rows // every
     colsum(x, ws[:COLSUM_BLOCKS])
-    reduce_parts(ws[:COLSUM_BLOCKS], ws[COLSUM_BLOCKS], 1, COLSUM_BLOCKS, C, scale=1.0 / (x.numel() // C))
+    reduce_parts(ws[:COLSUM_BLOCKS], ws[COLSUM_BLOCKS], 1, COLSUM_BLOCKS, C, scale=1.0 / rows)
     return ws[COLSUM_BLOCKS]
 
 

@@ -887,13 +887,6 @@ class HipEngine:
                                        [(True, g["enc_idx1d"])])
         (e_rx,) = self._rel_tables_all("e_x", [None] * cfg.enc_layers, [(False, g["enc_idxx"])])
         x_pre = None
-        if need_grad and self.overlap and not torch.cuda.is_current_stream_capturing() and "g16fwd" not in _EXP_SKIP:
-            with self._wgrad():          # (after everything the main stream has enqueued: the previous step's Adam read g16)
-                self.g16.zero_()
-                if getattr(self, "_g16_ev", None) is None:
-                    self._g16_ev = torch.cuda.Event()
-                self._g16_ev.record(self._side)
-                ctx["g16_zeroed"] = self._g16_ev
         bi = need_grad and w <= 64 and w % 8 == 0 and self.attn_bi in ("1", "auto")
         # which attentions: e(ncoder self), d(ecoder self), c(ross); IFSEG_ATTN_BI_WHICH overrides
         bi_which = os.environ.get("IFSEG_ATTN_BI_WHICH", "e+c" if (self.attn_bi == "auto" and w == 32) else "e+d+c").split("+") if bi else []
@@ -905,6 +898,13 @@ class HipEngine:
                     rel = hip.RelBias(P, g["gcode"], g["code_bias"], e_r2[l], e_r1[l], e_rx[l], grid_w=w)
                     ctx["dense"]["e%d" % l] = self._dense_bias("e%d" % l, H, T, T, ctx["e_pq"], ctx["e_pk"], rel, False, P)
                     self._dense_built(ctx, "e%d" % l)
+        if need_grad and self.overlap and not torch.cuda.is_current_stream_capturing() and "g16fwd" not in _EXP_SKIP:
+            with self._wgrad():          # (behind the encoder's dense biases, which the forward waits for; the previous step's Adam read g16)
+                self.g16.zero_()
+                if getattr(self, "_g16_ev", None) is None:
+                    self._g16_ev = torch.cuda.Event()
+                self._g16_ev.record(self._side)
+                ctx["g16_zeroed"] = self._g16_ev
         for l in range(cfg.enc_layers):
             p = "%slayers.%d." % (e, l)
             tg = "e%d" % l
@@ -1899,7 +1899,9 @@ class HipEngine:
         for gw, gb, x, tag in kf:
             key = "g_xmean_" + tag
             if key not in self._xsum_done:       # (the decoder's cross-attention key projections all read the encoder output)
-                hip.col_mean(x, self.buf(key, (hip.COLSUM_BLOCKS + 1, x.shape[-1]), torch.float32))
+                # (sum_j dK_j = 0 makes dK^T (x - 1 c^T) = dK^T x for EVERY c: the mean over every 8th row removes the
+                # token-common component just as well as the mean over all of them, at an eighth of the traffic)
+                hip.col_mean(x, self.buf(key, (hip.COLSUM_BLOCKS + 1, x.shape[-1]), torch.float32), every=8)
                 self._xsum_done.add(key)
             hip.kproj_common_mode(gw, gb, self.ws[key][hip.COLSUM_BLOCKS])
         pg, self._ffn_pg_tasks = self._ffn_pg_tasks, []
