@@ -8,7 +8,7 @@
 //     dV_b = gain P_b^T dO_b;  dS_b = P_b o (gain dO_b v_b^T - delta_b);  dQ_b = dS_b k_b;  dK_b = dS_b^T q_b
 //     dBias = sum_b dS_b      -> d abs-pos operands, d rel-pos tables (ifseg_attn_dbias_grads)
 //
-// MI355X formulation.  The bias is a dense fp32 operand D[h] (and its transpose Dt[h]) built once per layer and step by
+// MI355X formulation.  The bias is a dense fp32 operand D[h] ([Tp][Sp], padding and masked entries -inf) built once per layer and step by
 // ifseg_attn_dense_bias from parameters only (side stream, start of the step).  A workgroup of 8 waves owns
 // (head, 64 stationary rows = 2 blocks of 32, 4 batch elements): wave = (row block, batch element).  The 4 batch waves of a
 // row block read the SAME 32 x 32 bias tile from LDS (one LDS-DMA per tile instead of four regenerations by MFMA + table
@@ -33,7 +33,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 struct BiArgs {
   const bf16_t *q, *k, *v, *dO;
-  const float *lse, *delta, *D, *Dt, *gain;
+  const float *lse, *delta, *D, *gain;
   float* dgain_rows;
   bf16_t *dq, *dk, *dv, *dbias;
   bf16_t* out; float* lse_out; long long o_bs; int ldo;      // forward
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void attn_bi_fwd_kernel(BiArgs a) {
   }
   const bf16_t* kb_ = a.k + (long long)bc * a.k_bs + h * 64;
   const bf16_t* vb_ = a.v + (long long)bc * a.v_bs + h * 64;
-  const float* db_ = a.D + (long long)h * a.T * a.Sp;
+  const float* db_ = a.D + (long long)h * a.Tp * a.Sp;
   const unsigned lds0 = lds_addr(smem);
   const int r8 = lane >> 3, cp = lane & 7;
   auto issue = [&](int it, int st) {
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
 
   const bf16_t* kb_ = a.k + (long long)bc * a.k_bs + h * 64;
   const bf16_t* vb_ = a.v + (long long)bc * a.v_bs + h * 64;
-  const float* db_ = a.D + (long long)h * a.T * a.Sp;
+  const float* db_ = a.D + (long long)h * a.Tp * a.Sp;
   const unsigned lds0 = lds_addr(smem);
   // staging of block `it` into stage st: the four 1-KiB pieces of ONE operand tile of this wave's batch element (group 0:
   // V, group 1: K) and a quarter of this group's bias tile.  Lane l of a piece = row 8 p + (l >> 3), 16-byte position
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
   const bf16_t* ob_ = a.dO + (long long)bc * a.do_bs + h * 64;
   const float* lb_ = a.lse + ((long long)bc * a.H + h) * a.T;
   const float* eb_ = a.delta + ((long long)bc * a.H + h) * a.T;
-  const float* db_ = a.Dt + (long long)h * a.S * a.Tp;
+  const float* db_ = a.D + (long long)h * a.Tp * a.Sp;
   const unsigned lds0 = lds_addr(smem);
   const int r8 = lane >> 3, cp = lane & 7;
   auto issue = [&](int it, int st) {
@@ -541,11 +541,14 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
       lds_dma16_gs(src, (ir * ld + c * 8) * 2, dst + piece * 1024);
     }
     {
-      // bias tile (transposed bias: row = key) of key block kbw, rows 8 bl .. 8 bl + 7
-      const int row = bl * 8 + r8;
-      const int c = cp ^ vx_swz(row);
-      const int jr = min(k0 + kbw * 32 + row, a.S - 1);
-      lds_dma16_gs(db_, (jr * a.Tp + i0 + c * 4) * 4, base + ST_D + kbw * 4096 + bl * 1024);
+      // bias tile [32 queries][32 keys of key block kbw], rows 8 bl .. 8 bl + 7.  The accumulators want four CONSECUTIVE
+      // QUERIES of one key per lane -- a column of this tile -- so the seeds are read one float at a time (a row of 32 lanes
+      // = 32 banks); rows r and r + 4 (the two lane halves of one read) sit at positions of opposite parity = opposite bank
+      // halves: position(r) = r ^ ((r >> 2) & 1) within each group of eight.  (Until round 4 a second, transposed copy of the
+      // bias served this kernel with 16-byte reads; building it was half of the dense-bias kernel's HBM writes.)
+      const int row = bl * 8 + (r8 ^ ((r8 >> 2) & 1));
+      const int jc = min(k0 + kbw * 32, a.Sp - 32);          // (a key block entirely in the padding: any valid address)
+      lds_dma16_gs(db_, ((i0 + row) * a.Sp + jc + cp * 4) * 4, base + ST_D + kbw * 4096 + bl * 1024);
     }
     if (kbw == 0) {
       // lanes 0..31: lse, lanes 32..63: delta of this wave's batch element (LDS-DMA places lane i at base + 4 i)
@@ -565,6 +568,8 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
   int oR[4], oT[2][2][2];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) oR[ks] = vx_off(lane & 31, half * 16) ^ (ks << 5);
+  // bias seeds: element e of row group rg <-> query 8 rg + 4 half + e at position 8 rg + ((4 half + e) ^ half)
+  const int oD0 = ((4 * half) ^ half) * 32 + (lane & 31), oD1 = ((4 * half + 1) ^ half) * 32 + (lane & 31);
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -584,7 +589,7 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
     const unsigned char* stg = smem + st * STG_DKV;
     const unsigned char* sQ = stg + ST_A + bl * 4096;
     const unsigned char* sO = stg + ST_B + bl * 4096;
-    const unsigned char* sD = stg + ST_D + kbw * 4096;
+    const float* sD = reinterpret_cast<const float*>(stg + ST_D + kbw * 4096);
     const float* sL = reinterpret_cast<const float*>(stg + ST_L + bl * 256);
     f32x16 s, dp;
     float ls[16];
@@ -592,8 +597,8 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
     U128 fo[2][2], fq[2][2];
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      const float4 d4 = *reinterpret_cast<const float4*>(sD + oR[rg]);
-      s[rg * 4] = d4.x; s[rg * 4 + 1] = d4.y; s[rg * 4 + 2] = d4.z; s[rg * 4 + 3] = d4.w;
+      s[rg * 4] = sD[oD0 + rg * 256]; s[rg * 4 + 1] = sD[oD1 + rg * 256];
+      s[rg * 4 + 2] = sD[oD0 + rg * 256 + 64]; s[rg * 4 + 3] = sD[oD1 + rg * 256 + 64];
       const float4 e4 = *reinterpret_cast<const float4*>(sL + 32 + 8 * rg + 4 * half);
       dp[rg * 4] = e4.x; dp[rg * 4 + 1] = e4.y; dp[rg * 4 + 2] = e4.z; dp[rg * 4 + 3] = e4.w;
     }
@@ -674,13 +679,12 @@ struct DenseArgs {
   int rel_mode, P, code_bias, n2d, Lt, causal;
   const int* gcode;
   const float *rel2d, *rel1d, *relx;
-  float *D, *Dt;
+  float* D;
 };
 
-// D[h][i][j] = pos_q[i] . pos_k[j] + rel(i, j), -inf where (i, j) is masked (causal, "tail-first" order) or j >= S;
-// Dt[h][j][i] the transpose, -inf where masked or i >= T.  One workgroup per (head, 32-row strip): the head's delta table
-// and the grid codes sit in LDS, each wave walks 32 x 32 tiles of the strip and computes them in both orientations (the
-// accumulator row is the lane either way, so both outputs leave as 16-byte row segments without a transposition).
+// D[h][i][j] = pos_q[i] . pos_k[j] + rel(i, j) as [H][Tp][Sp], -inf where (i, j) is masked (causal, "tail-first" order),
+// j >= S or i >= T.  One workgroup per (head, 32-row strip): the head's delta table and the grid codes sit in LDS, each
+// wave walks 32 x 32 tiles of the strip (accumulator row = the lane: a tile leaves as 16-byte row segments).
 __global__ __launch_bounds__(512) void attn_dense_bias_kernel(DenseArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sT = reinterpret_cast<float*>(smem);                       // rel2d[h]
@@ -737,30 +741,13 @@ __global__ __launch_bounds__(512) void attn_dense_bias_kernel(DenseArgs a) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[ks], fq[ks], acc, 0, 0, 0);
     }
-    if (i0 + x < a.T) {
-      float* dp = a.D + ((long long)h * a.T + i0 + x) * a.Sp + j0 + 4 * half;
+    {
+      float* dp = a.D + ((long long)h * a.Tp + i0 + x) * a.Sp + j0 + 4 * half;
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = dead ? NEG_INF : entry(i0 + x, j0 + 8 * rg + 4 * half + e, acc[rg * 4 + e]);
-        *reinterpret_cast<float4*>(dp + 8 * rg) = make_float4(o[0], o[1], o[2], o[3]);
-      }
-    }
-    // (2) lane = key j0 + x, element r <-> query i0 + (r&3) + 8*(r>>2) + 4*half
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    if (a.pq && !dead) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[ks], fk[ks], acc, 0, 0, 0);
-    }
-    if (j0 + x < a.S) {
-      float* dp = a.Dt + ((long long)h * a.S + j0 + x) * a.Tp + i0 + 4 * half;
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = dead ? NEG_INF : entry(i0 + 8 * rg + 4 * half + e, j0 + x, acc[rg * 4 + e]);
         *reinterpret_cast<float4*>(dp + 8 * rg) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
@@ -1062,9 +1049,22 @@ __global__ __launch_bounds__(256) void attn_dbias_tables_kernel(DbArgs a) {
       t0 += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])) + tail;
     }
     // tail rows x grid columns: coalesced 16-byte chunks along the row
-    for (int ti = part; ti < Lt; ti += DB_NPARTS) {
+    // (four rows' loads in flight together: a long tail -- 239 rows at 640 x 640 / 171 classes -- made this the kernel's
+    // longest block by far, 60 dependent round trips)
+    for (int c = tid; c < (P >> 3); c += 256) {
       float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int c = tid; c < (P >> 3); c += 256)
+      int ti = part;
+      for (; ti + 3 * DB_NPARTS < Lt; ti += 4 * DB_NPARTS) {
+        uint4 v[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            v[u][g] = g < a.ng ? *reinterpret_cast<const uint4*>(hb + g * a.gs + (long long)(P + ti + u * DB_NPARTS) * a.Sp + c * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { add8(t, v[u][0]); add8(t, v[u][1]); }
+      }
+      for (; ti < Lt; ti += DB_NPARTS)
         for (int g = 0; g < a.ng; ++g) add8(t, *reinterpret_cast<const uint4*>(hb + g * a.gs + (long long)(P + ti) * a.Sp + c * 8));
       t1 += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     }
@@ -1084,10 +1084,10 @@ __global__ __launch_bounds__(256) void attn_dbias_tables_kernel(DbArgs a) {
 
 extern "C" int ifseg_attn_dense_bias(const void* pos_q, const void* pos_k, int ldpq, int ldpk, int H, int T, int S,
                                      int rel_mode, int P, const int* gcode, int code_bias, int n2d, const float* rel2d,
-                                     const float* rel1d, const float* relx, int causal, float* D, int Sp, float* Dt,
-                                     int Tp, void* stream) {
+                                     const float* rel1d, const float* relx, int causal, float* D, int Sp, int Tp,
+                                     void* stream) {
   (void)hipGetLastError();
-  if (!D || !Dt || H <= 0 || T <= 0 || S <= 0 || (Sp & 31) || (Tp & 31) || Sp < S || Tp < T) return IFSEG_ERR_BAD_ARG;
+  if (!D || H <= 0 || T <= 0 || S <= 0 || (Sp & 31) || (Tp & 31) || Sp < S || Tp < T) return IFSEG_ERR_BAD_ARG;
   if ((pos_q == nullptr) != (pos_k == nullptr) || ((ldpq | ldpk) & 7)) return IFSEG_ERR_BAD_ARG;
   if (rel_mode && (!gcode || !rel2d || !rel1d || !relx)) return IFSEG_ERR_BAD_ARG;
   if ((rel_mode || causal) && (P > T || P > S || P < 0)) return IFSEG_ERR_BAD_SHAPE;
@@ -1095,7 +1095,7 @@ extern "C" int ifseg_attn_dense_bias(const void* pos_q, const void* pos_k, int l
   a.pq = (const bf16_t*)pos_q; a.pk = (const bf16_t*)pos_k; a.ldpq = ldpq; a.ldpk = ldpk;
   a.H = H; a.T = T; a.S = S; a.Sp = Sp; a.Tp = Tp;
   a.rel_mode = rel_mode; a.P = (rel_mode || causal) ? P : S; a.code_bias = code_bias; a.n2d = rel_mode ? n2d : 0; a.Lt = rel_mode ? T - P : 0; a.causal = causal;
-  a.gcode = gcode; a.rel2d = rel2d; a.rel1d = rel1d; a.relx = relx; a.D = D; a.Dt = Dt;
+  a.gcode = gcode; a.rel2d = rel2d; a.rel1d = rel1d; a.relx = relx; a.D = D;
   const size_t lds = rel_mode ? ((((size_t)n2d + 3) & ~(size_t)3) + (((size_t)2 * a.Lt + 2) & ~(size_t)3) + (size_t)P) * 4 : 16;
   if (lds > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_dense_bias_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1107,10 +1107,10 @@ extern "C" int ifseg_attn_dense_bias(const void* pos_q, const void* pos_k, int l
 extern "C" int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* x, void* stream) {
   (void)hipGetLastError();
   if (!x || x->B <= 0 || x->H <= 0 || x->T <= 0 || x->S <= 0) return IFSEG_ERR_BAD_ARG;
-  if ((x->Sp & 31) || (x->Tp & 31) || x->Sp < x->S || x->Tp < x->T || !x->D || !x->Dt) return IFSEG_ERR_BAD_ARG;
+  if ((x->Sp & 31) || (x->Tp & 31) || x->Sp < x->S || x->Tp < x->T || !x->D) return IFSEG_ERR_BAD_ARG;
   BiArgs a{};
   a.q = (const bf16_t*)x->q; a.k = (const bf16_t*)x->k; a.v = (const bf16_t*)x->v; a.dO = (const bf16_t*)x->dout;
-  a.lse = x->lse; a.delta = x->delta; a.D = x->D; a.Dt = x->Dt; a.gain = (const float*)x->gain;
+  a.lse = x->lse; a.delta = x->delta; a.D = x->D; a.gain = (const float*)x->gain;
   a.dq = (bf16_t*)x->dq; a.dk = (bf16_t*)x->dk; a.dv = (bf16_t*)x->dv; a.dbias = (bf16_t*)x->dbias; a.dgain_rows = x->dgain_rows;
   a.B = x->B; a.H = x->H; a.T = x->T; a.S = x->S; a.Sp = x->Sp; a.Tp = x->Tp;
   a.q_bs = x->q_bs; a.k_bs = x->k_bs; a.v_bs = x->v_bs; a.do_bs = x->do_bs; a.dq_bs = x->dq_bs; a.dk_bs = x->dk_bs; a.dv_bs = x->dv_bs;
@@ -1126,7 +1126,7 @@ extern "C" int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* x, void* stream) {
     long long ldmax = a.ldq;
     for (long long l : {(long long)a.lddo, (long long)a.ldk, (long long)a.ldv}) ldmax = l > ldmax ? l : ldmax;
     const long long rows = a.T > a.S ? a.T : a.S;
-    if (rows * ldmax * 2 >= (1ll << 31) || (long long)a.T * a.Sp * 4 >= (1ll << 31) || (long long)a.S * a.Tp * 4 >= (1ll << 31))
+    if (rows * ldmax * 2 >= (1ll << 31) || (long long)a.Tp * a.Sp * 4 >= (1ll << 31))
       return IFSEG_ERR_BAD_SHAPE;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -1153,7 +1153,7 @@ extern "C" int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* x, void* stream) {
 extern "C" int ifseg_attn_fwd_bi(const ifseg_attn_bi_args* x, void* stream) {
   (void)hipGetLastError();
   if (!x || x->B <= 0 || x->H <= 0 || x->T <= 0 || x->S <= 0 || !x->q || !x->k || !x->v || !x->out || !x->lse || !x->D) return IFSEG_ERR_BAD_ARG;
-  if ((x->Sp & 31) || x->Sp < x->S) return IFSEG_ERR_BAD_ARG;
+  if ((x->Sp & 31) || x->Sp < x->S || (x->Tp & 31) || x->Tp < x->T) return IFSEG_ERR_BAD_ARG;
   BiArgs a{};
   a.q = (const bf16_t*)x->q; a.k = (const bf16_t*)x->k; a.v = (const bf16_t*)x->v; a.D = x->D; a.gain = (const float*)x->gain;
   a.out = (bf16_t*)x->out; a.lse_out = const_cast<float*>(x->lse); a.o_bs = x->out_bs; a.ldo = x->ldout;
@@ -1166,7 +1166,7 @@ extern "C" int ifseg_attn_fwd_bi(const ifseg_attn_bi_args* x, void* stream) {
   if (a.causal && ((a.P & 63) || a.P > a.T || a.P > a.S)) return IFSEG_ERR_BAD_SHAPE;
   {
     const long long ldmax = a.ldk > a.ldv ? a.ldk : a.ldv;
-    if ((long long)a.S * ldmax * 2 >= (1ll << 31) || (long long)a.T * a.Sp * 4 >= (1ll << 31)) return IFSEG_ERR_BAD_SHAPE;
+    if ((long long)a.S * ldmax * 2 >= (1ll << 31) || (long long)a.Tp * a.Sp * 4 >= (1ll << 31)) return IFSEG_ERR_BAD_SHAPE;
   }
   hipStream_t s = (hipStream_t)stream;
   const int lds = 2 * STG_DQ;

@@ -33,7 +33,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 11:
+        if _lib.ifseg_abi_version() != 12:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -377,13 +377,12 @@ def _pad32(n):
 
 
 class DenseBias:
-    """The batch-invariant attention bias of one layer as dense fp32 operands: D [H, T, Sp] and its transpose Dt [H, S, Tp]
-    (-inf = masked), built from parameters only by ifseg_attn_dense_bias."""
+    """The batch-invariant attention bias of one layer as a dense fp32 operand D [H, Tp, Sp] (-inf = masked or padding),
+    built from parameters only by ifseg_attn_dense_bias."""
 
     def __init__(self, H, T, S, device):
         self.H, self.T, self.S, self.Sp, self.Tp = H, T, S, _pad32(S), _pad32(T)
-        self.D = torch.empty(H, T, self.Sp, dtype=torch.float32, device=device)
-        self.Dt = torch.empty(H, S, self.Tp, dtype=torch.float32, device=device)
+        self.D = torch.empty(H, self.Tp, self.Sp, dtype=torch.float32, device=device)
 
 
 def attn_dense_bias(dense, pos_q, pos_k, rel=None, causal=False, P=None):
@@ -398,13 +397,13 @@ def attn_dense_bias(dense, pos_q, pos_k, rel=None, causal=False, P=None):
         c_int(rel.code_bias if rel is not None else 0), c_int(rel.rel2d.shape[1] if rel is not None else 0),
         _ptr(rel.rel2d) if rel is not None else None, _ptr(rel.rel1d) if rel is not None else None,
         _ptr(rel.relx) if rel is not None else None, c_int(1 if causal else 0), _ptr(dense.D), c_int(dense.Sp),
-        _ptr(dense.Dt), c_int(dense.Tp), _stream())
+        c_int(dense.Tp), _stream())
     _check(rc, "attn_dense_bias")
     return dense
 
 
 class _AttnBiArgs(ctypes.Structure):
-    _fields_ = ([(n, c_void_p) for n in ("q", "k", "v", "dout", "lse", "delta", "D", "Dt", "gain", "dq", "dk", "dv", "dbias")]
+    _fields_ = ([(n, c_void_p) for n in ("q", "k", "v", "dout", "lse", "delta", "D", "gain", "dq", "dk", "dv", "dbias")]
                 + [(n, c_int) for n in ("B", "H", "T", "S", "Sp", "Tp", "ldq", "ldk", "ldv", "lddo", "lddq", "lddk", "lddv")]
                 + [(n, c_ll) for n in ("q_bs", "k_bs", "v_bs", "do_bs", "dq_bs", "dk_bs", "dv_bs")]
                 + [("causal", c_int), ("P", c_int), ("dq_scale", c_float), ("phases", c_int), ("dgain_rows", c_void_p),
@@ -416,7 +415,7 @@ def attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S,
     """dbias: bf16 [ceil(B/4), H, T, dense.Sp] -- zero-filled once by the caller when causal (skipped blocks are not written)"""
     a = _AttnBiArgs()
     for name, t in (("q", q), ("k", k), ("v", v), ("dout", dout), ("lse", lse), ("delta", delta), ("D", dense.D),
-                    ("Dt", dense.Dt), ("gain", _f32(gain)), ("dq", dq), ("dk", dk), ("dv", dv), ("dbias", dbias)):
+                    ("gain", _f32(gain)), ("dq", dq), ("dk", dk), ("dv", dv), ("dbias", dbias)):
         setattr(a, name, _p(t))
     assert dbias.dtype == torch.bfloat16 and tuple(dbias.shape) == ((B + 3) // 4, H, T, dense.Sp) and dbias.is_contiguous()
     a.B, a.H, a.T, a.S, a.Sp, a.Tp = B, H, T, S, dense.Sp, dense.Tp
@@ -437,7 +436,7 @@ def dbias_nparts():
 def attn_fwd_bi(q, k, v, dense, out, lse, B, H, T, S, causal=False, P=None, gain=None):
     """out = gain softmax(q k^T + dense.D) v, four batch elements per workgroup (csrc/attention_bi.hip)"""
     a = _AttnBiArgs()
-    for name, t in (("q", q), ("k", k), ("v", v), ("lse", lse), ("D", dense.D), ("Dt", dense.Dt), ("gain", _f32(gain)), ("out", out)):
+    for name, t in (("q", q), ("k", k), ("v", v), ("lse", lse), ("D", dense.D), ("gain", _f32(gain)), ("out", out)):
         setattr(a, name, _p(t))
     a.B, a.H, a.T, a.S, a.Sp, a.Tp = B, H, T, S, dense.Sp, dense.Tp
     a.ldq, a.ldk, a.ldv, a.ldout = q.stride(1), k.stride(1), v.stride(1), out.stride(1)

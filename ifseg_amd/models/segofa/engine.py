@@ -102,7 +102,6 @@ class HipEngine:
         # k_proj.weight gradients without the product of dK's spurious column sum and the token mean of the projection's input
         # (an exact identity: sum_j dK_j = 0; csrc/rowops.hip ifseg_kproj_common_mode).  IFSEG_NO_KPROJ_FIX=1: as computed.
         self.kproj_fix = os.environ.get("IFSEG_NO_KPROJ_FIX") is None
-        self.fwd_dense = os.environ.get("IFSEG_ATTN_FWD_DENSE") == "1"
         # the forward through the batch-inner kernel wherever the layer's dense bias exists (IFSEG_ATTN_BI_FWD=0: round-3 forward)
         self.bi_fwd = os.environ.get("IFSEG_ATTN_BI_FWD", "1") != "0"
         self._ffn_pg_tasks = []
@@ -1173,12 +1172,9 @@ class HipEngine:
             # the forward of the batch-inner formulation: dense bias tile shared by four batch elements, no abs-pos columns in
             # the contraction, no table look-ups, one path for every grid width (csrc/attention_bi.hip: attn_bi_fwd_kernel)
             self._dense_wait(tg)
-            if self.fwd_dense:       # (experiment: the round-3 kernel seeded from the dense bias by global loads -- slower)
-                hip.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], None, None, o, lse, B, H, T, T, rel=None,
-                             causal=causal, P=rel.P, gain=gain, dense_bias=dd.D)
-            else:
-                hip.attn_fwd_bi(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], dd, o, lse, B, H, T, T, causal=causal,
-                                P=rel.P, gain=gain)
+            # (measured and dropped: the round-3 kernel seeded from the dense bias by global loads, 94.2 vs 91.3 ms on C4)
+            hip.attn_fwd_bi(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], dd, o, lse, B, H, T, T, causal=causal,
+                            P=rel.P, gain=gain)
         else:
             hip.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], pq, pk, o, lse, B, H, T, T, rel=rel,
                          causal=causal, gain=gain, dense_bias=dense)
@@ -1216,10 +1212,7 @@ class HipEngine:
         dd = self.ctx_building.get("dense", {}).get("dc") if (self.bi_fwd and self.ctx_building is not None) else None
         if dd is not None:
             self._dense_wait("dc")
-            if self.fwd_dense:
-                hip.attn_fwd(q, kv[:, :, :C], kv[:, :, C:], None, None, o, lse, B, H, Td, Te, gain=gain, dense_bias=dd.D)
-            else:
-                hip.attn_fwd_bi(q, kv[:, :, :C], kv[:, :, C:], dd, o, lse, B, H, Td, Te, gain=gain)
+            hip.attn_fwd_bi(q, kv[:, :, :C], kv[:, :, C:], dd, o, lse, B, H, Td, Te, gain=gain)
         else:
             hip.attn_fwd(q, kv[:, :, :C], kv[:, :, C:], cpq, cpk, o, lse, B, H, Td, Te, gain=gain)
         a = buf(tg + "_ca_a", (B * Td, C))

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 11
+#define IFSEG_ABI_VERSION 12
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -210,13 +210,14 @@ int ifseg_attn_bwd_reduce(const ifseg_attn_reduce_args* args, void* stream);
  * (encoder_module.py:757-771,790-809 with the expand at :317,791; decoder_module.py:553-558,603-627;
  * unify_multihead_attention.py:459-465).  These three entry points keep that structure:
  *
- * ifseg_attn_dense_bias: D[h][i][j] = pos_q[i].pos_k[j] + rel(i,j) as fp32 [H,T,Sp] and its transpose Dt [H,S,Tp]
- *   (Sp / Tp = S / T rounded up to 32); -inf where the causal mask ("tail-first" order of ifseg_attn_fwd) hides (i,j),
- *   for padded columns j >= S and, in Dt, padded columns i >= T.  Parameters only: built once per layer and step.
+ * ifseg_attn_dense_bias: D[h][i][j] = pos_q[i].pos_k[j] + rel(i,j) as fp32 [H,Tp,Sp] (Sp / Tp = S / T rounded up
+ *   to 32); -inf where the causal mask ("tail-first" order of ifseg_attn_fwd) hides (i,j), for padded columns j >= S
+ *   and padded rows i >= T.  Parameters only: built once per layer and step.  (Causal: 32 x 32 tiles no kernel's block
+ *   schedule reaches are not written.)
  *   rel(i,j) as documented at ifseg_attn_fwd (rel_mode = 1), pos_q / pos_k may be NULL (no abs-pos term). */
 int ifseg_attn_dense_bias(const void* pos_q, const void* pos_k, int ldpq, int ldpk, int H, int T, int S, int rel_mode,
                           int P, const int* gcode, int code_bias, int n2d, const float* rel2d, const float* rel1d,
-                          const float* relx, int causal, float* D, int Sp, float* Dt, int Tp, void* stream);
+                          const float* relx, int causal, float* D, int Sp, int Tp, void* stream);
 
 /* ifseg_attn_bwd_bi: dq (x dq_scale), dk, dv of S_b = q_b k_b^T + D (autograd of unify_multihead_attention.py:459-512)
  *   and dbias[g][h][i][j] = sum over the batch elements 4g .. 4g+3 of dS_b[h][i][j] (bf16 [ceil(B/4), H, T, Sp]).
@@ -226,7 +227,7 @@ int ifseg_attn_dense_bias(const void* pos_q, const void* pos_k, int ldpq, int ld
  *   the caller zero-fills the buffer once (the set of skipped blocks depends only on the shape).  No atomics. */
 typedef struct ifseg_attn_bi_args {
   const void *q, *k, *v, *dout;
-  const float *lse, *delta, *D, *Dt;
+  const float *lse, *delta, *D;
   const void* gain;            /* fp32 [H] or NULL */
   void *dq, *dk, *dv, *dbias;
   int B, H, T, S, Sp, Tp;

@@ -24,6 +24,8 @@ def main(kind="enc"):
         B, H, C = 4, 16, 1024
         gh = gw = 40; P = 1600
         Lt = 1 if kind in ("dec", "decfull") else 239
+    if os.environ.get("ATTN_BENCH_B"):
+        B = int(os.environ["ATTN_BENCH_B"])
     if os.environ.get("ATTN_BENCH_LT"):
         Lt = int(os.environ["ATTN_BENCH_LT"])
     T = S = P + Lt
@@ -64,6 +66,9 @@ def main(kind="enc"):
     print(kind, "bi dq (+ sum_b dS)      us %.1f" % timeit(lambda: bi(hip.ATTN_BWD_DQ)))
     print(kind, "bi dkv + dq             us %.1f" % timeit(lambda: bi(0)))
     print(kind, "dbias grads             us %.1f" % timeit(lambda: hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, causal=causal, **kw)))
+    print(kind, "  operands only         us %.1f" % timeit(lambda: hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, causal=causal)))
+    if kw:
+        print(kind, "  delta tables only     us %.1f" % timeit(lambda: hip.attn_dbias_grads(dbias, S, causal=causal, **kw)))
     # round-3 kernels
     dpqp = torch.zeros(B, T, C, device=dev, dtype=torch.bfloat16); dpkp = torch.zeros(B, S, C, device=dev, dtype=torch.bfloat16)
     nparts = B * ((S + 127) // 128)
