@@ -734,22 +734,22 @@ __global__ __launch_bounds__(512) void attn_dense_bias_kernel(DenseArgs a) {
       for (int ks = 0; ks < 4; ++ks) { U128 w; w.v = *reinterpret_cast<const uint4*>(kp + ks * 16); fk[ks] = w.b; }
     }
     f32x16 acc;
-    // (1) lane = query i0 + x, element r <-> key j0 + (r&3) + 8*(r>>2) + 4*half
+    // lane = key j0 + x, element r <-> query i0 + (r&3) + 8*(r>>2) + 4*half: a store instruction writes two whole 128-byte
+    // row segments (the other orientation -- a lane owning a query row, 16-byte stores -- put 32-byte pieces of 32 rows into
+    // every store and measured 1.3 x the algorithmic HBM write bytes, profiles/round4_hbm_traffic.json)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     if (a.pq && !dead) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[ks], fq[ks], acc, 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[ks], fk[ks], acc, 0, 0, 0);
     }
     {
-      float* dp = a.D + ((long long)h * a.Tp + i0 + x) * a.Sp + j0 + 4 * half;
+      float* dp = a.D + ((long long)h * a.Tp + i0 + 4 * half) * a.Sp + j0 + x;
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        float o[4];
+      for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = dead ? NEG_INF : entry(i0 + x, j0 + 8 * rg + 4 * half + e, acc[rg * 4 + e]);
-        *reinterpret_cast<float4*>(dp + 8 * rg) = make_float4(o[0], o[1], o[2], o[3]);
-      }
+        for (int e = 0; e < 4; ++e)
+          dp[(long long)(8 * rg + e) * a.Sp] = dead ? NEG_INF : entry(i0 + 8 * rg + 4 * half + e, j0 + x, acc[rg * 4 + e]);
     }
   }
 }
@@ -791,7 +791,9 @@ __global__ __launch_bounds__(256) void attn_dbias_grads_kernel(DbArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char sm[32768];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int blk = blockIdx.x;
+  // consecutive tiles of a head on ONE XCD, next to each other in time: a d pos_k block reads 64 bytes of every row and its
+  // neighbour the other half of the same 128-byte lines (round-robin placement measured 1.75 x the algorithmic read bytes)
+  int blk = blockIdx.x < a.nb_q ? xcd_remap(blockIdx.x, a.nb_q) : a.nb_q + xcd_remap(blockIdx.x - a.nb_q, a.nb_k);
   const int lr = lane >> 3, lc = lane & 7;        // tile staging: rows lr + 8 u, 16-byte chunk lc
   if (blk < a.nb_q) {
     // ---- d pos_q[i][h*64 + c] (+)= scale * sum_j dB[h][i][j] pos_k[j][h*64 + c]:  out^T[c][i], A = pos_k^T (tr), B = dB rows
@@ -951,7 +953,7 @@ __global__ __launch_bounds__(256) void attn_dbias_grads_kernel(DbArgs a) {
 __global__ __launch_bounds__(256) void attn_dbias_tables_kernel(DbArgs a) {
   __shared__ __attribute__((aligned(16))) float sf[2 * 4096];
   const int tid = threadIdx.x;
-  int blk = blockIdx.x;
+  int blk = blockIdx.x < a.nb_2d ? xcd_remap(blockIdx.x, a.nb_2d) : blockIdx.x;
   auto add8 = [](float* t, const uint4& v) {
     t[0] += bflo(v.x); t[1] += bfhi(v.x); t[2] += bflo(v.y); t[3] += bfhi(v.y);
     t[4] += bflo(v.z); t[5] += bfhi(v.z); t[6] += bflo(v.w); t[7] += bfhi(v.w);
@@ -961,7 +963,8 @@ __global__ __launch_bounds__(256) void attn_dbias_tables_kernel(DbArgs a) {
     // x_i - x_j = dx and y_i = part (mod DB_NPARTS).  A thread owns (x_i, 8 consecutive x_j) of every second row: 16-byte loads,
     // all of a thread's loads in flight together.
     const int ndy = 2 * a.gh - 1, w = a.gw, nch = w >> 3, npair = w * nch;
-    const int part = blk % DB_NPARTS, dy = (blk / DB_NPARTS) % ndy - (a.gh - 1), h = blk / (DB_NPARTS * ndy);
+    // (dy fastest, on one XCD: the blocks of dy and dy + 1 read the two halves of the same 128-byte lines on a 32-wide grid)
+    const int dy = blk % ndy - (a.gh - 1), part = (blk / ndy) % DB_NPARTS, h = blk / (DB_NPARTS * ndy);
     const int ylo = dy > 0 ? dy : 0, yhi = dy < 0 ? a.gh + dy : a.gh;
     const int y0 = ylo + ((part - ylo) % DB_NPARTS + DB_NPARTS) % DB_NPARTS;
     float* out = a.drel2d + ((long long)h * DB_NPARTS + part) * ndy * (2 * w - 1) + (long long)(dy + a.gh - 1) * (2 * w - 1);
