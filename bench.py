@@ -287,6 +287,7 @@ def main():
     t0 = time.time()
     for _ in range(a.steps):
         logs = one_step()
+    t_enq = time.time() - t0          # the host has ENQUEUED every step (it runs ahead of the GPU unless launches are the limit)
     sync()
     dt = time.time() - t0
     tt = torch.tensor([dt], device=dev)
@@ -384,6 +385,7 @@ def main():
         # the data-parallel leg as it actually ran (live from the reducer): N ranks in ONE RCCL communicator, how many
         # collectives and bytes per step.  Any N > 1 run that did not go through the direct communicator fails loudly below.
         out["rccl"] = rccl_stats
+        out["host_enqueue_ms_per_step"] = round(t_enq / a.steps * 1e3, 3)
         if steady is not None:
             out["steady_state"] = steady
         if not a.no_cpu_baseline and world == 1:

@@ -94,10 +94,10 @@ class HipEngine:
         # attention backward with the batch inside the workgroup (csrc/attention_bi.hip): the bias is a dense batch-invariant
         # operand built once per layer from parameters, sum_b dS leaves the dQ kernel once per tile.  IFSEG_ATTN_BI=0: the
         # round-3 kernels (one workgroup per (batch, head, tile), bias regenerated per batch element).
-        # Default "auto" (measured in the step, DESIGN round 4): on a 32-wide grid the encoder self-attention and the decoder
-        # cross-attention take this path (Base C2 17.52 vs 17.90 ms, C3 20.06 vs 20.66 ms) and the causal decoder self-attention
-        # keeps the round-3 kernels (its row-aligned 32-wide fast path is ahead by 0.1 ms); on every other grid width all
-        # three do (SegOFA-Large at 640^2: 87.3 vs 101.7 ms per step).  "1": everywhere, "0": nowhere.
+        # Default "auto" = "1": all three attentions of a training step take this path whenever the grid width is a multiple of
+        # 8 and <= 64 (measured in the step, DESIGN round 4, same box: Base C2 17.44 vs 18.03 ms with the round-3 kernels;
+        # SegOFA-Large at 640^2 83.4 vs 101.7 ms).  Until the dense bias lost its transposed copy the causal decoder
+        # self-attention was 0.1 ms better off on the round-3 kernels' 32-wide fast path; now it is 0.06 ms worse.  "0": nowhere.
         self.attn_bi = os.environ.get("IFSEG_ATTN_BI", "auto")
         # k_proj.weight gradients without the product of dK's spurious column sum and the token mean of the projection's input
         # (an exact identity: sum_j dK_j = 0; csrc/rowops.hip ifseg_kproj_common_mode).  IFSEG_NO_KPROJ_FIX=1: as computed.
@@ -888,7 +888,7 @@ class HipEngine:
         x_pre = None
         bi = need_grad and w <= 64 and w % 8 == 0 and self.attn_bi in ("1", "auto")
         # which attentions: e(ncoder self), d(ecoder self), c(ross); IFSEG_ATTN_BI_WHICH overrides
-        bi_which = os.environ.get("IFSEG_ATTN_BI_WHICH", "e+c" if (self.attn_bi == "auto" and w == 32) else "e+d+c").split("+") if bi else []
+        bi_which = os.environ.get("IFSEG_ATTN_BI_WHICH", "e+d+c").split("+") if bi else []
         ctx["dense"] = {}
         if bi and "e" in bi_which:
             # parameters only: every layer's dense bias on the side stream, under the first blocks of the forward

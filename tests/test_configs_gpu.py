@@ -170,14 +170,20 @@ def test_base_config1_batch2_vs_reference_golden(golden_dir):
     _golden_case(golden_dir, "base_c1_b2.npz", O.base_config(), 2)
 
 
-def test_base_config1_with_the_batch_inner_attention_backward(golden_dir, monkeypatch):
-    """The same golden with EVERY attention through csrc/attention_bi.hip (IFSEG_ATTN_BI=1; the default `auto` leaves the causal
-    decoder self-attention of a 32-wide grid to the round-3 kernels): dense batch-invariant biases built on the side stream,
-    forward and backward workgroups of four batch elements, sum_b dS -> operand / table gradients -- all 359 gradient tensors
-    element-wise, both autograd modes."""
-    monkeypatch.setenv("IFSEG_ATTN_BI", "1")
+def test_base_config1_default_is_the_batch_inner_attention_everywhere(golden_dir):
+    """The default path of a training step: EVERY attention through csrc/attention_bi.hip -- dense batch-invariant biases built
+    on the side stream, forward and backward workgroups of four batch elements, sum_b dS -> operand / table gradients; all 359
+    gradient tensors element-wise, both autograd modes (the golden run above) -- and the dispatch is what ran."""
     m, _, _, _ = _golden_case(golden_dir, "base_c1_b2.npz", O.base_config(), 2)
-    assert m.engine.attn_bi == "1" and len(m.engine.ctx.get("dense", {})) == 13      # 6 + 6 self-attention biases, one cross
+    assert m.engine.attn_bi == "auto" and len(m.engine.ctx.get("dense", {})) == 13   # 6 + 6 self-attention biases, one cross
+
+
+def test_base_config1_with_mixed_attention_kernels(golden_dir, monkeypatch):
+    """... with the causal decoder self-attention on the round-3 kernels and the other two on the batch-inner ones
+    (IFSEG_ATTN_BI_WHICH=e+c, the default until the dense bias lost its transposed copy): both families in one step."""
+    monkeypatch.setenv("IFSEG_ATTN_BI_WHICH", "e+c")
+    m, _, _, _ = _golden_case(golden_dir, "base_c1_b2.npz", O.base_config(), 2)
+    assert len(m.engine.ctx.get("dense", {})) == 7
 
 
 def test_base_config1_with_the_round3_attention_kernels(golden_dir, monkeypatch):

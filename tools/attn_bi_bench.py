@@ -66,7 +66,7 @@ def main(kind="enc"):
     print(kind, "bi dq (+ sum_b dS)      us %.1f" % timeit(lambda: bi(hip.ATTN_BWD_DQ)))
     print(kind, "bi dkv + dq             us %.1f" % timeit(lambda: bi(0)))
     print(kind, "dbias grads             us %.1f" % timeit(lambda: hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, causal=causal, **kw)))
-    print(kind, "  operands only         us %.1f" % timeit(lambda: hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, causal=causal)))
+    print(kind, "  operands only         us %.1f" % timeit(lambda: hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, causal=causal, P=P)))
     if kw:
         print(kind, "  delta tables only     us %.1f" % timeit(lambda: hip.attn_dbias_grads(dbias, S, causal=causal, **kw)))
     # round-3 kernels
