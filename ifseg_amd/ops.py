@@ -198,12 +198,14 @@ def bias_attention_bwd(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: 
         parts = [None, None, None]
         if rel is not None:
             parts = [torch.empty(H, nparts, t.shape[1], dtype=torch.float32, device=dev) for t in (rel2d, rel1d, relx)]
+        # per-row terms of d c_attn = sum_j P dP from the dQ kernel (no division of delta by the gain: exact at c_attn = 0)
+        dgr = torch.empty(B, H, T, dtype=torch.float32, device=dev)
         hip.attn_bwd(q, k, v, pos_q, pos_k, out, dout.contiguous(), lse, delta, dq, dk, dv, dpq, dpk, B, H, T, S, rel=rel,
                      causal=causal, P=P, gain=gain, drel2d_part=parts[0], drel1d_part=parts[1], drelx_part=parts[2],
-                     nparts=nparts)
+                     nparts=nparts, dgain_rows=dgr)
         e = torch.empty(0, dtype=torch.float32, device=dev)
         tabs = [p.sum(1) if p is not None else e for p in parts]
-        dgain = delta.sum((0, 2)) / gain.float()
+        dgain = dgr.sum((0, 2))
         return dq, dk, dv, dpq.float().sum(0).to(pos_q.dtype), dpk.float().sum(0).to(pos_k.dtype), dgain, tabs[0], tabs[1], tabs[2]
     finally:
         hip.set_stream(prev)

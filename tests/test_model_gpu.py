@@ -235,7 +235,7 @@ def test_dropout_path_wiring_and_training_mode(golden_dir):
     assert torch.isfinite(ga).all() and ga.norm() > 0
 
 
-def _parity_case(ocfg, batch_size, src_len, image_hw, tol_logits=2e-2, check_grads=True):
+def _parity_case(ocfg, batch_size, src_len, image_hw, tol_logits=2e-2, check_grads=True, tol_grads=8e-2, skip_gain=True):
     """HIP vs CPU oracle (run here, fp32) on a derived configuration."""
     from ifseg_amd.criterions import SegCriterion
     dev = torch.device("cuda:0")
@@ -260,12 +260,12 @@ def _parity_case(ocfg, batch_size, src_len, image_hw, tol_logits=2e-2, check_gra
         for k, og in o_grads.items():
             if k not in named or not named[k].requires_grad or og.norm() == 0:
                 continue
-            if k.endswith(("k_proj.bias", "pos_k_linear.bias", "c_attn")):
+            if k.endswith(("k_proj.bias", "pos_k_linear.bias") + (("c_attn",) if skip_gain else ())):
                 continue
             r = _rel(named[k].grad, og)
-            if r > 8e-2:
+            if r > tol_grads:
                 bad.append((round(r, 4), k))
-        assert not bad, bad[:8]
+        assert not bad, sorted(bad)[-8:]
 
 
 def test_many_classes_long_prompt_vs_oracle():
@@ -286,6 +286,18 @@ def test_large_geometry_vs_oracle():
     ocfg = O.SegOFAConfig(embed_dim=1024, ffn_dim=4096, heads=16, enc_layers=1, dec_layers=1, resnet_layers=(1, 1, 1),
                           num_seg_tokens=171, vocab_size=600, patch_image_size=640, orig_patch_image_size=640)
     _parity_case(ocfg, 1, 239, (640, 640))
+
+
+def test_large_geometry_depth4_gradient_values_vs_oracle():
+    """The same Large geometry at depth 4 + 4 (B = 1: three of a batch-inner workgroup's four batch waves are idle): logits,
+    loss and EVERY gradient tensor the oracle produces -- head gains included -- at the stated 6e-2, so an error that only
+    shows when gradients have passed through several 1024-wide layers on the 40-wide grid cannot hide at depth 1 + 1."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ocfg = O.SegOFAConfig(embed_dim=1024, ffn_dim=4096, heads=16, enc_layers=4, dec_layers=4, resnet_layers=(1, 1, 1),
+                          num_seg_tokens=171, vocab_size=600, patch_image_size=640, orig_patch_image_size=640)
+    _parity_case(ocfg, 1, 239, (640, 640), tol_grads=6e-2, skip_gain=False)
 
 
 def test_trunk_prefetch_matches_inline():
