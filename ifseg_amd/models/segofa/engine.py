@@ -1553,12 +1553,26 @@ class HipEngine:
             self._side_do(reductions)
 
     def _table_acc(self, tabname):
+        """fp32 accumulator of one rel-pos bucket table's gradient.  All of them are views of ONE flat buffer that the backward
+        clears with a single fill (`_tabacc_clear`) instead of one fill per table and step."""
         key = "g_tabacc_" + tabname
-        if key not in self._tab_touched:
-            t = self.buf(key, self.shapes[tabname], torch.float32)
-            t.zero_()
-            self._tab_touched[key] = tabname
+        if key not in self.ws:
+            names = sorted(n for n in self.shapes if "rel_pos_table_list" in n and self.offs[n] < self.n_train)
+            assert tabname in names, tabname
+            sizes = [(math.prod(self.shapes[n]) + 3) // 4 * 4 for n in names]
+            flat = self.ws["g_tabacc_flat"] = torch.zeros(sum(sizes), dtype=torch.float32, device=self.device)
+            o = 0
+            for n, sz in zip(names, sizes):
+                self.ws["g_tabacc_" + n] = flat[o:o + math.prod(self.shapes[n])].view(self.shapes[n])
+                o += sz
+        self._tab_touched.setdefault(key, tabname)
         return self.ws[key]
+
+    def _tabacc_clear(self):
+        """(side stream, ahead of the step's first attention reduction)"""
+        flat = self.ws.get("g_tabacc_flat")        # (None in the very first backward: created zero-filled further down the queue)
+        if flat is not None:
+            flat.zero_()
 
     def _self_block_bwd(self, tg, p, attn, ln1, ln2, dx1, B, T, pq, pk, scaling, dpq_acc, dpk_acc, first_pos, rel_grads,
                         da_pre=None, nxt=None):
@@ -1662,6 +1676,7 @@ class HipEngine:
         else:
             self.g16.zero_()
         self._tab_touched = {}
+        self._side_do(self._tabacc_clear)      # flushed with the first block's side work, ahead of every table reduction
         self._xsum_done = set()
         self._bt = "top"
         if ctx.get("dense_ready") is not None:      # the dense biases were built on the side stream during the forward
