@@ -386,6 +386,10 @@ def main():
         # collectives and bytes per step.  Any N > 1 run that did not go through the direct communicator fails loudly below.
         out["rccl"] = rccl_stats
         out["host_enqueue_ms_per_step"] = round(t_enq / a.steps * 1e3, 3)
+        if trainer.eng.drain_timing:             # IFSEG_DRAIN_TIMING=1: main-stream wait for the side queue at the end of the backward
+            torch.cuda.synchronize()
+            w = [t0.elapsed_time(t1) for t0, t1 in trainer.eng.drain_timing[-a.steps:]]
+            out["end_of_backward_wait_ms"] = round(sum(w) / len(w), 3)
         if steady is not None:
             out["steady_state"] = steady
         if not a.no_cpu_baseline and world == 1:

@@ -86,6 +86,11 @@ class HipEngine:
         self._ln_red_tasks, self._ln_red_acc = [], []    # (partials, [2, C] gradient view, ...) of LayerNorm backward launches
         self.dw_grouped = os.environ.get("IFSEG_NO_DW_GROUP") is None
         self.dw_split = os.environ.get("IFSEG_DW_SPLIT", "0") == "1"
+        # IFSEG_DRAIN_TIMING=1: event pair around the end-of-backward join (bench.py reports `end_of_backward_wait_ms`).
+        # Measured 0.49 ms per C2 step.  Moving the attentions' bias-gradient reductions to the third stream shortened it to
+        # 0.41 ms and made the step 0.45 ms SLOWER (a third busy queue under the dX chain); for the last layer only: 0.42 ms,
+        # step unchanged.  Not adopted.
+        self.drain_timing = [] if os.environ.get("IFSEG_DRAIN_TIMING") else None
         self.attn_bwd_timing = None      # {"stride": n, "seen": 0, "pairs": []} while bench.py times the attention backward
         self._rb_cache, self._wver = {}, 0   # dense resized rel-pos biases (eval on other aspect ratios), weights version
         # ffn_layernorm(gelu(fc1)) backward folded into the fc2 dX GEMM's epilogue (csrc/rowops.hip "FFN's ffn_layernorm",
@@ -1770,7 +1775,12 @@ class HipEngine:
         elif self.trunk_at == "fwd" and self._pf_request is not None and not torch.cuda.is_current_stream_capturing():
             req, self._pf_request = self._pf_request, None           # ("fwd1": passes start at a forward only -- measurement)
             self._prefetch_request(req, at_end=True)
+        if self.drain_timing is not None:       # (measurement: how long the main stream really waits for the side queue here)
+            t0 = torch.cuda.Event(enable_timing=True); t0.record()
         self._join_side()            # the optimizer (main stream) reads the whole gradient arena next
+        if self.drain_timing is not None:
+            t1 = torch.cuda.Event(enable_timing=True); t1.record()
+            self.drain_timing.append((t0, t1))
         self._notify(e)              # both halves of the tail are in: the last gradient slice may be reduced (main stream)
         return self.g16
 
