@@ -288,6 +288,7 @@ def main():
     for _ in range(a.steps):
         logs = one_step()
     t_enq = time.time() - t0          # the host has ENQUEUED every step (it runs ahead of the GPU unless launches are the limit)
+    n_marks = len(trainer.eng.marks) if trainer.eng.marks is not None else 0
     sync()
     dt = time.time() - t0
     tt = torch.tensor([dt], device=dev)
@@ -386,6 +387,18 @@ def main():
         # collectives and bytes per step.  Any N > 1 run that did not go through the direct communicator fails loudly below.
         out["rccl"] = rccl_stats
         out["host_enqueue_ms_per_step"] = round(t_enq / a.steps * 1e3, 3)
+        if trainer.eng.marks:                    # IFSEG_PHASE_TIMING=1: main-stream (and host) time between the phase marks
+            torch.cuda.synchronize()
+            mk = trainer.eng.marks[:n_marks][-7 * min(a.steps, 20):]       # the timed region's last steps
+            while mk and mk[0][0] != "step_start":
+                mk = mk[1:]
+            ph, hp = {}, {}
+            for i in range(len(mk) - 1):
+                k = mk[i][0] + "->" + mk[i + 1][0]
+                ph.setdefault(k, []).append(mk[i][1].elapsed_time(mk[i + 1][1]))
+                hp.setdefault(k, []).append((mk[i + 1][2] - mk[i][2]) * 1e3)
+            out["phase_ms"] = {k: round(sum(v) / len(v), 3) for k, v in ph.items()}
+            out["phase_host_ms"] = {k: round(sum(v) / len(v), 3) for k, v in hp.items()}
         if trainer.eng.drain_timing:             # IFSEG_DRAIN_TIMING=1: main-stream wait for the side queue at the end of the backward
             torch.cuda.synchronize()
             w = [t0.elapsed_time(t1) for t0, t1 in trainer.eng.drain_timing[-a.steps:]]

@@ -26,6 +26,7 @@ reference order [bos, patches...].
 import contextlib
 import math
 import os
+import time
 
 import torch
 
@@ -91,6 +92,9 @@ class HipEngine:
         # 0.41 ms and made the step 0.45 ms SLOWER (a third busy queue under the dX chain); for the last layer only: 0.42 ms,
         # step unchanged.  Not adopted.
         self.drain_timing = [] if os.environ.get("IFSEG_DRAIN_TIMING") else None
+        # IFSEG_PHASE_TIMING=1: a few timing events per step on the main stream (`mark`, with the host's clock next to each);
+        # bench.py reports the phases' GPU and host durations over the timed region (`phase_ms`, `phase_host_ms`)
+        self.marks = [] if os.environ.get("IFSEG_PHASE_TIMING") else None
         self.attn_bwd_timing = None      # {"stride": n, "seen": 0, "pairs": []} while bench.py times the attention backward
         self._rb_cache, self._wver = {}, 0   # dense resized rel-pos biases (eval on other aspect ratios), weights version
         # ffn_layernorm(gelu(fc1)) backward folded into the fc2 dX GEMM's epilogue (csrc/rowops.hip "FFN's ffn_layernorm",
@@ -343,6 +347,12 @@ class HipEngine:
                 t.view(torch.uint8).fill_(0xFF) if t.numel() else None
             self.ws[name] = t
         return t
+
+    def mark(self, name):
+        if self.marks is not None and not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.marks.append((name, ev, time.perf_counter()))
 
     def gbuf(self, name, shape, dtype=BF):
         """backward buffer that weight-gradient work on the side stream may still be reading while the main
@@ -927,6 +937,7 @@ class HipEngine:
             hip.ln_fwd(x.view(B * T, C), Wf(e + "layer_norm.weight"), Wf(e + "layer_norm.bias"), enc_out.view(B * T, C), mu, rs)
         ctx["e_x_final"] = x
         ctx["enc_out"] = enc_out
+        self.mark("enc_fwd_end")
 
         # ---- decoder (extract_features_scriptable_surrogate, decoder_module.py:486-677)
         d = "decoder."
@@ -1674,6 +1685,7 @@ class HipEngine:
         scaling = float(cfg.head_dim * cfg.attn_scale_factor) ** -0.5
         W, Wf, G, buf = self.W, self.Wf, self.G, self.buf
         g = self._geometry(h, w, L)
+        self.mark("bwd_start")
         if ctx.get("g16_zeroed") is not None:
             # the gradient arena (218 MB for SegOFA-Base) was cleared on the side stream during the forward: the main stream only
             # orders itself behind that fill instead of running it (50 us) at the head of the backward
@@ -1719,6 +1731,7 @@ class HipEngine:
             self._side_do(lambda p=p: (self._flush_tables(), self._notify(p)))   # final in side-stream order
             self._side_flush()
         # ---- decoder embedding LN (input = [enc_out[:, :P] | embed(bos)])
+        self.mark("dec_bwd_end")
         self._bt = "dtop"
         if self.overlap and getattr(self, "_dqs", None) is not None:      # d_enc_out was accumulated on the dQ stream
             ev = self._ev()
@@ -1777,7 +1790,9 @@ class HipEngine:
             self._prefetch_request(req, at_end=True)
         if self.drain_timing is not None:       # (measurement: how long the main stream really waits for the side queue here)
             t0 = torch.cuda.Event(enable_timing=True); t0.record()
+        self.mark("bwd_main_end")
         self._join_side()            # the optimizer (main stream) reads the whole gradient arena next
+        self.mark("joined")
         if self.drain_timing is not None:
             t1 = torch.cuda.Event(enable_timing=True); t1.record()
             self.drain_timing.append((t0, t1))

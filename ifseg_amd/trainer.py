@@ -398,6 +398,7 @@ class Trainer:
                     # update, then the next call's samples (HipEngine._prefetch_request)
                     eng._pf_request = [q["net_input"]["patch_images"] for q in list(samples[i + 1:]) + ahead
                                        if "patch_images" in q.get("net_input", {})]
+                eng.mark("step_start")
                 loss, ss, lg = self.task.train_step(sample, self.model, self.criterion, None, self.num_updates)
                 logs.append(lg)
                 sample_sizes.append(ss)
@@ -420,6 +421,7 @@ class Trainer:
             self._upload_hyper(lr, step, gscale)
         hip.adam_step(self.p32, eng.g16, self.m, self.v, eng.p16[: eng.n_train], lr, self.betas[0],
                       self.betas[1], self.eps, self.wd, step, gscale, self.clip, self.sumsq, self.overflow, hyper=self._hyper)
+        eng.mark("adam_end")
         if captured and eng._pf is not None:
             torch.cuda.current_stream().wait_event(eng._pf["done"])     # every forked stream rejoins before the capture ends
         return logs
