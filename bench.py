@@ -389,7 +389,7 @@ def main():
         out["host_enqueue_ms_per_step"] = round(t_enq / a.steps * 1e3, 3)
         if trainer.eng.marks:                    # IFSEG_PHASE_TIMING=1: main-stream (and host) time between the phase marks
             torch.cuda.synchronize()
-            mk = trainer.eng.marks[:n_marks][-7 * min(a.steps, 20):]       # the timed region's last steps
+            mk = trainer.eng.marks[:n_marks][-9 * min(a.steps, 20):]       # the timed region's last steps
             while mk and mk[0][0] != "step_start":
                 mk = mk[1:]
             ph, hp = {}, {}

@@ -836,6 +836,7 @@ class HipEngine:
                 raise RuntimeError("aux_input: %d bags for a batch of %d x %dx%d patches" % (bag[1].numel(), B, h, w))
         else:
             feat, h, w = self._trunk(patch_images)
+            self.mark("trunk_ready")
             # the next batch's trunk starts once this batch's features are taken -- or (IFSEG_TRUNK_AT=e<k> / end) later,
             # inside this step's backward, see `_trunk_launch_point`
             if self._pf_request is not None and (self.trunk_at in ("fwd", "fwd1") or not need_grad):
@@ -900,6 +901,7 @@ class HipEngine:
         (e_r1,) = self._rel_tables_all("e_tok", ["%stoken_rel_pos_table_list.%d.weight" % (e, l) for l in range(cfg.enc_layers)],
                                        [(True, g["enc_idx1d"])])
         (e_rx,) = self._rel_tables_all("e_x", [None] * cfg.enc_layers, [(False, g["enc_idxx"])])
+        self.mark("enc_layers_start")
         x_pre = None
         bi = need_grad and w <= 64 and w % 8 == 0 and self.attn_bi in ("1", "auto")
         # which attentions: e(ncoder self), d(ecoder self), c(ross); IFSEG_ATTN_BI_WHICH overrides

@@ -9,6 +9,7 @@ bash tools/attn_bi_pmc.sh enc > $o/attn_bi_pmc_enc.txt 2>&1
 python tools/attn_bi_bench.py enc dec cross 2>/dev/null > $o/attn_bi_bench_base.txt
 ATTN_BENCH_LARGE=1 ATTN_BENCH_B=8 python tools/attn_bi_bench.py enc dec cross 2>/dev/null > $o/attn_bi_bench_large.txt
 python bench.py > $o/c2_bench.json 2> $o/c2_bench.err
+IFSEG_PHASE_TIMING=1 IFSEG_DRAIN_TIMING=1 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --steady-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({k: d[k] for k in ('value','ms_per_step','host_enqueue_ms_per_step','end_of_backward_wait_ms','phase_ms','phase_host_ms')}, indent=1))" > $o/phase_timing.json
 python bench.py --config c3 --no-cpu-baseline > $o/c3_bench.json 2> $o/c3_bench.err
 python bench.py --config c4 --no-cpu-baseline > $o/c4_bench.json 2> $o/c4_bench.err
 for f in c2 c3 c4; do python -c "import json,sys; d=json.loads(open('$o/${f}_bench.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'])"; done

@@ -14,6 +14,7 @@ cp $a/attn_bi_pmc_enc.txt profiles/round4_attn_pmc_enc.txt
 cp $a/attn_bi_bench_base.txt profiles/round4_attn_bi_bench_base.txt
 cp $a/attn_bi_bench_large.txt profiles/round4_attn_bi_bench_large.txt
 for c in c2 c3 c4; do tail -1 $a/${c}_bench.json > profiles/round4_${c}_bench.json; done
+cp $a/phase_timing.json profiles/round4_phase_timing.json
 tail -3 $a/pytest_gpu.txt > profiles/round4_pytest_gpu.txt
 cp gpurun_out/r4_step0.txt profiles/round4_step0_bound_kernels.txt
 cp gpurun_out/r4_step0b.txt profiles/round4_step0_bound_step.txt
