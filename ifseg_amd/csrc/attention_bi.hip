@@ -764,7 +764,8 @@ struct DbArgs {
   const bf16_t *pq, *pk;      // [T, ldpq], [S, ldpk]
   int ldpq, ldpk;
   float *dpq, *dpk;           // fp32 [T, C], [S, C]
-  int accumulate;
+  int accumulate;             // operand gradients: add to what dpq / dpk hold
+  int tab_accumulate;         // partial delta tables: add to what they hold (slab pairs after the first)
   float dpq_scale;
   int P, gh, gw, Lt, causal;
   float *drel2d, *drel1d, *drelx;     // [H][DB_NPARTS][(2gh-1)(2gw-1)], [H][DB_NPARTS][2Lt-1], [H][DB_NPARTS][2]
@@ -969,7 +970,7 @@ __global__ __launch_bounds__(256) void attn_dbias_tables_kernel(DbArgs a) {
     const int y0 = ylo + ((part - ylo) % DB_NPARTS + DB_NPARTS) % DB_NPARTS;
     float* out = a.drel2d + ((long long)h * DB_NPARTS + part) * ndy * (2 * w - 1) + (long long)(dy + a.gh - 1) * (2 * w - 1);
     if (a.causal && dy < 0) {           // pairs with y_j > y_i are masked: nothing was written there
-      for (int d = tid; d < 2 * w - 1; d += 256) out[d] = 0.f;
+      if (!a.tab_accumulate) for (int d = tid; d < 2 * w - 1; d += 256) out[d] = 0.f;
       return;
     }
     const int nyp = npair <= 128 ? 2 : 1;                       // row phases handled side by side
@@ -1003,7 +1004,7 @@ __global__ __launch_bounds__(256) void attn_dbias_tables_kernel(DbArgs a) {
         t += sf[xi * w + (xi - dx)];
         if (nyp > 1) t += sf[4096 + xi * w + (xi - dx)];
       }
-      out[d] = t;
+      out[d] = (a.tab_accumulate ? out[d] : 0.f) + t;
     }
     return;
   }
@@ -1025,7 +1026,7 @@ __global__ __launch_bounds__(256) void attn_dbias_tables_kernel(DbArgs a) {
         t += bf2f(hb[o]);
         if (a.ng > 1) t += bf2f(hb[a.gs + o]);
       }
-      o1[d] = t;
+      o1[d] = (a.tab_accumulate ? o1[d] : 0.f) + t;
     }
     return;
   }
@@ -1078,7 +1079,7 @@ __global__ __launch_bounds__(256) void attn_dbias_tables_kernel(DbArgs a) {
       __syncthreads();
     }
     float* ox = a.drelx + ((long long)h * DB_NPARTS + part) * 2;
-    if (tid == 0) { ox[0] = sf[0]; ox[1] = sf[256]; }
+    if (tid == 0) { ox[0] = (a.tab_accumulate ? ox[0] : 0.f) + sf[0]; ox[1] = (a.tab_accumulate ? ox[1] : 0.f) + sf[256]; }
     return;
   }
 }
@@ -1183,7 +1184,7 @@ extern "C" int ifseg_attn_fwd_bi(const ifseg_attn_bi_args* x, void* stream) {
 
 extern "C" int ifseg_attn_dbias_grads(const ifseg_attn_dbias_args* x, void* stream) {
   (void)hipGetLastError();
-  if (!x || !x->dbias || x->ng <= 0 || x->ng > 2 || x->H <= 0 || x->T <= 0 || x->S <= 0 || (x->Sp & 31) || x->Sp < x->S)
+  if (!x || !x->dbias || x->ng <= 0 || x->H <= 0 || x->T <= 0 || x->S <= 0 || (x->Sp & 31) || x->Sp < x->S)
     return IFSEG_ERR_BAD_ARG;
   DbArgs a{};
   a.dbias = (const bf16_t*)x->dbias; a.gs = (long long)x->H * x->T * x->Sp; a.ng = x->ng;
@@ -1203,10 +1204,16 @@ extern "C" int ifseg_attn_dbias_grads(const ifseg_attn_dbias_args* x, void* stre
   a.nb_q = pos ? a.H * ((a.T + 31) / 32) : 0;
   a.nb_k = pos ? a.H * (a.Sp / 32) : 0;
   a.nb_2d = rel ? a.H * (2 * a.gh - 1) * DB_NPARTS : 0;
-  if (pos) {
-    hipLaunchKernelGGL(attn_dbias_grads_kernel, dim3(a.nb_q + a.nb_k), dim3(256), 0, (hipStream_t)stream, a);
+  // the kernels take the slabs (groups of four batch elements) two at a time: batches of more than eight per GPU run them
+  // once per pair, later pairs adding to the first pair's results in launch order (deterministic)
+  const int ng_all = x->ng;
+  for (int g0 = 0; g0 < ng_all; g0 += 2) {
+    a.dbias = (const bf16_t*)x->dbias + (long long)g0 * a.gs;
+    a.ng = ng_all - g0 < 2 ? ng_all - g0 : 2;
+    if (g0) { a.accumulate = 1; a.tab_accumulate = 1; }
+    if (pos) hipLaunchKernelGGL(attn_dbias_grads_kernel, dim3(a.nb_q + a.nb_k), dim3(256), 0, (hipStream_t)stream, a);
+    if (rel) hipLaunchKernelGGL(attn_dbias_tables_kernel, dim3(a.nb_2d + a.H * DB_NPARTS * (1 + DB_NSUB)), dim3(256), 0, (hipStream_t)stream, a);
   }
-  if (rel) hipLaunchKernelGGL(attn_dbias_tables_kernel, dim3(a.nb_2d + a.H * DB_NPARTS * (1 + DB_NSUB)), dim3(256), 0, (hipStream_t)stream, a);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

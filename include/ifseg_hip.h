@@ -255,7 +255,7 @@ int ifseg_attn_fwd_bi(const ifseg_attn_bi_args* args, void* stream);
  *     drel1d[h][p][(i-j)+Lt-1] = sum over tail pairs;  drelx[h][p][0] = sum_{i<P<=j<S} dB,  drelx[h][p][1] = sum_{j<P<=i<T} dB
  *   as NP = ifseg_attn_dbias_nparts() partial tables per head (part p = the rows i = p mod NP): they feed
  *   ifseg_attn_bwd_reduce with nparts = NP.  pos_q == NULL skips the operand gradients, drel2d == NULL the tables.
- *   Fixed summation order. */
+ *   Fixed summation order.  Any ng: the slabs are taken two per launch pair, later pairs add to the first's results. */
 typedef struct ifseg_attn_dbias_args {
   const void* dbias;           /* bf16 [ng][H][T][Sp] */
   int ng, H, T, S, Sp, C;

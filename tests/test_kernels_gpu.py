@@ -370,6 +370,10 @@ def _attn_case(case):
     elif case == "enc_b5":                # a partly filled second group of batch elements
         gh, gw, P, Lt = 8, 16, 128, 36
         H, B = 2, 5
+    elif case in ("enc_b11", "dec_b11"):  # more than eight per GPU: three slabs of sum_b dS, taken two at a time by the
+        gh, gw, P = 8, 16, 128             # bias-gradient kernels (the second launch adds to the first's results)
+        Lt, causal = (36, False) if case == "enc_b11" else (1, True)
+        H, B = 2, 11
     elif case == "dec_causal_bh8":
         gh, gw, P, Lt = 32, 32, 1024, 1
         H, B, causal = 4, 2, True
@@ -393,7 +397,7 @@ def _attn_case(case):
 
 
 @pytest.mark.parametrize("case", ["cross", "enc_rel", "dec_causal", "dec_full", "big_enc", "big_enc_b8", "enc_b5",
-                                  "dec_causal_bh8", "enc_w40", "dec_w40", "enc_w48", "enc_w40_full", "dec_w40_full",
+                                  "enc_b11", "dec_b11", "dec_causal_bh8", "enc_w40", "dec_w40", "enc_w48", "enc_w40_full", "dec_w40_full",
                                   "enc_long_text"])
 def test_attn_bwd_batch_inner(case):
     """csrc/attention_bi.hip: dense batch-invariant bias (ifseg_attn_dense_bias), the backward whose workgroups hold four
