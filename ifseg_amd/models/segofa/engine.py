@@ -1503,11 +1503,13 @@ class HipEngine:
         C, H = self.cfg.embed_dim, self.cfg.heads
         gbuf = self.gbuf
         ng = (B + 3) // 4
-        key = "g_dbias_%dx%d" % (T, dense.Sp) + ("@" + self._bt if self.overlap else "")
-        fresh = key not in self.ws
         dbias = gbuf("g_dbias_%dx%d" % (T, dense.Sp), (ng, H, T, dense.Sp))
-        if fresh:
-            dbias.zero_()          # causal launches never write the blocks above the diagonal (the same blocks every step)
+        if not getattr(dbias, "_ifseg_zeroed", False):
+            # causal launches never write the blocks above the diagonal (the same blocks every step), and on grids that are not
+            # 32 wide the table kernel reads masked pairs of a grid row that lie in such blocks: zero once per ALLOCATION (a
+            # smaller last batch reallocates the buffer under the same name)
+            dbias.zero_()
+            dbias._ifseg_zeroed = True
         if not have_delta:
             hip.attn_bwd(q, k, v, None, None, o, do, lse, delta, dq, dk, dv, None, None, B, H, T, S, phases=hip.ATTN_BWD_DELTA)
         timing = self.attn_bwd_timing

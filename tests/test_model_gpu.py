@@ -300,6 +300,47 @@ def test_large_geometry_depth4_gradient_values_vs_oracle():
     _parity_case(ocfg, 1, 239, (640, 640), tol_grads=6e-2, skip_gain=False)
 
 
+def test_smaller_last_batch_on_a_grid_that_is_not_32_wide(monkeypatch):
+    """A step with B = 5 followed by one with B = 1 (the last batch of an epoch) on a 40-wide grid: the causal decoder's sum_b dS
+    buffer (one slab per four batch elements) is reallocated under the same name and must be cleared again -- the table kernel reads masked pairs of a grid row
+    that lie in blocks no causal launch writes.  With fresh workspaces poisoned (0xFF bytes = NaN) the second step's gradients
+    must equal, bit for bit, those of a model that only ever saw the B = 1 batch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ifseg_amd.criterions import SegCriterion
+    from ifseg_amd.models.segofa import engine as eng_mod
+    monkeypatch.setattr(eng_mod, "_POISON", True)
+    dev = torch.device("cuda:0")
+    ocfg = O.SegOFAConfig(embed_dim=256, ffn_dim=512, heads=4, enc_layers=1, dec_layers=1, resnet_layers=(1, 1, 1),
+                          num_seg_tokens=5, vocab_size=400, patch_image_size=640, orig_patch_image_size=640)
+    sd = O.procedural_state_dict(ocfg)
+    crit = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+
+    def step(m, bs, seed):
+        torch.manual_seed(seed)
+        batch = O.synthetic_batch(ocfg, bs, 9, image_hw=(640, 640), seed=seed)
+        sample = {"net_input": {k: batch[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks", "prev_output_tokens")},
+                  "target": batch["target"].to(dev), "ntokens": 1, "nsentences": bs}
+        m.engine.step_seed = 5
+        loss, _, _ = crit(m, sample)
+        loss.backward()
+        torch.cuda.synchronize()
+        return m.engine.g16.clone()
+
+    def model():
+        m = _build(ocfg, sd, dev)
+        m.autograd_mode = "arena"
+        m.cfg.dropout, m.cfg.encoder_drop_path_rate, m.cfg.decoder_drop_path_rate = 0.0, 0.0, 0.0
+        return m.train()
+
+    a = model()
+    step(a, 5, 1)
+    g1 = step(a, 1, 2)
+    g2 = step(model(), 1, 2)
+    assert torch.isfinite(g1.float()).all()
+    assert torch.equal(g1, g2)
+
+
 def test_trunk_prefetch_matches_inline():
     """HipEngine.prefetch_trunk: features computed one batch ahead on the trunk stream give the same logits
     as the in-line trunk, and a different tensor falls back to the in-line path."""
