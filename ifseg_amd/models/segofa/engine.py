@@ -1348,7 +1348,11 @@ class HipEngine:
 
     def _bias_grad(self, dy2d, gout, accumulate=False):
         N = dy2d.shape[-1]
-        part = self.buf("colsum_%d" % N, (hip.COLSUM_BLOCKS, N), torch.float32)
+        # one partial buffer per STREAM: at the end of the backward the main stream (embedding half of the tail) and the side
+        # stream (last weight gradients; bias gradients of projections too small for the grouped dW launch) run this side by
+        # side -- with one shared buffer the two column sums raced (seen as a rare 1-ulp difference in a bias gradient of
+        # encoder layer 0 on small models; deterministic under IFSEG_POISON_WS=1)
+        part = self.buf("colsum_%d@%d" % (N, torch.cuda.current_stream().stream_id), (hip.COLSUM_BLOCKS, N), torch.float32)
         hip.colsum(dy2d, part)
         hip.reduce_parts(part, gout, 1, hip.COLSUM_BLOCKS, N, accumulate=accumulate)
 
