@@ -569,10 +569,15 @@ def test_eval_branch_vs_reference_golden(golden_dir):
     assert _rel(prob, ref) <= 2e-2
 
 
-def test_training_step_is_deterministic_across_streams():
-    """Two trainers stepped on the same batches (Base, B=2, dropout on; weight-gradient, dQ and trunk-prefetch streams
+@pytest.mark.parametrize("arch,size", [("segofa_base", 512), ("segofa_tiny", 128)])
+def test_training_step_is_deterministic_across_streams(arch, size, monkeypatch):
+    """Two trainers stepped on the same batches (B=2, dropout on; weight-gradient, dQ and trunk-prefetch streams
     active) produce bit-identical losses, gradients and updated parameters, and so does the single-stream execution:
-    no race between the streams, no order-dependent reduction anywhere in the step."""
+    no race between the streams, no order-dependent reduction anywhere in the step.  Base takes the grouped weight-gradient
+    launches; the tiny model the per-projection ones (bias gradients by separate column sums -- where round 4 found two streams
+    sharing a partial buffer).  Fresh workspaces are poisoned, so a read of memory nobody wrote shows up as NaN."""
+    from ifseg_amd.models.segofa import engine as eng_mod
+    monkeypatch.setattr(eng_mod, "_POISON", True)
     from ifseg_amd.criterions import SegCriterion
     from ifseg_amd.tasks.mm_tasks import SegmentationTask
     from ifseg_amd.trainer import Trainer
@@ -580,7 +585,7 @@ def test_training_step_is_deterministic_across_streams():
 
     def run(overlap=True):
         torch.manual_seed(0)
-        task = SegmentationTask(num_seg_tokens=15, patch_image_size=512, arch="segofa_base")
+        task = SegmentationTask(num_seg_tokens=15, patch_image_size=size, arch=arch)
         model = task.build_model()
         model.cfg.dropout, model.cfg.encoder_drop_path_rate, model.cfg.decoder_drop_path_rate = 0.1, 0.1, 0.1
         tr = Trainer(model, SegCriterion(task, unsupervised_segmentation=False, init_seg_with_text=False), task, device=dev)
