@@ -101,13 +101,13 @@ struct Sched {
 
 // Loop structure of both kernels: one s_barrier per 32-row block of the streamed side; the stage of block n+1 is in flight
 // (LDS-DMA, issued right after the barrier) while block n is computed; every LDS read of a block is requested before its first
-// MFMA.  What was measured on the way (encoder shape, B = 8, dK/dV kernel alone; profiles/round4_attention_bi.md):
+// MFMA.  What was measured on the way (encoder shape, B = 8, dK/dV kernel alone; DESIGN.md "Round 4" (1)):
 //   v1  lock-step waves, reads next to their MFMAs ................................ 122.6 us
 //   v2  the two wave groups of a SIMD phase-shifted inside the barrier interval ..... 121.6 us  (no gain: dropped)
 //   v3  all LDS reads of a block up front ......................................... 106.2 us  (kept)
 //   v4  + gradient MFMAs of block n-1 under the row reads of block n .................. 110.7 us  (dropped)
 //   v5  + staging two blocks ahead, ring of three stages ............................ 112.2 us  (dropped)
-// Ablation of v2 (tools/r4_bi_exp2.sh): without the S/dP MFMAs 109.8, without exp 115.8, without the gradient MFMAs 96.0,
+// Ablation of v2 (profiles/round4_attn_bi_ablation.txt; the variants were -D switches of that version of this file, since removed): without the S/dP MFMAs 109.8, without exp 115.8, without the gradient MFMAs 96.0,
 // without any MFMA 88.2, without any MFMA and without staging 67.8, staging + barriers alone 67.3 us: two waves per SIMD do
 // not hide the block's dependent LDS round trips, and no single pipe is the bound.
 
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
 
   // One 32-row block of the streamed side.  EVERY LDS read of the block is requested up front -- bias seeds, delta seeds,
   // Q / dO rows, row statistics and the transposed Q / dO fragments of the gradient MFMAs, 40 requests -- so a wave sleeps on
-  // LDS latency once per block instead of at five dependent points (ablation, tools/r4_bi_exp2.sh: with every MFMA and the
+  // LDS latency once per block instead of at five dependent points (ablation, profiles/round4_attn_bi_ablation.txt: with every MFMA and the
   // staging removed the v2 loop still took 68 of its 121 us: two waves per SIMD do not hide ~5 x 150 cycles of dependent LDS
   // round trips per block).  (Measured and dropped: the gradient MFMAs of block n-1 under the row reads of block n, 110.7 vs
   // 106.2 us.)
