@@ -1507,7 +1507,9 @@ class HipEngine:
         C, H = self.cfg.embed_dim, self.cfg.heads
         gbuf = self.gbuf
         ng = (B + 3) // 4
-        dbias = gbuf("g_dbias_%dx%d" % (T, dense.Sp), (ng, H, T, dense.Sp))
+        # (causal and full attentions never share a buffer -- single-stream execution has no per-block instances, and the
+        # decoder's self- and cross-attention can have the same padded shape: the causal one relies on blocks staying zero)
+        dbias = gbuf("g_dbias%s_%dx%d" % ("c" if causal else "", T, dense.Sp), (ng, H, T, dense.Sp))
         if not getattr(dbias, "_ifseg_zeroed", False):
             # causal launches never write the blocks above the diagonal (the same blocks every step), and on grids that are not
             # 32 wide the table kernel reads masked pairs of a grid row that lie in such blocks: zero once per ALLOCATION (a

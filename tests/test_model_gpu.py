@@ -53,7 +53,10 @@ def _oracle_all_grads(ocfg, sd, batch, hw):
     return logits.detach(), loss.detach(), {k: v.grad for k, v in sdg.items() if v.grad is not None}, (s.detach(), t)
 
 
-def test_fixture_forward_backward_vs_oracle(golden_dir):
+@pytest.mark.parametrize("streams", ["overlapped", "single_stream"])
+def test_fixture_forward_backward_vs_oracle(golden_dir, streams):
+    """(single_stream: the engine without its side streams -- no per-block instances of the backward buffers; on this fixture
+    the decoder's causal self-attention and its cross-attention have the same padded sum_b dS shape and once shared a buffer)"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from ifseg_amd.criterions import SegCriterion
@@ -67,6 +70,7 @@ def test_fixture_forward_backward_vs_oracle(golden_dir):
 
     m = _build(ocfg, sd, dev)
     m.train()
+    m.engine.overlap = streams == "overlapped"
     crit = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
     sample = {"net_input": {"src_tokens": batch["src_tokens"].to(dev), "src_lengths": torch.full((2,), 12).to(dev),
                             "patch_images": batch["patch_images"].to(dev), "patch_masks": batch["patch_masks"].to(dev),
