@@ -243,12 +243,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # discovery pass: every family timed over the last TWO warm-up steps -- one trunk pass serves two batches, so a single step
+    # either contains a whole pass (conv family counted twice) or none; per-step values are the two-step sums halved
+    n_disc = 2 if a.warmup >= 2 else 1
     for i in range(a.warmup):
-        if i == a.warmup - 1:
-            hip.prof_reset(); hip.prof_enable(0x1FF)      # discovery pass: every family
+        if i == a.warmup - n_disc:
+            hip.prof_reset(); hip.prof_enable(0x1FF)
         one_step()
     torch.cuda.synchronize()
     fam = [hip.prof_read(k) for k in range(len(hip.PROF_KINDS))]
+    for f in fam:
+        f["ms"] /= n_disc
     # the `roofline` object goes to the largest family BY MEASURED KERNEL TIME of this run (discovery pass above).  The
     # attention backward is one operation executed as two concurrent kernels (dK/dV and dQ): they count as one family
     # (sum of their kernel times); every family keeps its own entry in roofline_gemm_kernel / roofline_other_kernels.
