@@ -65,6 +65,107 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const bf16_t* in, const 
   }
 }
 
+// The same convolution on the matrix cores (round 4: the direct kernel above ran at 46 TFLOP/s, 424 us for 16 images of
+// 512 x 512 -- ten times its 40 us HBM bound: 134 MB of output).  Implicit GEMM with the filter row padded to 8 taps and the
+// channels to 4: K = 7 x 8 x 4 = 224 = 14 MFMA k-steps, k = ky*32 + kx*4 + ci (taps kx = 7 and channel 3 carry zero
+// weights).  Computed swapped, C^T[channel][pixel] = W[channel][k] . patch[k][pixel]: a lane is an output pixel holding runs of
+// 4 consecutive channels, and the B fragment of a k-step -- 8 consecutive k = two neighbouring input pixels x 4 channels -- is
+// ONE aligned 16-byte LDS read of the raw NHWC(4) patch (no im2col).  The 28 weight fragments of a wave (2 channel tiles x
+// 14 k-steps) stay in registers; workgroups walk output tiles of 8 x 32 pixels.
+// Weights as THREE bf16 terms (wt: bf16 [3][64][224], t0 = bf16(w), t1 = bf16(w - t0), t2 = bf16(w - t0 - t1): 24 mantissa bits,
+// the fp32 weight exactly): the direct kernel kept them in fp32; with plain bf16 weights the evaluation fixture's
+// neighbour-smoothed histograms moved three times further from the reference's (the first layer's rounding reaches every
+// feature), and with two terms 0.25 % of the stem's outputs still rounded the other way -- enough to move the plain argmax
+// agreement of the 150-class golden (a statistic of near-ties) from 0.9775 to 0.9688.  Terms 1 and 2 sit in LDS (row pitch 464
+// bytes: conflict-free 16-byte reads by 32 consecutive channels); three times the MFMAs of a kernel that is bound by its 134 MB
+// of output.
+constexpr int STM_PW = 72;                            // patch row pitch in pixels (>= 2*31 + 8)
+constexpr int STM_WP = 464;                           // lo-weight row pitch in bytes (224 bf16 = 448, padded)
+__global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const bf16_t* in, const bf16_t* wt, const float* shift,
+                                                             bf16_t* out, int B, int H, int W, int OH, int OW) {
+  __shared__ __attribute__((aligned(16))) uint2 sIn[ST_PH * STM_PW];       // 21 x 72 pixels x 8 bytes = 12 KiB
+  __shared__ __attribute__((aligned(16))) unsigned char sWl[2 * 64 * STM_WP];  // terms 1, 2: [2][64][224] bf16, 58 KiB
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, tx = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  bf16x8 wf[2][14];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int ks = 0; ks < 14; ++ks) {
+      U128 u; u.v = *reinterpret_cast<const uint4*>(wt + (ct * 32 + tx) * 224 + ks * 16 + half * 8);
+      wf[ct][ks] = u.b;
+    }
+  for (int i = tid; i < 2 * 64 * 28; i += 256) {      // 28 16-byte chunks per channel row
+    const int c = i / 28, ch = i - c * 28;             // c = term * 64 + channel
+    *reinterpret_cast<uint4*>(sWl + c * STM_WP + ch * 16) = *reinterpret_cast<const uint4*>(wt + 64 * 224 + c * 224 + ch * 8);
+  }
+  float sh[2][4][4];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 s4 = *reinterpret_cast<const float4*>(shift + ct * 32 + 8 * rg + 4 * half);
+      sh[ct][rg][0] = s4.x; sh[ct][rg][1] = s4.y; sh[ct][rg][2] = s4.z; sh[ct][rg][3] = s4.w;
+    }
+  const int tiles_x = (OW + ST_TW - 1) / ST_TW, tiles_y = (OH + ST_TH - 1) / ST_TH;
+  const int total = B * tiles_x * tiles_y;
+  for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    const int b = w / (tiles_x * tiles_y), t = w % (tiles_x * tiles_y);
+    const int oy0 = (t / tiles_x) * ST_TH, ox0 = (t % tiles_x) * ST_TW;
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    __syncthreads();                                  // the previous tile's reads are done
+    for (int i = tid; i < ST_PH * STM_PW; i += 256) {
+      const int py = i / STM_PW, px = i - py * STM_PW, iy = iy0 + py, ix = ix0 + px;
+      uint2 u = make_uint2(0, 0);
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) u = *reinterpret_cast<const uint2*>(in + (((long long)b * H + iy) * W + ix) * 4);
+      sIn[i] = u;
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][ct][e] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ty = wave * 2 + i;
+          const bf16x8 pf = lds_read_b128(reinterpret_cast<const unsigned char*>(sIn + (2 * ty + ky) * STM_PW + 2 * tx + 4 * g + 2 * half));
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) acc[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ct][ky * 2 + g], pf, acc[i][ct], 0, 0, 0);
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              const bf16x8 wl = lds_read_b128(sWl + (tm * 64 + ct * 32 + tx) * STM_WP + (ky * 2 + g) * 32 + half * 16);
+              acc[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, pf, acc[i][ct], 0, 0, 0);
+            }
+        }
+      }
+    // lane = pixel (oy0 + 2 wave + i, ox0 + tx); element r <-> channel ct*32 + 8*(r>>2) + 4*half + (r&3)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int oy = oy0 + wave * 2 + i, ox = ox0 + tx;
+      if (oy >= OH || ox >= OW) continue;
+      bf16_t* op = out + (((long long)b * OH + oy) * OW + ox) * 64 + 4 * half;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaxf(acc[i][ct][rg * 4 + e] + sh[ct][rg][e], 0.f);
+          *reinterpret_cast<uint2*>(op + ct * 32 + 8 * rg) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+        }
+    }
+  }
+}
+
 // 3x3 stride 2 pad 1 max-pool on NHWC bf16, 8 channels per thread
 __global__ void maxpool3x3s2_kernel(const bf16_t* in, bf16_t* out, int B, int H, int W, int C, int OH, int OW) {
   const int nch = C >> 3;
@@ -104,6 +205,19 @@ extern "C" int ifseg_stem_conv7x7(const void* in_nhwc4, const float* w, const fl
   (void)hipFuncSetAttribute((const void*)stem_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(stem_conv_kernel, dim3(B * tiles), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)in_nhwc4,
                      w, shift, (bf16_t*)out, B, H, W, OH, OW);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ifseg_stem_conv7x7_mfma(const void* in_nhwc4, const void* wt, const float* shift, void* out, int B, int H,
+                                       int W, void* stream) {
+  (void)hipGetLastError();
+  if (!in_nhwc4 || !wt || !shift || !out || B <= 0 || H <= 0 || W <= 0 || (((size_t)wt | (size_t)shift | (size_t)out) & 15)) return IFSEG_ERR_BAD_ARG;
+  const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
+  const int total = B * ((OH + ST_TH - 1) / ST_TH) * ((OW + ST_TW - 1) / ST_TW);
+  const int grid = total < 1024 ? total : 1024;
+  hipLaunchKernelGGL(stem_conv_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_nhwc4,
+                     (const bf16_t*)wt, shift, (bf16_t*)out, B, H, W, OH, OW);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

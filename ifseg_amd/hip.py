@@ -33,7 +33,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 12:
+        if _lib.ifseg_abi_version() != 13:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -706,7 +706,25 @@ def nchw_to_nhwc(x, out, Cpad):
     return out
 
 
+def stem_weights_mfma(w):
+    """fp32 [7][7][3][64] (BN scale folded) -> bf16 [3][64][224] for ifseg_stem_conv7x7_mfma: k = ky*32 + kx*4 + ci, three bf16
+    terms whose sum is the fp32 weight"""
+    wt = torch.zeros(64, 7, 8, 4, dtype=torch.float32, device=w.device)
+    wt[:, :, :7, :3] = w.permute(3, 0, 1, 2)
+    wt = wt.reshape(64, 224)
+    t0 = wt.to(torch.bfloat16)
+    t1 = (wt - t0.float()).to(torch.bfloat16)
+    t2 = (wt - t0.float() - t1.float()).to(torch.bfloat16)
+    return torch.stack([t0, t1, t2]).contiguous()
+
+
 def stem_conv(x4, w, shift, out, B, H, W):
+    """w: fp32 [7][7][3][64] (direct kernel) or bf16 [3][64][224] from stem_weights_mfma (matrix cores)"""
+    if w.dtype == torch.bfloat16:
+        assert tuple(w.shape) == (3, 64, 224) and w.is_contiguous()
+        _check(lib().ifseg_stem_conv7x7_mfma(_ptr(x4), _ptr(w), _ptr(shift), _ptr(out), c_int(B), c_int(H), c_int(W),
+                                             _stream()), "stem_conv_mfma")
+        return out
     _check(lib().ifseg_stem_conv7x7(_ptr(x4), _ptr(w), _ptr(shift), _ptr(out), c_int(B), c_int(H), c_int(W),
                                     _stream()), "stem_conv")
     return out

@@ -301,6 +301,10 @@ class HipEngine:
 
         w, sh = fold("conv1", "bn1")
         self.stem_w = w.permute(2, 3, 1, 0).contiguous().to(dev)          # [7][7][3][64] fp32
+        # (the matrix-core stem kernel takes bf16 weights, like every other convolution of the trunk; IFSEG_STEM_DIRECT=1: the
+        # round-1 direct fp32 kernel)
+        if os.environ.get("IFSEG_STEM_DIRECT") is None:
+            self.stem_w = hip.stem_weights_mfma(self.stem_w)
         self.stem_shift = sh.contiguous().to(dev)
         self.rn_blocks = []
         for li, nb in enumerate(self.cfg.resnet_layers, start=1):

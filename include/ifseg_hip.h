@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 12
+#define IFSEG_ABI_VERSION 13
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -407,6 +407,11 @@ int ifseg_droppath_scale(float* out, const float* keep, int n, int B, unsigned l
  * [7][7][3][64] with the BN scale folded, shift fp32 [64] (resnet.py:215-218). */
 int ifseg_stem_conv7x7(const void* in_nhwc4, const float* w, const float* shift, void* out, int B, int H, int W,
                        void* stream);
+/* The same on the matrix cores: wt bf16 [3][64][224], wt[0][c][ky*32 + kx*4 + ci] = bf16(w[ky][kx][ci][c]) (BN scale folded; the
+ * entries with kx = 7 or ci = 3 are zero), wt[1] = bf16(w - wt[0]), wt[2] = bf16(w - wt[0] - wt[1]): implicit GEMM,
+ * K = 7 x 8 x 4, the fp32 weights as three bf16 terms (resnet.py:215-218). */
+int ifseg_stem_conv7x7_mfma(const void* in_nhwc4, const void* wt, const float* shift, void* out, int B, int H, int W,
+                            void* stream);
 /* MaxPool2d(3, 2, 1) on NHWC bf16 (resnet.py:219). */
 int ifseg_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, void* stream);
 

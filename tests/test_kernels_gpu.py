@@ -621,6 +621,12 @@ def test_stem_and_maxpool():
     hip.stem_conv(x4, wk, shift, out, B, H, W)
     ref = torch.relu(F.conv2d(x4[..., :3].float().permute(0, 3, 1, 2), w, shift, 2, 3)).permute(0, 2, 3, 1)
     assert _rel(out, ref) < 6e-3, _rel(out, ref)
+    # the matrix-core kernel (what the engine runs): the fp32 weights as three bf16 terms, ragged tiles (OW = 48 is 1.5 tiles wide)
+    out2 = torch.full((B, OH, OW, 64), 7.0, dtype=torch.bfloat16, device=dev)
+    wt = hip.stem_weights_mfma(wk)
+    hip.stem_conv(x4, wt, shift, out2, B, H, W)
+    assert _rel(out2, ref) < 6e-3, _rel(out2, ref)
+    assert _rel(out2.float(), out.float()) < 3e-4           # the two kernels differ in a handful of output roundings only
     mp = torch.zeros(B, OH // 2, OW // 2, 64, dtype=torch.bfloat16, device=dev)
     hip.maxpool(out, mp, B, OH, OW, 64)
     refp = F.max_pool2d(out.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
