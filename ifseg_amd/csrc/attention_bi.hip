@@ -1016,17 +1016,30 @@ __global__ __launch_bounds__(256) void attn_dbias_tables_kernel(DbArgs a) {
     const int sub = blk % DB_NSUB, part = (blk / DB_NSUB) % DB_NPARTS, h = blk / (DB_NSUB * DB_NPARTS), P = a.P, Lt = a.Lt;
     const bf16_t* hb = a.dbias + (long long)h * a.T * a.Sp;
     float* o1 = a.drel1d + ((long long)h * DB_NPARTS + part) * (2 * Lt - 1);
-    for (int d = sub + DB_NSUB * tid; d < 2 * Lt - 1; d += DB_NSUB * 256) {
-      const int off = d - (Lt - 1);          // i - j
+    // 64 diagonals per pass, the rows of a diagonal dealt to four threads (a long prompt -- 215 text tokens at 150 classes --
+    // made one thread per diagonal a chain of 54 dependent round trips); the four sums meet in LDS in a fixed order
+    const int dl = tid & 63, rc = tid >> 6;
+    for (int d0 = sub; d0 < 2 * Lt - 1; d0 += DB_NSUB * 64) {
+      const int d = d0 + DB_NSUB * dl;
       float t = 0.f;
-      const int lo = off > 0 ? off : 0, hi = off < 0 ? Lt + off : Lt;
+      if (d < 2 * Lt - 1) {
+        const int off = d - (Lt - 1);          // i - j
+        const int lo = off > 0 ? off : 0, hi = off < 0 ? Lt + off : Lt;
+        const int first = lo + ((part - lo) % DB_NPARTS + DB_NPARTS) % DB_NPARTS;
 #pragma unroll 4
-      for (int ti = lo + ((part - lo) % DB_NPARTS + DB_NPARTS) % DB_NPARTS; ti < hi; ti += DB_NPARTS) {
-        const long long o = (long long)(P + ti) * a.Sp + P + ti - off;
-        t += bf2f(hb[o]);
-        if (a.ng > 1) t += bf2f(hb[a.gs + o]);
+        for (int ti = first + rc * DB_NPARTS; ti < hi; ti += 4 * DB_NPARTS) {
+          const long long o = (long long)(P + ti) * a.Sp + P + ti - off;
+          t += bf2f(hb[o]);
+          if (a.ng > 1) t += bf2f(hb[a.gs + o]);
+        }
       }
-      o1[d] = (a.tab_accumulate ? o1[d] : 0.f) + t;
+      __syncthreads();
+      sf[rc * 64 + dl] = t;
+      __syncthreads();
+      if (rc == 0 && d < 2 * Lt - 1) {
+        const float tt = (sf[dl] + sf[64 + dl]) + (sf[128 + dl] + sf[192 + dl]);
+        o1[d] = (a.tab_accumulate ? o1[d] : 0.f) + tt;
+      }
     }
     return;
   }
@@ -1040,35 +1053,55 @@ __global__ __launch_bounds__(256) void attn_dbias_tables_kernel(DbArgs a) {
       if (a.ng > 1) t += bf2f(hb[a.gs + (long long)i * a.Sp + j]);
       return t;
     };
-    // grid rows x tail columns: a thread takes whole rows, the tail columns in 16-byte chunks (P is a multiple of 8)
+    // grid rows x tail columns: (row, 16-byte chunk) pairs dealt to the threads chunk-fastest -- neighbouring lanes read
+    // neighbouring chunks of one row (a thread per row read 2 KB-strided pieces, 27 dependent steps at 215 text tokens) --
+    // eight loads in flight per thread; the columns past the last whole chunk one element at a time (P is a multiple of 8)
     float t0 = 0.f, t1 = 0.f;
-    for (int i = part + DB_NPARTS * tid; i < P; i += DB_NPARTS * 256) {
+    {
+      const int nrow = (P - part + DB_NPARTS - 1) / DB_NPARTS, nch = Lt >> 3, nit = nrow * nch;
       float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      int tj = 0;
-#pragma unroll 4
-      for (; tj + 8 <= Lt; tj += 8)
-        for (int g = 0; g < a.ng; ++g) add8(t, *reinterpret_cast<const uint4*>(hb + g * a.gs + (long long)i * a.Sp + P + tj));
+      for (int it0 = tid; it0 < nit; it0 += 4 * 256) {
+        uint4 v[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int it = it0 + u * 256, r = it / nch, ch = it - r * nch;
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            v[u][g] = (it < nit && g < a.ng) ? *reinterpret_cast<const uint4*>(hb + g * a.gs + (long long)(part + DB_NPARTS * r) * a.Sp + P + ch * 8)
+                                             : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { add8(t, v[u][0]); add8(t, v[u][1]); }
+      }
       float tail = 0.f;
-      for (; tj < Lt; ++tj) tail += dB(i, P + tj);
-      t0 += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])) + tail;
+      const int nt = Lt & 7;
+      for (int it = tid; it < nrow * nt; it += 256) {
+        const int r = it / nt, e = it - r * nt;
+        tail += dB(part + DB_NPARTS * r, P + (Lt & ~7) + e);
+      }
+      t0 = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])) + tail;
     }
     // tail rows x grid columns: coalesced 16-byte chunks along the row
     // (four rows' loads in flight together: a long tail -- 239 rows at 640 x 640 / 171 classes -- made this the kernel's
     // longest block by far, 60 dependent round trips)
-    for (int c = tid; c < (P >> 3); c += 256) {
+    // (column chunks x two interleaved row sets, so that a 32-wide grid's 128 chunks still occupy all 256 threads)
+    const int nchunk = P >> 3, nrs = nchunk <= 128 ? 2 : 1;
+    for (int cc = tid; cc < nchunk * nrs; cc += 256) {
+      const int c = cc % nchunk, rs = cc / nchunk;
       float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      int ti = part;
-      for (; ti + 3 * DB_NPARTS < Lt; ti += 4 * DB_NPARTS) {
+      int ti = part + rs * DB_NPARTS;
+      const int tstep = nrs * DB_NPARTS;
+      for (; ti + 3 * tstep < Lt; ti += 4 * tstep) {
         uint4 v[4][2];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int g = 0; g < 2; ++g)
-            v[u][g] = g < a.ng ? *reinterpret_cast<const uint4*>(hb + g * a.gs + (long long)(P + ti + u * DB_NPARTS) * a.Sp + c * 8) : make_uint4(0, 0, 0, 0);
+            v[u][g] = g < a.ng ? *reinterpret_cast<const uint4*>(hb + g * a.gs + (long long)(P + ti + u * tstep) * a.Sp + c * 8) : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) { add8(t, v[u][0]); add8(t, v[u][1]); }
       }
-      for (; ti < Lt; ti += DB_NPARTS)
+      for (; ti < Lt; ti += tstep)
         for (int g = 0; g < a.ng; ++g) add8(t, *reinterpret_cast<const uint4*>(hb + g * a.gs + (long long)(P + ti) * a.Sp + c * 8));
       t1 += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     }
