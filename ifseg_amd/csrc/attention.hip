@@ -1510,6 +1510,17 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(ReduceArgs r) {
       // then thread r adds the entries of bucket r in entry order -- several entries may share a bucket (log-spaced
       // buckets beyond +-128), and a fixed order keeps the sum bit-reproducible (no atomics)
       const int n = a.tab_n[t], h = blk;
+      if (a.nparts <= 8) {
+        // few partial tables (the batch-inner path hands over 4): a thread per entry, one pass -- the grouped passes below
+        // cost two barriers per 32 entries (14 passes for the 429 offsets of a 215-token prompt).  Same order of additions.
+        for (int j = tid; j < n; j += 256) {
+          const float* p = a.tab_part[t] + (long long)h * a.nparts * n + j;
+          float sum = 0.f;
+          for (int q = 0; q < a.nparts; ++q) sum += p[(long long)q * n];
+          tsmall[j] = sum;
+        }
+        __syncthreads();
+      } else
       for (int j0 = 0; j0 < n; j0 += 32) {          // 32 entries x 8 groups of partials per pass
         const int j = j0 + (tid & 31), g = tid >> 5;
         float sum = 0.f;
@@ -1528,12 +1539,16 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(ReduceArgs r) {
         }
         __syncthreads();
       }
-      const int* idx = a.tab_idx[t];
+      // (the entry -> bucket map staged in LDS: every thread walks all n entries, and n dependent-latency global loads per
+      // thread -- 429 for a 215-token prompt -- were most of this block's time)
+      __shared__ int sidx[SMALL_TAB_MAX];
+      for (int j = tid; j < n; j += 256) sidx[j] = a.tab_idx[t][j];
+      __syncthreads();
       for (int rb = tid; rb < a.tab_nbucket[t]; rb += 256) {
         float tot = 0.f;
         bool any = false;
         for (int j = 0; j < n; ++j)
-          if (idx[j] == rb) { tot += tsmall[j]; any = true; }
+          if (sidx[j] == rb) { tot += tsmall[j]; any = true; }
         if (any) a.tab_acc[t][(long long)rb * a.H + h] += tot;
       }
       return;
