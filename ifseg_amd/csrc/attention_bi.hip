@@ -545,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
       // QUERIES of one key per lane -- a column of this tile -- so the seeds are read one float at a time (a row of 32 lanes
       // = 32 banks); rows r and r + 4 (the two lane halves of one read) sit at positions of opposite parity = opposite bank
       // halves: position(r) = r ^ ((r >> 2) & 1) within each group of eight.  (An earlier version kept a second, transposed copy of the
-      // bias served this kernel with 16-byte reads; building it was half of the dense-bias kernel's HBM writes.)
+      // bias, which served this kernel with 16-byte reads; building it was half of the dense-bias kernel's HBM writes.)
       const int row = bl * 8 + (r8 ^ ((r8 >> 2) & 1));
       const int jc = min(k0 + kbw * 32, a.Sp - 32);          // (a key block entirely in the padding: any valid address)
       lds_dma16_gs(db_, ((i0 + row) * a.Sp + jc + cp * 4) * 4, base + ST_D + kbw * 4096 + bl * 1024);
