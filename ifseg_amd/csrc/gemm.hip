@@ -16,94 +16,11 @@
 // slabs that a second launch sums: a fused "last workgroup reduces" was measured 2-3x slower on MI355X -- the
 // agent-scope release/acquire it needs writes back / invalidates the per-XCD L2s.
 #include <cstdlib>
-#include "common.h"
+#include "gemm_common.h"
 #include "prof.h"
-#include "../../include/ifseg_hip.h"
+#include "gemm_ring.h"
 
 namespace {
-
-constexpr int GBK = 64;
-// LDS stages: 2 (64 KiB, two workgroups per CU, loads overlap the MFMAs inside the workgroup) when the
-// grid is at most ~2 rounds of that occupancy; 1 (32 KiB, four workgroups per CU overlap each other) for
-// the many-tile shapes.  Measured on the SegOFA-Base shapes, tools/gemm_bench.py.
-constexpr int TWO_STAGE_MAX_WGS = 1024;
-constexpr int BM = 128;   // BN, BK and the LDS stage count are template parameters
-enum { A_KC = 0, A_KS = 1, A_CONV = 2 };
-constexpr unsigned OOB = 0x80000000u;   // byte offset beyond every buffer (< 2 GiB each): the load returns zeros
-
-struct GemmArgs {
-  const bf16_t* A; const bf16_t* B; void* C;
-  int M, N, K, lda, ldb, ldc;
-  const bf16_t* bias; const bf16_t* resid; int ldr;
-  float alpha; int alpha_ncols; int flags;
-  int cH, cW, cC, cKW, cStride, cPad, cOH, cOW;
-  long long sA, sB, sC, sR;
-  int splitk, kchunk; long long sCsplit;
-  unsigned nrecA, nrecB;   // bytes addressable through the A / B buffer descriptors (per batch)
-  // optional row-dot epilogue (attention backward's delta): dot_out[(m / dot_T) * (N/64) + n/64][m % dot_T] =
-  // sum over the 64 columns of head n/64 of C[m][n] (as stored in bf16) * dot[m][n]
-  const bf16_t* dot; int ldd; float* dot_out; int dot_T;
-  int xcd_groups;          // > 0: split-K slices pinned to XCDs (see the kernel), grid = tiles * splitk workgroups in x
-  // optional "GELU + LayerNorm backward" epilogue (EPI_GLN, the FFN's ffn_layernorm(gelu(fc1)) on the way back): the GEMM
-  // result is dz = d(LN output); the epilogue turns it into du = d(fc1 output) without dz ever reaching HBM:
-  //   g = gelu(u), xh = (g - mean_m) rstd_m, du = rstd_m (gamma_n dz - c1_m - xh c2_m) gelu'(u)
-  // c1 / c2 = the two row means of the LayerNorm backward, supplied by the caller (ifseg_ffn_ln_rowstats computes them from
-  // 768-wide tensors: the row sums over the 3072 columns are linear in dz = dY . W)
-  const bf16_t* gln_u; int gln_ldu; const float* gln_gamma; const float* gln_mean; const float* gln_rstd; const float* gln_c;
-};
-
-// ---- LDS tile images -------------------------------------------------------
-// Tiles are filled by LDS-DMA (buffer_load_dwordx4 ... lds): one wave instruction
-// writes 1 KiB, lane l at byte 16 l, so the image is lane-linear and the XOR
-// swizzle is applied on the SOURCE address (x_src below) and again on the read
-// (x_off); both are the same involution inside a 256-byte line.
-//   KC tile: [rows][BK k], k contiguous in global.   BK = 64: kc_off (common.h).
-//            BK = 32: 64-byte rows, chunk ^= (row >> 2) & 3.
-//   KS tile: [BK k][128 cols], cols contiguous in global: ks_off (common.h).
-template <int BK>
-__device__ __forceinline__ int kct_off(int r, int c) {
-  if constexpr (BK == 64) return kc_off(r, c);
-  else return r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
-}
-template <int BK>
-__device__ __forceinline__ void kct_src(int seg, int l, int& row, int& c) {
-  if constexpr (BK == 64) {
-    const int line = seg * 4 + (l >> 4), s = (l & 15) ^ (line & 15);
-    row = line * 2 + (s >> 3);
-    c = s & 7;
-  } else {
-    row = seg * 16 + (l >> 2);
-    c = (l & 3) ^ ((row >> 2) & 3);
-  }
-}
-__device__ __forceinline__ void ks_src(int seg, int l, int& kr, int& col) {
-  kr = seg * 4 + (l >> 4);
-  const int slot = l & 15;
-  col = ((((slot >> 2) ^ (kr & 3)) << 2) | (slot & 3)) * 8;
-}
-template <int BK>
-__device__ __forceinline__ bf16x8 frag_kct(const unsigned char* tile, int rb, int ks, int lane) {
-  return lds_read_b128(tile + kct_off<BK>(rb + (lane & 31), ks * 2 + (lane >> 5)));
-}
-
-typedef int v4i32 __attribute__((ext_vector_type(4)));
-// buffer descriptor (raw, stride 0) over `bytes` bytes at p; every field is made wave-uniform
-__device__ __forceinline__ v4i32 make_rsrc(const void* p, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)p;
-  v4i32 r;
-  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-  r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
-  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-  r.w = 0x00020000;
-  return r;
-}
-// One LDS-DMA piece: 64 lanes x 16 bytes from rs[voff] to LDS bytes [lds_base, lds_base + 1024).
-// Issued from inline asm so the compiler does not serialise the following ds_reads behind it;
-// completion is counted by hand (s_waitcnt vmcnt(0) before the barrier that publishes the tile).
-__device__ __forceinline__ void lds_dma16(v4i32 rs, unsigned lds_base, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :: "s"(lds_base), "v"(voff), "s"(rs) : "memory");
-}
 
 // One output tile (and, with split-K, one k-slice of it).  bx / by / bz are the workgroup's tile, batch and k-slice
 // coordinates (blockIdx of the plain kernel; the grouped kernel passes the tile index inside its problem);
@@ -496,11 +413,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_gln_kernel(GemmArgs g) {
 // split-K, no fp32 slabs, no reduction launches; db rides on the same pass (COLSUM) and dW / db are written once, as
 // bf16, straight into the gradient arena.  A single dW product of SegOFA-Base has 36..144 tiles (it cannot fill 256
 // CUs without split-K); a layer's products together have 432 (encoder) / 576 (decoder).
-struct GroupArgs {
-  int n, total;
-  int start[IFSEG_GEMM_GROUP_MAX + 1];     // first (XCD-remapped) tile of problem i; start[n] = total
-  GemmArgs p[IFSEG_GEMM_GROUP_MAX];
-};
 // The grid is capped (gridDim.x <= total, a multiple of 8): a workgroup walks tiles blockIdx.x, + gridDim.x, ... .  The
 // launch runs on the weight-gradient stream NEXT to the dX chain: with one workgroup per CU it leaves half of every
 // CU's LDS and wave slots to the main stream's kernels -- launched with one workgroup per tile, its long-running
@@ -522,6 +434,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(GroupArgs ga) {
 // by the caller when N % 8 == 0; otherwise see ifseg_rowdot in rowops.hip.
 
 }  // namespace
+
+// tile configuration of the persistent ring kernel (gemm_ring.hip) for a problem, 0 = the one-tile-per-workgroup kernel of
+// this file.  IFSEG_GEMM_RING=<id> forces a configuration (A/B measurements), IFSEG_GEMM_RING=0 turns the ring kernel off.
+static int ring_cfg(int M, int N, int K, bool group) {
+  (void)M; (void)N; (void)K; (void)group;
+  const char* e = getenv(group ? "IFSEG_GEMM_RING_GROUP" : "IFSEG_GEMM_RING");
+  if (e) return atoi(e);
+  return 0;
+}
 
 static int gemm_impl(int layout, const void* A, const void* B, void* C, int M, int N, int K,
                      int lda, int ldb, int ldc, const void* bias, float alpha, int alpha_ncols,
@@ -576,6 +497,16 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, int M, i
   if ((flags & IFSEG_GEMM_COLSUM) && layout != IFSEG_GEMM_TN) return IFSEG_ERR_BAD_ARG;
   const double nb = batch > 0 ? batch : 1;
   ifseg_prof_begin(IFSEG_K_GEMM_NT + layout, s, 2.0 * M * N * K * nb, 2.0 * nb * ((double)M * K + (double)N * K + (double)M * N));
+  if (g.splitk == 1 && batch <= 1 && !narrow && layout != IFSEG_GEMM_TN) {
+    const int cfg = ring_cfg(M, N, K, false);
+    if (cfg > 0) {
+      const int rc = gemm_ring_launch(&g, A_KC, layout == IFSEG_GEMM_NN, 0, cfg, stream);
+      ifseg_prof_end(IFSEG_K_GEMM_NT + layout, s);
+      if (rc) return rc;
+      IFSEG_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   const bool two_stage = (long long)tiles * g.splitk * (batch > 0 ? batch : 1) <= TWO_STAGE_MAX_WGS;
 #define LAUNCH2(AM, BKS, BNV)                                                                        \
   do {                                                                                               \
@@ -642,6 +573,13 @@ extern "C" int ifseg_gemm_tn_group(int n, const ifseg_gemm_tn_problem* probs, in
   ga.total = total;
   hipStream_t s = (hipStream_t)stream;
   ifseg_prof_begin(IFSEG_K_GEMM_TN, s, flops, bytes);
+  if (const int cfg = ring_cfg(0, 0, 0, true)) {
+    const int rc = gemm_ring_group_launch(&ga, cfg, max_workgroups, stream);
+    ifseg_prof_end(IFSEG_K_GEMM_TN, s);
+    if (rc) return rc;
+    IFSEG_CHECK_LAUNCH();
+    return 0;
+  }
   int grid = total;
   if (max_workgroups > 0 && max_workgroups < total) grid = max_workgroups >= 8 ? (max_workgroups & ~7) : max_workgroups;
   hipLaunchKernelGGL(gemm_tn_group_kernel<2>, dim3(grid), dim3(256), 0, s, ga);
@@ -675,6 +613,13 @@ extern "C" int ifseg_gemm_nn_gelu_ln_bwd(const void* A, const void* B, void* C, 
   hipStream_t s = (hipStream_t)stream;
   // (timed with the NN family; flops of the GEMM only)
   ifseg_prof_begin(IFSEG_K_GEMM_NT + IFSEG_GEMM_NN, s, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + 2.0 * M * N));
+  if (const int cfg = ring_cfg(M, N, K, false)) {
+    const int rc = gemm_ring_launch(&g, A_KC, 1, 1, cfg, stream);
+    ifseg_prof_end(IFSEG_K_GEMM_NT + IFSEG_GEMM_NN, s);
+    if (rc) return rc;
+    IFSEG_CHECK_LAUNCH();
+    return 0;
+  }
   if (tiles <= TWO_STAGE_MAX_WGS) hipLaunchKernelGGL(gemm_nn_gln_kernel<2>, dim3(tiles), dim3(256), 0, s, g);
   else hipLaunchKernelGGL(gemm_nn_gln_kernel<1>, dim3(tiles), dim3(256), 0, s, g);
   ifseg_prof_end(IFSEG_K_GEMM_NT + IFSEG_GEMM_NN, s);
@@ -706,6 +651,15 @@ extern "C" int ifseg_conv2d_nhwc_bf16(const void* in, const void* w, const void*
   const bool narrow = g.N <= 64 || tiles128 < 384;
   const int tiles = narrow ? ((g.M + BM - 1) / BM) * ((g.N + 63) / 64) : tiles128;
   ifseg_prof_begin(IFSEG_K_CONV, (hipStream_t)stream, 2.0 * g.M * g.N * g.K, 2.0 * ((double)B * H * W * Cin + (double)g.N * g.K + (double)g.M * g.N));
+  if (!narrow) {
+    if (const int cfg = ring_cfg(g.M, g.N, g.K, false)) {
+      const int rc = gemm_ring_launch(&g, A_CONV, 0, 0, cfg, stream);
+      ifseg_prof_end(IFSEG_K_CONV, (hipStream_t)stream);
+      if (rc) return rc;
+      IFSEG_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   const bool two_stage = tiles <= TWO_STAGE_MAX_WGS;
   const dim3 grid(tiles, 1), block(256);
   hipStream_t s = (hipStream_t)stream;
