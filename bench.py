@@ -15,6 +15,7 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                   sample (4 images) of the same workload.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -175,6 +176,13 @@ def main():
                     help="the recipe's image-free step (SURVEY 8f row 1, coco_unseen.sh:51): loss on an artificial image "
                          "(EmbeddingBag patches, no trunk) + a no-grad pass over the real images for the metrics")
     a = ap.parse_args()
+    # a record must not come from a run that leaves work out: experiment switches (IFSEG_EXP_*: kernels skipped, bias work
+    # compiled out) abort the run, and every IFSEG_* variable that was set is printed into the line (config.env)
+    env_seen = {k: v for k, v in sorted(os.environ.items()) if k.startswith("IFSEG_")}
+    exp = [k for k in env_seen if k.startswith("IFSEG_EXP_") or k in ("IFSEG_RING_ABLATE",)]
+    if exp:
+        sys.stderr.write("bench.py: experiment switch(es) %s set -- they leave work out of the step; refusing to report a number\n" % ", ".join(exp))
+        sys.exit(3)
     C = CONFIGS[a.config]
     if a.batch is None:
         a.batch = C["batch"]
@@ -208,6 +216,11 @@ def main():
     from ifseg_amd.criterions import SegCriterion
     from ifseg_amd.tasks.mm_tasks import SegmentationTask
     from ifseg_amd.trainer import Trainer
+    hip.lib().ifseg_experimental_build.restype = ctypes.c_int
+    if hip.lib().ifseg_experimental_build():
+        sys.stderr.write("bench.py: %s was compiled with a measurement switch that leaves work out (ifseg_experimental_build() = %d); "
+                         "refusing to report a number\n" % (os.environ.get("IFSEG_LIB", "libifseg_hip.so"), hip.lib().ifseg_experimental_build()))
+        sys.exit(3)
 
     torch.manual_seed(0)
     task = SegmentationTask(num_seg_tokens=a.nseg, patch_image_size=size, arch=arch)
@@ -245,7 +258,8 @@ def main():
 
     # discovery pass: every family timed over the last TWO warm-up steps -- one trunk pass serves two batches, so a single step
     # either contains a whole pass (conv family counted twice) or none; per-step values are the two-step sums halved
-    n_disc = 2 if a.warmup >= 2 else 1
+    n_disc = (1 if a.no_prefetch else max(1, trainer.eng.trunk_lookahead))
+    n_disc = n_disc if a.warmup >= n_disc else 1
     for i in range(a.warmup):
         if i == a.warmup - n_disc:
             hip.prof_reset(); hip.prof_enable(0x1FF)
@@ -375,7 +389,8 @@ def main():
                                       "" if a.no_prefetch else " (one pass per %d future batches on a second stream; a ring of %d synthetic batches, every batch through the trunk exactly once)" % (trainer.eng.trunk_lookahead, RING),
                                       a.dropout, a.drop_path,
                                       "; every step is one replay of the HIP-graph-captured update" if graphed else "; steps enqueued from the host"),
-                       "global_batch": a.batch * world, "parallelism": "dp%d" % world, "loss": round(loss, 4)},
+                       "global_batch": a.batch * world, "parallelism": "dp%d" % world, "loss": round(loss, 4),
+                       "env": env_seen},
             "roofline": {"bound": "mfma", "kernel": dom["kind"], "achieved": round(ach, 2), "peak": MFMA_PEAK_TF,
                          "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": dom["traffic"],
                          "traffic_source": _traffic_source(),
@@ -394,7 +409,9 @@ def main():
         out["host_enqueue_ms_per_step"] = round(t_enq / a.steps * 1e3, 3)
         if trainer.eng.marks:                    # IFSEG_PHASE_TIMING=1: main-stream (and host) time between the phase marks
             torch.cuda.synchronize()
-            mk = trainer.eng.marks[:n_marks][-9 * min(a.steps, 20):]       # the timed region's last steps
+            allm = trainer.eng.marks[:n_marks]
+            per_step = max(1, len(allm) // max(1, sum(1 for m in allm if m[0] == "step_start")))
+            mk = allm[-per_step * min(a.steps, 20):]       # the timed region's last steps
             while mk and mk[0][0] != "step_start":
                 mk = mk[1:]
             ph, hp = {}, {}

@@ -1765,3 +1765,11 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
   IFSEG_CHECK_LAUNCH();
   return 0;
 }
+
+int ifseg_exp_attention() {
+#if defined(IFSEG_EXP_NOBIAS_FWD) || defined(IFSEG_EXP_NOBIAS_BWD)
+  return 1;
+#else
+  return 0;
+#endif
+}

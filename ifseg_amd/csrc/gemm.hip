@@ -138,20 +138,40 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       cc0 += BK;
       if (cc0 >= g.cC) { cc0 = 0; if (++ckx == g.cKW) { ckx = 0; ++cky; } }
     } else {
+      // (a full k-tile: the k offset rides in the instruction's scalar offset -- no per-piece VALU; a k-tail takes its zero
+      // padding from the per-lane offset)
       const unsigned ka = (unsigned)kt * kadvA;
+#ifdef GEMM_NO_SOFF
+      if (false) {
+#else
+      if (!tail) {
+#endif
 #pragma unroll
-      for (int i = 0; i < LA; ++i) {
-        unsigned v = offA[i] + ka;
-        if (AMODE == A_KC && tail && c8A[i] >= krem) v = OOB;
-        lds_dma16(rsA, dA + i * 1024, v);
+        for (int i = 0; i < LA; ++i) lds_dma16_s(rsA, dA + i * 1024, offA[i], ka);
+      } else {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+          unsigned v = offA[i] + ka;
+          if (AMODE == A_KC && c8A[i] >= krem) v = OOB;
+          lds_dma16(rsA, dA + i * 1024, v);
+        }
       }
     }
     const unsigned kb = (unsigned)kt * kadvB;
+#ifdef GEMM_NO_SOFF
+    if (false) {
+#else
+    if (!tail) {
+#endif
 #pragma unroll
-    for (int i = 0; i < LB; ++i) {
-      unsigned v = offB[i] + kb;
-      if (!B_KS && tail && c8B[i] >= krem) v = OOB;
-      lds_dma16(rsB, dB + i * 1024, v);
+      for (int i = 0; i < LB; ++i) lds_dma16_s(rsB, dB + i * 1024, offB[i], kb);
+    } else {
+#pragma unroll
+      for (int i = 0; i < LB; ++i) {
+        unsigned v = offB[i] + kb;
+        if (!B_KS && c8B[i] >= krem) v = OOB;
+        lds_dma16(rsB, dB + i * 1024, v);
+      }
     }
   };
 
@@ -444,6 +464,12 @@ static int ring_cfg(int M, int N, int K, bool group) {
   return 0;
 }
 
+static int two_stage_max() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("IFSEG_GEMM_TWO_STAGE_MAX"); v = e ? atoi(e) : TWO_STAGE_MAX_WGS; }
+  return v;
+}
+
 static int gemm_impl(int layout, const void* A, const void* B, void* C, int M, int N, int K,
                      int lda, int ldb, int ldc, const void* bias, float alpha, int alpha_ncols,
                      const void* resid, int ldr, int flags, int batch, long long strideA,
@@ -507,7 +533,7 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, int M, i
       return 0;
     }
   }
-  const bool two_stage = (long long)tiles * g.splitk * (batch > 0 ? batch : 1) <= TWO_STAGE_MAX_WGS;
+  const bool two_stage = (long long)tiles * g.splitk * (batch > 0 ? batch : 1) <= two_stage_max();
 #define LAUNCH2(AM, BKS, BNV)                                                                        \
   do {                                                                                               \
     if (two_stage) hipLaunchKernelGGL((gemm_kernel<AM, BKS, BNV, GBK, 2>), grid, block, 0, s, g);    \
@@ -582,7 +608,8 @@ extern "C" int ifseg_gemm_tn_group(int n, const ifseg_gemm_tn_problem* probs, in
   }
   int grid = total;
   if (max_workgroups > 0 && max_workgroups < total) grid = max_workgroups >= 8 ? (max_workgroups & ~7) : max_workgroups;
-  hipLaunchKernelGGL(gemm_tn_group_kernel<2>, dim3(grid), dim3(256), 0, s, ga);
+  if (getenv("IFSEG_GEMM_GROUP_ONE_STAGE")) hipLaunchKernelGGL(gemm_tn_group_kernel<1>, dim3(grid), dim3(256), 0, s, ga);
+  else hipLaunchKernelGGL(gemm_tn_group_kernel<2>, dim3(grid), dim3(256), 0, s, ga);
   ifseg_prof_end(IFSEG_K_GEMM_TN, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
@@ -620,7 +647,7 @@ extern "C" int ifseg_gemm_nn_gelu_ln_bwd(const void* A, const void* B, void* C, 
     IFSEG_CHECK_LAUNCH();
     return 0;
   }
-  if (tiles <= TWO_STAGE_MAX_WGS) hipLaunchKernelGGL(gemm_nn_gln_kernel<2>, dim3(tiles), dim3(256), 0, s, g);
+  if (tiles <= two_stage_max()) hipLaunchKernelGGL(gemm_nn_gln_kernel<2>, dim3(tiles), dim3(256), 0, s, g);
   else hipLaunchKernelGGL(gemm_nn_gln_kernel<1>, dim3(tiles), dim3(256), 0, s, g);
   ifseg_prof_end(IFSEG_K_GEMM_NT + IFSEG_GEMM_NN, s);
   IFSEG_CHECK_LAUNCH();
@@ -660,7 +687,7 @@ extern "C" int ifseg_conv2d_nhwc_bf16(const void* in, const void* w, const void*
       return 0;
     }
   }
-  const bool two_stage = tiles <= TWO_STAGE_MAX_WGS;
+  const bool two_stage = tiles <= two_stage_max();
   const dim3 grid(tiles, 1), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (narrow) LAUNCH2(A_CONV, false, 64);
@@ -671,3 +698,7 @@ extern "C" int ifseg_conv2d_nhwc_bf16(const void* in, const void* w, const void*
 }
 
 extern "C" int ifseg_abi_version(void) { return IFSEG_ABI_VERSION; }
+// every object of the library reports its own measurement switches; any one of them marks the build
+int ifseg_exp_attention();
+int ifseg_exp_gemm_ring();
+extern "C" int ifseg_experimental_build(void) { return ifseg_exp_attention() | (ifseg_exp_gemm_ring() << 1); }

@@ -90,6 +90,11 @@ __device__ __forceinline__ void lds_dma16(v4i32 rs, unsigned lds_base, unsigned 
 }
 
 
+// the same with a scalar byte offset added to every lane's (the k offset of a k-tile: no per-lane add per request)
+__device__ __forceinline__ void lds_dma16_s(v4i32 rs, unsigned lds_base, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_base), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
 struct GroupArgs {
   int n, total;
   int start[IFSEG_GEMM_GROUP_MAX + 1];     // first (XCD-remapped) tile of problem i; start[n] = total

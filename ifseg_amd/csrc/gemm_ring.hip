@@ -14,16 +14,32 @@
 // column-range alpha, residual, ReLU, fp32 / bf16 output, accumulate, row-dot, GELU + LayerNorm backward, grouped TN with
 // fused column sums.  Same MFMA sequence per output element as gemm.hip => bit-identical results.
 #include <cstdlib>
+#include <utility>
 #include "gemm_common.h"
 #include "prof.h"
 #include "gemm_ring.h"
 
 namespace {
 
+__device__ __forceinline__ v4i32 uniform4(v4i32 r) {
+  r.x = __builtin_amdgcn_readfirstlane(r.x); r.y = __builtin_amdgcn_readfirstlane(r.y);
+  r.z = __builtin_amdgcn_readfirstlane(r.z); r.w = __builtin_amdgcn_readfirstlane(r.w);
+  return r;
+}
 template <int N>
-__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void vm_wait() {
+#ifndef RING_NOWAIT
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
 // every earlier LDS access of this wave has completed, then rendezvous (LDS-DMA requests stay in flight across it)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void lds_barrier() {
+#ifndef RING_NOBAR
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
 
 template <int TM_, int TN_, int TK_, int NWM_, int NWN_, int S_>
 struct RingCfg {
@@ -35,11 +51,11 @@ struct RingCfg {
   static constexpr int P = LA + LB;
   static constexpr int KSTEPS = TK / 16;
   static constexpr int KS_SUB = TK * 256;                                    // bytes of one 128-column k-strided sub-tile
-  static constexpr int LDS = S * STAGE;
+  static constexpr int RING = S * STAGE, LDS = RING + NW * 4096;         // ring + the epilogue's parking area
   static_assert(TJ == 2, "a wave owns 64 output columns (one head; the staged epilogue writes 128-byte row segments)");
   static_assert(LA * 1024 * NW == A_BYTES && LB * 1024 * NW == B_BYTES, "DMA pieces must divide evenly among the waves");
-  static_assert(NW * 4096 <= STAGE, "the epilogue parks 32 x 64 bf16 per wave in the stage it has just consumed");
   static_assert((S - 2) * P <= 63 && S >= 2, "vmcnt is a 6-bit counter");
+  static_assert(KSTEPS == 1 || KSTEPS % 2 == 0, "fragment sets alternate per k-slice");
   static_assert(LDS <= 160 * 1024, "LDS per CU");
 };
 
@@ -66,6 +82,11 @@ __device__ __forceinline__ void ring_run(const GemmArgs* __restrict__ probs, con
     n0 = (t % tiles_n) * TN;
   };
 
+  // measurement only (-DRING_ABLATE=n builds, wrong results): leave out the MFMAs (1), the operand requests (2), the fragment reads (4)
+#ifndef RING_ABLATE
+#define RING_ABLATE 0
+#endif
+  constexpr int ablate = RING_ABLATE;
   // ------------------------------------------------------------------ loader (runs S-1 k-steps ahead of the MFMAs)
   int lj = 0, lkt = 0, lnk = 0, lK = 0, ls = 0;
   bool lvalid = ntw > 0;
@@ -132,62 +153,138 @@ __device__ __forceinline__ void ring_run(const GemmArgs* __restrict__ probs, con
       cv_interior = g.cPad == 0 && g.cKW == 1;
     }
   };
-  // request k-tile lkt of the loader's tile into stage ls, then step the loader
-  auto issue_next = [&]() {
+  // request piece group Q (of G = KSTEPS groups) of k-tile lkt of the loader's tile into stage ls; the last group steps the
+  // loader.  A stage's pieces are spread over the k-slices of a k-step so that every MFMA group carries one or two of them.
+  auto issue_group = [&](auto qtag) {
+    constexpr int Q = decltype(qtag)::value, G = KSTEPS;
     const unsigned dA = lds0 + ls * STAGE + wave * (LA * 1024);
     const unsigned dB = lds0 + ls * STAGE + A_BYTES + wave * (LB * 1024);
     const int krem = lK - lkt * TK;                       // valid k in this tile (>= TK except on a tail)
     const bool tail = krem < TK;
-    if (AMODE == A_CONV) {
-      const int delta = ((cky * cvW + ckx) * cvC + cc0) * 2;        // wave-uniform byte offset of this tap / channel block
+    const int delta = (AMODE == A_CONV) ? ((cky * cvW + ckx) * cvC + cc0) * 2 : 0;   // wave-uniform offset of this tap / channel block
+    const unsigned ka = (unsigned)lkt * kadvA, kb = (unsigned)lkt * kadvB;
 #pragma unroll
-      for (int i = 0; i < LA; ++i) {
-        const unsigned v = (unsigned)(cv_base[i] + delta);
-        const bool ok = cv_interior ? cv_iy0[i] >= 0
-                                    : ((unsigned)(cv_iy0[i] + cky) < (unsigned)cvH && (unsigned)(cv_ix0[i] + ckx) < (unsigned)cvW);
-        lds_dma16(rsA, dA + i * 1024, ok ? v : OOB);
-      }
-      cc0 += TK;
-      if (cc0 >= cvC) { cc0 = 0; if (++ckx == cvKW) { ckx = 0; ++cky; } }
-    } else {
-      const unsigned ka = (unsigned)lkt * kadvA;
-#pragma unroll
-      for (int i = 0; i < LA; ++i) {
-        unsigned v = offA[i] + ka;
-        if (AMODE == A_KC && tail) {
-          int row, c;
-          kct_src<TK>(wave * LA + i, lane, row, c);
-          if (c * 8 >= krem) v = OOB;
+    for (int p = 0; p < P; ++p) {
+      if ((p * G) / P != Q || (ablate & 2)) continue;
+      if (p < LA) {
+        const int i = p;
+        unsigned v;
+        if (AMODE == A_CONV) {
+          const bool ok = cv_interior ? cv_iy0[i] >= 0
+                                      : ((unsigned)(cv_iy0[i] + cky) < (unsigned)cvH && (unsigned)(cv_ix0[i] + ckx) < (unsigned)cvW);
+          v = ok ? (unsigned)(cv_base[i] + delta) : OOB;
+        } else {
+          v = offA[i] + ka;
+          if (AMODE == A_KC && tail) {
+            int row, c;
+            kct_src<TK>(wave * LA + i, lane, row, c);
+            if (c * 8 >= krem) v = OOB;
+          }
         }
         lds_dma16(rsA, dA + i * 1024, v);
+      } else {
+        const int i = p - LA;
+        unsigned v = offB[i] + kb;
+        if (!B_KS && tail) {
+          int row, c;
+          kct_src<TK>(wave * LB + i, lane, row, c);
+          if (c * 8 >= krem) v = OOB;
+        }
+        lds_dma16(rsB, dB + i * 1024, v);
       }
     }
-    const unsigned kb = (unsigned)lkt * kadvB;
+    if (Q == G - 1) {
+      if (AMODE == A_CONV) {
+        cc0 += TK;
+        if (cc0 >= cvC) { cc0 = 0; if (++ckx == cvKW) { ckx = 0; ++cky; } }
+      }
+      ls = (ls + 1 == S) ? 0 : ls + 1;
+      if (++lkt == lnk) {
+        lkt = 0;
+        if (++lj < ntw) loader_tile(lj); else lvalid = false;
+      }
+    }
+  };
+  // The same for a FULL k-tile that is not the last of the loader's tile, with nothing to decide: the k offset rides in the
+  // instruction's scalar offset (no per-piece VALU), no tail test, no tile switch.  (A k-tail must go through issue_group: its
+  // zero padding comes from the per-lane offset.)
+  auto issue_group_fast = [&](auto qtag) {
+    constexpr int Q = decltype(qtag)::value, G = KSTEPS;
+    const unsigned dA = lds0 + ls * STAGE + wave * (LA * 1024);
+    const unsigned dB = dA - wave * (LA * 1024) + A_BYTES + wave * (LB * 1024);
+    const unsigned ka = (unsigned)lkt * kadvA, kb = (unsigned)lkt * kadvB;
+    const int delta = (AMODE == A_CONV) ? ((cky * cvW + ckx) * cvC + cc0) * 2 : 0;
 #pragma unroll
-    for (int i = 0; i < LB; ++i) {
-      unsigned v = offB[i] + kb;
-      if (!B_KS && tail) {
-        int row, c;
-        kct_src<TK>(wave * LB + i, lane, row, c);
-        if (c * 8 >= krem) v = OOB;
+    for (int p = 0; p < P; ++p) {
+      if ((p * G) / P != Q || (ablate & 2)) continue;
+      if (p < LA) {
+        const int i = p;
+        if (AMODE == A_CONV) {
+          const bool ok = cv_interior ? cv_iy0[i] >= 0
+                                      : ((unsigned)(cv_iy0[i] + cky) < (unsigned)cvH && (unsigned)(cv_ix0[i] + ckx) < (unsigned)cvW);
+          lds_dma16(rsA, dA + i * 1024, ok ? (unsigned)(cv_base[i] + delta) : OOB);
+        } else {
+          lds_dma16_s(rsA, dA + i * 1024, offA[i], ka);
+        }
+      } else {
+        const int i = p - LA;
+        lds_dma16_s(rsB, dB + i * 1024, offB[i], kb);
       }
-      lds_dma16(rsB, dB + i * 1024, v);
     }
-    ls = (ls + 1 == S) ? 0 : ls + 1;
-    if (++lkt == lnk) {
-      lkt = 0;
-      if (++lj < ntw) loader_tile(lj); else lvalid = false;
+    if (Q == G - 1) {
+      if (AMODE == A_CONV) {
+        cc0 += TK;
+        if (cc0 >= cvC) { cc0 = 0; if (++ckx == cvKW) { ckx = 0; ++cky; } }
+      }
+      ls = (ls + 1 == S) ? 0 : ls + 1;
+      ++lkt;
     }
+  };
+  auto issue_stage = [&]() {
+    [&]<int... Q>(std::integer_sequence<int, Q...>) { (issue_group(std::integral_constant<int, Q>{}), ...); }
+    (std::make_integer_sequence<int, KSTEPS>{});
   };
 
   // ------------------------------------------------------------------ consumer
+  // Register double-buffered fragments: the reads of k-slice s+1 are requested before the MFMAs of slice s; the barrier of a
+  // k-step sits BEFORE its last slice, so the first fragments of the next stage are requested under the last MFMAs of this one.
   f32x16 acc[TI][2];
   f32x16 accb[COLSUM ? TI : 1];
-  int inflight = 0, cs = 0;
+  bf16x8 fa[2][TI], fb[2][2];
+  auto ldfrag = [&](auto settag, int st, int ks) {
+    constexpr int SET = decltype(settag)::value;
+    if (ablate & 4) return;
+    const unsigned char* sA = smem + st * STAGE;
+    const unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int r = wm * C::WTM + i * 32;
+      fa[SET][i] = (AMODE == A_KS) ? frag_ks(sA + (r >> 7) * C::KS_SUB, r & 127, ks, lane) : frag_kct<TK>(sA, r, ks, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = wn * 64 + j * 32;
+      fb[SET][j] = B_KS ? frag_ks(sB + (r >> 7) * C::KS_SUB, r & 127, ks, lane) : frag_kct<TK>(sB, r, ks, lane);
+    }
+  };
+  auto wait_younger = [&](int younger) {
+    if (S >= 6 && younger >= 4) vm_wait<(S >= 6 ? 4 : 0) * P>();
+    else if (S >= 5 && younger >= 3) vm_wait<(S >= 5 ? 3 : 0) * P>();
+    else if (S >= 4 && younger >= 2) vm_wait<(S >= 4 ? 2 : 0) * P>();
+    else if (S >= 3 && younger >= 1) vm_wait<(S >= 3 ? 1 : 0) * P>();
+    else vm_wait<0>();
+  };
+  int issued = 0, it = 0, cs = 0;       // stages requested in full; global k-step index; stage being consumed
+  bool lopen = false;                   // a stage is partly requested (its group 0 went out after the last barrier)
   if (lvalid) loader_tile(0);
 #pragma unroll 1
-  for (int p = 0; p < S - 1; ++p)
-    if (lvalid) { issue_next(); ++inflight; }
+  for (int p = 0; p < S; ++p)
+    if (lvalid) { issue_stage(); ++issued; }
+  if (ntw > 0) {
+    wait_younger(issued - 1);
+    lds_barrier();
+    ldfrag(std::integral_constant<int, 0>{}, 0, 0);
+  }
 
 #pragma unroll 1
   for (int cj = 0; cj < ntw; ++cj) {
@@ -214,68 +311,95 @@ __device__ __forceinline__ void ring_run(const GemmArgs* __restrict__ probs, con
     constexpr bool PRE_BIAS = AMODE != A_KS && !B_KS;
     uint2 biasr[PRE_BIAS ? 2 : 1][4];
 
-#pragma unroll 1
-    for (int kt = 0; kt < nk; ++kt) {
-      // (a) this wave's pieces of the stage about to be consumed have landed: at most the younger stages stay in flight
-      {
-        const int younger = inflight - 1;
-        if (S >= 6 && younger >= 4) vm_wait<(S >= 6 ? 4 : 0) * P>();
-        else if (S >= 5 && younger >= 3) vm_wait<(S >= 5 ? 3 : 0) * P>();
-        else if (S >= 4 && younger >= 2) vm_wait<(S >= 4 ? 2 : 0) * P>();
-        else if (S >= 3 && younger >= 1) vm_wait<(S >= 3 ? 1 : 0) * P>();
-        else vm_wait<0>();
-      }
-      // (b) everybody's pieces have landed, and everybody has finished reading the stage consumed one step ago
-      lds_barrier();
-      // (c) refill that stage
-      if (lvalid) { issue_next(); ++inflight; }
-      // (d)
-      if (PRE_BIAS && kt == nk - 1 && g.bias) {
+    auto prefetch_bias = [&]() {
+      if (PRE_BIAS && g.bias) {
+        // hidden from the compiler's wait counting (a load it knows of makes it drain the whole ring at the first use);
+        // columns beyond N read zeros through the descriptor; waited for by hand in front of the epilogue
+        const v4i32 rsb = make_rsrc(g.bias, (unsigned)g.N * 2);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
-            const int n = n0 + wn * 64 + j * 32 + 8 * rg + 4 * (lane >> 5);
-            biasr[j][rg] = (n < g.N) ? *reinterpret_cast<const uint2*>(g.bias + n) : make_uint2(0, 0);
+            const unsigned nb = (unsigned)(n0 + wn * 64 + j * 32 + 8 * rg + 4 * (lane >> 5)) * 2;
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(biasr[j][rg]) : "v"(nb), "s"(rsb) : "memory");
           }
       }
-      {
-        const unsigned char* sA = smem + cs * STAGE;
-        const unsigned char* sB = sA + A_BYTES;
+    };
+    auto mma = [&](auto curtag) {
+      constexpr int cur = decltype(curtag)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      if (ablate & 1) {
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          bf16x8 fa[TI], fb[2];
+        for (int i = 0; i < TI; ++i) asm volatile("" ::"v"(fa[cur][i]));
 #pragma unroll
-          for (int i = 0; i < TI; ++i) {
-            const int r = wm * C::WTM + i * 32;
-            fa[i] = (AMODE == A_KS) ? frag_ks(sA + (r >> 7) * C::KS_SUB, r & 127, ks, lane) : frag_kct<TK>(sA, r, ks, lane);
-          }
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(fb[cur][j]));
+      } else {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int r = wn * 64 + j * 32;
-            fb[j] = B_KS ? frag_ks(sB + (r >> 7) * C::KS_SUB, r & 127, ks, lane) : frag_kct<TK>(sB, r, ks, lane);
-          }
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-          for (int i = 0; i < TI; ++i)
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
+      }
+      if constexpr (COLSUM) {
+        if (do_colsum) {
+          U128 one;
+          one.w[0] = one.w[1] = one.w[2] = one.w[3] = 0x3F803F80u;      // eight bf16 1.0
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-          if constexpr (COLSUM) {
-            if (do_colsum) {
-              U128 one;
-              one.w[0] = one.w[1] = one.w[2] = one.w[3] = 0x3F803F80u;      // eight bf16 1.0
-#pragma unroll
-              for (int i = 0; i < TI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one.b, fa[i], accb[i], 0, 0, 0);
-            }
-          }
+          for (int i = 0; i < TI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one.b, fa[cur][i], accb[i], 0, 0, 0);
         }
       }
-      --inflight;
-      cs = (cs + 1 == S) ? 0 : cs + 1;
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    int kt = 0;
+#pragma unroll 1
+    while (kt < nk) {
+      // (the descriptors ARE wave-uniform; restated for the compiler, whose analysis loses it across this loop's back edges --
+      // the inline-asm "s" operands would not compile -- folds to nothing)
+      rsA = uniform4(rsA); rsB = uniform4(rsB);
+      // hot k-step: the ring is full (a stage is open: its group 0 went out after the last barrier), the open k-tile and the
+      // next one are FULL k-tiles of the loader's current tile, and another k-step follows.  Its requests take the scalar
+      // k offset (no per-piece VALU, no tail test, no tile switch) and its wait is the steady-state constant; everything
+      // else goes the general way (loader at a tile boundary or on a k-tail, ring filling or draining, last step).
+      const bool more = !(cj == ntw - 1 && kt == nk - 1);     // another k-step follows (maybe of the next tile)
+      const bool hot = lopen && lvalid && more && lkt + 2 <= lK / TK;
+      const int ns = (cs + 1 == S) ? 0 : cs + 1;
+      if (kt == nk - 1) prefetch_bias();
+      [&]<int... KS>(std::integer_sequence<int, KS...>) {
+        ([&] {
+          constexpr int ks = KS, cur = KS & 1, nxt = cur ^ 1;
+          if constexpr (ks < KSTEPS - 1) {
+            ldfrag(std::integral_constant<int, nxt>{}, cs, ks + 1);
+            if (hot) {
+              issue_group_fast(std::integral_constant<int, ks + 1>{});
+              if (ks + 1 == KSTEPS - 1) ++issued;
+            } else if (lopen) {
+              issue_group(std::integral_constant<int, ks + 1>{});
+              if (ks + 1 == KSTEPS - 1) { lopen = false; ++issued; }
+            }
+          } else {
+            // every wave's pieces of the next stage have landed, and every wave holds its last fragments of this one:
+            // this stage is free for the request after next
+            if (hot) vm_wait<(S - 2) * P>();
+            else if (more) wait_younger(issued - (it + 2));
+            lds_barrier();
+            if (more) ldfrag(std::integral_constant<int, nxt>{}, ns, 0);
+            if (hot) {
+              issue_group_fast(std::integral_constant<int, 0>{});
+              if (KSTEPS == 1) ++issued;
+            } else if (lvalid) {
+              issue_group(std::integral_constant<int, 0>{});
+              if (KSTEPS == 1) ++issued; else lopen = true;
+            }
+          }
+          mma(std::integral_constant<int, cur>{});
+        }(), ...);
+      }(std::make_integer_sequence<int, KSTEPS>{});
+      cs = ns;
+      ++kt; ++it;
     }
 
     // ---------------------------------------------------------------- epilogue of tile cj
-    const int est = (cs == 0) ? S - 1 : cs - 1;           // the stage consumed last: nothing in flight targets it
     if constexpr (COLSUM) {
       // every row of accb holds sum_k A[k][m]; lanes 0..31 carry row 0 in register 0: db (bf16) sits right behind
       // dW [M x ldc] in the gradient arena
@@ -288,14 +412,21 @@ __device__ __forceinline__ void ring_run(const GemmArgs* __restrict__ probs, con
         }
       }
     }
+    if (PRE_BIAS && g.bias) {
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(biasr[0][0]), "+v"(biasr[0][1]), "+v"(biasr[0][2]), "+v"(biasr[0][3]), "+v"(biasr[PRE_BIAS ? 1 : 0][0]),
+                     "+v"(biasr[PRE_BIAS ? 1 : 0][1]), "+v"(biasr[PRE_BIAS ? 1 : 0][2]), "+v"(biasr[PRE_BIAS ? 1 : 0][3])
+                   :: "memory");
+    }
     const bool relu = g.flags & IFSEG_GEMM_RELU, out_f32 = g.flags & IFSEG_GEMM_OUT_F32, accum = g.flags & IFSEG_GEMM_ACCUMULATE;
     const bf16_t* Rb = g.resid;
     // bf16 output leaves through LDS (see gemm.hip): a lane owns a ROW of the MFMA tile, so direct stores write 32-byte
     // pieces of 32 rows per instruction; each wave parks 32 x 64 outputs in its own 4 KiB of the stage consumed last
     // (16-byte chunks XOR-swizzled by the row) and writes them back as 8 full 128-byte row segments per instruction.
+    // The parking area lies behind the ring and is private to the wave: the epilogue needs no barrier and the ring keeps
+    // filling under it.
     const bool lds_out = !out_f32 && !accum && !(g.ldc & 7) && !((size_t)g.C & 15);
-    unsigned char* sOut = smem + est * STAGE + wave * 4096;
-    lds_barrier();                                         // every wave has read its last fragments of that stage
+    unsigned char* sOut = smem + C::RING + wave * 4096;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       const int mrow0 = m0 + wm * C::WTM + i * 32;
@@ -429,13 +560,13 @@ int num_cus() {
 }
 
 // tile configurations (id = what IFSEG_GEMM_RING / the selection heuristic names)
-using C128x3 = RingCfg<128, 128, 64, 2, 2, 3>;   // 1:  96 KiB
-using C128x4 = RingCfg<128, 128, 64, 2, 2, 4>;   // 2: 128 KiB
-using C256x128 = RingCfg<256, 128, 64, 4, 2, 3>; // 3: 144 KiB, 8 waves of 64 x 64
-using C128x256 = RingCfg<128, 256, 64, 2, 4, 3>; // 4: 144 KiB, 8 waves of 64 x 64
-using C256x256 = RingCfg<256, 256, 32, 2, 4, 4>; // 5: 128 KiB, 8 waves of 128 x 64, 32-deep k-steps
-using C128x2 = RingCfg<128, 128, 64, 2, 2, 2>;   // 6:  64 KiB (two workgroups per CU)
-using C256x256b = RingCfg<256, 256, 64, 2, 4, 2>; // 7: 128 KiB, 8 waves of 128 x 64, 64-deep k-steps, two stages
+// (LDS = ring + 4 KiB of parking area per wave)
+using C1 = RingCfg<128, 128, 64, 2, 2, 3>;    // 112 KiB
+using C3 = RingCfg<256, 128, 64, 4, 2, 2>;    // 128 KiB, 8 waves of 64 x 64
+using C4 = RingCfg<128, 256, 64, 2, 4, 2>;    // 128 KiB, 8 waves of 64 x 64
+using C5 = RingCfg<256, 256, 32, 2, 4, 4>;    // 160 KiB, 8 waves of 128 x 64, 32-deep k-steps
+using C6 = RingCfg<128, 128, 64, 2, 2, 2>;    //  80 KiB: two workgroups per CU
+using C7 = RingCfg<256, 256, 64, 2, 4, 2>;    // 160 KiB, 8 waves of 128 x 64
 
 template <class C, int AMODE, bool B_KS, bool EPI_GLN>
 int launch1(const GemmArgs& g, int wgs_per_cu, hipStream_t s) {
@@ -443,7 +574,7 @@ int launch1(const GemmArgs& g, int wgs_per_cu, hipStream_t s) {
   a.p = g;
   const int total = ((g.M + C::TM - 1) / C::TM) * ((g.N + C::TN - 1) / C::TN);
   a.start[0] = 0; a.start[1] = total;
-  int grid = num_cus() * wgs_per_cu;
+  int grid = wgs_per_cu > 0 ? num_cus() * wgs_per_cu : total;       // 0: one workgroup per tile (not persistent)
   if (grid > total) grid = total;
   hipLaunchKernelGGL((gemm_ring_kernel<C, AMODE, B_KS, EPI_GLN>), dim3(grid), dim3(C::THREADS), 0, s, a, total);
   return 0;
@@ -452,13 +583,12 @@ int launch1(const GemmArgs& g, int wgs_per_cu, hipStream_t s) {
 template <int AMODE, bool B_KS, bool EPI_GLN>
 int launch_cfg(int cfg, const GemmArgs& g, hipStream_t s) {
   switch (cfg) {
-    case 1: return launch1<C128x3, AMODE, B_KS, EPI_GLN>(g, 1, s);
-    case 2: return launch1<C128x4, AMODE, B_KS, EPI_GLN>(g, 1, s);
-    case 3: return launch1<C256x128, AMODE, B_KS, EPI_GLN>(g, 1, s);
-    case 4: return launch1<C128x256, AMODE, B_KS, EPI_GLN>(g, 1, s);
-    case 5: return launch1<C256x256, AMODE, B_KS, EPI_GLN>(g, 1, s);
-    case 6: return launch1<C128x2, AMODE, B_KS, EPI_GLN>(g, 2, s);
-    case 7: return launch1<C256x256b, AMODE, B_KS, EPI_GLN>(g, 1, s);
+    case 1: return launch1<C1, AMODE, B_KS, EPI_GLN>(g, 1, s);
+    case 3: return launch1<C3, AMODE, B_KS, EPI_GLN>(g, 1, s);
+    case 4: return launch1<C4, AMODE, B_KS, EPI_GLN>(g, 1, s);
+    case 5: return launch1<C5, AMODE, B_KS, EPI_GLN>(g, 1, s);
+    case 6: return launch1<C6, AMODE, B_KS, EPI_GLN>(g, 2, s);
+    case 7: return launch1<C7, AMODE, B_KS, EPI_GLN>(g, 1, s);
   }
   return IFSEG_ERR_BAD_ARG;
 }
@@ -485,9 +615,9 @@ int gemm_ring_group_launch(const void* group_args, int cfg, int max_workgroups, 
   const GroupArgs& ga = *reinterpret_cast<const GroupArgs*>(group_args);
   hipStream_t s = (hipStream_t)stream;
   switch (cfg) {
-    case 1: return launch_group<C128x3>(ga, max_workgroups, s);
-    case 3: return launch_group<C256x128>(ga, max_workgroups, s);
-    case 4: return launch_group<C128x256>(ga, max_workgroups, s);
+    case 1: return launch_group<C1>(ga, max_workgroups, s);
+    case 3: return launch_group<C3>(ga, max_workgroups, s);
+    case 4: return launch_group<C4>(ga, max_workgroups, s);
   }
   return IFSEG_ERR_BAD_ARG;
 }
@@ -503,3 +633,11 @@ int gemm_ring_launch(const void* gemm_args, int amode, int b_ks, int epi_gln, in
   return IFSEG_ERR_BAD_ARG;
 }
 
+
+int ifseg_exp_gemm_ring() {
+#if RING_ABLATE != 0 || defined(RING_NOBAR) || defined(RING_NOWAIT)
+  return 1;
+#else
+  return 0;
+#endif
+}

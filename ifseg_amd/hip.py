@@ -33,7 +33,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 13:
+        if _lib.ifseg_abi_version() != 14:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -155,6 +155,10 @@ def ffn_ln_param_grads(w2, dw2, db2, gamma, beta, dgamma, dbeta, dy=None, u=None
     """dy [M, J], u [M, N], mean / rstd [M]: the operands of the rescue path for gains too small to divide by (csrc/ffn_ln.hip)"""
     J, N = w2.shape
     assert w2.is_contiguous() and dw2.is_contiguous()
+    if J > 1024:
+        # the rescue kernel stages one fc2.weight column (J values) in LDS: embed dims above 1024 (segofa_huge: 1280) run without
+        # it -- a gain of exactly 0 then yields a zero gradient instead of the value from the definition (ADVICE r4)
+        dy = None
     ws = _pg_ws.get((w2.device, N))
     if ws is None:
         ws = _pg_ws[(w2.device, N)] = torch.empty(16 * N, dtype=torch.float32, device=w2.device)

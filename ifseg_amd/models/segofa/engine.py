@@ -737,7 +737,14 @@ class HipEngine:
                 # resized rel-pos biases, which were built from the old tables.
                 ver = sum(p._version for p in self.trainable_params())
                 changed = ver != getattr(self, "_pver_seen", None)
-                if need_grad or self._master_stale or changed:
+                # (`.data` edits bump no version counter -- an EMA swap by p.data.copy_ ahead of a validation pass.
+                # The first evaluation forward after a training forward always re-syncs; edits BETWEEN two evaluation
+                # forwards need `weights_changed()`, which the model's load_state_dict / swap hooks call.)
+                entering_eval = (not need_grad) and getattr(self, "_last_fwd_train", True)
+                self._last_fwd_train = bool(need_grad)
+                if entering_eval:
+                    self._wver += 1
+                if need_grad or self._master_stale or changed or entering_eval:
                     hip.sync_master(self.master, self.p16[: self.n_train])
                     self._master_stale = False
                 if changed:
@@ -1513,7 +1520,9 @@ class HipEngine:
         ng = (B + 3) // 4
         # (causal and full attentions never share a buffer -- single-stream execution has no per-block instances, and the
         # decoder's self- and cross-attention can have the same padded shape: the causal one relies on blocks staying zero)
-        dbias = gbuf("g_dbias%s_%dx%d" % ("c" if causal else "", T, dense.Sp), (ng, H, T, dense.Sp))
+        # (the causal buffer's name also carries P: the blocks a causal launch skips depend on it, and they must never have been
+        # written under this name -- ADVICE r4)
+        dbias = gbuf("g_dbias%s_%dx%d" % ("c%d" % (rel.P if rel is not None else 0) if causal else "", T, dense.Sp), (ng, H, T, dense.Sp))
         if not getattr(dbias, "_ifseg_zeroed", False):
             # causal launches never write the blocks above the diagonal (the same blocks every step), and on grids that are not
             # 32 wide the table kernel reads masked pairs of a grid row that lie in such blocks: zero once per ALLOCATION (a

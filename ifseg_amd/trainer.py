@@ -154,9 +154,8 @@ class ArenaReducer:
             self.works.append(_W(end))
         elif self.fp32:
             wide = self.flat[lo:hi].float()
-            if wide.is_cuda:
-                # allocated on the calling (weight-gradient) stream, read back by finish() on the main stream
-                wide.record_stream(torch.cuda.default_stream(wide.device))
+            # allocated on the calling (weight-gradient) stream, read back by finish() on whatever stream finish() runs on:
+            # kept alive in `_wide` until then, and finish() tells the allocator about its stream
             self._wide.append((lo, hi, wide))
             self.works.append(dist.all_reduce(wide, async_op=True))
         else:
@@ -191,6 +190,8 @@ class ArenaReducer:
         for w in self.works:
             w.wait()
         for lo, hi, wide in self._wide:
+            if wide.is_cuda:
+                wide.record_stream(torch.cuda.current_stream(wide.device))
             self.flat[lo:hi].copy_(wide)            # one rounding, after the fp32 sum
         self.works, self.done, self._wide = [], [], []
         self._last, self._cnt = (self._cnt[0], self._cnt[1]), [0, 0]
@@ -435,6 +436,7 @@ class Trainer:
         launch instead of ~9 ms of host enqueue per step.  The sample tensors are the graph's static inputs: a data
         iterator copies each new batch into them (bench.py alternates two resident batches)."""
         self.check_overflow()
+        self._quiesced_for_eval = False
         eng = self.eng
         if not self.model.training:
             self.model.train()
@@ -503,4 +505,9 @@ class Trainer:
         return float(self.sumsq.sqrt().item()) * self._last_gscale
 
     def valid_step(self, sample):
+        if self.dist_on and not getattr(self, "_quiesced_for_eval", False):
+            # the first validation batch after training: c10d collectives of the evaluation (log sums, checkpoint barriers)
+            # must not be issued beside queued direct-RCCL ones
+            self.quiesce()
+        self._quiesced_for_eval = True
         return self.task.valid_step(sample, self.model, self.criterion)

@@ -19,11 +19,14 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 13
+#define IFSEG_ABI_VERSION 14
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
 int ifseg_abi_version(void);
+/* non-zero when the library was compiled with a measurement switch that leaves work out or changes results (IFSEG_EXP_*,
+ * RING_ABLATE / RING_NOBAR / RING_NOWAIT builds of tools/variant.py): bench.py refuses to report a number from such a build */
+int ifseg_experimental_build(void);
 
 /* ------------------------------------------------------------------ GEMM */
 #define IFSEG_GEMM_NT 0 /* C[M,N] = A[M,K] . B[N,K]^T   (F.linear forward)        */

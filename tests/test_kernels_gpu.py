@@ -1229,3 +1229,74 @@ def test_ffn_layernorm_gains_of_zero_small_and_negative_values():
     hip.ffn_ln_param_grads(w2, dw2, db2, gamma, beta, dgam, dbet)
     torch.cuda.synchronize()
     assert torch.isfinite(dgam.float()).all() and dgam[0].item() == 0.0
+
+
+# ----------------------------------------------------------------------------- persistent ring GEMM (opt-in, csrc/gemm_ring.hip)
+@pytest.mark.parametrize("cfg", [1, 3, 5, 6])
+def test_ring_gemm_is_bit_equal_to_the_tile_kernel(cfg, monkeypatch):
+    """IFSEG_GEMM_RING=<cfg> routes NT / NN / GELU+LN-backward / row-dot / convolution launches through the persistent ring
+    kernel (tile shapes 128x128 .. 256x256, k-tails, ragged M / N, every epilogue): the same MFMA sequence per output element
+    as the tile kernel => identical bits."""
+    from ifseg_amd import hip
+    dev = _dev()
+
+    def both(fn):
+        monkeypatch.delenv("IFSEG_GEMM_RING", raising=False)
+        a = fn()
+        monkeypatch.setenv("IFSEG_GEMM_RING", str(cfg))
+        b = fn()
+        monkeypatch.delenv("IFSEG_GEMM_RING", raising=False)
+        torch.cuda.synchronize()
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+    for (M, N, K) in [(1000, 776, 136), (2120, 768, 768), (300, 2304, 64)]:
+        x, w, wT = _rand((M, K), dev, 1, 0.5), _rand((N, K), dev, 2, 0.5), _rand((K, N), dev, 5, 0.5)
+        bias, res = _rand((N,), dev, 3), _rand((M, N), dev, 4)
+        both(lambda: [hip.linear_fwd(x, w, bias, alpha=0.37, alpha_ncols=(N // 16) * 8, resid=res), hip.linear_fwd(x, w)])
+        both(lambda: [hip.linear_dx(x, wT), hip.linear_dx(x, wT, resid=res)])
+        acc = _rand((M, N), dev, 6)
+        both(lambda: [hip.linear_dx(x, wT, out=acc.clone(), accumulate=True)])
+    # row-dot epilogue (attention backward's delta)
+    B, T, C = 2, 530, 768
+    da, wo, o = _rand((B * T, C), dev, 7, 0.5), _rand((C, C), dev, 8, 0.1), _rand((B * T, C), dev, 9)
+    def rowdot():
+        out = torch.empty(B * T, C, dtype=torch.bfloat16, device=dev)
+        delta = torch.zeros(B, C // 64, T, dtype=torch.float32, device=dev)
+        hip.linear_dx_rowdot(da, wo, out, o, delta, T)
+        return [out, delta]
+    both(rowdot)
+    # convolution (implicit GEMM)
+    Bc, H, W, Cin, Cout = 2, 20, 24, 128, 256
+    xi, wc = _rand((Bc, H, W, Cin), dev, 10), _rand((Cout, 3, 3, Cin), dev, 11, 1.0 / math.sqrt(Cin * 9))
+    sh, rs = _rand((Cout,), dev, 12), _rand((Bc, H, W, Cout), dev, 13)
+    def conv():
+        out = torch.empty(Bc, H, W, Cout, dtype=torch.bfloat16, device=dev)
+        hip.conv2d_nhwc(xi, wc, sh, rs, out, Bc, H, W, Cin, Cout, 3, 3, 1, 1, True)
+        return [out]
+    both(conv)
+
+
+@pytest.mark.parametrize("cfg", [1, 3, 4])
+def test_ring_grouped_weight_gradients_are_bit_equal(cfg, monkeypatch):
+    """IFSEG_GEMM_RING_GROUP=<cfg>: the grouped dW (+ db) launch through the ring kernel (k-tail of the token count, strided
+    dY, problems of different K) against the tile kernel's grouped launch."""
+    from ifseg_amd import hip
+    dev = _dev()
+    shapes = [(768, 3072, 1060 * 2 + 8), (2304, 768, 1060 * 2 + 8), (768, 768, 2056)]
+    def run():
+        flats, tasks = [], []
+        for i, (N, K, Mi) in enumerate(shapes):
+            dy, x = _rand((Mi, N + 8), dev, 300 + i, 0.5)[:, :N], _rand((Mi, K), dev, 320 + i, 0.5)
+            flat = torch.full((N * K + N + 8,), 7.0, dtype=torch.bfloat16, device=dev)
+            tasks.append((dy, x, flat[: N * K].view(N, K), flat[N * K: N * K + N] if i != 2 else None))
+            flats.append(flat)
+        hip.linear_dw_group(tasks)
+        torch.cuda.synchronize()
+        return flats
+    monkeypatch.delenv("IFSEG_GEMM_RING_GROUP", raising=False)
+    a = run()
+    monkeypatch.setenv("IFSEG_GEMM_RING_GROUP", str(cfg))
+    b = run()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

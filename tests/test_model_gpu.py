@@ -713,3 +713,79 @@ def test_unsupported_inputs_are_refused_without_a_per_step_sync():
             m(patch_masks=masks, **good)
             torch.cuda.synchronize()
             m(**good)
+
+
+def test_parameters_stepped_from_outside_are_seen_by_the_next_forward(golden_dir):
+    """`master_owned=False` (the plugin under the reference's own trainer: fairseq's FP16Optimizer owns fp32 masters and writes
+    the half parameters back with `p.data.copy_(p32)`, custom_fairseq/fairseq/optim/fp16_optimizer.py:96-222 -- no version
+    counter moves): a stand-in optimizer steps every trainable tensor from OUTSIDE the engine; the next training forward /
+    backward and the first evaluation forward after a further `.data` edit of the LayerNorm gains (which the engine reads from
+    its own fp32 copy) must match the oracle on the stepped values."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ifseg_amd.criterions import SegCriterion
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    batch = O.synthetic_batch(ocfg, 2, 12)
+    m = _build(ocfg, sd, dev)
+    m.train()
+    assert not m.engine.master_owned
+    crit = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+    sample = {"net_input": {"src_tokens": batch["src_tokens"].to(dev), "src_lengths": torch.full((2,), 12).to(dev),
+                            "patch_images": batch["patch_images"].to(dev), "patch_masks": batch["patch_masks"].to(dev),
+                            "prev_output_tokens": batch["prev_output_tokens"].to(dev)},
+              "target": batch["target"].to(dev), "ntokens": 1, "nsentences": 2}
+    loss, _, _ = crit(m, sample)
+    logits0 = m.engine.ws["logits_pad"][:, :, : ocfg.num_seg_tokens].float().cpu()
+    loss.backward()
+    named = dict(m.named_parameters())
+    # the stand-in optimizer: fp32 masters, a normalised-gradient step of up to 5 % of a tensor's mean magnitude, written back
+    # through .data (exactly what FP16Optimizer._sync_fp32_params_to_fp16 does)
+    with torch.no_grad():
+        for k, p in named.items():
+            if not p.requires_grad or p.grad is None:
+                continue
+            p32 = p.data.float()
+            g = p.grad.float()
+            p32 -= 0.05 * p32.abs().mean() * g / (g.abs().max() + 1e-12)
+            p.data.copy_(p32)
+            p.grad = None
+    def oracle_on_current(edit=None):
+        sd2 = {k: v.clone() for k, v in sd.items()}
+        for k, p in named.items():
+            if k in sd2 and p.requires_grad:
+                sd2[k] = p.data.float().cpu()
+        return sd2
+    sd2 = oracle_on_current()
+    o_logits, o_loss, o_grads, _ = _oracle_all_grads(ocfg, sd2, batch, (128, 128))
+    loss, _, _ = crit(m, sample)
+    logits = m.engine.ws["logits_pad"][:, :, : ocfg.num_seg_tokens].float().cpu()
+    moved = _rel(logits, logits0)
+    print("external step: logits moved by %.4f, vs oracle on the stepped values %.4f, loss d %.5f" % (moved, _rel(logits, o_logits), abs(loss.item() - o_loss.item())))
+    assert moved > 5e-2                                   # the step is visible at all (the test has power)
+    assert _rel(logits, o_logits) <= 2e-2 and abs(loss.item() - o_loss.item()) <= 1e-2
+    loss.backward()
+    torch.cuda.synchronize()
+    bad = []
+    for k, og in o_grads.items():
+        if k in named and named[k].requires_grad and og.norm() > 0 and not k.endswith(("k_proj.bias", "pos_k_linear.bias", "c_attn")):
+            e = _rel(named[k].grad, og)
+            if e > 6e-2:
+                bad.append((round(e, 4), k))
+    assert not bad, bad[:10]
+    # an EMA-like swap of the LayerNorm gains through .data, then evaluation: the engine's fp32 copy must follow
+    with torch.no_grad():
+        for k, p in named.items():
+            if p.requires_grad and "layer_norm" in k and k.endswith("weight"):
+                p.data.copy_(p.data.float() * 1.25)
+    sd3 = oracle_on_current()
+    with torch.no_grad():
+        o_eval, _ = O.segofa_forward(sd3, ocfg, batch["src_tokens"], batch["patch_images"])
+    m.eval()
+    with torch.no_grad():
+        le, _ = m(**sample["net_input"])
+    le = le[..., : ocfg.num_seg_tokens].float().cpu() if le.shape[-1] != o_eval.shape[-1] else le.float().cpu()
+    print("eval after a .data edit of the LayerNorm gains: rel-L2 %.4f (against the pre-edit logits %.4f)" % (_rel(le, o_eval), _rel(le, o_logits)))
+    assert _rel(o_eval, o_logits) > 5e-2                  # the edit is visible in the oracle
+    assert _rel(le, o_eval) <= 2e-2

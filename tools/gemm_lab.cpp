@@ -62,17 +62,16 @@ static double time_us(F&& fn, int iters) {
   return t[2];
 }
 
-static const std::vector<int> CFGS = {0, 6, 1, 2, 3, 4, 5, 7};
+static std::vector<int> CFGS = {0, 6, 1, 3, 4, 5, 7};
 static const char* cfg_name(int c) {
   switch (c) {
-    case 0: return "old 128x128 1-2st";
-    case 1: return "ring 128x128 S3";
-    case 2: return "ring 128x128 S4";
-    case 3: return "ring 256x128 S3";
-    case 4: return "ring 128x256 S3";
-    case 5: return "ring 256x256k32 S4";
-    case 6: return "ring 128x128 S2 x2";
-    case 7: return "ring 256x256k64 S2";
+    case 0: return "tile 128x128 (gemm.hip)";
+    case 1: return "ring 128x128x64 S3";
+    case 3: return "ring 256x128x64 S2";
+    case 4: return "ring 128x256x64 S2";
+    case 5: return "ring 256x256x32 S4";
+    case 6: return "ring 128x128x64 S2 2/CU";
+    case 7: return "ring 256x256x64 S2";
   }
   return "?";
 }
@@ -109,18 +108,18 @@ static void bench_cases(const std::vector<Case>& cases, int iters, bool check_on
       HC(hipMemcpy(C.d, C0.d, cbytes, hipMemcpyDeviceToDevice));
       int rc = run_gemm(c, A, B, C, bias, resid);
       HC(hipDeviceSynchronize());
-      if (rc) { printf("%s M%d N%d K%d epi%d  %-20s rc=%d\n", ln, c.M, c.N, c.K, c.epi, cfg_name(cfg), rc); continue; }
+      if (rc) { printf("%s M%d N%d K%d epi%d  %-24s rc=%d\n", ln, c.M, c.N, c.K, c.epi, cfg_name(cfg), rc); continue; }
       std::vector<unsigned char> out = C.host();
       size_t bad = 0;
       if (cfg == 0) ref = out;
-      else {
+      else if (!ref.empty()) {
         const size_t el = c.epi == 3 ? 4 : 2;
         for (size_t i = 0; i < cel; ++i) bad += memcmp(&out[i * el], &ref[i * el], el) != 0;
       }
       double us = 0;
       if (!check_only && c.epi != 3 && c.epi != 4) us = time_us([&] { run_gemm(c, A, B, C, bias, resid); }, iters);
-      printf("%s M%-5d N%-5d K%-5d epi%d  %-20s %8.1f us %7.1f TF/s  %s\n", ln, c.M, c.N, c.K, c.epi, cfg_name(cfg), us,
-             us > 0 ? gf / us * 1e3 : 0.0, cfg == 0 ? "ref" : bad ? "MISMATCH" : "bit-equal");
+      printf("%s M%-5d N%-5d K%-5d epi%d  %-24s %8.1f us %7.1f TF/s  %s\n", ln, c.M, c.N, c.K, c.epi, cfg_name(cfg), us,
+             us > 0 ? gf / us * 1e3 : 0.0, cfg == 0 ? "ref" : ref.empty() ? "-" : bad ? "MISMATCH" : "bit-equal");
       if (bad) printf("    mismatching elements: %zu of %zu\n", bad, cel);
       fflush(stdout);
     }
@@ -154,7 +153,7 @@ static void bench_group(int iters) {
       else for (size_t e = 0; e < h.size() / 2; ++e) bad += memcmp(&h[e * 2], &ref[i][e * 2], 2) != 0;
     }
     double us = time_us([&] { ifseg_gemm_tn_group(4, pr, 256, nullptr); }, iters);
-    printf("TN group (encoder layer, %.0f GF)  %-20s rc=%d %8.1f us %7.1f TF/s  %s\n", gf, cfg_name(cfg), rc, us, gf / us * 1e3,
+    printf("TN group (encoder layer, %.0f GF)  %-24s rc=%d %8.1f us %7.1f TF/s  %s\n", gf, cfg_name(cfg), rc, us, gf / us * 1e3,
            cfg == 0 ? "ref" : bad ? "MISMATCH" : "bit-equal");
     if (bad) printf("    mismatching elements: %zu\n", bad);
     fflush(stdout);
@@ -164,6 +163,10 @@ static void bench_group(int iters) {
 int main(int argc, char** argv) {
   const std::string mode = argc > 1 ? argv[1] : "perf";
   const int iters = argc > 2 ? atoi(argv[2]) : 20;
+  if (argc > 3) {          // explicit configuration list: "0,6,3"
+    CFGS.clear();
+    for (char* t = strtok(argv[3], ","); t; t = strtok(nullptr, ",")) CFGS.push_back(atoi(t));
+  }
   HC(hipSetDevice(0));
   printf("abi %d\n", ifseg_abi_version());
   if (mode == "check") {
@@ -195,6 +198,21 @@ int main(int argc, char** argv) {
     bench_cases(cs, iters, false);
   } else if (mode == "group") {
     bench_group(iters);
+  } else if (mode == "ablate") {
+    // ablate <iters> <cfgs>: the k-loop with parts left out (wrong results; what each part costs)
+    const char* names[] = {"full", "no MFMA", "no DMA", "no MFMA, no DMA", "no LDS reads", "no MFMA, no LDS reads (DMA only)", "no DMA, no LDS reads (MFMA only)", "barriers only"};
+    for (auto sh : {std::pair<int, int>{768, 3072}, {3072, 768}}) {
+      for (int ab = 0; ab < 8; ++ab) {
+        char b[8]; snprintf(b, sizeof b, "%d", ab); setenv("IFSEG_RING_ABLATE", b, 1);
+        printf("---- ablation %d: %s\n", ab, names[ab]);
+        bench_cases({{IFSEG_GEMM_NT, 8480, sh.first, sh.second, 0}}, iters, false);
+      }
+    }
+    unsetenv("IFSEG_RING_ABLATE");
+  } else if (mode == "one") {
+    // one <iters> <cfgs> <layout> <M> <N> <K> [epi]: a single shape (profiling)
+    if (argc < 8) { fprintf(stderr, "one <iters> <cfgs> <layout> <M> <N> <K> [epi]\n"); return 2; }
+    bench_cases({{atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), argc > 8 ? atoi(argv[8]) : 0}}, iters, false);
   }
   return 0;
 }
