@@ -802,28 +802,23 @@ __global__ __launch_bounds__(256) void attn_dbias_grads_kernel(DbArgs a) {
     const int h = blk / nit, i0 = (blk % nit) * 32;
     const int i = i0 + (lane & 31);
     const int ir = i < a.T ? i : a.T - 1;
-    unsigned char* tile = sm + wave * 4096;
+    unsigned char* tile = sm + wave * 8192;       // pos_k tile [32 j][64 c]; behind it the dB tile [32 i][ng x 32 j] (64-byte halves)
     f32x16 acc[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
-    uint4 t4[4];
-    uint2 lo[2][2], hi[2][2];
+    uint4 t4[4], d4[4];
+    // both tiles arrive as whole 64-byte row pieces (16 bytes per lane) and go through LDS; the B fragments -- a lane's
+    // eight dB values of ITS row in the k-slot order of the transposed A read -- are two 8-byte LDS reads each.  (Fetched
+    // straight into fragment shape, a wave instruction took 16 bytes out of each of 32 rows: a quarter of every 64-byte
+    // segment it touched, four times over.)
     auto fetch = [&](int j0) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {          // pos_k tile [32 j][64 c], rows past S are zero
-        t4[u] = make_uint4(0, 0, 0, 0);
+        t4[u] = make_uint4(0, 0, 0, 0); d4[u] = make_uint4(0, 0, 0, 0);
         if (j0 + lr + 8 * u < a.S) t4[u] = *reinterpret_cast<const uint4*>(a.pk + (long long)(j0 + lr + 8 * u) * a.ldpk + h * 64 + lc * 8);
+        const int g = lc >> 2, irow = min(i0 + lr + 8 * u, a.T - 1);
+        if (g < a.ng) d4[u] = *reinterpret_cast<const uint4*>(a.dbias + g * a.gs + ((long long)h * a.T + irow) * a.Sp + j0 + (lc & 3) * 8);
       }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          lo[s2][g] = make_uint2(0, 0); hi[s2][g] = make_uint2(0, 0);
-          if (g < a.ng) {
-            const bf16_t* rp = a.dbias + g * a.gs + ((long long)h * a.T + ir) * a.Sp + j0 + 16 * s2 + 4 * half;
-            lo[s2][g] = *reinterpret_cast<const uint2*>(rp); hi[s2][g] = *reinterpret_cast<const uint2*>(rp + 8);
-          }
-        }
     };
     // (causal: sum_b dS is zero -- and was never written -- for the grid columns beyond the block's last row, and for every
     // grid column when the rows are tail rows; the schedule of the dQ kernel, step by step)
@@ -834,15 +829,25 @@ __global__ __launch_bounds__(256) void attn_dbias_grads_kernel(DbArgs a) {
       if (!live(j0)) { if (j0 + 128 < a.Sp) fetch(j0 + 128); continue; }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4*>(tile + vx_off(lr + 8 * u, lc * 16)) = t4[u];
+      for (int u = 0; u < 4; ++u) {
+        const int o = vx_off(lr + 8 * u, lc * 16);
+        *reinterpret_cast<uint4*>(tile + o) = t4[u];
+        *reinterpret_cast<uint4*>(tile + 4096 + o) = d4[u];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (j0 + 128 < a.Sp) fetch(j0 + 128);
       U128 bfr[2][2];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) { bfr[s2][g].w[0] = lo[s2][g].x; bfr[s2][g].w[1] = lo[s2][g].y; bfr[s2][g].w[2] = hi[s2][g].x; bfr[s2][g].w[3] = hi[s2][g].y; }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (j0 + 128 < a.Sp) fetch(j0 + 128);
+        for (int g = 0; g < 2; ++g) {
+          // row = the lane's query, columns j0 + 16 s2 + 4 half .. + 3 and the same + 8 (group g's 64-byte half of the row)
+          const int cb = g * 64 + (16 * s2 + 4 * half) * 2;
+          const uint2 lo = *reinterpret_cast<const uint2*>(tile + 4096 + vx_off(lane & 31, cb));
+          const uint2 hi = *reinterpret_cast<const uint2*>(tile + 4096 + vx_off(lane & 31, cb + 16));
+          bfr[s2][g].w[0] = lo.x; bfr[s2][g].w[1] = lo.y; bfr[s2][g].w[2] = hi.x; bfr[s2][g].w[3] = hi.y;
+        }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 a0 = tr_frag(tile, 16 * s2, 0, lane), a1 = tr_frag(tile, 16 * s2, 1, lane);
@@ -855,11 +860,12 @@ __global__ __launch_bounds__(256) void attn_dbias_grads_kernel(DbArgs a) {
       }
       __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();                                   // (the tiles are dead: the sum reuses their LDS)
     // fixed-order sum of the four waves' accumulators, one column block at a time: [wave][r][lane]
-    float* red = reinterpret_cast<float*>(sm + 16384);
+    float* red = reinterpret_cast<float*>(sm);
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-      __syncthreads();
+      if (cb) __syncthreads();
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[cb][r];
       __syncthreads();
