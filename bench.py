@@ -336,6 +336,17 @@ def main():
         t_ss = ts.item()
         steady = {"steps": n_ss, "seconds": round(t_ss, 3), "ms_per_step": round(t_ss / n_ss * 1e3, 3),
                   "images_per_sec": round(a.batch * world * n_ss / t_ss, 2)}
+    # what one step costs the HOST: the enqueue of a step into an EMPTY GPU queue (device drained first), so that no
+    # back-pressure from a full queue is inside the figure -- `host_enqueue_ms_per_step` of the timed region converges to the
+    # GPU time whenever the host is ahead.  Median of 7, after the timed regions.
+    host_empty = []
+    for _ in range(7):
+        torch.cuda.synchronize()
+        th = time.time()
+        one_step()
+        host_empty.append((time.time() - th) * 1e3)
+    torch.cuda.synchronize()
+    host_empty.sort()
     if graphed:
         use_graph[0] = False
         dominant_pass(min(10, a.steps))
@@ -407,6 +418,7 @@ def main():
         # collectives and bytes per step.  Any N > 1 run that did not go through the direct communicator fails loudly below.
         out["rccl"] = rccl_stats
         out["host_enqueue_ms_per_step"] = round(t_enq / a.steps * 1e3, 3)
+        out["host_ms_per_step_empty_queue"] = round(host_empty[len(host_empty) // 2], 3)
         if trainer.eng.marks:                    # IFSEG_PHASE_TIMING=1: main-stream (and host) time between the phase marks
             torch.cuda.synchronize()
             allm = trainer.eng.marks[:n_marks]

@@ -58,6 +58,7 @@ class HipEngine:
         self._saved_grad, self._saved_aux = {}, {}
         self.ws, self.saved = self._ws_grad, self._saved_grad
         self._gctx = None                 # ctx of the forward awaiting its backward
+        self._popt = None                 # events of a still-running optimizer (params_pending)
         self.ctx_building = None          # ctx of the forward being enqueued
         self._views = {}
         self.geo = {}
@@ -717,10 +718,35 @@ class HipEngine:
         self._master_stale = True
         self._wver += 1
 
+    # ----------------------------------------------------------------- a still-running optimizer (Trainer, defer_optimizer)
+    def params_pending(self, events):
+        """`events`: {slice key: event} recorded on the optimizer's stream as the slices of the parameter arena become final, in
+        the order the forward first reads them ("g0": everything outside the layers and the token table, "emb": the token
+        table, "e<l>": encoder layer l, "all": the last launch).  Whatever reads parameters waits for what it needs
+        (`_params_wait`); the optimizer of step n then runs underneath the start of the forward of step n + 1."""
+        self._popt = dict(events) if events else None
+
+    def _params_wait(self, keys=None, stream=None):
+        po = self._popt
+        if not po:
+            return
+        st = stream if stream is not None else torch.cuda.current_stream()
+        if keys is None:
+            st.wait_event(po["all"])
+            if stream is None:
+                self._popt = None          # the main stream is behind the whole update: nothing left to wait for
+            return
+        for k in keys:
+            ev = po.get(k)
+            if ev is not None:
+                st.wait_event(ev)
+
     # ----------------------------------------------------------------- forward
     def forward(self, *args, **kw):
         prev = hip.set_stream(torch.cuda.current_stream().cuda_stream)    # one stream lookup per pass, not per launch
         need_grad = kw.get("need_grad", True)
+        if self._popt and not need_grad:
+            self._params_wait(None)        # (only the training forward waits slice by slice)
         aux = (not need_grad) and self._gctx is not None
         self.ws, self.saved = (self._ws_aux, self._saved_aux) if aux else (self._ws_grad, self._saved_grad)
         prev_sa = None
@@ -875,9 +901,11 @@ class HipEngine:
                "src_tokens": src_tokens, "feat": feat}
         self.ctx_building = ctx
         e = "encoder."
+        self._params_wait(["g0"])
         # ---- embeddings (forward_embedding, encoder_module.py:388-446)
         img_pre = buf("img_pre", (B * P, C))
         if bag is not None:
+            self._params_wait(["emb"])
             hip.embed_bag_mean(W(e + "embed_tokens.weight"), bag[0].contiguous(), bag[1].contiguous(),
                                W(e + "type_embedding.weight")[1], img_pre)
         else:
@@ -889,6 +917,7 @@ class HipEngine:
         hip.ln_fwd(img_pre.view(B, P, C), Wf(e + "patch_layernorm_embedding.weight"),
                    Wf(e + "patch_layernorm_embedding.bias"), x[:, :P], mu, rs, drop=self._dropargs(1))
         tok_pre = buf("tok_pre", (B * L, C))
+        self._params_wait(["emb"])
         hip.embed_rows(W(e + "embed_tokens.weight"), src_tokens.reshape(-1).contiguous(),
                        W(e + "type_embedding.weight")[0], tok_pre)
         mu, rs = self._ln_stats("tok_ln", B * L)
@@ -927,6 +956,7 @@ class HipEngine:
                     self._dense_built(ctx, "e%d" % l)
         if need_grad and self.overlap and not torch.cuda.is_current_stream_capturing() and "g16fwd" not in _EXP_SKIP:
             with self._wgrad():          # (behind the encoder's dense biases, which the forward waits for; the previous step's Adam read g16)
+                self._params_wait(None, stream=self._side)      # (a deferred optimizer is still reading the gradients)
                 self.g16.zero_()
                 if getattr(self, "_g16_ev", None) is None:
                     self._g16_ev = torch.cuda.Event()
@@ -935,6 +965,7 @@ class HipEngine:
         for l in range(cfg.enc_layers):
             p = "%slayers.%d." % (e, l)
             tg = "e%d" % l
+            self._params_wait([tg])
             rel = hip.RelBias(P, g["gcode"], g["code_bias"], e_r2[l], e_r1[l], e_rx[l], grid_w=w)
             x, xn = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", x, B, T,
                                          ctx["e_pq"], ctx["e_pk"], rel, False, scaling, site=("e", l, 0), xn_pre=x_pre,
@@ -951,6 +982,7 @@ class HipEngine:
         ctx["e_x_final"] = x
         ctx["enc_out"] = enc_out
         self.mark("enc_fwd_end")
+        self._params_wait(None)           # everything from here on (decoder, all layers' fc2 for the FFN coefficients)
 
         # ---- decoder (extract_features_scriptable_surrogate, decoder_module.py:486-677)
         d = "decoder."

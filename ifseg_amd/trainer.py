@@ -13,7 +13,9 @@ is issued per layer slice from inside the backward (engine.grad_ready_hook) so i
 the xGMI links while the remaining backward kernels run; scaling, clipping, Adam and the
 bf16 write-back are ONE kernel over the arena with the norm kept on the device.
 """
+import contextlib
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -38,6 +40,40 @@ def layer_slices(eng):
         a, b = sl.get(key, (lo, hi))
         sl[key] = (min(a, lo), max(b, hi))
     return sl
+
+
+def optimizer_plan(eng):
+    """[(key, [(lo, hi), ...])] -- the trainable arena cut into the slices the forward first reads, in that order:
+    "g0": everything outside the transformer layers except the token table (embedding LayerNorms, position tables and their
+    projections, image_proj, ... and EVERY encoder layer's rel-pos tables: the forward gathers them for all layers before
+    layer 0), "emb": the token table (the largest tensor: 42 % of Base), "e<l>": encoder layer l, "rest": the decoder.
+    Every element of [0, n_train) lies in exactly one range (tests/test_ddp_gloo.py::test_optimizer_plan_*)."""
+    key_of = {}
+    for n in eng.trainable_names():
+        parts = n.split(".")
+        if parts[0] == "encoder" and parts[1] == "layers":
+            k = "e%s" % parts[2]
+        elif parts[0] == "encoder" and parts[1] == "embed_tokens":
+            k = "emb"
+        elif parts[0] == "encoder":
+            k = "g0"
+        else:
+            k = "rest"
+        key_of[n] = k
+    order = ["g0", "emb"] + ["e%d" % l for l in range(eng.cfg.enc_layers)] + ["rest"]
+    ranges = {k: [] for k in order}
+    # the arena pads every tensor to a multiple of 8 elements: a slice runs up to the next tensor's offset
+    names = [n for n in eng.order if eng.offs[n] < eng.n_train]
+    for i, n in enumerate(names):
+        lo = eng.offs[n]
+        hi = eng.offs[names[i + 1]] if i + 1 < len(names) else eng.n_train
+        k = key_of.get(n, "rest")
+        r = ranges[k]
+        if r and r[-1][1] == lo:
+            r[-1] = (r[-1][0], hi)
+        else:
+            r.append((lo, hi))
+    return [(k, ranges[k]) for k in order if ranges[k]]
 
 
 class ArenaReducer:
@@ -204,6 +240,7 @@ class Trainer:
         self.lr0, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip_norm
         self.max_update, self.min_lr, self.seed = max_update, min_lr, seed
         self.num_updates = 0
+        self._defer = False                 # clip + Adam underneath the next forward (train_step(defer_optimizer=...))
         self.lazy_logs = lazy_logs          # data-parallel runs: cross-rank log sums stay on the device (see _sync_logs)
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -420,14 +457,58 @@ class Trainer:
         step = self.num_updates + 1
         if not captured:
             self._upload_hyper(lr, step, gscale)
-        hip.adam_step(self.p32, eng.g16, self.m, self.v, eng.p16[: eng.n_train], lr, self.betas[0],
-                      self.betas[1], self.eps, self.wd, step, gscale, self.clip, self.sumsq, self.overflow, hyper=self._hyper)
+        if self._defer and not captured and eng.overlap and torch.device(self.device).type == "cuda":
+            self._adam_deferred(lr, step, gscale)
+        else:
+            hip.adam_step(self.p32, eng.g16, self.m, self.v, eng.p16[: eng.n_train], lr, self.betas[0],
+                          self.betas[1], self.eps, self.wd, step, gscale, self.clip, self.sumsq, self.overflow, hyper=self._hyper)
         eng.mark("adam_end")
         if captured and eng._pf is not None:
             torch.cuda.current_stream().wait_event(eng._pf["done"])     # every forked stream rejoins before the capture ends
         return logs
 
-    def train_step(self, samples, prefetch=None, graph=False):
+    def _adam_deferred(self, lr, step, gscale):
+        """clip + Adam of this update on the optimizer's own stream, one launch per range of `optimizer_plan`, in the order the
+        NEXT forward reads the parameters; an event per slice (HipEngine.params_pending): that forward starts while the bulk
+        of the update (3 GB of HBM traffic, nothing for the matrix cores) is still running.  Element-wise the same kernel as
+        the single launch: the parameters are bit-equal (test_deferred_optimizer_*).  trainer.py:865-907, optim/adam.py:45-110."""
+        eng = self.eng
+        if getattr(self, "_opt_stream", None) is None:
+            # (no stream of its own: a fifth stream shares a hardware queue with one of the other four and serialises against it
+            # -- measured 25.7 vs 17.1 ms per step; the dQ stream is idle from the end of a backward to the next one)
+            self._opt_stream = eng._dq_stream_get()
+            self._opt_plan = optimizer_plan(eng)
+            self._opt_events = {}
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)                  # the gradient norm and the hyper-parameter upload are queued on the main stream
+        self._opt_stream.wait_event(fork)
+        events = {}
+        with torch.cuda.stream(self._opt_stream):
+            prev = hip.set_stream(self._opt_stream.cuda_stream)
+            try:
+                p16 = eng.p16
+                for key, ranges in self._opt_plan:
+                    for lo, hi in ranges:
+                        hip.adam_step(self.p32[lo:hi], eng.g16[lo:hi], self.m[lo:hi], self.v[lo:hi], p16[lo:hi], lr, self.betas[0],
+                                      self.betas[1], self.eps, self.wd, step, gscale, self.clip, self.sumsq, self.overflow,
+                                      hyper=self._hyper)
+                    ev = self._opt_events.get(key)
+                    if ev is None:
+                        ev = self._opt_events[key] = torch.cuda.Event()
+                    ev.record(self._opt_stream)
+                    events[key] = ev
+            finally:
+                hip.set_stream(prev)
+        events["all"] = events[self._opt_plan[-1][0]]
+        eng.params_pending(events)
+
+    def params_ready(self):
+        """the calling stream waits for a deferred optimizer: before anything but the engine's forward reads the parameters
+        (evaluation outside the engine, checkpoints, the fp32 masters / Adam moments of this trainer)"""
+        self.eng._params_wait(None)
+
+    def train_step(self, samples, prefetch=None, graph=False, defer_optimizer=None):
         """One update.  `prefetch`: the samples of the NEXT call(s), in order, as far as the data iterator already holds
         them: their frozen-trunk features are computed on a second stream underneath this step (HipEngine.prefetch_trunk);
         with more than one, `IFSEG_TRUNK_LOOKAHEAD` (default 2) batches go through the trunk in one pass.
@@ -437,6 +518,10 @@ class Trainer:
         iterator copies each new batch into them (bench.py alternates two resident batches)."""
         self.check_overflow()
         self._quiesced_for_eval = False
+        # defer_optimizer (default: IFSEG_DEFER_OPTIMIZER, off): clip + Adam run on their own stream underneath the NEXT
+        # forward, which waits per parameter slice; the caller must not read parameters / optimizer state from another
+        # stream without `params_ready()` (valid_step, close and grad_norm call it)
+        self._defer = (os.environ.get("IFSEG_DEFER_OPTIMIZER", "0") == "1") if defer_optimizer is None else bool(defer_optimizer)
         eng = self.eng
         if not self.model.training:
             self.model.train()
@@ -449,9 +534,11 @@ class Trainer:
                 self._ahead = list(prefetch)
             logs = self._step_body(samples)
         self.num_updates += 1
-        self._ovf_host.copy_(self.overflow, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        ost = getattr(self, "_opt_stream", None) if (self._defer and eng._popt) else None
+        with torch.cuda.stream(ost) if ost is not None else contextlib.nullcontext():
+            self._ovf_host.copy_(self.overflow, non_blocking=True)      # (behind the optimizer that may raise the flag)
+            ev = torch.cuda.Event()
+            ev.record()
         self._ovf_events = self._ovf_events[-3:] + [ev]
         return self._sync_logs(logs)
 
@@ -490,6 +577,7 @@ class Trainer:
     def close(self):
         """end of training: nothing of the direct RCCL communicator may still be queued when it is destroyed, and no c10d
         collective (a checkpoint barrier, destroy_process_group) may be issued beside queued direct ones"""
+        self.params_ready()
         if torch.device(self.device).type == "cuda":
             torch.cuda.synchronize(self.device)
         self.reducer.close()
@@ -505,6 +593,7 @@ class Trainer:
         return float(self.sumsq.sqrt().item()) * self._last_gscale
 
     def valid_step(self, sample):
+        self.params_ready()
         if self.dist_on and not getattr(self, "_quiesced_for_eval", False):
             # the first validation batch after training: c10d collectives of the evaluation (log sums, checkpoint barriers)
             # must not be issued beside queued direct-RCCL ones

@@ -191,3 +191,52 @@ def test_bucket_plan_covers_the_gradient_arena_exactly_once(arch, nseg, size, mo
     # few, large collectives: the layers merge into ~48 MB buckets inside the backward, the rest (top-level tensors) in finish()
     assert in_backward <= nbytes // (48 << 20) + 2 and len(calls) <= in_backward + 4, (in_backward, len(calls))
     print(arch, "arena %.1f MB bf16 -> %d collectives (%d issued inside the backward)" % (nbytes / 2 ** 20, len(calls), in_backward))
+
+
+@pytest.mark.parametrize("arch,nseg,size", [("segofa_base", 15, 512), ("segofa_large", 171, 640)])
+def test_optimizer_plan_covers_the_parameter_arena_exactly_once(arch, nseg, size):
+    """The deferred optimizer (Trainer.train_step(defer_optimizer=True)) runs clip + Adam as one launch per range of
+    `optimizer_plan`, in the order the next forward reads the parameters: the ranges must tile [0, n_train) with no gap and no
+    overlap, the token table must be its own slice, and every encoder layer's rel-pos tables must be in the first slice (the
+    forward gathers them for all layers before layer 0)."""
+    from ifseg_amd.models.segofa import SegOFAModel, make_config
+    from ifseg_amd.models.segofa.engine import _pad8
+    from ifseg_amd.trainer import optimizer_plan
+    with torch.device("meta"):
+        m = SegOFAModel(make_config(arch, num_seg_tokens=nseg, vocab_size=59458, patch_image_size=size))
+    eng = m.engine
+    order, ntn = eng._arena_order()
+    names = dict(m.named_parameters())
+
+    class Layout:
+        offs, cfg = {}, eng.cfg
+
+        @staticmethod
+        def trainable_names():
+            return order[:ntn]
+    off = 0
+    for n in order:
+        Layout.offs[n] = off
+        off += _pad8(names[n].numel())
+    Layout.order = order
+    Layout.n_train = Layout.offs[order[ntn]] if ntn < len(order) else off
+    plan = optimizer_plan(Layout)
+    keys = [k for k, _ in plan]
+    # (the shipped recipe freezes the token table and image_proj -- coco_unseen.sh:31-33 -- so they are not in the trainable
+    # arena and there is no "emb" slice; a trainable token table gets its own)
+    assert [k for k in keys if k != "emb"] == ["g0"] + ["e%d" % l for l in range(eng.cfg.enc_layers)] + ["rest"]
+    spans = sorted(r for _, rs in plan for r in rs)
+    cur = 0
+    for lo, hi in spans:
+        assert lo == cur and hi > lo and lo % 8 == 0, (lo, hi, cur)
+        cur = hi
+    assert cur == Layout.n_train
+    by = dict(plan)
+    inside = lambda n, k: any(lo <= Layout.offs[n] < hi for lo, hi in by[k])
+    if "emb" in by:
+        assert inside("encoder.embed_tokens.weight", "emb") and len(by["emb"]) == 1
+    for l in range(eng.cfg.enc_layers):
+        assert inside("encoder.token_rel_pos_table_list.%d.weight" % l, "g0")
+        assert inside("encoder.image_rel_pos_table_list.%d.weight" % l, "g0")
+        assert inside("encoder.layers.%d.fc1.weight" % l, "e%d" % l)
+    assert inside("encoder.pos_q_linear.weight", "g0") and inside("decoder.layers.0.fc2.weight", "rest")

@@ -789,3 +789,40 @@ def test_parameters_stepped_from_outside_are_seen_by_the_next_forward(golden_dir
     print("eval after a .data edit of the LayerNorm gains: rel-L2 %.4f (against the pre-edit logits %.4f)" % (_rel(le, o_eval), _rel(le, o_logits)))
     assert _rel(o_eval, o_logits) > 5e-2                  # the edit is visible in the oracle
     assert _rel(le, o_eval) <= 2e-2
+
+
+def test_deferred_optimizer_is_bit_equal_and_the_next_forward_waits_for_its_slices():
+    """Trainer.train_step(defer_optimizer=True): clip + Adam of update n run per parameter slice on their own stream while the
+    forward of update n + 1 starts (trainer.py:865-907 / optim/adam.py:45-110 semantics unchanged).  Six updates with dropout
+    (the masks depend on the step seed only) against the same six updates with the single launch on the main stream:
+    parameters, fp32 masters, both Adam moments and the losses bit-equal; an evaluation right behind a deferred update sees
+    the updated weights (valid_step waits)."""
+    from ifseg_amd.criterions import SegCriterion
+    from ifseg_amd.tasks.mm_tasks import SegmentationTask
+    from ifseg_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    task = SegmentationTask(num_seg_tokens=5, patch_image_size=128, arch="segofa_tiny")
+
+    def make():
+        torch.manual_seed(0)
+        model = task.build_model()
+        return Trainer(model, SegCriterion(task, unsupervised_segmentation=False, init_seg_with_text=False), task, lr=1e-3, device=dev)
+
+    samples = [task.synthetic_sample(2, dev, seed=s) for s in range(3)]
+    runs = []
+    for defer in (False, True):
+        tr = make()
+        losses = []
+        for k in range(6):
+            logs = tr.train_step([samples[k % 3]], prefetch=[samples[(k + 1) % 3]], defer_optimizer=defer)
+            losses.append(logs[0]["loss"])
+        vl = tr.valid_step(samples[0])                       # right behind the last (possibly still running) update
+        torch.cuda.synchronize()
+        assert tr.eng._popt is None
+        runs.append((tr.eng.p16.clone(), tr.p32.clone(), tr.m.clone(), tr.v.clone(), [float(x) for x in losses],
+                     float(vl[0] if isinstance(vl, (tuple, list)) else vl)))
+        tr.close()
+    a, b = runs
+    for x, y, name in zip(a[:4], b[:4], ("p16", "p32", "m", "v")):
+        assert torch.equal(x, y), name
+    assert a[4] == b[4] and a[5] == b[5], (a[4], b[4], a[5], b[5])
