@@ -99,14 +99,14 @@ def _self_spawn(n, argv):
 PROF_STRIDE = 3
 
 
-TRAFFIC_JSON = os.environ.get("IFSEG_TRAFFIC_JSON", "profiles/round4_hbm_traffic.json")
+TRAFFIC_JSON = os.environ.get("IFSEG_TRAFFIC_JSON", "profiles/round5_hbm_traffic.json")
 
 
 def _pmc_traffic(kind):
     """HBM bytes per launch of a kernel family.  NOT measured in this run: read from the committed PMC collection
     (TRAFFIC_JSON: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 x2 correction on
     FETCH_SIZE, tools/pmc_traffic.sh); the bench line names the file in `traffic_source`.  None if not collected."""
-    for rel in (TRAFFIC_JSON, "profiles/round3_hbm_traffic.json"):
+    for rel in (TRAFFIC_JSON, "profiles/round4_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 return json.load(f)[kind]["bytes_per_launch"]
@@ -116,7 +116,7 @@ def _pmc_traffic(kind):
 
 
 def _traffic_source():
-    for rel in (TRAFFIC_JSON, "profiles/round3_hbm_traffic.json"):
+    for rel in (TRAFFIC_JSON, "profiles/round4_hbm_traffic.json"):
         if os.path.exists(os.path.join(ROOT, rel)):
             return rel + " (rocprofv3 --pmc passes of this command, committed; not collected in this run)"
     return None
