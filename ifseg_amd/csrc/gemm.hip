@@ -601,10 +601,13 @@ extern "C" int ifseg_gemm_tn_group(int n, const ifseg_gemm_tn_problem* probs, in
   ifseg_prof_begin(IFSEG_K_GEMM_TN, s, flops, bytes);
   if (const int cfg = ring_cfg(0, 0, 0, true)) {
     const int rc = gemm_ring_group_launch(&ga, cfg, max_workgroups, stream);
-    ifseg_prof_end(IFSEG_K_GEMM_TN, s);
-    if (rc) return rc;
-    IFSEG_CHECK_LAUNCH();
-    return 0;
+    if (rc <= 0) {
+      ifseg_prof_end(IFSEG_K_GEMM_TN, s);
+      if (rc) return rc;
+      IFSEG_CHECK_LAUNCH();
+      return 0;
+    }
+    // (rc > 0: the configuration does not take this group -- the tile kernel below does)
   }
   int grid = total;
   if (max_workgroups > 0 && max_workgroups < total) grid = max_workgroups >= 8 ? (max_workgroups & ~7) : max_workgroups;

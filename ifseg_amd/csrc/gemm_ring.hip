@@ -602,6 +602,9 @@ int launch_group(GroupArgs ga, int max_workgroups, hipStream_t s) {
   }
   ga.start[ga.n] = total;
   ga.total = total;
+  // one tile per workgroup and CU, or not at all: a second, nearly empty round of 133-k-step tiles costs more than the wider
+  // tile saves (a decoder layer's seven products are 288 tiles of 256 x 128) -- the caller falls back to the tile kernel
+  if (total > num_cus() && !getenv("IFSEG_GEMM_RING_GROUP_ANY")) return 1;
   int grid = num_cus();
   if (max_workgroups > 0 && max_workgroups < grid) grid = max_workgroups >= 8 ? (max_workgroups & ~7) : max_workgroups;
   if (grid > total) grid = total;
