@@ -1,3 +1,5 @@
+# profiles/round5_gemm_small_m_and_ksweep.txt: the same per-workgroup work with fewer workgroups (operand-request-only build
+# variants/a5.so, see tools/abl_lab.sh), the full kernels, and time against K for the tile kernel
 # is the operand feed (LDS-DMA only build, variants/a5.so) limited per CU or chip-wide?  same per-workgroup work, fewer workgroups
 P="/opt/rocm/lib/libamdhip64.so $GRAFT_REPO_ROOT/ifseg_amd/lib/variants/a5.so"
 for M in 512 1024 2048 4096 8192 16384; do
