@@ -42,6 +42,7 @@ struct BiArgs {
   int ldq, ldk, ldv, lddo, lddq, lddk, lddv;
   int causal, P;
   float dq_scale;
+  const int* kv_len;          // optional [B]: keys at or beyond kv_len[b] are padding (masked for batch element b)
 };
 
 // 32 x (128-byte row) tile image read BOTH row-wise (ds_read_b128: 16 rows x one 16-byte chunk per lane group) and
@@ -56,6 +57,16 @@ __device__ __forceinline__ int vx_swz(int r) { const int u = r >> 1; return ((u 
 __device__ __forceinline__ void consume_frag(const bf16x8& f) {
   typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
   asm volatile("" :: "v"(__builtin_bit_cast(u32x4_t, f)));
+}
+
+// Key padding (unify_multihead_attention.py:477-489: attn_weights.masked_fill(key_padding_mask, -inf); the padding mask of a
+// batch element is a suffix of its key sequence, encoder_module.py:730-752): score seeds of keys at or beyond the element's
+// valid count become -inf (the MFMA adds the products onto the seed: -inf stays).  Layout of a tile whose lane is the QUERY:
+// element e <-> key j0 + (e & 3) + 8 (e >> 2) + 4 half.
+__device__ __forceinline__ void mask_padded_keys(f32x16& s, int j0, int half, int kl) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    if (j0 + (e & 3) + 8 * (e >> 2) + 4 * half >= kl) s[e] = NEG_INF;
 }
 
 __device__ __forceinline__ uint4 scale_bf16x8(uint4 v, float f) {
@@ -159,6 +170,7 @@ __global__ __launch_bounds__(512, 2) void attn_bi_fwd_kernel(BiArgs a) {
   const float* db_ = a.D + (long long)h * a.Tp * a.Sp;
   const unsigned lds0 = lds_addr(smem);
   const int r8 = lane >> 3, cp = lane & 7;
+  const int kl = a.kv_len ? __builtin_amdgcn_readfirstlane(a.kv_len[bc]) : 0x7fffffff;
   auto issue = [&](int it, int st) {
     const int j0 = sc.block(it) * 32;
     const unsigned base = lds0 + st * STG_DQ;
@@ -213,6 +225,7 @@ __global__ __launch_bounds__(512, 2) void attn_bi_fwd_kernel(BiArgs a) {
       const float4 d4 = *reinterpret_cast<const float4*>(sD + oR[rg]);
       s[rg * 4] = d4.x; s[rg * 4 + 1] = d4.y; s[rg * 4 + 2] = d4.z; s[rg * 4 + 3] = d4.w;
     }
+    if (sc.block(it) * 32 + 32 > kl) mask_padded_keys(s, sc.block(it) * 32, half, kl);      // (wave-uniform: no padding, no cost)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) kf[ks] = lds_read_b128(sK + oR[ks]);
 #pragma unroll
@@ -293,6 +306,7 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
   const bool qvalid = qi < a.T;
   const int qrow = qvalid ? qi : a.T - 1;
   const float gain = a.gain ? a.gain[h] : 1.f;
+  const int kl = a.kv_len ? __builtin_amdgcn_readfirstlane(a.kv_len[bc]) : 0x7fffffff;
 
   bf16x8 qf[4], dof[4];
   {
@@ -403,6 +417,7 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
       const float4 d4 = *reinterpret_cast<const float4*>(sD + oR[rg]);
       s[rg * 4] = d4.x; s[rg * 4 + 1] = d4.y; s[rg * 4 + 2] = d4.z; s[rg * 4 + 3] = d4.w;
     }
+    if (sc.block(it) * 32 + 32 > kl) mask_padded_keys(s, sc.block(it) * 32, half, kl);      // (wave-uniform: no padding, no cost)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) kf[ks] = lds_read_b128(sK + oR[ks]);
 #pragma unroll
@@ -493,6 +508,10 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
   const bool kvalid = kj < a.S;
   const int krow = kvalid ? kj : a.S - 1;
   const float gain = a.gain ? a.gain[h] : 1.f;
+  // key padding: this lane's key is beyond the batch element's valid count (all of its 16 scores are masked); `anypad`: the
+  // wave's key block touches the padding at all (wave-uniform)
+  const int kl = a.kv_len ? __builtin_amdgcn_readfirstlane(a.kv_len[bc]) : 0x7fffffff;
+  const bool kpad = kj >= kl, anypad = k0 + kbw * 32 + 32 > kl;
 
   bf16x8 kf[4], vfn[4];
   {
@@ -601,6 +620,10 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
       s[rg * 4 + 2] = sD[oD0 + rg * 256 + 64]; s[rg * 4 + 3] = sD[oD1 + rg * 256 + 64];
       const float4 e4 = *reinterpret_cast<const float4*>(sL + 32 + 8 * rg + 4 * half);
       dp[rg * 4] = e4.x; dp[rg * 4 + 1] = e4.y; dp[rg * 4 + 2] = e4.z; dp[rg * 4 + 3] = e4.w;
+    }
+    if (anypad) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = kpad ? NEG_INF : s[e];
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = lds_read_b128(sQ + oR[ks]);
@@ -1159,7 +1182,7 @@ extern "C" int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* x, void* stream) {
   a.q_bs = x->q_bs; a.k_bs = x->k_bs; a.v_bs = x->v_bs; a.do_bs = x->do_bs; a.dq_bs = x->dq_bs; a.dk_bs = x->dk_bs; a.dv_bs = x->dv_bs;
   a.dbias_gs = (long long)x->H * x->T * x->Sp;
   a.ldq = x->ldq; a.ldk = x->ldk; a.ldv = x->ldv; a.lddo = x->lddo; a.lddq = x->lddq; a.lddk = x->lddk; a.lddv = x->lddv;
-  a.causal = x->causal; a.P = x->causal ? x->P : x->S; a.dq_scale = x->dq_scale;
+  a.causal = x->causal; a.P = x->causal ? x->P : x->S; a.dq_scale = x->dq_scale; a.kv_len = x->kv_len;
   if ((a.ldq | a.ldk | a.ldv | a.lddo | a.lddq | a.lddk | a.lddv) & 7) return IFSEG_ERR_BAD_SHAPE;
   if (((size_t)a.q | (size_t)a.k | (size_t)a.v | (size_t)a.dO | (size_t)a.dq | (size_t)a.dk | (size_t)a.dv | (size_t)a.dbias) & 15)
     return IFSEG_ERR_BAD_ARG;
@@ -1202,7 +1225,7 @@ extern "C" int ifseg_attn_fwd_bi(const ifseg_attn_bi_args* x, void* stream) {
   a.out = (bf16_t*)x->out; a.lse_out = const_cast<float*>(x->lse); a.o_bs = x->out_bs; a.ldo = x->ldout;
   a.B = x->B; a.H = x->H; a.T = x->T; a.S = x->S; a.Sp = x->Sp; a.Tp = x->Tp;
   a.q_bs = x->q_bs; a.k_bs = x->k_bs; a.v_bs = x->v_bs; a.ldq = x->ldq; a.ldk = x->ldk; a.ldv = x->ldv;
-  a.causal = x->causal; a.P = x->causal ? x->P : x->S;
+  a.causal = x->causal; a.P = x->causal ? x->P : x->S; a.kv_len = x->kv_len;
   if ((a.ldq | a.ldk | a.ldv | a.ldo) & 7) return IFSEG_ERR_BAD_SHAPE;
   if (((size_t)a.q | (size_t)a.k | (size_t)a.v | (size_t)a.out) & 15) return IFSEG_ERR_BAD_ARG;
   if ((a.q_bs | a.k_bs | a.v_bs | a.o_bs) & 7) return IFSEG_ERR_BAD_SHAPE;

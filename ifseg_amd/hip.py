@@ -33,7 +33,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 14:
+        if _lib.ifseg_abi_version() != 15:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -411,12 +411,20 @@ class _AttnBiArgs(ctypes.Structure):
                 + [(n, c_int) for n in ("B", "H", "T", "S", "Sp", "Tp", "ldq", "ldk", "ldv", "lddo", "lddq", "lddk", "lddv")]
                 + [(n, c_ll) for n in ("q_bs", "k_bs", "v_bs", "do_bs", "dq_bs", "dk_bs", "dv_bs")]
                 + [("causal", c_int), ("P", c_int), ("dq_scale", c_float), ("phases", c_int), ("dgain_rows", c_void_p),
-                   ("out", c_void_p), ("ldout", c_int), ("out_bs", c_ll)])   # == ifseg_attn_bi_args
+                   ("out", c_void_p), ("ldout", c_int), ("out_bs", c_ll), ("kv_len", c_void_p)])   # == ifseg_attn_bi_args
+
+
+def _kvlen(kv_len, B):
+    if kv_len is None:
+        return None
+    assert kv_len.dtype == torch.int32 and kv_len.is_cuda and kv_len.numel() == B and kv_len.is_contiguous()
+    return kv_len
 
 
 def attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=False, P=None, gain=None,
-                dq_scale=1.0, phases=0, dgain_rows=None):
-    """dbias: bf16 [ceil(B/4), H, T, dense.Sp] -- zero-filled once by the caller when causal (skipped blocks are not written)"""
+                dq_scale=1.0, phases=0, dgain_rows=None, kv_len=None):
+    """dbias: bf16 [ceil(B/4), H, T, dense.Sp] -- zero-filled once by the caller when causal (skipped blocks are not written);
+    kv_len: int32 [B] valid key counts (key padding), None = no padding"""
     a = _AttnBiArgs()
     for name, t in (("q", q), ("k", k), ("v", v), ("dout", dout), ("lse", lse), ("delta", delta), ("D", dense.D),
                     ("gain", _f32(gain)), ("dq", dq), ("dk", dk), ("dv", dv), ("dbias", dbias)):
@@ -430,6 +438,7 @@ def attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S,
     a.causal, a.P = (1 if causal else 0), (P if P is not None else S)
     a.dq_scale, a.phases = dq_scale, phases
     a.dgain_rows = _p(dgain_rows)
+    a.kv_len = _p(_kvlen(kv_len, B))
     _check(lib().ifseg_attn_bwd_bi(ctypes.byref(a), _stream()), "attn_bwd_bi")
 
 
@@ -437,7 +446,7 @@ def dbias_nparts():
     return lib().ifseg_attn_dbias_nparts()
 
 
-def attn_fwd_bi(q, k, v, dense, out, lse, B, H, T, S, causal=False, P=None, gain=None):
+def attn_fwd_bi(q, k, v, dense, out, lse, B, H, T, S, causal=False, P=None, gain=None, kv_len=None):
     """out = gain softmax(q k^T + dense.D) v, four batch elements per workgroup (csrc/attention_bi.hip)"""
     a = _AttnBiArgs()
     for name, t in (("q", q), ("k", k), ("v", v), ("lse", lse), ("D", dense.D), ("gain", _f32(gain)), ("out", out)):
@@ -446,6 +455,7 @@ def attn_fwd_bi(q, k, v, dense, out, lse, B, H, T, S, causal=False, P=None, gain
     a.ldq, a.ldk, a.ldv, a.ldout = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
     a.q_bs, a.k_bs, a.v_bs, a.out_bs = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     a.causal, a.P = (1 if causal else 0), (P if P is not None else S)
+    a.kv_len = _p(_kvlen(kv_len, B))
     _check(lib().ifseg_attn_fwd_bi(ctypes.byref(a), _stream()), "attn_fwd_bi")
     return out
 

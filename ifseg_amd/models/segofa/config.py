@@ -42,6 +42,11 @@ class SegOFAConfig:
     # freezes of the shipped recipe (coco_unseen.sh:31-33,76)
     freeze_resnet: bool = True
     freeze_embeddings: bool = True
+    # prompts of different lengths in one batch (right-padded with <pad>: encoder_padding_mask, encoder_module.py:730-752, masks
+    # those keys in the encoder self- and the decoder cross-attention, unify_multihead_attention.py:477-489).  Off: a padded
+    # batch is refused (the IFSeg recipe gives every sample the same prompt) and a step carries no per-batch length tensor;
+    # on (or IFSEG_PADDED_PROMPTS=1): every batch carries its valid key counts to the attention kernels.
+    padded_prompts: bool = False
 
     @property
     def head_dim(self):

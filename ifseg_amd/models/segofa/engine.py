@@ -860,9 +860,19 @@ class HipEngine:
         dev = src_tokens.device if bag is not None else patch_images.device
         if not self.packed or self.device != dev:
             self.pack(dev)
-        self.deferred_check(src_tokens, lambda t: t.eq(1).any(),
-                            "ifseg_amd HIP engine: padded source tokens are not supported "
-                            "(every IFSeg sample carries the same unpadded prompt)")
+        pads = bool(getattr(cfg, "padded_prompts", False)) or os.environ.get("IFSEG_PADDED_PROMPTS") == "1"
+        if pads:
+            if bag is not None:
+                raise NotImplementedError("ifseg_amd HIP engine: padded prompts in the image-free branch are not supported")
+            # the padding of a sample must be a suffix of its prompt (collate pads on the right): a valid key COUNT per sample
+            self.deferred_check(src_tokens, lambda t: (t[:, :-1].eq(1) & t[:, 1:].ne(1)).any() | t[:, 0].eq(1).any(),
+                                "ifseg_amd HIP engine: <pad> tokens must form a suffix of every prompt (right padding)",
+                                exc=ValueError)
+        else:
+            self.deferred_check(src_tokens, lambda t: t.eq(1).any(),
+                                "ifseg_amd HIP engine: padded source tokens need cfg.padded_prompts = True "
+                                "(or IFSEG_PADDED_PROMPTS=1): every IFSeg sample carries the same unpadded prompt, so by "
+                                "default a step carries no per-sample key counts")
         B, L = src_tokens.shape
         C, Fd, H = cfg.embed_dim, cfg.ffn_dim, cfg.heads
         scaling = float(cfg.head_dim * cfg.attn_scale_factor) ** -0.5
@@ -889,6 +899,8 @@ class HipEngine:
             # eval-time images whose feature grid differs from the trained one (seg_criterion.py:194-217,
             # batch 1, native aspect ratio): position tables / rel-pos biases are bilinear-resized exactly
             # like the reference and handed to the attention kernel as a dense fp32 bias.  Forward only.
+            if pads:
+                raise NotImplementedError("ifseg_amd HIP engine: padded prompts on a resized feature grid are not supported")
             if need_grad:
                 raise NotImplementedError("ifseg_amd HIP engine: training on a feature grid (%dx%d) other than the "
                                           "trained one (%dx%d) is not supported (eval-only slow path)" % (h, w, oh, oh))
@@ -899,6 +911,11 @@ class HipEngine:
         self._train_fwd = bool(need_grad)
         ctx = {"B": B, "L": L, "P": P, "T": T, "Td": Td, "h": h, "w": w, "full": bool(full_context_alignment),
                "src_tokens": src_tokens, "feat": feat}
+        if pads:
+            # encoder_padding_mask as valid key counts: the P patch tokens + the prompt tokens in front of the padding
+            nonpad = src_tokens.ne(1)
+            ctx["nonpad"] = nonpad
+            ctx["klen"] = (nonpad.sum(1) + P).to(torch.int32).contiguous()
         self.ctx_building = ctx
         e = "encoder."
         self._params_wait(["g0"])
@@ -923,6 +940,8 @@ class HipEngine:
         mu, rs = self._ln_stats("tok_ln", B * L)
         hip.ln_fwd(tok_pre.view(B, L, C), Wf(e + "layernorm_embedding.weight"), Wf(e + "layernorm_embedding.bias"),
                    x[:, P:], mu, rs, drop=self._dropargs(2))
+        if pads:
+            x[:, P:].mul_(ctx["nonpad"].unsqueeze(-1).to(x.dtype))      # x = x * (1 - encoder_padding_mask), encoder_module.py:738-742
         # ---- abs-pos operands (encoder_module.py:757-771): LN over the table rows in place
         bsz = cfg.image_bucket_size
         img_pos_view = W(e + "embed_image_positions.weight")[1:1 + bsz * h].view(h, bsz, C)[:, :w]
@@ -943,9 +962,12 @@ class HipEngine:
         (e_rx,) = self._rel_tables_all("e_x", [None] * cfg.enc_layers, [(False, g["enc_idxx"])])
         self.mark("enc_layers_start")
         x_pre = None
-        bi = need_grad and w <= 64 and w % 8 == 0 and self.attn_bi in ("1", "auto")
+        bi = (need_grad or pads) and w <= 64 and w % 8 == 0 and self.attn_bi in ("1", "auto")
         # which attentions: e(ncoder self), d(ecoder self), c(ross); IFSEG_ATTN_BI_WHICH overrides
         bi_which = os.environ.get("IFSEG_ATTN_BI_WHICH", "e+d+c").split("+") if bi else []
+        if pads and not (bi and "e" in bi_which and "c" in bi_which and self.bi_fwd):
+            raise NotImplementedError("ifseg_amd HIP engine: key padding is implemented by the batch-inner attention kernels "
+                                      "(grids up to 64 wide, a multiple of 8; IFSEG_ATTN_BI / _WHICH / _FWD at their defaults)")
         ctx["dense"] = {}
         if bi and "e" in bi_which:
             # parameters only: every layer's dense bias on the side stream, under the first blocks of the forward
@@ -1235,7 +1257,7 @@ class HipEngine:
             self._dense_wait(tg)
             # (measured and dropped: the round-3 kernel seeded from the dense bias by global loads, 94.2 vs 91.3 ms on C4)
             hip.attn_fwd_bi(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], dd, o, lse, B, H, T, T, causal=causal,
-                            P=rel.P, gain=gain)
+                            P=rel.P, gain=gain, kv_len=self.ctx_building.get("klen") if tg[0] == "e" else None)
         else:
             hip.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], pq, pk, o, lse, B, H, T, T, rel=rel,
                          causal=causal, gain=gain, dense_bias=dense)
@@ -1273,7 +1295,7 @@ class HipEngine:
         dd = self.ctx_building.get("dense", {}).get("dc") if (self.bi_fwd and self.ctx_building is not None) else None
         if dd is not None:
             self._dense_wait("dc")
-            hip.attn_fwd_bi(q, kv[:, :, :C], kv[:, :, C:], dd, o, lse, B, H, Td, Te, gain=gain)
+            hip.attn_fwd_bi(q, kv[:, :, :C], kv[:, :, C:], dd, o, lse, B, H, Td, Te, gain=gain, kv_len=self.ctx_building.get("klen"))
         else:
             hip.attn_fwd(q, kv[:, :, :C], kv[:, :, C:], cpq, cpk, o, lse, B, H, Td, Te, gain=gain)
         a = buf(tg + "_ca_a", (B * Td, C))
@@ -1477,9 +1499,14 @@ class HipEngine:
         have_delta = delta is not None
         if not have_delta:
             delta = gbuf("g_delta_%d" % T, (B, H, T), torch.float32)
+        # key padding: the keys of the encoder's self-attention (tags e<l>) and of the decoder's cross-attention (d<l>c) are the
+        # encoder positions
+        kv_len = self.ctx.get("klen") if (tag[0] == "e" or tag.endswith("c")) else None
         if dense is not None:
             return self._attn_core_bwd_bi(q, k, v, pq, pk, o, lse, do, dq, dk, dv, B, T, S, rel, causal, gain, gain_name,
-                                          scaling, dpq_acc, dpk_acc, first_pos, rel_grads, delta, have_delta, dense)
+                                          scaling, dpq_acc, dpk_acc, first_pos, rel_grads, delta, have_delta, dense, kv_len)
+        if kv_len is not None:
+            raise NotImplementedError("ifseg_amd HIP engine: key padding needs the batch-inner attention backward")
         dpq_part = gbuf("g_dpq_part_%d" % T, (B, T, C))        # bf16 per-batch partials, summed by attn_bwd_reduce
         dpk_part = gbuf("g_dpk_part_%d" % S, (B, S, C))
         nparts = B * ((S + 127) // 128)
@@ -1543,7 +1570,7 @@ class HipEngine:
             self._side_do(reductions)
 
     def _attn_core_bwd_bi(self, q, k, v, pq, pk, o, lse, do, dq, dk, dv, B, T, S, rel, causal, gain, gain_name, scaling,
-                          dpq_acc, dpk_acc, first_pos, rel_grads, delta, have_delta, dense):
+                          dpq_acc, dpk_acc, first_pos, rel_grads, delta, have_delta, dense, kv_len=None):
         """csrc/attention_bi.hip: the bias is the dense operand `dense` (built once per layer by the forward's side stream),
         a workgroup holds four batch elements, sum_b dS leaves the dQ kernel once per tile; everything behind that sum --
         abs-pos operand gradients, rel-pos tables, c_attn -- is two launches on the weight-gradient stream."""
@@ -1587,15 +1614,15 @@ class HipEngine:
             # the second, partly filled round of workgroups of one leaves CUs to the other
             with self._fork(self._dq_stream_get()):
                 hip.attn_bwd_bi(q, k, v, do, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain,
-                                dq_scale=scaling, phases=hip.ATTN_BWD_DQ, dgain_rows=dgr)
+                                dq_scale=scaling, phases=hip.ATTN_BWD_DQ, dgain_rows=dgr, kv_len=kv_len)
                 dq_done = self._ev()
                 dq_done.record(self._dqs)
             hip.attn_bwd_bi(q, k, v, do, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain,
-                            dq_scale=scaling, phases=hip.ATTN_BWD_DKV)
+                            dq_scale=scaling, phases=hip.ATTN_BWD_DKV, kv_len=kv_len)
             torch.cuda.current_stream().wait_event(dq_done)
         elif ph >= 0:
             hip.attn_bwd_bi(q, k, v, do, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain,
-                            dq_scale=scaling, phases=ph, dgain_rows=dgr)
+                            dq_scale=scaling, phases=ph, dgain_rows=dgr, kv_len=kv_len)
         if timing is not None:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record()
@@ -1934,6 +1961,10 @@ class HipEngine:
         e = "encoder."
         dx3 = dx.view(B, T, C)
         dxi, dxt = dx3[:, :P], dx3[:, P:]
+        if self.ctx.get("nonpad") is not None:
+            # adjoint of x * (1 - encoder_padding_mask): padded rows pass no gradient into the embeddings (they hold exact
+            # zeros already -- nothing downstream reads a padded position -- this keeps it so by construction)
+            dxt.mul_(self.ctx["nonpad"].unsqueeze(-1).to(dxt.dtype))
         dimg = buf("g_dimg_pre", (B, P, C))
         self._ln_bwd(dxi, self.ws["img_pre"].view(B, P, C), e + "patch_layernorm_embedding", "img_ln", dimg,
                      drop=self._dropargs(1))

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 14
+#define IFSEG_ABI_VERSION 15
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -243,6 +243,9 @@ typedef struct ifseg_attn_bi_args {
                                   (unify_multihead_attention.py:509-512) computed WITHOUT dividing delta by c_attn: exact at c_attn = 0 */
   void* out;                   /* ifseg_attn_fwd_bi: O [B,T,ldout] bf16 (x gain) */
   int ldout; long long out_bs;
+  const int* kv_len;           /* optional device int32 [B]: key padding (unify_multihead_attention.py:477-489 with the suffix masks of
+                                  encoder_module.py:730-752): keys j >= kv_len[b] are masked for batch element b in the forward and in
+                                  all three gradients; NULL = no padding.  kv_len[b] >= 1 */
 } ifseg_attn_bi_args;
 int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* args, void* stream);
 /* ifseg_attn_fwd_bi: the forward of the same formulation -- out = gain softmax_fp32(q k^T + D) v, `lse` (written) as

@@ -139,7 +139,7 @@ def sub_index(name, numel, n=SUB_N):
 
 
 def case_train(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys, full_grads=True, diversify=False, sub_all=False,
-               bf16_weights=False):
+               bf16_weights=False, pad_tail=None):
     """bf16_weights: the procedural weights are rounded to bf16-representable values on both sides (identical weights);
     diversify: the (frozen, tied) seg projection is replaced by O.diversify_seg_projection(...) (measured in round 3: it
     removes the dominant common component of the logits, so the relative error of the HIP path grows by the same factor
@@ -149,6 +149,15 @@ def case_train(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys, f
     model, sd = build_reference(cfg, arch, overrides)
     crit = build_criterion(cfg)
     batch = O.synthetic_batch(cfg, batch_size, src_len)
+    if pad_tail is not None:
+        # padded prompts (collate pads shorter prompts on the right, data/mm_data/segmentation_dataset.py collate ->
+        # data_utils.collate_tokens): sample b ends with pad_tail[b] pad tokens, eos in front of them; the reference then
+        # builds encoder_padding_mask (encoder_module.py:730-752) and masks those keys in the encoder self-attention and the
+        # decoder cross-attention (unify_multihead_attention.py:477-489)
+        for b, n in enumerate(pad_tail):
+            if n:
+                batch["src_tokens"][b, -n:] = O.PAD
+                batch["src_tokens"][b, -n - 1] = O.EOS
     if bf16_weights:      # identical weight values on both sides of the parity test (O.round_weights_bf16)
         sd = O.round_weights_bf16(sd)
     if diversify:
@@ -182,6 +191,8 @@ def case_train(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys, f
     save = {"logits_causal": ref_logits.numpy(), "logits_full": ref_full.numpy(),
             "loss": np.float64(loss.item()),
             "batch_size": batch_size, "src_len": src_len, "diversified": int(diversify), "bf16_weights": int(bf16_weights)}
+    if pad_tail is not None:
+        save["src_tokens"] = batch["src_tokens"].numpy()
     if sub_all:
         nsub = 0
         for k, p_ in params.items():
@@ -454,7 +465,7 @@ def main():
     ap.add_argument("--skip-base", action="store_true")
     ap.add_argument("--only-imfree", action="store_true")
     ap.add_argument("--only-eval", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of: optim, upgrade, lazy, base_b2, base_c3")
+    ap.add_argument("--only", default="", help="comma list of: optim, upgrade, lazy, base_b2, base_c3, padded")
     a = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -469,6 +480,8 @@ def main():
             case_upgrade(fx, "tiny", ov, "fixture_upgrade.npz")
         if "lazy" in only:
             case_lazy_init(fx, "tiny", ov, "fixture_lazy_init.npz")
+        if "padded" in only:       # prompts of different lengths in one batch: key padding in encoder self- and decoder cross-attention
+            case_train(fx, "tiny", ov, 3, 12, "fixture_padded.npz", GRAD_KEYS, pad_tail=[0, 3, 5])
         if "base_b2" in only:      # BASELINE config 1 as written: B = 2
             case_train(O.base_config(), "base", None, 2, 36, "base_c1_b2.npz", GRAD_KEYS, full_grads=False, sub_all=True, bf16_weights=True)
         if "base_c3" in only:      # BASELINE config 3 geometry on one device: Base width, 150 classes, L = 215 (T_enc 1239)

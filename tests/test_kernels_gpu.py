@@ -1301,3 +1301,64 @@ def test_ring_grouped_weight_gradients_are_bit_equal(cfg, monkeypatch):
     b = run()
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("case", ["enc_rel", "cross", "enc_b5"])
+def test_attn_batch_inner_key_padding(case):
+    """Key padding in the batch-inner kernels (ifseg_attn_bi_args.kv_len; unify_multihead_attention.py:477-489 with the suffix
+    masks of encoder_module.py:730-752): per batch element, keys at or beyond its valid count are masked in the forward and in
+    dq / dk / dv / sum_b dS -- against fp32 autograd with the same boolean mask.  Masked keys get EXACTLY zero dk / dv; an
+    element without padding is bit-identical to the launch without kv_len."""
+    from ifseg_amd import hip
+    dev = _dev()
+    H, B, T, S, P, Lt, gh, gw, causal = _attn_case(case)
+    C = H * 64
+    q, k, v = _rand((B, T, C), dev, 20, 0.35), _rand((B, S, C), dev, 21), _rand((B, S, C), dev, 22)
+    pq, pk = _rand((T, C), dev, 23, 0.35), _rand((S, C), dev, 24)
+    dout = _rand((B, T, C), dev, 25)
+    gain = (1.0 + 0.2 * torch.randn(H, generator=torch.Generator().manual_seed(5))).to(dev)
+    rel, tabs, bias_ref = None, None, None
+    if P is not None:
+        gcode, code_bias, n2d = _grid_codes(gh, gw)
+        g = torch.Generator().manual_seed(30)
+        tabs = [torch.randn(H, n2d, generator=g), torch.randn(H, 2 * Lt - 1, generator=g), torch.randn(H, 2, generator=g)]
+        rel = hip.RelBias(P, gcode.to(dev), code_bias, tabs[0].to(dev), tabs[1].to(dev), tabs[2].to(dev), grid_w=gw)
+        bias_ref = _dense_rel(H, T, S, P, gcode.long(), code_bias, *tabs).to(dev)
+    # valid key counts: element 0 unpadded, the others lose 1 .. 40 trailing keys (a partly and a fully masked 32-key block)
+    lens = [S] + [S - (1 + (13 * i) % 40) for i in range(1, B)]
+    kv_len = torch.tensor(lens, dtype=torch.int32, device=dev)
+    kmask = (torch.arange(S, device=dev)[None, :] >= kv_len[:, None].long())[:, None, None, :]        # [B,1,1,S]
+    qf, kf, vf = [t.float().clone().requires_grad_(True) for t in (q, k, v)]
+    o_ref, _ = _attn_ref(qf, kf, vf, pq, pk, bias_ref, kmask)
+    o_ref = (o_ref.view(B, T, H, 64) * gain.view(1, 1, H, 1)).reshape(B, T, C)
+    (o_ref * dout.float()).sum().backward()
+    dense = hip.DenseBias(H, T, S, dev)
+    hip.attn_dense_bias(dense, pq, pk, rel=rel, causal=False, P=P)
+    out, lse = torch.zeros(B, T, C, dtype=torch.bfloat16, device=dev), torch.zeros(B, H, T, device=dev)
+    hip.attn_fwd_bi(q, k, v, dense, out, lse, B, H, T, S, P=P, gain=gain, kv_len=kv_len)
+    out0, lse0 = torch.zeros_like(out), torch.zeros_like(lse)
+    hip.attn_fwd_bi(q, k, v, dense, out0, lse0, B, H, T, S, P=P, gain=gain)
+    torch.cuda.synchronize()
+    assert _rel(out, o_ref) < 1e-2, _rel(out, o_ref)
+    assert torch.equal(out[0], out0[0]) and torch.equal(lse[0], lse0[0]) and not torch.equal(out[1], out0[1])
+    delta = (dout.float() * out.float()).view(B, T, H, 64).sum(-1).permute(0, 2, 1).contiguous()
+    dq, dk, dv = torch.full_like(q, 3.0), torch.full_like(k, 3.0), torch.full_like(v, 3.0)
+    dbias = torch.zeros((B + 3) // 4, H, T, dense.Sp, dtype=torch.bfloat16, device=dev)
+    hip.attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, P=P, gain=gain, kv_len=kv_len)
+    torch.cuda.synchronize()
+    errs = {"dq": _rel(dq, qf.grad), "dk": _rel(dk, kf.grad), "dv": _rel(dv, vf.grad)}
+    with torch.no_grad():
+        qh = q.float().view(B, T, H, 64).transpose(1, 2); kh = k.float().view(B, S, H, 64).transpose(1, 2)
+        vh = v.float().view(B, S, H, 64).transpose(1, 2)
+        sc = qh @ kh.transpose(2, 3) + (pq.float().view(T, H, 64).transpose(0, 1) @ pk.float().view(S, H, 64).permute(1, 2, 0))
+        if bias_ref is not None:
+            sc = sc + bias_ref
+        pr = torch.softmax(sc.masked_fill(kmask, float("-inf")), -1)
+        doh = dout.float().view(B, T, H, 64).transpose(1, 2) * gain.view(1, H, 1, 1)
+        dSb = (pr * (doh @ vh.transpose(2, 3) - delta.unsqueeze(-1))).sum(0)
+    errs["dbias"] = _rel(dbias.float().sum(0)[:, :, :S], dSb)
+    print(case, lens, {k_: round(v_, 5) for k_, v_ in errs.items()})
+    for k_, v_ in errs.items():
+        assert v_ < 2e-2, (k_, v_)
+    for b in range(1, B):
+        assert dk[b, lens[b]:].abs().max().item() == 0.0 and dv[b, lens[b]:].abs().max().item() == 0.0

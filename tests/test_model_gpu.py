@@ -826,3 +826,65 @@ def test_deferred_optimizer_is_bit_equal_and_the_next_forward_waits_for_its_slic
     for x, y, name in zip(a[:4], b[:4], ("p16", "p32", "m", "v")):
         assert torch.equal(x, y), name
     assert a[4] == b[4] and a[5] == b[5], (a[4], b[4], a[5], b[5])
+
+
+def test_padded_prompts_vs_reference_golden(golden_dir):
+    """Prompts of different lengths in one batch (right-padded with <pad>): the reference builds encoder_padding_mask
+    (encoder_module.py:730-752), zeroes those embedding rows and masks those keys in the encoder self-attention and the decoder
+    cross-attention (unify_multihead_attention.py:477-489).  Here: `cfg.padded_prompts` -> valid key counts per sample into the
+    batch-inner attention kernels (ifseg_attn_bi_args.kv_len).  tests/golden/fixture_padded.npz is the REFERENCE's output for
+    B = 3 with 0 / 3 / 5 padded tokens (oracle/gen_golden.py --only padded); logits, loss and every gradient the oracle
+    produces are compared, training and evaluation; without the switch the batch is refused."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ifseg_amd.criterions import SegCriterion
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    g = np.load(os.path.join(golden_dir, "fixture_padded.npz"))
+    B = int(g["batch_size"])
+    batch = O.synthetic_batch(ocfg, B, int(g["src_len"]))
+    batch["src_tokens"] = torch.from_numpy(g["src_tokens"])
+    assert (batch["src_tokens"] == O.PAD).sum(1).tolist() == [0, 3, 5]
+    o_logits, o_loss, o_grads, _ = _oracle_all_grads(ocfg, sd, batch, (128, 128))
+    assert np.abs(o_logits.numpy() - g["logits_causal"]).max() <= 1e-5 and abs(o_loss.item() - float(g["loss"])) <= 1e-5
+    crit = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+    sample = {"net_input": {"src_tokens": batch["src_tokens"].to(dev), "src_lengths": torch.full((B,), 12).to(dev),
+                            "patch_images": batch["patch_images"].to(dev), "patch_masks": batch["patch_masks"].to(dev),
+                            "prev_output_tokens": batch["prev_output_tokens"].to(dev)},
+              "target": batch["target"].to(dev), "ntokens": 1, "nsentences": B}
+    m = _build(ocfg, sd, dev)
+    m.train()
+    with pytest.raises(NotImplementedError):          # default: a padded batch is refused (first check of its kind on an engine: synchronous)
+        crit(m, sample)
+    m.cfg.padded_prompts = True
+    loss, _, logs = crit(m, sample)
+    logits = m.engine.ws["logits_pad"][:, :, : ocfg.num_seg_tokens].float().cpu()
+    ref = torch.from_numpy(g["logits_causal"])
+    print("padded prompts: logits rel-L2 %.4f (unpadded sample %.4f, 5 pads %.4f), loss %.5f vs %.5f"
+          % (_rel(logits, ref), _rel(logits[0], ref[0]), _rel(logits[2], ref[2]), loss.item(), float(g["loss"])))
+    assert _rel(logits, ref) <= 2e-2 and abs(loss.item() - float(g["loss"])) <= 1e-2
+    assert (logits.argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.99
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(m.named_parameters())
+    gain_scale = max(v.abs().max().item() for k, v in o_grads.items() if k.endswith("c_attn"))
+    bad, n = [], 0
+    for k, og in sorted(o_grads.items()):
+        if k not in named or not named[k].requires_grad or og.norm() == 0 or k.endswith(("k_proj.bias", "pos_k_linear.bias")):
+            continue
+        hg = named[k].grad
+        if k.endswith("c_attn"):
+            assert (hg.float().cpu() - og).abs().max().item() <= 5e-2 * gain_scale, k
+            continue
+        n += 1
+        if _rel(hg, og) > 6e-2:
+            bad.append((round(_rel(hg, og), 4), k))
+    assert n > 100 and not bad, bad[:10]
+    for k in g.files:                                   # the reference's own gradients of the golden's keys
+        if k.startswith("grad:") and not k.endswith("c_attn"):
+            assert _rel(named[k[5:]].grad, torch.from_numpy(g[k])) <= 6e-2, k
+    m.eval()
+    with torch.no_grad():
+        lf, _ = m(**sample["net_input"], full_context_alignment=True)
+    assert _rel(lf, torch.from_numpy(g["logits_full"])) <= 2e-2
