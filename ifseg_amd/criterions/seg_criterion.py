@@ -56,7 +56,7 @@ class _FusedSegLossFn(torch.autograd.Function):
     forward kernel already produced."""
 
     @staticmethod
-    def forward(ctx, logits, logits_pad, target, hp, wp, H, W, nseg, seg0, bufs):
+    def forward(ctx, logits, logits_pad, target, hp, wp, H, W, nseg, seg0, bufs, eps=0.0):
         B = logits_pad.shape[0]
         dev = logits_pad.device
         n_tiles = B * hp * wp
@@ -72,7 +72,7 @@ class _FusedSegLossFn(torch.autograd.Function):
             bufs["loss"] = torch.empty(1, dtype=torch.float32, device=dev)
             bufs["bad"] = torch.zeros(1, dtype=torch.int32, device=dev)
         hip.seg_loss(logits_pad, target, hp, wp, H, W, nseg, seg0, bufs["tile"], bufs["sp"], bufs["stats"],
-                     bufs["dl"], bufs["loss"], bad_label=bufs["bad"])
+                     bufs["dl"], bufs["loss"], bad_label=bufs["bad"], label_smoothing=float(eps))
         ctx.dl = bufs["dl"]
         ctx.nseg = nseg
         # fresh tensors: callers keep them in logging outputs across calls (update_freq > 1, validation loops)
@@ -81,9 +81,10 @@ class _FusedSegLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, gstats):
         g = ctx.dl[:, :, : ctx.nseg]
-        return g * gloss.to(g.dtype), None, None, None, None, None, None, None, None, None
+        return g * gloss.to(g.dtype), None, None, None, None, None, None, None, None, None, None
 
 PAD, EOS = 1, 2
+FUSED_MAX_CLASSES = 512      # csrc/loss.hip NS_MAX
 
 
 @register_criterion("seg_criterion", dataclass=SegCriterionConfig)
@@ -198,11 +199,11 @@ class SegCriterion(CriterionBase):
         hp, wp = extra["encoder_returns"]["image_embed_shape"][0]
         h, w = 16 * hp, 16 * wp
         pad = extra.get("logits_padded")
-        if (pad is not None and self.eps == 0.0 and self.num_seg <= 192 and target.shape[1] == h * w + 1):
+        if (pad is not None and self.num_seg <= FUSED_MAX_CLASSES and target.shape[1] == h * w + 1):
             if not hasattr(self, "_bufs_imfree"):
                 self._bufs_imfree = {}
             loss, _ = _FusedSegLossFn.apply(scores_low, pad, target.contiguous(), hp, wp, h, w, self.num_seg,
-                                            self.seg_id_offset, self._bufs_imfree)
+                                            self.seg_id_offset, self._bufs_imfree, self.eps)
             return loss
         scores = self.upsample_logits(scores_low.float(), hp, wp, h, w)[:, :-1]
         tgt = target[:, :-1]
@@ -245,12 +246,12 @@ class SegCriterion(CriterionBase):
         hp, wp = extra["encoder_returns"]["image_embed_shape"][0]
         h, w = sample["net_input"]["patch_images"].shape[-2:]
         pad = extra.get("logits_padded")
-        if (pad is not None and self.eps == 0.0 and self.upscale_lprobs and h == 16 * hp and w == 16 * wp
-                and self.num_seg <= 192 and target.shape[1] == h * w + 1):
+        if (pad is not None and self.upscale_lprobs and h == 16 * hp and w == 16 * wp
+                and self.num_seg <= FUSED_MAX_CLASSES and target.shape[1] == h * w + 1):
             if not hasattr(self, bufs_name):
                 setattr(self, bufs_name, {})
             loss, stats = _FusedSegLossFn.apply(scores_low, pad, target.contiguous(), hp, wp, h, w, self.num_seg,
-                                                self.seg_id_offset, getattr(self, bufs_name))
+                                                self.seg_id_offset, getattr(self, bufs_name), self.eps)
             # the loss kernel flags labels that are neither a class nor pad / eos / ignore (read back without a sync)
             model.engine.deferred_check(
                 getattr(self, bufs_name)["bad"], lambda t: ((t[0] != 0).clone(), t.zero_())[0],

@@ -19,18 +19,20 @@ namespace {
 
 constexpr int TS = 16;       // pixels per cell side
 constexpr int CH = 16;       // classes per gradient chunk
-constexpr int NS_MAX = 192;  // max classes
+constexpr int NS_MAX = 512;  // max classes (LDS: 9 x (nseg | 1) floats + 3 x nseg ints, sized per launch)
 
 __global__ __launch_bounds__(256) void seg_loss_tile_kernel(const bf16_t* logits, int ldl, long long lbs,
                                                             const long long* target, long long tbs, int hp, int wp,
                                                             int W, int nseg, long long seg0, long long pad_id,
                                                             long long eos_id, float* tile_partial, float* stats_part,
-                                                            int* bad_label) {
-  __shared__ float sLog[9][NS_MAX + 1];      // (+1: the four taps of a pixel, rows k apart, fall into different banks)
+                                                            int* bad_label, float eps) {
+  extern __shared__ float dyn[];
+  const int ls = nseg | 1;                   // row stride of the 3 x 3 cells' logits: odd, so the four taps of a pixel
+  float* sLog = dyn;                         // (rows k apart) fall into different banks
+  int* sHist = reinterpret_cast<int*>(dyn + 9 * ls);      // [3][nseg]
   __shared__ float sWY[TS][3], sWX[TS][3];
   __shared__ float sD[256][CH + 1];
   __shared__ float sE[TS][3][CH];
-  __shared__ int sHist[3][NS_MAX];
   __shared__ float sRed[8];
   const int tid = threadIdx.x;
   const int ncell = hp * wp;
@@ -43,9 +45,9 @@ __global__ __launch_bounds__(256) void seg_loss_tile_kernel(const bf16_t* logits
     const int ry = cy - 1 + k / 3, rx = cx - 1 + k % 3;
     float v = 0.f;
     if (ry >= 0 && ry < hp && rx >= 0 && rx < wp) v = bf2f(logits[b * lbs + (long long)(ry * wp + rx) * ldl + c]);
-    sLog[k][c] = v;
+    sLog[k * ls + c] = v;
   }
-  for (int i = tid; i < 3 * nseg; i += 256) sHist[i / nseg][i % nseg] = 0;
+  for (int i = tid; i < 3 * nseg; i += 256) sHist[i] = 0;
   if (tid < 2 * TS) {
     // source index of F.interpolate(mode='bilinear', align_corners=False): max((dst+0.5)/s-0.5, 0)
     const bool isx = tid >= TS;
@@ -73,13 +75,13 @@ __global__ __launch_bounds__(256) void seg_loss_tile_kernel(const bf16_t* logits
   const int kyl = (wy0 != 0.f) ? 0 : 1, kxl = (wx0 != 0.f) ? 0 : 1;
   const float wya = kyl ? wy1 : wy0, wyb = kyl ? wy2 : wy1, wxa = kxl ? wx1 : wx0, wxb = kxl ? wx2 : wx1;
   const float wA = wya * wxa, wB = wya * wxb, wC = wyb * wxa, wD = wyb * wxb;
-  const float* lg = &sLog[kyl * 3 + kxl][0];
+  const float* lg = sLog + (kyl * 3 + kxl) * ls;
   auto value = [&](int c) {
     float v = 0.f;
     v += wA * lg[c];
-    v += wB * lg[(NS_MAX + 1) + c];
-    v += wC * lg[3 * (NS_MAX + 1) + c];
-    v += wD * lg[4 * (NS_MAX + 1) + c];
+    v += wB * lg[ls + c];
+    v += wC * lg[3 * ls + c];
+    v += wD * lg[4 * ls + c];
     return v;
   };
   const long long tg = target[b * tbs + (long long)(cy * TS + py) * W + (cx * TS + px)];
@@ -89,20 +91,25 @@ __global__ __launch_bounds__(256) void seg_loss_tile_kernel(const bf16_t* logits
   const int label = valid ? (int)(tg - seg0) : 0;
   // (rare) report a label that is neither a class nor pad / eos / ignore: the criterion raises on the flag
   if (bad_label && !valid && !(tg == pad_id || tg == eos_id || tg == seg0 + nseg)) bad_label[0] = 1;
-  float m = -INFINITY, sum = 0.f, vl = 0.f;
+  float m = -INFINITY, sum = 0.f, vl = 0.f, vall = 0.f;
   int pred = 0;
   for (int c = 0; c < nseg; ++c) {
     const float v = value(c);
     if (v > m) { sum = sum * __expf(m - v) + 1.f; m = v; pred = c; }
     else sum += __expf(v - m);
     if (c == label) vl = v;
+    vall += v;
   }
   const float lse = m + __logf(sum);
+  // F.cross_entropy(label_smoothing = eps): (1 - eps) * nll(label) + eps * mean_c nll(c)   (seg_criterion.py:269-287 with
+  // --label-smoothing; eps == 0 keeps the plain expression, bit for bit)
   float lpix = valid ? (lse - vl) : 0.f, cnt = valid ? 1.f : 0.f;
+  if (eps != 0.f && valid) lpix = (1.f - eps) * (lse - vl) + eps * (lse - vall / nseg);
+  const float hot = 1.f - eps, unif = eps / nseg;
   if (valid) {
-    atomicAdd(&sHist[1][pred], 1);
-    atomicAdd(&sHist[2][label], 1);
-    if (pred == label) atomicAdd(&sHist[0][label], 1);
+    atomicAdd(&sHist[nseg + pred], 1);
+    atomicAdd(&sHist[2 * nseg + label], 1);
+    if (pred == label) atomicAdd(&sHist[label], 1);
   }
   lpix = warp_sum(lpix); cnt = warp_sum(cnt);
   if ((tid & 63) == 0) { sRed[tid >> 6] = lpix; sRed[4 + (tid >> 6)] = cnt; }
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(256) void seg_loss_tile_kernel(const bf16_t* logits
     for (int cc = 0; cc < CH; ++cc) {
       const int c = c0 + cc;
       float d = 0.f;
-      if (valid && c < nseg) d = __expf(value(c) - lse) - (c == label ? 1.f : 0.f);
+      if (valid && c < nseg) d = __expf(value(c) - lse) - (c == label ? hot : 0.f) - unif;
       sD[tid][cc] = d;
     }
     __syncthreads();
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256) void seg_loss_tile_kernel(const bf16_t* logits
   }
   float* sp = stats_part + (long long)blockIdx.x * nstat;
   if (tid == 0) { sp[0] = sRed[0] + sRed[1] + sRed[2] + sRed[3]; sp[1] = sRed[4] + sRed[5] + sRed[6] + sRed[7]; }
-  for (int i = tid; i < 3 * nseg; i += 256) sp[2 + i] = (float)sHist[i / nseg][i % nseg];
+  for (int i = tid; i < 3 * nseg; i += 256) sp[2 + i] = (float)sHist[i];
 }
 
 // dlogits[b, cell, c] = (1/Nvalid) * sum over the <=9 tiles whose 3x3 stencil contains `cell`
@@ -175,12 +182,15 @@ __global__ void seg_loss_gather_kernel(const float* tile_partial, const float* s
 extern "C" int ifseg_seg_loss_tiles(const void* logits, int ldl, long long logits_bs, const long long* target,
                                     long long target_bs, int B, int hp, int wp, int H, int W, int nseg,
                                     long long seg_id_offset, long long pad_id, long long eos_id,
-                                    float* tile_partial, float* stats_part, int* bad_label, void* stream) {
+                                    float* tile_partial, float* stats_part, int* bad_label, float label_smoothing,
+                                    void* stream) {
   (void)hipGetLastError();
   if (H != hp * TS || W != wp * TS || nseg > NS_MAX || nseg < 1) return IFSEG_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(seg_loss_tile_kernel, dim3(B * hp * wp), dim3(256), 0, (hipStream_t)stream,
+  if (!(label_smoothing >= 0.f && label_smoothing <= 1.f)) return IFSEG_ERR_BAD_ARG;
+  const size_t dyn = (size_t)(9 * (nseg | 1) + 3 * nseg) * 4;
+  hipLaunchKernelGGL(seg_loss_tile_kernel, dim3(B * hp * wp), dim3(256), dyn, (hipStream_t)stream,
                      (const bf16_t*)logits, ldl, logits_bs, target, target_bs, hp, wp, W, nseg, seg_id_offset, pad_id,
-                     eos_id, tile_partial, stats_part, bad_label);
+                     eos_id, tile_partial, stats_part, bad_label, label_smoothing);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }

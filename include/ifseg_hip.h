@@ -432,12 +432,13 @@ int ifseg_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, vo
  * the caller sums stats_part over tiles (ifseg_reduce_parts) into stats[2+3*nseg]; step 2
  * gathers dlogits (bf16 [B, P+1, ldl], eos row and padding columns zero) scaled by 1/valid and
  * writes the mean loss.  target: int64 [B, H*W+1] dictionary ids; a pixel is ignored when its
- * target is pad, eos or <seg_nseg>.  Requires H == 16*hp, W == 16*wp, label_smoothing == 0. */
+ * target is pad, eos or <seg_nseg>.  label_smoothing in [0, 1]: F.cross_entropy's epsilon (seg_criterion.py:265; 0 = plain CE,
+ * bit-identical to ABI <= 14).  Requires H == 16*hp, W == 16*wp, 1 <= nseg <= 512. */
 int ifseg_seg_loss_tiles(const void* logits, int ldl, long long logits_bs, const long long* target,
                          long long target_bs, int B, int hp, int wp, int H, int W, int nseg,
                          long long seg_id_offset, long long pad_id, long long eos_id, float* tile_partial,
                          float* stats_part, int* bad_label /* device flag, set to 1 when a target is neither a class nor
-                         pad / eos / ignore (F.cross_entropy would raise); may be NULL */, void* stream);
+                         pad / eos / ignore (F.cross_entropy would raise); may be NULL */, float label_smoothing, void* stream);
 int ifseg_seg_loss_gather(const float* tile_partial, const float* stats, void* dlogits, int ldl,
                           long long dlogits_bs, int B, int hp, int wp, int nseg, float* loss_out, void* stream);
 

@@ -661,10 +661,12 @@ def test_adam_and_gradnorm():
     assert _rel(p16, pr) < 5e-3
 
 
-@pytest.mark.parametrize("nseg,B,hp,wp", [(15, 2, 8, 8), (150, 1, 4, 6), (5, 2, 32, 32)])
-def test_fused_seg_loss(nseg, B, hp, wp):
+@pytest.mark.parametrize("nseg,B,hp,wp,eps", [(15, 2, 8, 8, 0.0), (150, 1, 4, 6, 0.0), (5, 2, 32, 32, 0.0),
+                                                (15, 2, 8, 8, 0.1), (171, 1, 4, 6, 0.2), (300, 1, 3, 4, 0.0), (512, 1, 2, 3, 0.1)])
+def test_fused_seg_loss(nseg, B, hp, wp, eps):
     """fused upsample+CE+grad+histogram kernel vs the PyTorch composition of the reference ops
-    (seg_criterion.py:237-244,269-362)."""
+    (seg_criterion.py:237-244,269-362), with --label-smoothing (F.cross_entropy's epsilon, :265) and with more classes
+    than any shipped recipe (the class axis of the kernel's LDS image is sized per launch, <= 512)."""
     from ifseg_amd import hip
     from ifseg_amd.criterions import SegCriterion
     import torch.nn.functional as F
@@ -682,14 +684,14 @@ def test_fused_seg_loss(nseg, B, hp, wp):
     stats = torch.empty(2 + 3 * nseg, device=dev)
     dl = torch.full((B, P + 1, npad), 3.0, dtype=torch.bfloat16, device=dev)
     loss = torch.empty(1, device=dev)
-    hip.seg_loss(lp, tgt, hp, wp, H, W, nseg, seg0, tile, sp, stats, dl, loss)
+    hip.seg_loss(lp, tgt, hp, wp, H, W, nseg, seg0, tile, sp, stats, dl, loss, label_smoothing=eps)
     # reference
     lf = lp[:, :, :nseg].float().clone().requires_grad_(True)
     scores = SegCriterion.upsample_logits(lf, hp, wp, H, W)
     mask = (tgt == 1) | (tgt == seg0 + nseg) | (tgt == 2)
     t = tgt[~mask] - seg0
     sc = scores[~mask]
-    ref = F.cross_entropy(sc, t)
+    ref = F.cross_entropy(sc, t, label_smoothing=eps)
     ref.backward()
     ai, ap, al, au = SegCriterion.compute_metric(sc.detach(), t)
     torch.cuda.synchronize()

@@ -888,3 +888,35 @@ def test_padded_prompts_vs_reference_golden(golden_dir):
     with torch.no_grad():
         lf, _ = m(**sample["net_input"], full_context_alignment=True)
     assert _rel(lf, torch.from_numpy(g["logits_full"])) <= 2e-2
+
+
+def test_label_smoothing_runs_in_the_fused_criterion():
+    """--label-smoothing > 0 (seg_criterion.py:142,265: F.cross_entropy(label_smoothing=eps)) stays on the fused loss kernel:
+    loss, metrics and the gradient handed to the decoder equal the torch composition of the reference ops on the same logits."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ifseg_amd.criterions import SegCriterion
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    batch = O.synthetic_batch(ocfg, 2, 12)
+    m = _build(ocfg, sd, dev)
+    m.train()
+    sample = {"net_input": {k: batch[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks", "prev_output_tokens")},
+              "target": batch["target"].to(dev), "ntokens": 1, "nsentences": 2}
+    sample["net_input"]["src_lengths"] = torch.full((2,), 12).to(dev)
+    crit = SegCriterion(label_smoothing=0.1, unsupervised_segmentation=False, init_seg_with_text=False,
+                        num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+    out = m(**sample["net_input"])
+    loss, metrics, _ = crit.compute_loss(m, out, sample, 0)
+    assert "dl" in crit._bufs, "the fused kernel did not run"
+    fused_grad = crit._bufs["dl"][:, :, : ocfg.num_seg_tokens].float().clone()
+    lg = out[0].detach().float().requires_grad_(True)
+    tl, tm, _ = crit.compute_loss_torch(m, (lg, out[1]), sample, 0)
+    tl.backward()
+    plain, _, _ = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens,
+                               seg_id_offset=ocfg.seg_id_offset).compute_loss(m, out, sample, 0)
+    print("label smoothing 0.1: fused %.6f torch %.6f (plain CE %.6f)" % (loss.item(), tl.item(), plain.item()))
+    assert abs(loss.item() - tl.item()) <= 2e-4 * max(1.0, abs(tl.item())) and abs(loss.item() - plain.item()) > 1e-4   # (near-uniform logits: smoothing moves the loss little)
+    assert _rel(fused_grad, lg.grad) <= 6e-3
+    assert torch.equal(metrics["area_label"].cpu(), tm["area_label"].cpu())
