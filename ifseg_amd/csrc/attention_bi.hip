@@ -43,7 +43,33 @@ struct BiArgs {
   int causal, P;
   float dq_scale;
   const int* kv_len;          // optional [B]: keys at or beyond kv_len[b] are padding (masked for batch element b)
+  float drop_p;               // attention dropout (unify_multihead_attention.py:498): probability, 0 = off
+  unsigned long long drop_seed; const unsigned long long* drop_seed_add;
 };
+
+// Attention dropout: P_drop = P o keep / (1 - p) between the softmax and P V (unify_multihead_attention.py:498-512).  keep is a
+// counter-based hash of (seed, (b, h, query), key) -- the three kernels regenerate the same mask whichever of query / key is
+// their lane, nothing is stored; the RNG stream necessarily differs from torch's.  The softmax denominator (lse) is that of
+// the undropped P; delta = dO . O already contains the mask (rowsum(P_drop o dP_drop)), so
+//     dS = P o (keep / (1 - p) * gain dO v^T - delta),   dV = gain P_drop^T dO.
+struct AttnDrop { unsigned lo, hi, thr; float inv; };
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+  return x;
+}
+__device__ __forceinline__ AttnDrop attn_drop_setup(float p, unsigned long long seed, const unsigned long long* seed_add) {
+  const unsigned long long sd = seed + (seed_add ? *seed_add : 0ull);
+  AttnDrop d;
+  d.lo = (unsigned)sd; d.hi = (unsigned)(sd >> 32);
+  d.thr = (unsigned)(p * 16777216.f);
+  d.inv = 1.f / (1.f - p);
+  return d;
+}
+__device__ __forceinline__ unsigned attn_row_key(const AttnDrop& d, unsigned rowid) { return mix32(d.lo ^ rowid) ^ d.hi; }
+// keep / (1 - p) of score (row, key j)
+__device__ __forceinline__ float attn_keep(const AttnDrop& d, unsigned rk, int j) {
+  return (mix32(rk + (unsigned)j * 0x9E3779B9u) >> 8) >= d.thr ? d.inv : 0.f;
+}
 
 // 32 x (128-byte row) tile image read BOTH row-wise (ds_read_b128: 16 rows x one 16-byte chunk per lane group) and
 // transposed (ds_read_b64_tr_b16: 4 consecutive rows x one 64-byte granule): chunk index XOR-ed with a bit-rotated row id
@@ -129,7 +155,8 @@ struct Sched {
 // dense operand D).  Flash-style online softmax in the exp2 domain with a lazily raised reference maximum (as csrc/attention.hip);
 // computed swapped (S^T = K Q^T, O^T = V^T P^T) so a query is a lane.
 constexpr float LAZY_MAX_SLACK = 8.f;
-__global__ __launch_bounds__(512, 2) void attn_bi_fwd_kernel(BiArgs a) {
+template <bool DROP>
+__device__ __forceinline__ void attn_bi_fwd_body(const BiArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,6 +198,9 @@ __global__ __launch_bounds__(512, 2) void attn_bi_fwd_kernel(BiArgs a) {
   const unsigned lds0 = lds_addr(smem);
   const int r8 = lane >> 3, cp = lane & 7;
   const int kl = a.kv_len ? __builtin_amdgcn_readfirstlane(a.kv_len[bc]) : 0x7fffffff;
+  AttnDrop dr{};
+  unsigned rk = 0;
+  if (DROP) { dr = attn_drop_setup(a.drop_p, a.drop_seed, a.drop_seed_add); rk = attn_row_key(dr, ((unsigned)bc * a.H + h) * a.T + qi); }
   auto issue = [&](int it, int st) {
     const int j0 = sc.block(it) * 32;
     const unsigned base = lds0 + st * STG_DQ;
@@ -263,9 +293,13 @@ __global__ __launch_bounds__(512, 2) void attn_bi_fwd_kernel(BiArgs a) {
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[s2 * 8 + e], LOG2E, -m_use));
-        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[s2 * 8 + e + 1], LOG2E, -m_use));
-        ps4[(e >> 1) & 3] += p0 + p1;
+        float p0 = __builtin_amdgcn_exp2f(fmaf(s[s2 * 8 + e], LOG2E, -m_use));
+        float p1 = __builtin_amdgcn_exp2f(fmaf(s[s2 * 8 + e + 1], LOG2E, -m_use));
+        ps4[(e >> 1) & 3] += p0 + p1;                     // the denominator is the undropped row sum
+        if (DROP) {
+          const int r = s2 * 8 + e, j = sc.block(it) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          p0 *= attn_keep(dr, rk, j); p1 *= attn_keep(dr, rk, j + 1);
+        }
         pf[s2].w[e >> 1] = pack2bf(p0, p1);
       }
     l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
@@ -284,9 +318,12 @@ __global__ __launch_bounds__(512, 2) void attn_bi_fwd_kernel(BiArgs a) {
     if (qvalid && half == 0) a.lse_out[((long long)b * a.H + h) * a.T + qi] = m_run + __log2f(l_tot);
   }
 }
+__global__ __launch_bounds__(512, 2) void attn_bi_fwd_kernel(BiArgs a) { attn_bi_fwd_body<false>(a); }
+__global__ __launch_bounds__(512, 2) void attn_bi_fwd_drop_kernel(BiArgs a) { attn_bi_fwd_body<true>(a); }
 
 // ---------------------------------------------------------------------------------------------- dQ (+ sum_b dS)
-__global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
+template <bool DROP>
+__device__ __forceinline__ void attn_bi_dq_body(const BiArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* slots = smem + 2 * STG_DQ;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
@@ -307,6 +344,9 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
   const int qrow = qvalid ? qi : a.T - 1;
   const float gain = a.gain ? a.gain[h] : 1.f;
   const int kl = a.kv_len ? __builtin_amdgcn_readfirstlane(a.kv_len[bc]) : 0x7fffffff;
+  AttnDrop dr{};
+  unsigned rk = 0;
+  if (DROP) { dr = attn_drop_setup(a.drop_p, a.drop_seed, a.drop_seed_add); rk = attn_row_key(dr, ((unsigned)bc * a.H + h) * a.T + qi); }
 
   bf16x8 qf[4], dof[4];
   {
@@ -448,8 +488,10 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const float p = __builtin_amdgcn_exp2f(fmaf(s[e], LOG2E, nlse));
-      ds[e] = p * fmaf(gain, dp[e], -del);
-      pdp = fmaf(p, dp[e], pdp);          // sum_j P_ij dP_ij = dO_i . (P V)_i : the c_attn gradient without dividing by c_attn
+      float dpe = dp[e];
+      if (DROP) dpe *= attn_keep(dr, rk, sc.block(it) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half);
+      ds[e] = p * fmaf(gain, dpe, -del);
+      pdp = fmaf(p, dpe, pdp);            // sum_j P_ij dP_ij = dO_i . (P V)_i : the c_attn gradient without dividing by c_attn
     }
     unsigned char* sl = slots + ((it & 1) * 8 + wv) * SLOT;
 #pragma unroll
@@ -490,9 +532,12 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) {
     for (int db = 0; db < 2; ++db) store_tile_bf16(dqp + db * 32, dq[db], a.dq_scale, half, qvalid);
   }
 }
+__global__ __launch_bounds__(512, 2) void attn_bi_dq_kernel(BiArgs a) { attn_bi_dq_body<false>(a); }
+__global__ __launch_bounds__(512, 2) void attn_bi_dq_drop_kernel(BiArgs a) { attn_bi_dq_body<true>(a); }
 
 // ---------------------------------------------------------------------------------------------- dK / dV
-__global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
+template <bool DROP>
+__device__ __forceinline__ void attn_bi_dkv_body(const BiArgs& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -512,6 +557,9 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
   // wave's key block touches the padding at all (wave-uniform)
   const int kl = a.kv_len ? __builtin_amdgcn_readfirstlane(a.kv_len[bc]) : 0x7fffffff;
   const bool kpad = kj >= kl, anypad = k0 + kbw * 32 + 32 > kl;
+  AttnDrop dr{};
+  if (DROP) dr = attn_drop_setup(a.drop_p, a.drop_seed, a.drop_seed_add);
+  const unsigned rowbase = ((unsigned)bc * a.H + h) * a.T;
 
   bf16x8 kf[4], vfn[4];
   {
@@ -611,7 +659,7 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
     const float* sD = reinterpret_cast<const float*>(stg + ST_D + kbw * 4096);
     const float* sL = reinterpret_cast<const float*>(stg + ST_L + bl * 256);
     f32x16 s, dp;
-    float ls[16];
+    float ls[16], de[DROP ? 16 : 1];
     bf16x8 qf[4], of[4];
     U128 fo[2][2], fq[2][2];
 #pragma unroll
@@ -620,6 +668,7 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
       s[rg * 4 + 2] = sD[oD0 + rg * 256 + 64]; s[rg * 4 + 3] = sD[oD1 + rg * 256 + 64];
       const float4 e4 = *reinterpret_cast<const float4*>(sL + 32 + 8 * rg + 4 * half);
       dp[rg * 4] = e4.x; dp[rg * 4 + 1] = e4.y; dp[rg * 4 + 2] = e4.z; dp[rg * 4 + 3] = e4.w;
+      if (DROP) { de[rg * 4] = e4.x; de[rg * 4 + 1] = e4.y; de[rg * 4 + 2] = e4.z; de[rg * 4 + 3] = e4.w; }
     }
     if (anypad) {
 #pragma unroll
@@ -664,8 +713,16 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
         const int r = s2 * 8 + e;
         const float p0 = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -ls[r]));
         const float p1 = __builtin_amdgcn_exp2f(fmaf(s[r + 1], LOG2E, -ls[r + 1]));
-        up[s2].w[e >> 1] = pack2bf(p0, p1);
-        ud[s2].w[e >> 1] = pack2bf(-p0 * dp[r], -p1 * dp[r + 1]);
+        if (DROP) {
+          // the accumulator holds delta - gain dP: with the mask, -(dS / P) = delta - keep / (1 - p) * gain dP
+          const int i = sc.block(it) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float k0_ = attn_keep(dr, attn_row_key(dr, rowbase + i), kj), k1_ = attn_keep(dr, attn_row_key(dr, rowbase + i + 1), kj);
+          up[s2].w[e >> 1] = pack2bf(p0 * k0_, p1 * k1_);
+          ud[s2].w[e >> 1] = pack2bf(-p0 * (de[r] - k0_ * (de[r] - dp[r])), -p1 * (de[r + 1] - k1_ * (de[r + 1] - dp[r + 1])));
+        } else {
+          up[s2].w[e >> 1] = pack2bf(p0, p1);
+          ud[s2].w[e >> 1] = pack2bf(-p0 * dp[r], -p1 * dp[r + 1]);
+        }
       }
     // dV^T += dO^T P ; dK^T += Q^T dS ; slot (kh, e) <-> query 16*s2 + 4*kh + (e&3) + 8*(e>>2)
 #pragma unroll
@@ -693,6 +750,19 @@ __global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) {
       store_tile_bf16(dkp + db * 32, dk[db], 1.f, half, true);
     }
   }
+}
+__global__ __launch_bounds__(512, 2) void attn_bi_dkv_kernel(BiArgs a) { attn_bi_dkv_body<false>(a); }
+__global__ __launch_bounds__(512, 2) void attn_bi_dkv_drop_kernel(BiArgs a) { attn_bi_dkv_body<true>(a); }
+
+// the mask the three kernels apply, written out (tests; a debugging aid): keep[b, h, i, j] in {0, 1}
+__global__ void attn_drop_mask_kernel(unsigned char* out, int B, int H, int T, int S, float p, unsigned long long seed,
+                                      const unsigned long long* seed_add) {
+  const long long n = (long long)B * H * T * S, id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= n) return;
+  const AttnDrop dr = attn_drop_setup(p, seed, seed_add);
+  const int j = (int)(id % S);
+  const unsigned row = (unsigned)(id / S);            // (b * H + h) * T + i
+  out[id] = attn_keep(dr, attn_row_key(dr, row), j) != 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------- dense bias
@@ -1183,6 +1253,9 @@ extern "C" int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* x, void* stream) {
   a.dbias_gs = (long long)x->H * x->T * x->Sp;
   a.ldq = x->ldq; a.ldk = x->ldk; a.ldv = x->ldv; a.lddo = x->lddo; a.lddq = x->lddq; a.lddk = x->lddk; a.lddv = x->lddv;
   a.causal = x->causal; a.P = x->causal ? x->P : x->S; a.dq_scale = x->dq_scale; a.kv_len = x->kv_len;
+  a.drop_p = x->drop_p; a.drop_seed = x->drop_seed; a.drop_seed_add = x->drop_seed_add;
+  if (!(a.drop_p >= 0.f && a.drop_p < 1.f)) return IFSEG_ERR_BAD_ARG;
+  const bool dropping = a.drop_p > 0.f;
   if ((a.ldq | a.ldk | a.ldv | a.lddo | a.lddq | a.lddk | a.lddv) & 7) return IFSEG_ERR_BAD_SHAPE;
   if (((size_t)a.q | (size_t)a.k | (size_t)a.v | (size_t)a.dO | (size_t)a.dq | (size_t)a.dk | (size_t)a.dv | (size_t)a.dbias) & 15)
     return IFSEG_ERR_BAD_ARG;
@@ -1200,16 +1273,18 @@ extern "C" int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* x, void* stream) {
   const int ph = x->phases ? x->phases : (IFSEG_ATTN_BWD_DKV | IFSEG_ATTN_BWD_DQ);
   if (ph & IFSEG_ATTN_BWD_DKV) {
     if (!a.dk || !a.dv) return IFSEG_ERR_BAD_ARG;
-    (void)hipFuncSetAttribute((const void*)attn_bi_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
+    auto kern = dropping ? attn_bi_dkv_drop_kernel : attn_bi_dkv_kernel;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
     ifseg_prof_begin(IFSEG_K_ATTN_DKV, s, 6.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);
-    hipLaunchKernelGGL(attn_bi_dkv_kernel, dim3(((a.S + 63) / 64) * a.H * nbg), dim3(512), LDS_DKV, s, a);
+    hipLaunchKernelGGL(kern, dim3(((a.S + 63) / 64) * a.H * nbg), dim3(512), LDS_DKV, s, a);
     ifseg_prof_end(IFSEG_K_ATTN_DKV, s);
   }
   if (ph & IFSEG_ATTN_BWD_DQ) {
     if (!a.dq || !a.dbias) return IFSEG_ERR_BAD_ARG;
-    (void)hipFuncSetAttribute((const void*)attn_bi_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
+    auto kern = dropping ? attn_bi_dq_drop_kernel : attn_bi_dq_kernel;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
     ifseg_prof_begin(IFSEG_K_ATTN_DQ, s, 2.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);
-    hipLaunchKernelGGL(attn_bi_dq_kernel, dim3(((a.T + 63) / 64) * a.H * nbg), dim3(512), LDS_DQ, s, a);
+    hipLaunchKernelGGL(kern, dim3(((a.T + 63) / 64) * a.H * nbg), dim3(512), LDS_DQ, s, a);
     ifseg_prof_end(IFSEG_K_ATTN_DQ, s);
   }
   IFSEG_CHECK_LAUNCH();
@@ -1226,6 +1301,8 @@ extern "C" int ifseg_attn_fwd_bi(const ifseg_attn_bi_args* x, void* stream) {
   a.B = x->B; a.H = x->H; a.T = x->T; a.S = x->S; a.Sp = x->Sp; a.Tp = x->Tp;
   a.q_bs = x->q_bs; a.k_bs = x->k_bs; a.v_bs = x->v_bs; a.ldq = x->ldq; a.ldk = x->ldk; a.ldv = x->ldv;
   a.causal = x->causal; a.P = x->causal ? x->P : x->S; a.kv_len = x->kv_len;
+  a.drop_p = x->drop_p; a.drop_seed = x->drop_seed; a.drop_seed_add = x->drop_seed_add;
+  if (!(a.drop_p >= 0.f && a.drop_p < 1.f)) return IFSEG_ERR_BAD_ARG;
   if ((a.ldq | a.ldk | a.ldv | a.ldo) & 7) return IFSEG_ERR_BAD_SHAPE;
   if (((size_t)a.q | (size_t)a.k | (size_t)a.v | (size_t)a.out) & 15) return IFSEG_ERR_BAD_ARG;
   if ((a.q_bs | a.k_bs | a.v_bs | a.o_bs) & 7) return IFSEG_ERR_BAD_SHAPE;
@@ -1236,9 +1313,10 @@ extern "C" int ifseg_attn_fwd_bi(const ifseg_attn_bi_args* x, void* stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   const int lds = 2 * STG_DQ;
-  (void)hipFuncSetAttribute((const void*)attn_bi_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  auto kern = a.drop_p > 0.f ? attn_bi_fwd_drop_kernel : attn_bi_fwd_kernel;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   ifseg_prof_begin(IFSEG_K_ATTN_FWD, s, 4.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);
-  hipLaunchKernelGGL(attn_bi_fwd_kernel, dim3(((a.T + 63) / 64) * a.H * ((a.B + 3) / 4)), dim3(512), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(((a.T + 63) / 64) * a.H * ((a.B + 3) / 4)), dim3(512), lds, s, a);
   ifseg_prof_end(IFSEG_K_ATTN_FWD, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
@@ -1281,3 +1359,13 @@ extern "C" int ifseg_attn_dbias_grads(const ifseg_attn_dbias_args* x, void* stre
 }
 
 extern "C" int ifseg_attn_dbias_nparts(void) { return DB_NPARTS; }
+
+extern "C" int ifseg_attn_dropout_mask(unsigned char* keep, int B, int H, int T, int S, float p, unsigned long long seed,
+                                       const unsigned long long* seed_add, void* stream) {
+  (void)hipGetLastError();
+  if (!keep || B <= 0 || H <= 0 || T <= 0 || S <= 0 || !(p >= 0.f && p < 1.f) || (long long)B * H * T >= (1ll << 32)) return IFSEG_ERR_BAD_ARG;
+  const long long n = (long long)B * H * T * S;
+  hipLaunchKernelGGL(attn_drop_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keep, B, H, T, S, p, seed, seed_add);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}

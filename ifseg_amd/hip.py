@@ -411,7 +411,22 @@ class _AttnBiArgs(ctypes.Structure):
                 + [(n, c_int) for n in ("B", "H", "T", "S", "Sp", "Tp", "ldq", "ldk", "ldv", "lddo", "lddq", "lddk", "lddv")]
                 + [(n, c_ll) for n in ("q_bs", "k_bs", "v_bs", "do_bs", "dq_bs", "dk_bs", "dv_bs")]
                 + [("causal", c_int), ("P", c_int), ("dq_scale", c_float), ("phases", c_int), ("dgain_rows", c_void_p),
-                   ("out", c_void_p), ("ldout", c_int), ("out_bs", c_ll), ("kv_len", c_void_p)])   # == ifseg_attn_bi_args
+                   ("out", c_void_p), ("ldout", c_int), ("out_bs", c_ll), ("kv_len", c_void_p), ("drop_p", c_float),
+                   ("drop_seed", ctypes.c_uint64), ("drop_seed_add", c_void_p)])   # == ifseg_attn_bi_args
+
+
+def _attn_drop(a, drop):
+    """drop = (p, seed) or None: attention dropout of the batch-inner kernels (the per-update seed word is the global seed_add)"""
+    if drop is not None and drop[0] > 0:
+        a.drop_p, a.drop_seed, a.drop_seed_add = float(drop[0]), drop[1] & 0xFFFFFFFFFFFFFFFF, _seed_add_ptr()
+
+
+def attn_dropout_mask(B, H, T, S, p, seed, device):
+    """uint8 [B, H, T, S]: the keep mask the attention kernels apply for (p, seed) and the current seed_add"""
+    out = torch.empty(B, H, T, S, dtype=torch.uint8, device=device)
+    _check(lib().ifseg_attn_dropout_mask(_ptr(out), c_int(B), c_int(H), c_int(T), c_int(S), c_float(p),
+                                         ctypes.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), c_void_p(_seed_add_ptr()), _stream()), "attn_dropout_mask")
+    return out
 
 
 def _kvlen(kv_len, B):
@@ -422,7 +437,7 @@ def _kvlen(kv_len, B):
 
 
 def attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=False, P=None, gain=None,
-                dq_scale=1.0, phases=0, dgain_rows=None, kv_len=None):
+                dq_scale=1.0, phases=0, dgain_rows=None, kv_len=None, drop=None):
     """dbias: bf16 [ceil(B/4), H, T, dense.Sp] -- zero-filled once by the caller when causal (skipped blocks are not written);
     kv_len: int32 [B] valid key counts (key padding), None = no padding"""
     a = _AttnBiArgs()
@@ -439,6 +454,7 @@ def attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S,
     a.dq_scale, a.phases = dq_scale, phases
     a.dgain_rows = _p(dgain_rows)
     a.kv_len = _p(_kvlen(kv_len, B))
+    _attn_drop(a, drop)
     _check(lib().ifseg_attn_bwd_bi(ctypes.byref(a), _stream()), "attn_bwd_bi")
 
 
@@ -446,7 +462,7 @@ def dbias_nparts():
     return lib().ifseg_attn_dbias_nparts()
 
 
-def attn_fwd_bi(q, k, v, dense, out, lse, B, H, T, S, causal=False, P=None, gain=None, kv_len=None):
+def attn_fwd_bi(q, k, v, dense, out, lse, B, H, T, S, causal=False, P=None, gain=None, kv_len=None, drop=None):
     """out = gain softmax(q k^T + dense.D) v, four batch elements per workgroup (csrc/attention_bi.hip)"""
     a = _AttnBiArgs()
     for name, t in (("q", q), ("k", k), ("v", v), ("lse", lse), ("D", dense.D), ("gain", _f32(gain)), ("out", out)):
@@ -456,6 +472,7 @@ def attn_fwd_bi(q, k, v, dense, out, lse, B, H, T, S, causal=False, P=None, gain
     a.q_bs, a.k_bs, a.v_bs, a.out_bs = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     a.causal, a.P = (1 if causal else 0), (P if P is not None else S)
     a.kv_len = _p(_kvlen(kv_len, B))
+    _attn_drop(a, drop)
     _check(lib().ifseg_attn_fwd_bi(ctypes.byref(a), _stream()), "attn_fwd_bi")
     return out
 

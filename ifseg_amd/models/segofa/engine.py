@@ -676,6 +676,13 @@ class HipEngine:
             v = self._dp_rows[i] = self.dp_scale[i]
         return v
 
+    def _attn_drop(self, tag, p):
+        """(p, seed) of the attention dropout of block `tag` (e<l> | d<l> | d<l>c), or None"""
+        if not p:
+            return None
+        kind = 3000 if tag.endswith("c") else (1000 if tag[0] == "e" else 2000)
+        return (p, self._site_seed(kind + int(tag[1:].rstrip("c"))))
+
     def _site_seed(self, site):
         # full seed = (step_seed * 1000003 + site) * 0x100000001B3 + 0x9E3779B97F4A7C15 (mod 2^64); the step part is
         # `step_dev[0]` on the device (upload_step_seed)
@@ -780,6 +787,7 @@ class HipEngine:
             if need_grad:
                 self._gctx = self.ctx
                 self.ctx["drop_state"] = (self.drop_on, getattr(self, "dp_scale", None), getattr(self, "_dp_rows", None))
+                self.ctx["attn_drop_p"] = self.attn_drop_p
             return out
         finally:
             hip.set_seed_add(prev_sa)
@@ -857,6 +865,7 @@ class HipEngine:
         trunk and image_proj are not run; `patch_images` is ignored."""
         cfg = self.cfg
         self.ctx_building = None
+        self.attn_drop_p = float(getattr(cfg, "attention_dropout", 0.0)) if need_grad else 0.0
         dev = src_tokens.device if bag is not None else patch_images.device
         if not self.packed or self.device != dev:
             self.pack(dev)
@@ -1257,7 +1266,10 @@ class HipEngine:
             self._dense_wait(tg)
             # (measured and dropped: the round-3 kernel seeded from the dense bias by global loads, 94.2 vs 91.3 ms on C4)
             hip.attn_fwd_bi(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], dd, o, lse, B, H, T, T, causal=causal,
-                            P=rel.P, gain=gain, kv_len=self.ctx_building.get("klen") if tg[0] == "e" else None)
+                            P=rel.P, gain=gain, kv_len=self.ctx_building.get("klen") if tg[0] == "e" else None,
+                            drop=self._attn_drop(tg, self.attn_drop_p))
+        elif self.attn_drop_p:
+            raise NotImplementedError("ifseg_amd HIP engine: attention dropout needs the batch-inner attention kernels")
         else:
             hip.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], pq, pk, o, lse, B, H, T, T, rel=rel,
                          causal=causal, gain=gain, dense_bias=dense)
@@ -1295,7 +1307,10 @@ class HipEngine:
         dd = self.ctx_building.get("dense", {}).get("dc") if (self.bi_fwd and self.ctx_building is not None) else None
         if dd is not None:
             self._dense_wait("dc")
-            hip.attn_fwd_bi(q, kv[:, :, :C], kv[:, :, C:], dd, o, lse, B, H, Td, Te, gain=gain, kv_len=self.ctx_building.get("klen"))
+            hip.attn_fwd_bi(q, kv[:, :, :C], kv[:, :, C:], dd, o, lse, B, H, Td, Te, gain=gain, kv_len=self.ctx_building.get("klen"),
+                            drop=self._attn_drop(tg + "c", self.attn_drop_p))
+        elif self.attn_drop_p:
+            raise NotImplementedError("ifseg_amd HIP engine: attention dropout needs the batch-inner attention kernels")
         else:
             hip.attn_fwd(q, kv[:, :, :C], kv[:, :, C:], cpq, cpk, o, lse, B, H, Td, Te, gain=gain)
         a = buf(tg + "_ca_a", (B * Td, C))
@@ -1502,9 +1517,12 @@ class HipEngine:
         # key padding: the keys of the encoder's self-attention (tags e<l>) and of the decoder's cross-attention (d<l>c) are the
         # encoder positions
         kv_len = self.ctx.get("klen") if (tag[0] == "e" or tag.endswith("c")) else None
+        adrop = self._attn_drop(tag, self.ctx.get("attn_drop_p", 0.0))
         if dense is not None:
             return self._attn_core_bwd_bi(q, k, v, pq, pk, o, lse, do, dq, dk, dv, B, T, S, rel, causal, gain, gain_name,
-                                          scaling, dpq_acc, dpk_acc, first_pos, rel_grads, delta, have_delta, dense, kv_len)
+                                          scaling, dpq_acc, dpk_acc, first_pos, rel_grads, delta, have_delta, dense, kv_len, adrop)
+        if adrop is not None:
+            raise NotImplementedError("ifseg_amd HIP engine: attention dropout needs the batch-inner attention backward")
         if kv_len is not None:
             raise NotImplementedError("ifseg_amd HIP engine: key padding needs the batch-inner attention backward")
         dpq_part = gbuf("g_dpq_part_%d" % T, (B, T, C))        # bf16 per-batch partials, summed by attn_bwd_reduce
@@ -1570,7 +1588,7 @@ class HipEngine:
             self._side_do(reductions)
 
     def _attn_core_bwd_bi(self, q, k, v, pq, pk, o, lse, do, dq, dk, dv, B, T, S, rel, causal, gain, gain_name, scaling,
-                          dpq_acc, dpk_acc, first_pos, rel_grads, delta, have_delta, dense, kv_len=None):
+                          dpq_acc, dpk_acc, first_pos, rel_grads, delta, have_delta, dense, kv_len=None, adrop=None):
         """csrc/attention_bi.hip: the bias is the dense operand `dense` (built once per layer by the forward's side stream),
         a workgroup holds four batch elements, sum_b dS leaves the dQ kernel once per tile; everything behind that sum --
         abs-pos operand gradients, rel-pos tables, c_attn -- is two launches on the weight-gradient stream."""
@@ -1614,15 +1632,15 @@ class HipEngine:
             # the second, partly filled round of workgroups of one leaves CUs to the other
             with self._fork(self._dq_stream_get()):
                 hip.attn_bwd_bi(q, k, v, do, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain,
-                                dq_scale=scaling, phases=hip.ATTN_BWD_DQ, dgain_rows=dgr, kv_len=kv_len)
+                                dq_scale=scaling, phases=hip.ATTN_BWD_DQ, dgain_rows=dgr, kv_len=kv_len, drop=adrop)
                 dq_done = self._ev()
                 dq_done.record(self._dqs)
             hip.attn_bwd_bi(q, k, v, do, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain,
-                            dq_scale=scaling, phases=hip.ATTN_BWD_DKV, kv_len=kv_len)
+                            dq_scale=scaling, phases=hip.ATTN_BWD_DKV, kv_len=kv_len, drop=adrop)
             torch.cuda.current_stream().wait_event(dq_done)
         elif ph >= 0:
             hip.attn_bwd_bi(q, k, v, do, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain,
-                            dq_scale=scaling, phases=ph, dgain_rows=dgr, kv_len=kv_len)
+                            dq_scale=scaling, phases=ph, dgain_rows=dgr, kv_len=kv_len, drop=adrop)
         if timing is not None:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record()

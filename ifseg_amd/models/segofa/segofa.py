@@ -223,7 +223,7 @@ class SegOFAModel(ModelBase):
         for k in must_false:
             if g(k, False):
                 refuse("--%s" % k.replace("_", "-"))
-        for k in ("attention_dropout", "activation_dropout", "relu_dropout", "resnet_drop_path_rate", "encoder_layerdrop",
+        for k in ("activation_dropout", "relu_dropout", "resnet_drop_path_rate", "encoder_layerdrop",
                   "decoder_layerdrop", "quant_noise_pq", "quant_noise_scalar"):
             if float(g(k, 0.0) or 0.0) != 0.0:
                 refuse("--%s > 0" % k.replace("_", "-"))
@@ -259,7 +259,8 @@ class SegOFAModel(ModelBase):
             image_bucket_size=int(g("image_bucket_size")), token_bucket_size=int(g("token_bucket_size")),
             attn_scale_factor=float(g("attn_scale_factor")), max_source_positions=int(g("max_source_positions", 1024) or 1024),
             max_target_positions=int(g("max_target_positions", 1024) or 1024), code_image_size=int(g("code_image_size")),
-            dropout=float(g("dropout", 0.0) or 0.0), encoder_drop_path_rate=float(g("encoder_drop_path_rate", 0.0) or 0.0),
+            dropout=float(g("dropout", 0.0) or 0.0), attention_dropout=float(g("attention_dropout", 0.0) or 0.0),
+            encoder_drop_path_rate=float(g("encoder_drop_path_rate", 0.0) or 0.0),
             decoder_drop_path_rate=float(g("decoder_drop_path_rate", 0.0) or 0.0))
         model = cls(cfg, args=args)
         model.encoder.dictionary = src_dict

@@ -246,12 +246,21 @@ typedef struct ifseg_attn_bi_args {
   const int* kv_len;           /* optional device int32 [B]: key padding (unify_multihead_attention.py:477-489 with the suffix masks of
                                   encoder_module.py:730-752): keys j >= kv_len[b] are masked for batch element b in the forward and in
                                   all three gradients; NULL = no padding.  kv_len[b] >= 1 */
+  float drop_p;                /* attention dropout (unify_multihead_attention.py:498: dropout_module(attn_weights)): P o keep / (1 - p)
+                                  between the softmax and P V, keep ~ Bernoulli(1 - p) from a counter-based hash of
+                                  (drop_seed + *drop_seed_add, b, h, query, key) that forward and the three gradients regenerate
+                                  (ifseg_attn_dropout_mask writes it out); 0 = off.  `delta` must come from the dropped output. */
+  unsigned long long drop_seed;
+  const unsigned long long* drop_seed_add;   /* device word or NULL (as ifseg_drop_args.seed_add) */
 } ifseg_attn_bi_args;
 int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* args, void* stream);
 /* ifseg_attn_fwd_bi: the forward of the same formulation -- out = gain softmax_fp32(q k^T + D) v, `lse` (written) as
  * ifseg_attn_fwd's (log2 units); reads q, k, v, D, gain, causal / P (tile schedule only: the mask is inside D).  A workgroup
  * holds four batch elements and fetches each 32 x 32 bias tile once for them (unify_multihead_attention.py:459-512). */
 int ifseg_attn_fwd_bi(const ifseg_attn_bi_args* args, void* stream);
+/* keep[b, h, i, j] in {0, 1} (uint8 [B, H, T, S]): the attention-dropout mask of the kernels above for these seeds */
+int ifseg_attn_dropout_mask(unsigned char* keep, int B, int H, int T, int S, float p, unsigned long long seed,
+                            const unsigned long long* seed_add, void* stream);
 
 /* ifseg_attn_dbias_grads: everything downstream of dbias (two launches: operand gradients, tables) (the autograd of the bias construction,
  *   encoder_module.py:757-771,790-809 / decoder_module.py:553-558,603-627), with dB = sum_g dbias[g]:

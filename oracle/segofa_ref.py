@@ -338,6 +338,12 @@ def resnet_trunk(sd, p, x, layers):
     return x
 
 
+# Attention dropout (unify_multihead_attention.py:498: attn_probs = self.dropout_module(attn_weights), 0.0 in every shipped
+# script): a test that wants it installs ATTN_PROB_HOOK(prefix, probs) -> probs, e.g. probs * keep / (1 - p) with the keep mask
+# of the implementation under test (F.dropout with a known mask); None = the recipe's identity.
+ATTN_PROB_HOOK = None
+
+
 def mha(sd, p, cfg, xq, xkv, bias, causal=False, key_padding_mask=None):
     """unify_multihead_attention.py:327-513, batch-first.
 
@@ -361,6 +367,8 @@ def mha(sd, p, cfg, xq, xkv, bias, causal=False, key_padding_mask=None):
     if key_padding_mask is not None:
         s = s.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
     pr = F.softmax(s.float(), dim=-1).type_as(s)
+    if ATTN_PROB_HOOK is not None:
+        pr = ATTN_PROB_HOOK(p, pr)
     o = torch.matmul(pr, v)                       # [B,H,T,d]
     o = o * sd[p + ".c_attn"].view(1, H, 1, 1)
     o = o.transpose(1, 2).reshape(B, T, C)

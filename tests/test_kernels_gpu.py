@@ -1364,3 +1364,78 @@ def test_attn_batch_inner_key_padding(case):
         assert v_ < 2e-2, (k_, v_)
     for b in range(1, B):
         assert dk[b, lens[b]:].abs().max().item() == 0.0 and dv[b, lens[b]:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("case", ["enc_rel", "cross", "dec_causal", "enc_b5"])
+def test_attn_batch_inner_attention_dropout(case):
+    """Attention dropout inside the batch-inner kernels (ifseg_attn_bi_args.drop_p; unify_multihead_attention.py:498:
+    attn_probs = dropout(attn_weights) between the softmax and P V).  The keep mask is a counter-based hash the forward and the
+    three gradients regenerate; ifseg_attn_dropout_mask writes the same mask out, and fp32 autograd with THAT mask is the
+    reference: out, dq, dk, dv, sum_b dS.  Keep rate, seed dependence, p = 0 == the plain kernels."""
+    from ifseg_amd import hip
+    dev = _dev()
+    H, B, T, S, P, Lt, gh, gw, causal = _attn_case(case)
+    C, p, seed = H * 64, 0.2, 0x1234567890ABCDEF
+    q, k, v = _rand((B, T, C), dev, 20, 0.35), _rand((B, S, C), dev, 21), _rand((B, S, C), dev, 22)
+    pq, pk = _rand((T, C), dev, 23, 0.35), _rand((S, C), dev, 24)
+    dout = _rand((B, T, C), dev, 25)
+    gain = (1.0 + 0.2 * torch.randn(H, generator=torch.Generator().manual_seed(5))).to(dev)
+    rel, bias_ref = None, None
+    if P is not None:
+        gcode, code_bias, n2d = _grid_codes(gh, gw)
+        g = torch.Generator().manual_seed(30)
+        tabs = [torch.randn(H, n2d, generator=g), torch.randn(H, 2 * Lt - 1, generator=g), torch.randn(H, 2, generator=g)]
+        rel = hip.RelBias(P, gcode.to(dev), code_bias, tabs[0].to(dev), tabs[1].to(dev), tabs[2].to(dev), grid_w=gw)
+        bias_ref = _dense_rel(H, T, S, P, gcode.long(), code_bias, *tabs).to(dev)
+    cmask = _causal_mask(T, S, P).to(dev) if causal else None
+    keep = hip.attn_dropout_mask(B, H, T, S, p, seed, dev)
+    keep2 = hip.attn_dropout_mask(B, H, T, S, p, seed + 1, dev)
+    rate = keep.float().mean().item()
+    assert abs(rate - (1 - p)) < 5e-3 and not torch.equal(keep, keep2), rate
+    for dims, cnt in (((0, 1, 2), B * H * T), ((0, 1, 3), B * H * S)):          # no key / query column is favoured (5 sigma)
+        assert abs(keep.float().mean(dims) - (1 - p)).max().item() < 5 * (p * (1 - p) / cnt) ** 0.5
+    km = keep.float() / (1 - p)
+
+    def ref(qf, kf, vf):
+        qh = qf.view(B, T, H, 64).transpose(1, 2); kh = kf.view(B, S, H, 64).transpose(1, 2); vh = vf.view(B, S, H, 64).transpose(1, 2)
+        sc = qh @ kh.transpose(2, 3) + (pq.float().view(T, H, 64).transpose(0, 1) @ pk.float().view(S, H, 64).permute(1, 2, 0))
+        if bias_ref is not None:
+            sc = sc + bias_ref
+        if cmask is not None:
+            sc = sc.masked_fill(cmask, float("-inf"))
+        pr = torch.softmax(sc, -1)
+        o = ((pr * km) @ vh) * gain.view(1, H, 1, 1)
+        return o.transpose(1, 2).reshape(B, T, C), pr
+
+    qf, kf, vf = [t.float().clone().requires_grad_(True) for t in (q, k, v)]
+    o_ref, pr = ref(qf, kf, vf)
+    (o_ref * dout.float()).sum().backward()
+    dense = hip.DenseBias(H, T, S, dev)
+    hip.attn_dense_bias(dense, pq, pk, rel=rel, causal=causal, P=P)
+    out, lse = torch.zeros(B, T, C, dtype=torch.bfloat16, device=dev), torch.zeros(B, H, T, device=dev)
+    hip.attn_fwd_bi(q, k, v, dense, out, lse, B, H, T, S, causal=causal, P=P, gain=gain, drop=(p, seed))
+    out0, lse0 = torch.zeros_like(out), torch.zeros_like(lse)
+    hip.attn_fwd_bi(q, k, v, dense, out0, lse0, B, H, T, S, causal=causal, P=P, gain=gain)
+    outz = torch.zeros_like(out)
+    hip.attn_fwd_bi(q, k, v, dense, outz, lse0, B, H, T, S, causal=causal, P=P, gain=gain, drop=(0.0, seed))
+    torch.cuda.synchronize()
+    assert _rel(out, o_ref) < 1e-2, _rel(out, o_ref)
+    assert torch.equal(lse, lse0) and torch.equal(outz, out0) and not torch.equal(out, out0)     # lse: the undropped softmax
+    delta = (dout.float() * out.float()).view(B, T, H, 64).sum(-1).permute(0, 2, 1).contiguous()
+    dq, dk, dv = torch.full_like(q, 3.0), torch.full_like(k, 3.0), torch.full_like(v, 3.0)
+    dbias = torch.zeros((B + 3) // 4, H, T, dense.Sp, dtype=torch.bfloat16, device=dev)
+    dgr = torch.zeros(B, H, T, device=dev)
+    hip.attn_bwd_bi(q, k, v, dout, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain,
+                    dgain_rows=dgr, drop=(p, seed))
+    torch.cuda.synchronize()
+    errs = {"dq": _rel(dq, qf.grad), "dk": _rel(dk, kf.grad), "dv": _rel(dv, vf.grad)}
+    with torch.no_grad():
+        vh = v.float().view(B, S, H, 64).transpose(1, 2)
+        doh = dout.float().view(B, T, H, 64).transpose(1, 2)
+        dpd = doh @ vh.transpose(2, 3)                                   # d P_drop (before the gain)
+        dSb = (pr * (gain.view(1, H, 1, 1) * km * dpd - delta.unsqueeze(-1))).sum(0)
+        errs["dbias"] = _rel(dbias.float().sum(0)[:, :, :S], dSb)
+        errs["dgain_rows"] = _rel(dgr, (pr * km * dpd).sum(-1))
+    print(case, "keep %.4f" % rate, {k_: round(v_, 5) for k_, v_ in errs.items()})
+    for k_, v_ in errs.items():
+        assert v_ < 2e-2, (k_, v_)

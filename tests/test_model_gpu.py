@@ -920,3 +920,93 @@ def test_label_smoothing_runs_in_the_fused_criterion():
     assert abs(loss.item() - tl.item()) <= 2e-4 * max(1.0, abs(tl.item())) and abs(loss.item() - plain.item()) > 1e-4   # (near-uniform logits: smoothing moves the loss little)
     assert _rel(fused_grad, lg.grad) <= 6e-3
     assert torch.equal(metrics["area_label"].cpu(), tm["area_label"].cpu())
+
+
+def test_attention_dropout_against_the_oracle_with_the_same_masks():
+    """--attention-dropout > 0 (unify_multihead_attention.py:498; 0.0 in every shipped script): the mask lives inside the
+    attention kernels (counter-based, regenerated by the backward).  ifseg_attn_dropout_mask writes out the masks of one step;
+    the oracle applies exactly those after its softmax (oracle.ATTN_PROB_HOOK) -- logits, loss and every gradient must then
+    agree as they do without dropout.  Also: the masks change with the update number, and evaluation applies none."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ifseg_amd import hip
+    from ifseg_amd.criterions import SegCriterion
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    B, p = 3, 0.25
+    batch = O.synthetic_batch(ocfg, B, 12)
+    m = _build(ocfg, sd, dev)
+    m.cfg.attention_dropout = p
+    m.train()
+    eng = m.engine
+    eng.step_seed = 17
+    crit = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+    sample = {"net_input": {k: batch[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks", "prev_output_tokens")},
+              "target": batch["target"].to(dev), "ntokens": 1, "nsentences": B}
+    sample["net_input"]["src_lengths"] = torch.full((B,), 12).to(dev)
+    loss, _, _ = crit(m, sample)
+    logits = eng.ws["logits_pad"][:, :, : ocfg.num_seg_tokens].float().cpu()
+    loss.backward()
+    torch.cuda.synchronize()
+    H, P = ocfg.heads, (ocfg.patch_image_size // 16) ** 2
+    Te, Td = P + 12, P + 1
+    masks = {}
+    prev = hip.set_seed_add(eng.step_dev)
+    try:
+        for l in range(ocfg.enc_layers):
+            masks["encoder.layers.%d.self_attn" % l] = hip.attn_dropout_mask(B, H, Te, Te, p, eng._attn_drop("e%d" % l, p)[1], dev)
+        for l in range(ocfg.dec_layers):
+            masks["decoder.layers.%d.self_attn" % l] = hip.attn_dropout_mask(B, H, Td, Td, p, eng._attn_drop("d%d" % l, p)[1], dev)
+            masks["decoder.layers.%d.encoder_attn" % l] = hip.attn_dropout_mask(B, H, Td, Te, p, eng._attn_drop("d%dc" % l, p)[1], dev)
+    finally:
+        hip.set_seed_add(prev)
+    torch.cuda.synchronize()
+    masks = {k: v.float().cpu() / (1 - p) for k, v in masks.items()}
+    # the engine keeps the decoder's rows as [patches..., bos] (its causal schedule's "tail"), the reference as [bos, patches...]
+    perm = torch.tensor([P] + list(range(P)))
+    for l in range(ocfg.dec_layers):
+        ks, kc = "decoder.layers.%d.self_attn" % l, "decoder.layers.%d.encoder_attn" % l
+        masks[ks] = masks[ks][:, :, perm][:, :, :, perm]
+        masks[kc] = masks[kc][:, :, perm]
+    assert all(abs(v.mean().item() - 1.0) < 0.05 for v in masks.values())
+    assert not torch.equal(masks["encoder.layers.0.self_attn"], masks["encoder.layers.1.self_attn"])
+    seen = []
+
+    def hook(prefix, pr):
+        seen.append(prefix)
+        return pr * masks[prefix].to(pr.dtype)
+    O.ATTN_PROB_HOOK = hook
+    try:
+        o_logits, o_loss, o_grads, _ = _oracle_all_grads(ocfg, sd, batch, (128, 128))
+    finally:
+        O.ATTN_PROB_HOOK = None
+    assert len(seen) == ocfg.enc_layers + 2 * ocfg.dec_layers
+    plain_logits, plain_loss, _, _ = _oracle_all_grads(ocfg, sd, batch, (128, 128))
+    print("attention dropout %.2f: logits rel-L2 %.4f (the masks move the oracle's logits by %.4f), loss %.5f vs %.5f"
+          % (p, _rel(logits, o_logits), _rel(o_logits, plain_logits), loss.item(), o_loss.item()))
+    assert _rel(o_logits, plain_logits) > 5 * _rel(logits, o_logits)
+    assert _rel(logits, o_logits) <= 2e-2 and abs(loss.item() - o_loss.item()) <= 1e-2
+    named = dict(m.named_parameters())
+    gain_scale = max(v.abs().max().item() for k, v in o_grads.items() if k.endswith("c_attn"))
+    bad, n = [], 0
+    for k, og in sorted(o_grads.items()):
+        if k not in named or not named[k].requires_grad or og.norm() == 0 or k.endswith(("k_proj.bias", "pos_k_linear.bias")):
+            continue
+        hg = named[k].grad
+        if k.endswith("c_attn"):
+            assert (hg.float().cpu() - og).abs().max().item() <= 5e-2 * gain_scale, k
+            continue
+        n += 1
+        if _rel(hg, og) > 6e-2:
+            bad.append((round(_rel(hg, og), 4), k))
+    assert n > 100 and not bad, bad[:10]
+    # another update number: other masks; evaluation: none
+    eng.step_seed = 18
+    crit(m, sample)
+    l2 = eng.ws["logits_pad"][:, :, : ocfg.num_seg_tokens].float().cpu()
+    assert _rel(l2, logits) > 1e-3
+    m.eval()
+    with torch.no_grad():
+        le, _ = m(**sample["net_input"])
+    assert _rel(le, plain_logits) <= 2e-2
