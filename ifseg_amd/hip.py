@@ -62,6 +62,16 @@ def set_stream(handle):
     return prev
 
 
+def cumask_stream(mask_hex, device):
+    """torch.cuda.ExternalStream over a HIP stream restricted to the CUs of `mask_hex` (bit i = CU i; IFSEG_CUMASK_* switches)"""
+    v = int(mask_hex, 16)
+    words = [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+    arr = (ctypes.c_uint32 * 8)(*words)
+    out = c_void_p()
+    _check(lib().ifseg_stream_create_cumask(arr, c_int(8), ctypes.byref(out)), "stream_create_cumask")
+    return torch.cuda.ExternalStream(out.value, device=device)
+
+
 def _stream():
     if _stream_handle is not None:
         return c_void_p(_stream_handle)

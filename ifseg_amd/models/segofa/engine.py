@@ -370,9 +370,16 @@ class HipEngine:
         self._evi = (self._evi + 1) % len(self._evs)
         return e
 
+    def _new_stream(self, which, priority=0):
+        """a side stream; IFSEG_CUMASK_<which>=<hex> (laboratory) restricts it to those compute units"""
+        m = os.environ.get("IFSEG_CUMASK_" + which)
+        if m:
+            return hip.cumask_stream(m, self.device)
+        return torch.cuda.Stream(device=self.device, priority=priority)
+
     def _wgrad_init(self):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = self._new_stream("SIDE")
             self._evs = [torch.cuda.Event() for _ in range(128)]
             self._evi = 0
 
@@ -418,7 +425,7 @@ class HipEngine:
     def _dq_stream_get(self):
         if getattr(self, "_dqs", None) is None:
             self._wgrad_init()
-            self._dqs = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("IFSEG_DQ_PRIO", "0")))
+            self._dqs = self._new_stream("DQ", int(os.environ.get("IFSEG_DQ_PRIO", "0")))
         return self._dqs
 
     @contextlib.contextmanager
@@ -520,7 +527,7 @@ class HipEngine:
         if self._trunk_stream is None:
             # high priority: the ~100 small convolutions must finish within the step they run under -- at normal priority
             # they were starved by the main / weight-gradient queues and the NEXT forward waited 2.6 ms for its features
-            self._trunk_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("IFSEG_TRUNK_PRIO", "-1")))
+            self._trunk_stream = self._new_stream("TRUNK", int(os.environ.get("IFSEG_TRUNK_PRIO", "-1")))
         cur = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(cur)                                   # the images were produced on the caller's stream

@@ -503,6 +503,8 @@ int ifseg_crf_norm(const float* k1, float* n, int N, void* stream);
  * 5 ATTN_BWD_DKV, 6 ATTN_BWD_DQ, 7 LN_FWD, 8 LN_BWD.  ifseg_prof_read returns the summed
  * kernel time and the summed ALGORITHMIC flops / bytes of the recorded launches. */
 int ifseg_prof_enable(unsigned mask);
+/* laboratory: a HIP stream restricted to the compute units of `mask` (nwords x 32 bits; hipExtStreamCreateWithCUMask) */
+int ifseg_stream_create_cumask(const unsigned* mask, int nwords, void** stream);
 int ifseg_prof_stride(int stride); /* time only every stride-th launch of an enabled family (default 1) */
 int ifseg_prof_reset(void);
 int ifseg_prof_read(int kind, double* ms, double* flops, double* bytes, int* launches);
