@@ -1011,6 +1011,40 @@ extern "C" int ifseg_dropout(const void* x, const void* resid, void* out, long l
   return 0;
 }
 
+// out = keep ? x : fill (NO rescaling) with ifseg_dropout's mask for (seed, element): the activation dropout between GELU and the
+// FFN LayerNorm (unify_transformer_layer.py:280,556) is applied to the PRE-activation u, in place, with fill = -30:
+// gelu(-30) = -0 and gelu'(-30) = 0 exactly in fp32 (exp(-450) underflows, the erf polynomial returns -1), so every kernel
+// that recomputes gelu(u) -- LayerNorm forward / backward, the fused GEMM epilogue, the ffn_ln gradient kernels -- sees
+// a = keep * gelu(u) and da/du = keep * gelu'(u) without knowing about the mask.  The missing factor 1 / (1 - p) cancels in the
+// LayerNorm that follows: LN(a / (1 - p); eps) == LN(a; eps (1 - p)^2), forward and backward (the caller passes that eps).
+namespace {
+__global__ void dropout_fill_kernel(const bf16_t* x, bf16_t* out, long long nchunks, float p, unsigned long long seed,
+                                    const unsigned long long* seed_add, float fill) {
+  const long long c8 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c8 >= nchunks) return;
+  float f[8], k[8];
+  unpack8(*reinterpret_cast<const uint4*>(x + c8 * 8), f);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) k[e] = 1.f;
+  drop8(k, DropArgs{1, p, seed, nullptr, 1, seed_add}, c8, 0);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = k[e] != 0.f ? f[e] : fill;
+  *reinterpret_cast<uint4*>(out + c8 * 8) = pack8(f);
+}
+}  // namespace
+
+extern "C" int ifseg_dropout_fill(const void* x, void* out, long long n, float p, unsigned long long seed,
+                                  const unsigned long long* seed_add, float fill, void* stream) {
+  (void)hipGetLastError();
+  if (n <= 0) return 0;
+  if ((n & 7) || p < 0.f || p >= 1.f || !x || !out) return IFSEG_ERR_BAD_ARG;
+  const long long nchunks = n / 8;
+  hipLaunchKernelGGL(dropout_fill_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)out, nchunks, p, seed, seed_add, fill);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
 // DropPath keep masks (unify_transformer_layer.py:19-35): out[i][b] = Bernoulli(keep[i]) / keep[i] for residual branch i
 // and sample b, from the same counter-based generator as the dropout masks (replay-safe: no host RNG state)
 namespace {

@@ -955,6 +955,14 @@ def dropout(x, resid, out, p, seed, drop_path_scale=None, rows_per_batch=None):
     return out
 
 
+def dropout_fill(x, out, p, seed, fill=-30.0):
+    """out = keep ? x : fill (contiguous bf16, no rescaling; the activation dropout on the FFN pre-activation, see rowops.hip)"""
+    assert x.is_contiguous() and out.is_contiguous() and x.dtype == torch.bfloat16 and out.shape == x.shape
+    _check(lib().ifseg_dropout_fill(_ptr(x), _ptr(out), c_ll(x.numel()), c_float(p), ctypes.c_ulonglong(seed & 0xFFFFFFFFFFFFFFFF),
+                                    c_void_p(_seed_add_ptr()), c_float(fill), _stream()), "dropout_fill")
+    return out
+
+
 # ---------------------------------------------------------------------- dense CRF (crf.py:19-37)
 def crf_bilateral(feat4, gx, gy, qn, out, H, W):
     """out fp32 [Cp, N] = exact bilateral filter of qn bf16 [Cp, ldq]"""

@@ -37,6 +37,7 @@ class SegOFAConfig:
     # stochastic regularisers (coco_unseen.sh:19-22: dropout 0.1, encoder/decoder drop-path 0.1,
     # attention_dropout 0.0).  Parity is defined at 0 (the RNG stream cannot match torch's).
     dropout: float = 0.0
+    activation_dropout: float = 0.0     # between GELU and ffn_layernorm (unify_transformer_layer.py:142-147,280; alias --relu-dropout)
     attention_dropout: float = 0.0      # on the softmax probabilities (unify_multihead_attention.py:498); inside the attention kernels
     encoder_drop_path_rate: float = 0.0
     decoder_drop_path_rate: float = 0.0

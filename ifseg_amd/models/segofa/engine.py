@@ -873,6 +873,7 @@ class HipEngine:
         cfg = self.cfg
         self.ctx_building = None
         self.attn_drop_p = float(getattr(cfg, "attention_dropout", 0.0)) if need_grad else 0.0
+        self.act_drop_p = float(getattr(cfg, "activation_dropout", 0.0)) if need_grad else 0.0
         dev = src_tokens.device if bag is not None else patch_images.device
         if not self.packed or self.device != dev:
             self.pack(dev)
@@ -1342,7 +1343,14 @@ class HipEngine:
         hip.linear_fwd(xn, W(p + "fc1.weight"), W(p + "fc1.bias"), out=u)
         z = buf(tg + "_z", (rows, Fd))
         mu, rs = self._ln_stats(tg + "_fln2", rows)
-        hip.ln_fwd(u, Wf(p + "ffn_layernorm.weight"), Wf(p + "ffn_layernorm.bias"), z, mu, rs, gelu=True)
+        eps = 1e-5
+        if self.act_drop_p:
+            # activation dropout (unify_transformer_layer.py:280,556: between GELU and ffn_layernorm): dropped pre-activations
+            # become -30 in place (gelu = gelu' = 0 exactly: every kernel that recomputes gelu(u), forward and backward, then
+            # sees the mask); the 1 / (1 - p) cancels in the LayerNorm that follows, exactly, with eps (1 - p)^2 (csrc/rowops.hip)
+            hip.dropout_fill(u, u, self.act_drop_p, self._site_seed((4000 if tg[0] == "e" else 5000) + int(tg[1:])))
+            eps = 1e-5 * (1.0 - self.act_drop_p) ** 2
+        hip.ln_fwd(u, Wf(p + "ffn_layernorm.weight"), Wf(p + "ffn_layernorm.bias"), z, mu, rs, gelu=True, eps=eps)
         x2 = buf(tg + "_x2", x1.shape)
         nxt = None
         dropping = self.drop_on and site is not None

@@ -223,8 +223,7 @@ class SegOFAModel(ModelBase):
         for k in must_false:
             if g(k, False):
                 refuse("--%s" % k.replace("_", "-"))
-        for k in ("activation_dropout", "relu_dropout", "resnet_drop_path_rate", "encoder_layerdrop",
-                  "decoder_layerdrop", "quant_noise_pq", "quant_noise_scalar"):
+        for k in ("resnet_drop_path_rate", "encoder_layerdrop", "decoder_layerdrop", "quant_noise_pq", "quant_noise_scalar"):
             if float(g(k, 0.0) or 0.0) != 0.0:
                 refuse("--%s > 0" % k.replace("_", "-"))
         if g("activation_fn", "gelu") != "gelu":
@@ -260,6 +259,7 @@ class SegOFAModel(ModelBase):
             attn_scale_factor=float(g("attn_scale_factor")), max_source_positions=int(g("max_source_positions", 1024) or 1024),
             max_target_positions=int(g("max_target_positions", 1024) or 1024), code_image_size=int(g("code_image_size")),
             dropout=float(g("dropout", 0.0) or 0.0), attention_dropout=float(g("attention_dropout", 0.0) or 0.0),
+            activation_dropout=float(g("activation_dropout", 0.0) or 0.0) or float(g("relu_dropout", 0.0) or 0.0),
             encoder_drop_path_rate=float(g("encoder_drop_path_rate", 0.0) or 0.0),
             decoder_drop_path_rate=float(g("decoder_drop_path_rate", 0.0) or 0.0))
         model = cls(cfg, args=args)

@@ -412,6 +412,12 @@ int ifseg_resize_rows_bilinear(const void* src, void* dst, int C, int h, int w, 
 int ifseg_dropout(const void* x, const void* resid, void* out, long long rows, int C, float p,
                   unsigned long long seed, const float* drop_path_scale, int rows_per_batch, int rpb, long long x_bs,
                   int ldx, long long r_bs, int ldr, long long o_bs, int ldo, const unsigned long long* seed_add, void* stream);
+/* out[i] = keep(i) ? x[i] : fill on n contiguous bf16 elements (n % 8 == 0), ifseg_dropout's mask, NO rescaling: the
+ * activation dropout between GELU and the FFN LayerNorm (unify_transformer_layer.py:280,556) applied to the pre-activation
+ * with fill = -30 (gelu and gelu' are exactly 0 there); the 1 / (1 - p) cancels in the LayerNorm: pass eps (1 - p)^2 to
+ * ifseg_ln_fwd (csrc/rowops.hip). */
+int ifseg_dropout_fill(const void* x, void* out, long long n, float p, unsigned long long seed,
+                       const unsigned long long* seed_add, float fill, void* stream);
 /* DropPath keep masks (drop_path, unify_transformer_layer.py:19-35): out[i][b] = Bernoulli(keep[i]) / keep[i] for residual
  * branch i < n and sample b < B, from the counter-based generator of ifseg_dropout (seed + *seed_add). */
 int ifseg_droppath_scale(float* out, const float* keep, int n, int B, unsigned long long seed,

@@ -342,6 +342,9 @@ def resnet_trunk(sd, p, x, layers):
 # script): a test that wants it installs ATTN_PROB_HOOK(prefix, probs) -> probs, e.g. probs * keep / (1 - p) with the keep mask
 # of the implementation under test (F.dropout with a known mask); None = the recipe's identity.
 ATTN_PROB_HOOK = None
+# Activation dropout (unify_transformer_layer.py:280,556: between the activation and ffn_layernorm; 0 in every shipped script):
+# ACT_HOOK(prefix, a) -> a, as above.
+ACT_HOOK = None
 
 
 def mha(sd, p, cfg, xq, xkv, bias, causal=False, key_padding_mask=None):
@@ -379,6 +382,8 @@ def _ffn(sd, p, cfg, x):
     """unify_transformer_layer.py:276-289 / :552-566 (pre-LN, scale_fc)."""
     y = _ln(sd, p + "final_layer_norm", x)
     y = _gelu(_lin(sd, p + "fc1", y))
+    if ACT_HOOK is not None:
+        y = ACT_HOOK(p, y)
     y = _ln(sd, p + "ffn_layernorm", y)
     y = _lin(sd, p + "fc2", y)
     return x + y

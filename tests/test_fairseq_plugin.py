@@ -68,15 +68,16 @@ assert isinstance(crit, FairseqCriterion) and crit.unsupervised_segmentation and
 assert crit.num_seg == 15 and len(crit.id2rawtext) == 15 and crit.seg_id_offset == 59457
 # refused, not ignored: a value the HIP path does not implement
 import copy
-bad = copy.copy(args); bad.activation_dropout = 0.1
+bad = copy.copy(args); bad.encoder_layerdrop = 0.1
 try:
     M.build_model(bad, task)
 except NotImplementedError:
     pass
 else:
-    raise AssertionError("activation_dropout > 0 was accepted")
-ok = copy.copy(args); ok.attention_dropout = 0.1
-assert M.build_model(ok, task).cfg.attention_dropout == 0.1        # inside the attention kernels since round 5
+    raise AssertionError("encoder_layerdrop > 0 was accepted")
+ok = copy.copy(args); ok.attention_dropout = 0.1; ok.activation_dropout = 0.2
+mk = M.build_model(ok, task)
+assert mk.cfg.attention_dropout == 0.1 and mk.cfg.activation_dropout == 0.2        # built in round 5
 print("PLUGIN-OK")
 '''
 

@@ -1439,3 +1439,37 @@ def test_attn_batch_inner_attention_dropout(case):
     print(case, "keep %.4f" % rate, {k_: round(v_, 5) for k_, v_ in errs.items()})
     for k_, v_ in errs.items():
         assert v_ < 2e-2, (k_, v_)
+
+
+def test_dropout_fill_and_the_layernorm_identity_behind_activation_dropout():
+    """ifseg_dropout_fill (keep ? x : fill, ifseg_dropout's mask, no rescale) and the identity the engine's activation dropout
+    rests on: LN(gelu(u) * keep / (1 - p); eps) == ln_fwd(gelu=True, eps (1 - p)^2) on u with dropped entries set to -30 --
+    forward, and backward through ln_bwd(gelu=True) with the saved statistics (unify_transformer_layer.py:279-283)."""
+    from ifseg_amd import hip
+    import torch.nn.functional as F
+    dev = _dev()
+    rows, C, p, seed = 300, 512, 0.3, 99
+    u = _rand((rows, C), dev, 70, 1.5)
+    ones = torch.ones(rows, C, dtype=torch.bfloat16, device=dev)
+    keep = hip.dropout_fill(ones, torch.empty_like(ones), p, seed, fill=0.0).float()
+    ref_mask = torch.empty_like(ones)
+    hip.dropout(ones, None, ref_mask, p, seed)
+    assert torch.equal(keep != 0, ref_mask != 0) and abs(keep.mean().item() - (1 - p)) < 5e-3      # ifseg_dropout's mask
+    uf = hip.dropout_fill(u, torch.empty_like(u), p, seed)
+    assert torch.equal(uf[keep != 0], u[keep != 0]) and (uf[keep == 0] == -30).all()
+    gam = (1 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(1))).to(dev)
+    bet = (0.1 * torch.randn(C, generator=torch.Generator().manual_seed(2))).to(dev)
+    z = torch.empty_like(u); mu = torch.empty(rows, device=dev); rs = torch.empty(rows, device=dev)
+    hip.ln_fwd(uf, gam, bet, z, mu, rs, gelu=True, eps=1e-5 * (1 - p) ** 2)
+    x = u.float().clone().requires_grad_(True)
+    a = F.gelu(x) * keep / (1 - p)
+    zr = F.layer_norm(a, (C,), gam, bet, 1e-5)
+    assert _rel(z, zr) < 6e-3, _rel(z, zr)
+    dy = _rand((rows, C), dev, 71)
+    (zr * dy.float()).sum().backward()
+    dx = torch.empty_like(u)
+    part = torch.empty(2, hip.LN_BWD_BLOCKS, C, device=dev)
+    hip.ln_bwd(dy, uf, gam, mu, rs, dx, part[0], part[1], gelu=True)
+    torch.cuda.synchronize()
+    assert _rel(dx, x.grad) < 1e-2, _rel(dx, x.grad)
+    assert dx[keep == 0].abs().max().item() == 0.0              # a dropped activation passes no gradient, exactly

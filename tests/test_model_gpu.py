@@ -1010,3 +1010,83 @@ def test_attention_dropout_against_the_oracle_with_the_same_masks():
     with torch.no_grad():
         le, _ = m(**sample["net_input"])
     assert _rel(le, plain_logits) <= 2e-2
+
+
+def test_activation_dropout_against_the_oracle_with_the_same_masks():
+    """--activation-dropout > 0 (unify_transformer_layer.py:142-147,280,556; 0 in every shipped script): dropped FFN
+    pre-activations are set to -30 in place (gelu = gelu' = 0 exactly), the 1 / (1 - p) cancels in ffn_layernorm via
+    eps (1 - p)^2 -- no kernel of the FFN forward / backward knows about the mask.  The oracle applies the same masks
+    (oracle.ACT_HOOK): logits, loss and every gradient agree as without dropout."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ifseg_amd import hip
+    from ifseg_amd.criterions import SegCriterion
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    B, p = 3, 0.3
+    batch = O.synthetic_batch(ocfg, B, 12)
+    m = _build(ocfg, sd, dev)
+    m.cfg.activation_dropout = p
+    m.train()
+    eng = m.engine
+    eng.step_seed = 5
+    crit = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+    sample = {"net_input": {k: batch[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks", "prev_output_tokens")},
+              "target": batch["target"].to(dev), "ntokens": 1, "nsentences": B}
+    sample["net_input"]["src_lengths"] = torch.full((B,), 12).to(dev)
+    loss, _, _ = crit(m, sample)
+    logits = eng.ws["logits_pad"][:, :, : ocfg.num_seg_tokens].float().cpu()
+    loss.backward()
+    torch.cuda.synchronize()
+    P, Fd = (ocfg.patch_image_size // 16) ** 2, ocfg.ffn_dim
+    Te, Td = P + 12, P + 1
+    masks = {}
+    prev = hip.set_seed_add(eng.step_dev)
+    try:
+        for kind, n, T, base in (("encoder", ocfg.enc_layers, Te, 4000), ("decoder", ocfg.dec_layers, Td, 5000)):
+            for l in range(n):
+                ones = torch.ones(B * T, Fd, dtype=torch.bfloat16, device=dev)
+                masks["%s.layers.%d." % (kind, l)] = hip.dropout_fill(ones, torch.empty_like(ones), p, eng._site_seed(base + l), fill=0.0).view(B, T, Fd)
+    finally:
+        hip.set_seed_add(prev)
+    torch.cuda.synchronize()
+    masks = {k: v.float().cpu() / (1 - p) for k, v in masks.items()}
+    perm = torch.tensor([P] + list(range(P)))          # engine rows [patches..., bos] -> reference rows [bos, patches...]
+    for l in range(ocfg.dec_layers):
+        masks["decoder.layers.%d." % l] = masks["decoder.layers.%d." % l][:, perm]
+    assert all(abs(v.mean().item() - 1.0) < 0.02 for v in masks.values())
+    seen = []
+
+    def hook(prefix, a):
+        seen.append(prefix)
+        return a * masks[prefix].to(a.dtype)
+    O.ACT_HOOK = hook
+    try:
+        o_logits, o_loss, o_grads, _ = _oracle_all_grads(ocfg, sd, batch, (128, 128))
+    finally:
+        O.ACT_HOOK = None
+    assert len(seen) == ocfg.enc_layers + ocfg.dec_layers
+    plain_logits, _, _, _ = _oracle_all_grads(ocfg, sd, batch, (128, 128))
+    print("activation dropout %.2f: logits rel-L2 %.4f (the masks move the oracle's logits by %.4f), loss %.5f vs %.5f"
+          % (p, _rel(logits, o_logits), _rel(o_logits, plain_logits), loss.item(), o_loss.item()))
+    assert _rel(o_logits, plain_logits) > 5 * _rel(logits, o_logits)
+    assert _rel(logits, o_logits) <= 2e-2 and abs(loss.item() - o_loss.item()) <= 1e-2
+    named = dict(m.named_parameters())
+    gain_scale = max(v.abs().max().item() for k, v in o_grads.items() if k.endswith("c_attn"))
+    bad, n = [], 0
+    for k, og in sorted(o_grads.items()):
+        if k not in named or not named[k].requires_grad or og.norm() == 0 or k.endswith(("k_proj.bias", "pos_k_linear.bias")):
+            continue
+        hg = named[k].grad
+        if k.endswith("c_attn"):
+            assert (hg.float().cpu() - og).abs().max().item() <= 5e-2 * gain_scale, k
+            continue
+        n += 1
+        if _rel(hg, og) > 6e-2:
+            bad.append((round(_rel(hg, og), 4), k))
+    assert n > 100 and not bad, bad[:10]
+    m.eval()
+    with torch.no_grad():
+        le, _ = m(**sample["net_input"])
+    assert _rel(le, plain_logits) <= 2e-2

@@ -207,7 +207,8 @@ def test_recipe_flags_reach_the_config_without_fairseq():
     m2 = SegOFAModel.build_model(a, task)
     assert m2.cfg.dropout == 0.0 and m2.cfg.image_bucket_size == 20 and m2.cfg.attn_scale_factor == 4.0
     assert SegOFAModel.build_model(recipe_args("segofa_tiny", num_seg_tokens=5, attention_dropout=0.1), task).cfg.attention_dropout == 0.1
-    for bad in (dict(activation_dropout=0.1), dict(scale_attn=False), dict(freeze_entire_resnet="false"),
+    assert SegOFAModel.build_model(recipe_args("segofa_tiny", num_seg_tokens=5, relu_dropout=0.2), task).cfg.activation_dropout == 0.2
+    for bad in (dict(encoder_layerdrop=0.1), dict(scale_attn=False), dict(freeze_entire_resnet="false"),
                 dict(decoder_input_type="encoder_input"), dict(tie_seg_projection="false")):
         with pytest.raises(NotImplementedError):
             SegOFAModel.build_model(recipe_args("segofa_tiny", num_seg_tokens=5, **bad), task)
