@@ -465,7 +465,7 @@ def main():
     ap.add_argument("--skip-base", action="store_true")
     ap.add_argument("--only-imfree", action="store_true")
     ap.add_argument("--only-eval", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of: optim, upgrade, lazy, base_b2, base_c3, padded")
+    ap.add_argument("--only", default="", help="comma list of: optim, upgrade, lazy, base_b2, base_c3, padded, base_padded")
     a = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -482,6 +482,9 @@ def main():
             case_lazy_init(fx, "tiny", ov, "fixture_lazy_init.npz")
         if "padded" in only:       # prompts of different lengths in one batch: key padding in encoder self- and decoder cross-attention
             case_train(fx, "tiny", ov, 3, 12, "fixture_padded.npz", GRAD_KEYS, pad_tail=[0, 3, 5])
+        if "base_padded" in only:  # configs[0] geometry with prompts of different lengths (sample 1 ends in 9 <pad>): key padding at Base size
+            case_train(O.base_config(), "base", None, 2, 36, "base_c1_padded.npz", GRAD_KEYS, full_grads=False, sub_all=True, bf16_weights=True,
+                       pad_tail=[0, 9])
         if "base_b2" in only:      # BASELINE config 1 as written: B = 2
             case_train(O.base_config(), "base", None, 2, 36, "base_c1_b2.npz", GRAD_KEYS, full_grads=False, sub_all=True, bf16_weights=True)
         if "base_c3" in only:      # BASELINE config 3 geometry on one device: Base width, 150 classes, L = 215 (T_enc 1239)

@@ -118,14 +118,16 @@ def _golden_weights(g, sd, ocfg, batch):
     return sd
 
 
-def _golden_case(golden_dir, name, ocfg, B):
+def _golden_case(golden_dir, name, ocfg, B, **model_over):
     dev = torch.device("cuda:0")
     g = np.load(os.path.join(golden_dir, name))
     assert int(g["batch_size"]) == B
     sd = O.procedural_state_dict(ocfg)
     batch = O.synthetic_batch(ocfg, B, int(g["src_len"]))
+    if "src_tokens" in g.files:          # a golden made on edited prompts (padded tails) carries them
+        batch["src_tokens"] = torch.from_numpy(g["src_tokens"])
     sd = _golden_weights(g, sd, ocfg, batch)
-    m = _base_model(ocfg, sd, dev).train()
+    m = _base_model(ocfg, sd, dev, **model_over).train()
     n = ocfg.num_seg_tokens
     loss, _, logs = _crit(ocfg)(m, _sample(batch, dev))
     loss.backward()
@@ -171,6 +173,22 @@ def _golden_case(golden_dir, name, ocfg, B):
 def test_base_config1_batch2_vs_reference_golden(golden_dir):
     """BASELINE configs[0] as written: SegOFA-Base, B = 2, 512x512, 15 classes (reference outputs: base_c1_b2.npz)."""
     _golden_case(golden_dir, "base_c1_b2.npz", O.base_config(), 2)
+
+
+def test_base_config1_padded_prompts_vs_reference_golden(golden_dir):
+    """configs[0] geometry (Base, B = 2, 512x512) with prompts of different lengths: sample 1 ends in 9 <pad> tokens.  The
+    REFERENCE's outputs with its encoder_padding_mask (encoder_module.py:730-752, unify_multihead_attention.py:477-489) are in
+    base_c1_padded.npz; the HIP path takes per-sample key counts (`padded_prompts`): the masked keys sit inside the last of the
+    34 key blocks of the encoder's self-attention and of the decoder's cross-attention.  Same tolerances as the unpadded golden."""
+    m, batch, logits, g = _golden_case(golden_dir, "base_c1_padded.npz", O.base_config(), 2, padded_prompts=True)
+    assert (batch["src_tokens"] == O.PAD).sum(1).tolist() == [0, 9]
+    un = np.load(os.path.join(golden_dir, "base_c1_b2.npz"))
+    # the padding matters: sample 1 of the reference moved against the unpadded golden (same weights, same images), sample 0 did not
+    d0 = _rel(torch.from_numpy(g["logits_causal"][0]), torch.from_numpy(un["logits_causal"][0]))
+    d1 = _rel(torch.from_numpy(g["logits_causal"][1]), torch.from_numpy(un["logits_causal"][1]))
+    e1, e1_un = _rel(logits[1], torch.from_numpy(g["logits_causal"][1])), _rel(logits[1], torch.from_numpy(un["logits_causal"][1]))
+    print("reference, padded vs unpadded golden: sample 0 %.2e, sample 1 %.4f; HIP sample 1 vs padded golden %.4f, vs unpadded golden %.4f" % (d0, d1, e1, e1_un))
+    assert d0 == 0.0 and d1 > 1e-2 and e1 < e1_un        # (at random init nine prompt tokens move the patch logits by ~2e-2 only)
 
 
 def test_base_config1_default_is_the_batch_inner_attention_everywhere(golden_dir):
