@@ -1305,7 +1305,7 @@ def test_ring_grouped_weight_gradients_are_bit_equal(cfg, monkeypatch):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("case", ["enc_rel", "cross", "enc_b5"])
+@pytest.mark.parametrize("case", ["enc_rel", "cross", "enc_b5", "big_enc"])
 def test_attn_batch_inner_key_padding(case):
     """Key padding in the batch-inner kernels (ifseg_attn_bi_args.kv_len; unify_multihead_attention.py:477-489 with the suffix
     masks of encoder_module.py:730-752): per batch element, keys at or beyond its valid count are masked in the forward and in
@@ -1366,7 +1366,7 @@ def test_attn_batch_inner_key_padding(case):
         assert dk[b, lens[b]:].abs().max().item() == 0.0 and dv[b, lens[b]:].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("case", ["enc_rel", "cross", "dec_causal", "enc_b5"])
+@pytest.mark.parametrize("case", ["enc_rel", "cross", "dec_causal", "enc_b5", "big_enc", "dec_causal_bh8"])
 def test_attn_batch_inner_attention_dropout(case):
     """Attention dropout inside the batch-inner kernels (ifseg_attn_bi_args.drop_p; unify_multihead_attention.py:498:
     attn_probs = dropout(attn_weights) between the softmax and P V).  The keep mask is a counter-based hash the forward and the
@@ -1436,6 +1436,7 @@ def test_attn_batch_inner_attention_dropout(case):
         dSb = (pr * (gain.view(1, H, 1, 1) * km * dpd - delta.unsqueeze(-1))).sum(0)
         errs["dbias"] = _rel(dbias.float().sum(0)[:, :, :S], dSb)
         errs["dgain_rows"] = _rel(dgr, (pr * km * dpd).sum(-1))
+        assert dgr.abs().sum().item() > 0
     print(case, "keep %.4f" % rate, {k_: round(v_, 5) for k_, v_ in errs.items()})
     for k_, v_ in errs.items():
         assert v_ < 2e-2, (k_, v_)
