@@ -885,6 +885,49 @@ extern "C" int ifseg_embed_bag_mean(const void* table, const long long* ids, con
   return 0;
 }
 
+// Gradient of an embedding look-up (nn.Embedding / nn.EmbeddingBag(mode='mean') backward: the token table when
+// --freeze-encoder-embedding / --freeze-decoder-embedding are false, unify_transformer.py:362-371): entries sorted by token id
+// (stable: the caller's torch.sort), entry j contributes weight[j] * src[src_row[j], :] to row sorted_ids[j] of the table
+// gradient.  One workgroup per entry; the FIRST entry of a run of equal ids sums the whole run in order and adds it to the
+// table row -- fixed summation order, no atomics, no data-dependent launch shape.  ids outside [0, V) are skipped.
+namespace {
+__global__ __launch_bounds__(256) void rows_segment_sum_kernel(const bf16_t* src, const long long* src_row, const float* weight,
+                                                               const long long* sorted_ids, bf16_t* table_grad, long long m,
+                                                               int C, long long V, long long skip_id) {
+  const long long j = blockIdx.x;
+  const long long id = sorted_ids[j];
+  if (id < 0 || id >= V || id == skip_id) return;
+  if (j > 0 && sorted_ids[j - 1] == id) return;
+  for (int c = threadIdx.x * 8; c < C; c += blockDim.x * 8) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long jj = j; jj < m && sorted_ids[jj] == id; ++jj) {
+      const float w = weight ? weight[jj] : 1.f;
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(src + src_row[jj] * C + c), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(w, f[e], acc[e]);
+    }
+    float g[8];
+    bf16_t* gp = table_grad + id * C + c;
+    unpack8(*reinterpret_cast<const uint4*>(gp), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] += acc[e];
+    *reinterpret_cast<uint4*>(gp) = pack8(g);
+  }
+}
+}  // namespace
+
+extern "C" int ifseg_rows_segment_sum(const void* src, const long long* src_row, const float* weight, const long long* sorted_ids,
+                                      void* table_grad, long long m, int C, long long V, long long skip_id, void* stream) {
+  (void)hipGetLastError();
+  if (m <= 0) return 0;
+  if ((C & 7) || !src || !src_row || !sorted_ids || !table_grad || V <= 0 || m >= (1ll << 31)) return IFSEG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(rows_segment_sum_kernel, dim3((unsigned)m), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, src_row,
+                     weight, sorted_ids, (bf16_t*)table_grad, m, C, V, skip_id);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int ifseg_cast_f32_bf16(const float* in, void* out, long long n, float scale, void* stream) {
   (void)hipGetLastError();
   if (n <= 0) return 0;

@@ -726,6 +726,16 @@ def embed_rows(table, ids, add, out):
     return out
 
 
+def rows_segment_sum(src, src_row, weight, sorted_ids, table_grad, skip_id=-1):
+    """table_grad[sorted_ids[j]] += weight[j] * src[src_row[j]] over runs of equal (sorted) ids; see csrc/rowops.hip"""
+    C = src.shape[-1]
+    assert src.is_contiguous() and table_grad.is_contiguous() and table_grad.shape[1] == C
+    assert src_row.dtype == torch.int64 and sorted_ids.dtype == torch.int64 and (weight is None or weight.dtype == torch.float32)
+    _check(lib().ifseg_rows_segment_sum(_ptr(src), _ptr(src_row), _ptr(weight), _ptr(sorted_ids), _ptr(table_grad),
+                                        c_ll(sorted_ids.numel()), c_int(C), c_ll(table_grad.shape[0]), c_ll(skip_id), _stream()),
+           "rows_segment_sum")
+
+
 def sync_master(master, p16):
     _check(lib().ifseg_sync_master(_ptr(master), _ptr(p16), c_ll(master.numel()), _stream()), "sync_master")
 

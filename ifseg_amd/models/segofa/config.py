@@ -11,7 +11,7 @@ reference's key names (SURVEY.md section 8a "state-dict contract").
 import math
 from collections import OrderedDict
 from dataclasses import dataclass
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 
@@ -43,7 +43,8 @@ class SegOFAConfig:
     decoder_drop_path_rate: float = 0.0
     # freezes of the shipped recipe (coco_unseen.sh:31-33,76)
     freeze_resnet: bool = True
-    freeze_embeddings: bool = True
+    freeze_embeddings: bool = True                 # the shared token table (encoder / decoder embed_tokens)
+    freeze_seg_embedding: Optional[bool] = None    # the seg embeddings = tied seg projection; None: as freeze_embeddings
     # prompts of different lengths in one batch (right-padded with <pad>: encoder_padding_mask, encoder_module.py:730-752, masks
     # those keys in the encoder self- and the decoder cross-attention, unify_multihead_attention.py:477-489).  Off: a padded
     # batch is refused (the IFSeg recipe gives every sample the same prompt) and a step carries no per-batch length tensor;
@@ -125,6 +126,7 @@ def param_spec(cfg: SegOFAConfig):
     C, Fd, H = cfg.embed_dim, cfg.ffn_dim, cfg.heads
     s = OrderedDict()
     fe = not cfg.freeze_embeddings
+    fs = not (cfg.freeze_embeddings if cfg.freeze_seg_embedding is None else cfg.freeze_seg_embedding)
     fr = not cfg.freeze_resnet
 
     def lin(p, o, i, tr=True):
@@ -148,7 +150,7 @@ def param_spec(cfg: SegOFAConfig):
 
     e = "encoder."
     s[e + "embed_tokens.weight"] = ((cfg.vocab_size, C), "embed", fe)
-    s[e + "seg_embed_tokens.weight"] = ((cfg.num_seg_tokens, C), "seg_embed", fe)
+    s[e + "seg_embed_tokens.weight"] = ((cfg.num_seg_tokens, C), "seg_embed", fs)
     s[e + "embed_tokens_bag.weight"] = ((cfg.vocab_size, C), "alias:encoder.embed_tokens.weight", fe)
     ln(e + "layernorm_embedding", C)
     s[e + "type_embedding.weight"] = ((2, C), "embed", True)
@@ -195,8 +197,8 @@ def param_spec(cfg: SegOFAConfig):
         s["%simage_rel_pos_table_list.%d.weight" % (e, i)] = ((n_img, H), "rel", True)
 
     d = "decoder."
-    s[d + "seg_embed_tokens.weight"] = ((cfg.num_seg_tokens, C), "alias:encoder.seg_embed_tokens.weight", fe)
-    s[d + "seg_projection.weight"] = ((cfg.num_seg_tokens, C), "alias:encoder.seg_embed_tokens.weight", fe)
+    s[d + "seg_embed_tokens.weight"] = ((cfg.num_seg_tokens, C), "alias:encoder.seg_embed_tokens.weight", fs)
+    s[d + "seg_projection.weight"] = ((cfg.num_seg_tokens, C), "alias:encoder.seg_embed_tokens.weight", fs)
     s[d + "embed_tokens.weight"] = ((cfg.vocab_size, C), "alias:encoder.embed_tokens.weight", fe)
     ln(d + "layernorm_embedding", C)
     s[d + "embed_positions.weight"] = ((cfg.max_target_positions + 2, C), "embed", True)

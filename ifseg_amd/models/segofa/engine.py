@@ -193,7 +193,11 @@ class HipEngine:
         names = dict(m.named_parameters())
         order, n_train_names = self._arena_order()
         unsupported = [n for n in order[n_train_names:] if names[n].requires_grad]
-        unsupported += [n for n, p in names.items() if "embed_images" in n and p.requires_grad]
+        unsupported += [n for n, p in names.items() if ("embed_images" in n or "image_proj" in n) and p.requires_grad]
+        # token table / seg embeddings: frozen by every shipped script; trainable ones (--freeze-*-embedding false,
+        # unify_transformer.py:362-373) get their gradients from `_embed_grads` / the seg-projection dW
+        self.train_tok = bool(names["encoder.embed_tokens.weight"].requires_grad)
+        self.train_seg = bool(names["encoder.seg_embed_tokens.weight"].requires_grad)
         if unsupported:
             raise NotImplementedError(
                 "ifseg_amd HIP engine: gradients for %s are not implemented (the shipped IFSeg recipe freezes "
@@ -935,6 +939,13 @@ class HipEngine:
             ctx["klen"] = (nonpad.sum(1) + P).to(torch.int32).contiguous()
         self.ctx_building = ctx
         e = "encoder."
+        if need_grad and getattr(self, "train_tok", False):
+            if bag is not None:
+                # (the reference steps encoder.embed_tokens_bag.weight -- EmbeddingBag.from_pretrained: a SECOND Parameter over the
+                # token table's storage, encoder_module.py:147 -- with an optimizer state of its own; not reproduced)
+                raise NotImplementedError("ifseg_amd HIP engine: the image-free entry with a trainable token table "
+                                          "(--freeze-encoder-embedding false) is not supported")
+            ctx["src_ids"] = src_tokens.reshape(-1).contiguous()
         self._params_wait(["g0"])
         # ---- embeddings (forward_embedding, encoder_module.py:388-446)
         img_pre = buf("img_pre", (B * P, C))
@@ -1043,6 +1054,7 @@ class HipEngine:
         bos = (prev_output_tokens[:, :1] if prev_output_tokens is not None
                else torch.zeros(B, 1, dtype=torch.long, device=dev))
         hip.embed_rows(W(e + "embed_tokens.weight"), bos.reshape(-1).contiguous(), None, y0b)
+        ctx["bos_ids"] = bos.reshape(-1).contiguous()
         y = buf("d_y_in", (B, Td, C))
         mu, rs = self._ln_stats("d_emb_ln_p", B * P)
         hip.ln_fwd(enc_out[:, :P], Wf(d + "layernorm_embedding.weight"), Wf(d + "layernorm_embedding.bias"), y[:, :P],
@@ -1109,6 +1121,8 @@ class HipEngine:
         mu, rs = self._ln_stats("d_final_ln_b", B)
         hip.ln_fwd(y[:, P:], Wf(d + "layer_norm.weight"), Wf(d + "layer_norm.bias"), featb[:, :1], mu, rs)
         logits = buf("logits_pad", (B, Td, self.npad))
+        if self.train_seg:      # the tied projection follows the (trainable) seg embeddings: the padded copy is rebuilt per forward
+            self.wseg_pad[: cfg.num_seg_tokens].copy_(W("encoder.seg_embed_tokens.weight"))
         hip.linear_fwd(featb.view(B * Td, C), self.wseg_pad, out=logits.view(B * Td, self.npad))   # :290-294
         self.ctx = ctx
         return logits, ctx
@@ -1241,6 +1255,8 @@ class HipEngine:
         hip.ln_fwd(y[:, :P], Wf(d + "layer_norm.weight"), Wf(d + "layer_norm.bias"), featb[:, 1:])
         hip.ln_fwd(y[:, P:], Wf(d + "layer_norm.weight"), Wf(d + "layer_norm.bias"), featb[:, :1])
         logits = buf("logits_pad", (B, Td, self.npad))
+        if getattr(self, "train_seg", False):
+            self.wseg_pad[: cfg.num_seg_tokens].copy_(W("encoder.seg_embed_tokens.weight"))
         hip.linear_fwd(featb.view(B * Td, C), self.wseg_pad, out=logits.view(B * Td, self.npad))
         self.ctx = ctx
         return logits, ctx
@@ -1820,6 +1836,11 @@ class HipEngine:
         dl.view(B, Td, self.npad)[:, :, : cfg.num_seg_tokens].copy_(dlogits)
         dfeat = buf("g_dfeat", (B, Td, C))
         hip.linear_dx(dl, self.wseg_pad, out=dfeat.view(B * Td, C))
+        if self.train_seg:
+            # tied seg projection (decoder_module.py:133-141,290-294): d seg_embed_tokens = dlogits^T feat
+            dwseg = buf("g_dwseg", (self.npad, C))
+            hip.linear_dw(dl, self.ws["d_feat"].view(B * Td, C), dwseg)
+            G("encoder.seg_embed_tokens.weight").copy_(dwseg[: cfg.num_seg_tokens])
         y = ctx["d_y_final"]
         dy = buf("g_dy_final", (B, Td, C))
         self._ln_bwd(dfeat[:, 1:], y[:, :P], d + "layer_norm", "d_final_ln_p", dy[:, :P])
@@ -1860,6 +1881,8 @@ class HipEngine:
         scratch = buf("g_bos_scratch", (B, 1, C))
         self._ln_bwd(dyb, self.ws["d_bos"], d + "layernorm_embedding", "d_emb_ln_b", scratch, accumulate=True,
                      drop=self._dropargs(4))
+        if self.train_tok:      # d embed_tokens[bos] (decoder.embed_tokens is the encoder's table: share_all_embeddings)
+            self._embed_grads(scratch.view(B, C), ctx["bos_ids"])
         # ---- decoder position operands: parameter gradients only, from accumulators the side stream filled -> the whole
         # section runs there, in order (no join of the main stream at the decoder -> encoder hand-over)
         pos_all = self.ws["e_pos_all"]
@@ -2005,10 +2028,18 @@ class HipEngine:
         self._ln_bwd(dxt, self.ws["tok_pre"].view(B, L, C), e + "layernorm_embedding", "tok_ln", dtok,
                      drop=self._dropargs(2))
         gt = G(e + "type_embedding.weight")
+        if self.train_tok:
+            self._embed_grads(dtok.view(B * L, C), self.ctx["src_ids"])
         self._bias_grad(dtok.view(B * L, C), gt[0])
         self._bias_grad(dimg.view(B * P, C), gt[1])
         self._dw_flush()                 # the LayerNorm partials of this half
         assert not self._ln_red_tasks and not self._ln_red_acc and not self._dw_tasks
+
+    def _embed_grads(self, drows, ids):
+        """nn.Embedding backward into the token table's gradient (padding_idx row excluded, as F.embedding does): rows sorted
+        by token id (torch.sort, stable, no host sync), runs of equal ids summed in order by one workgroup each"""
+        sid, perm = torch.sort(ids.reshape(-1), stable=True)
+        hip.rows_segment_sum(drows, perm, None, sid, self.G("encoder.embed_tokens.weight"), skip_id=1)
 
     def _dec_pos_bwd(self, B, P, T, Td, dspq, dspk, dcpq, dcpk, pos_all, dpos_all):
         """gradients of the decoder's position operands (self / cross abs-pos projections, seg positions) -- side stream"""

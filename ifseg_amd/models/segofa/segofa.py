@@ -234,9 +234,10 @@ class SegOFAModel(ModelBase):
             refuse("--decoder-input-type %s" % g("decoder_input_type"))
         if not str_bool(g("tie_seg_projection")):
             refuse("--tie-seg-projection=false")
-        for k in ("freeze_entire_resnet", "freeze_encoder_embedding", "freeze_decoder_embedding", "freeze_seg_embedding"):
-            if not str_bool(g(k)):
-                refuse("--%s=false (gradients of the ResNet trunk / token embeddings)" % k.replace("_", "-"))
+        if not str_bool(g("freeze_entire_resnet")):
+            refuse("--freeze-entire-resnet=false (gradients of the ResNet trunk / image_proj)")
+        # --freeze-encoder-embedding / --freeze-decoder-embedding / --freeze-seg-embedding false: built (the token table is ONE
+        # tensor under share_all_embeddings -- unify_transformer.py:340-372 -- so either flag freezes it)
         if str_bool(g("freeze_encoder_transformer")) or int(g("freeze_encoder_transformer_layers", 0) or 0):
             refuse("--freeze-encoder-transformer")
         if g("encoder_layers_to_keep") or g("decoder_layers_to_keep"):
@@ -261,7 +262,9 @@ class SegOFAModel(ModelBase):
             dropout=float(g("dropout", 0.0) or 0.0), attention_dropout=float(g("attention_dropout", 0.0) or 0.0),
             activation_dropout=float(g("activation_dropout", 0.0) or 0.0) or float(g("relu_dropout", 0.0) or 0.0),
             encoder_drop_path_rate=float(g("encoder_drop_path_rate", 0.0) or 0.0),
-            decoder_drop_path_rate=float(g("decoder_drop_path_rate", 0.0) or 0.0))
+            decoder_drop_path_rate=float(g("decoder_drop_path_rate", 0.0) or 0.0),
+            freeze_embeddings=str_bool(g("freeze_encoder_embedding")) or str_bool(g("freeze_decoder_embedding")),
+            freeze_seg_embedding=str_bool(g("freeze_seg_embedding")))
         model = cls(cfg, args=args)
         model.encoder.dictionary = src_dict
         model.decoder.dictionary = tgt_dict

@@ -366,6 +366,13 @@ int ifseg_colsum_bf16(const void* x, float* part, int nblk_rows, int M, int N, i
 int ifseg_kproj_common_mode(void* gw, const void* db, const float* xmean, int N, int C, void* stream);
 int ifseg_embed_rows(const void* table, const long long* ids, const void* add, void* out, int n, int C, int rpb,
                      long long o_bs, int ldo, void* stream);
+/* Backward of the embedding look-ups above into the token table's gradient (trainable token embeddings:
+ * --freeze-encoder-embedding / --freeze-decoder-embedding false, unify_transformer.py:362-371; nn.Embedding /
+ * nn.EmbeddingBag(mean) backward).  m entries sorted by token id (stable); entry j adds weight[j] (NULL: 1) x src[src_row[j], :]
+ * (bf16 [*, C] contiguous) to row sorted_ids[j] of table_grad (bf16 [V, C], accumulated in place); ids outside [0, V) and
+ * skip_id (the padding index, -1: none) are skipped.  Deterministic: the first entry of a run sums the run in order. */
+int ifseg_rows_segment_sum(const void* src, const long long* src_row, const float* weight, const long long* sorted_ids,
+                           void* table_grad, long long m, int C, long long V, long long skip_id, void* stream);
 /* Image-free patch embeddings: out[b,p,:] = mean of table rows ids[b, ends[b,p-1]:ends[b,p]] + add
  * (nn.EmbeddingBag(mode='mean') sharing embed_tokens.weight, encoder_module.py:147-148,529-538, + the image
  * type embedding :589-591).  ids int64 [B,maxlen] (row-padded), ends int64 [B,P] per-sample cumulative bag ends

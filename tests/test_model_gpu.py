@@ -19,17 +19,17 @@ def _rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-def _product_cfg(ocfg):
+def _product_cfg(ocfg, **over):
     from ifseg_amd.models.segofa import make_config
-    return make_config("segofa_tiny", embed_dim=ocfg.embed_dim, ffn_dim=ocfg.ffn_dim, heads=ocfg.heads,
+    return make_config("segofa_tiny", **over, embed_dim=ocfg.embed_dim, ffn_dim=ocfg.ffn_dim, heads=ocfg.heads,
                        enc_layers=ocfg.enc_layers, dec_layers=ocfg.dec_layers, resnet_layers=ocfg.resnet_layers,
                        num_seg_tokens=ocfg.num_seg_tokens, vocab_size=ocfg.vocab_size,
                        patch_image_size=ocfg.patch_image_size, orig_patch_image_size=ocfg.orig_patch_image_size)
 
 
-def _build(ocfg, sd, dev):
+def _build(ocfg, sd, dev, **over):
     from ifseg_amd.models.segofa import SegOFAModel
-    m = SegOFAModel(_product_cfg(ocfg))
+    m = SegOFAModel(_product_cfg(ocfg, **over))
     missing, unexpected = torch.nn.Module.load_state_dict(m, sd, strict=False)
     assert not unexpected, unexpected
     assert all(k.endswith(("_rp_bucket", "version", "image_position_idx", "_offset", "region_prefix")) for k in missing), missing
@@ -1090,3 +1090,112 @@ def test_activation_dropout_against_the_oracle_with_the_same_masks():
     with torch.no_grad():
         le, _ = m(**sample["net_input"])
     assert _rel(le, plain_logits) <= 2e-2
+
+
+
+def test_trainable_token_and_seg_embeddings_vs_the_oracle():
+    """--freeze-encoder-embedding / --freeze-decoder-embedding / --freeze-seg-embedding false (unify_transformer.py:362-373;
+    every shipped script freezes all three): the token table's gradient is the nn.Embedding backward of the prompt tokens and
+    of the decoder's bos row (one shared tensor; padding_idx row excluded), the seg embeddings' gradient is the tied projection's
+    dlogits^T feat.  Against the oracle's autograd on the same (here: padded, repeated-token) batch; every other gradient
+    unchanged; an optimizer step moves both tensors and the next forward -- training and evaluation -- projects with the
+    stepped seg embeddings; the image-free entry with a trainable token table is refused by name."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ifseg_amd.criterions import SegCriterion
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    B = 3
+    batch = O.synthetic_batch(ocfg, B, 12)
+    batch["src_tokens"][1, -3:] = O.PAD; batch["src_tokens"][1, -4] = O.EOS            # one padded prompt
+    batch["src_tokens"][2, 3] = batch["src_tokens"][0, 5]                              # a token shared between samples
+    m = _build(ocfg, sd, dev, freeze_embeddings=False, padded_prompts=True)
+    assert m.encoder.embed_tokens.weight.requires_grad and m.decoder.seg_projection.weight.requires_grad
+    m.train()
+    crit = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+    sample = {"net_input": {k: batch[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks", "prev_output_tokens")},
+              "target": batch["target"].to(dev), "ntokens": 1, "nsentences": B}
+    sample["net_input"]["src_lengths"] = torch.full((B,), 12).to(dev)
+    loss, _, _ = crit(m, sample)
+    logits = m.engine.ws["logits_pad"][:, :, : ocfg.num_seg_tokens].float().cpu()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert m.engine.train_tok and m.engine.train_seg
+    o_logits, o_loss, o_grads, _ = _oracle_all_grads(ocfg, sd, batch, (128, 128))
+    assert _rel(logits, o_logits) <= 2e-2 and abs(loss.item() - o_loss.item()) <= 1e-2
+    named = dict(m.named_parameters())
+    gt, ot = named["encoder.embed_tokens.weight"].grad.float().cpu(), o_grads["encoder.embed_tokens.weight"]
+    gs, os_ = named["encoder.seg_embed_tokens.weight"].grad.float().cpu(), o_grads["encoder.seg_embed_tokens.weight"]
+    used = ot.abs().sum(1) > 0
+    print("token table: %d rows with a gradient, rel-L2 %.4f; seg embeddings rel-L2 %.4f" % (int(used.sum()), _rel(gt, ot), _rel(gs, os_)))
+    assert int(used.sum()) >= 12 and gt[~used].abs().max().item() == 0.0 and gt[O.PAD].abs().max().item() == 0.0
+    assert _rel(gt, ot) <= 6e-2 and _rel(gs, os_) <= 6e-2
+    for r in torch.nonzero(used).flatten().tolist():                     # row by row (bos: encoder + decoder contributions)
+        assert _rel(gt[r], ot[r]) <= 8e-2, r
+    bad = []
+    for k, og in sorted(o_grads.items()):
+        if k in named and named[k].requires_grad and og.norm() > 0 and not k.endswith(("k_proj.bias", "pos_k_linear.bias", "c_attn")):
+            if _rel(named[k].grad, og) > 6e-2:
+                bad.append((round(_rel(named[k].grad, og), 4), k))
+    assert not bad, bad[:10]
+    # one plain SGD step from outside on the two tensors: the tied projection follows in training and evaluation
+    with torch.no_grad():
+        for k in ("encoder.embed_tokens.weight", "encoder.seg_embed_tokens.weight"):
+            named[k].data.add_(named[k].grad, alpha=-0.5)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    spec = O.state_dict_spec(ocfg)
+    for k in ("encoder.embed_tokens.weight", "encoder.seg_embed_tokens.weight"):
+        sd2[k] = named[k].data.float().cpu()
+    for k, (_, kind) in spec.items():
+        if kind.startswith("alias:") and kind[6:] in ("encoder.embed_tokens.weight", "encoder.seg_embed_tokens.weight"):
+            sd2[k] = sd2[kind[6:]]
+    loss2, _, _ = crit(m, sample)
+    l2 = m.engine.ws["logits_pad"][:, :, : ocfg.num_seg_tokens].float().cpu()
+    o2, _, _, _ = _oracle_all_grads(ocfg, sd2, batch, (128, 128))
+    assert _rel(o2, o_logits) > 5e-2 and _rel(l2, o2) <= 2e-2, (_rel(o2, o_logits), _rel(l2, o2))
+    m.eval()
+    with torch.no_grad():
+        le, _ = m(**sample["net_input"])
+    assert _rel(le, o2) <= 2e-2
+    m.train()
+    aux = O.synthetic_aux_batch(ocfg, B, 12)
+    with pytest.raises(NotImplementedError):
+        m(**sample["net_input"], aux_input={k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in aux["aux_input"].items()})
+
+
+def test_trainer_steps_trainable_embeddings_through_the_reference_flags():
+    """The fairseq surface: --freeze-encoder-embedding=false --freeze-decoder-embedding=false --freeze-seg-embedding=false
+    (segofa.py build_model -> SegOFAConfig.freeze_embeddings / freeze_seg_embedding).  The bundled Trainer's arena then holds
+    the token table ("emb" slice of optimizer_plan) and the seg embeddings; three updates move both, only in the rows that
+    received a gradient (weight decay 0), and the loss of the fixed batch goes down."""
+    from ifseg_amd.criterions import SegCriterion
+    from ifseg_amd.models.segofa.segofa import SegOFAModel, recipe_args
+    from ifseg_amd.tasks.mm_tasks import SegmentationTask
+    from ifseg_amd.trainer import Trainer, optimizer_plan
+    dev = torch.device("cuda:0")
+    task = SegmentationTask(num_seg_tokens=5, patch_image_size=128, arch="segofa_tiny")
+    torch.manual_seed(0)
+    args = recipe_args("segofa_tiny", num_seg_tokens=5, patch_image_size=128, orig_patch_image_size=128, dropout=0.0,
+                       encoder_drop_path_rate=0.0, decoder_drop_path_rate=0.0, freeze_encoder_embedding="false",
+                       freeze_decoder_embedding="false", freeze_seg_embedding="false")
+    model = SegOFAModel.build_model(args, task)
+    assert not model.cfg.freeze_embeddings and model.cfg.freeze_seg_embedding is False
+    tr = Trainer(model, SegCriterion(task, unsupervised_segmentation=False, init_seg_with_text=False), task, lr=3e-4, weight_decay=0.0, device=dev)
+    s = task.synthetic_sample(2, dev, seed=0)
+    tok0 = model.encoder.embed_tokens.weight.detach().float().clone()
+    seg0 = model.decoder.seg_projection.weight.detach().float().clone()
+    losses = [float(tr.train_step([s])[0]["loss"]) for _ in range(8)]
+    torch.cuda.synchronize()
+    plan = dict(optimizer_plan(tr.eng))
+    assert "emb" in plan
+    dt = (model.encoder.embed_tokens.weight.detach().float() - tok0).abs().sum(1)
+    ds = (model.decoder.seg_projection.weight.detach().float() - seg0).abs().sum(1)
+    used = torch.zeros(tok0.shape[0], dtype=torch.bool, device=dev)
+    used[s["net_input"]["src_tokens"].reshape(-1)] = True
+    used[s["net_input"]["prev_output_tokens"][:, 0]] = True
+    used[1] = False                                                        # padding_idx
+    print("trainable embeddings through the trainer: losses", [round(x, 4) for x in losses], "rows moved", int((dt > 0).sum()), "of", int(used.sum()))
+    assert (dt[used] > 0).all() and (dt[~used] == 0).all() and (ds > 0).all()
+    assert losses[-1] < losses[0]
+    tr.close()
