@@ -211,6 +211,8 @@ def main():
             dist.init_process_group(backend)                       # functional test on a 1-GPU box
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if os.environ.get("IFSEG_MAIN_PRIO"):       # laboratory: the step's main stream as a created stream of this priority
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["IFSEG_MAIN_PRIO"])))
 
     from ifseg_amd import hip
     from ifseg_amd.criterions import SegCriterion
