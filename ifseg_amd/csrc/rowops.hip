@@ -188,8 +188,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const bf16
 // WPR = waves per row: 1 (narrow rows: a wave owns a row, four rows per block in flight) or 4 (wide rows: the
 // block owns a row, a thread keeps NCH <= 2 chunks so the three per-column accumulators stay in registers).
 // The next row's x / dy are fetched (as packed bf16) while the current row is reduced.
+#ifndef LN_BWD_MINWAVES
+#define LN_BWD_MINWAVES 1
+#endif
 template <int NCH, bool GELU, int WPR>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
+__global__ __launch_bounds__(256, LN_BWD_MINWAVES) void ln_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
                                                      const float* mean, const float* rstd, const bf16_t* dx_add,
                                                      bf16_t* dx, float* dgamma_part, float* dbeta_part, int rows, int C,
                                                      RowMap mdy, RowMap mx, RowMap mdx, RowMap madd, DropArgs drop, int pf32) {
@@ -316,6 +319,112 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
             const float sum = r4[0][t] + r4[1][t] + r4[2][t] + r4[3][t];
             (pass ? dbeta_part : dgamma_part)[(long long)blockIdx.x * C + c * 8 + (t & 7)] = sum;
           }
+        }
+      }
+    }
+  }
+}
+
+// ln_bwd, narrow rows (C <= 1024, one wave per row, no GELU), register-lean: the row's dy / x stay PACKED (bf16) across the two
+// row reductions and the second pass recomputes g and xhat from them with the same statements (bit-identical results) instead of
+// holding two fp32 copies of the row; no software prefetch.  ~100 VGPRs instead of 146: next to the grouped weight-gradient
+// GEMM of the side stream (two workgroups per CU, 2 x 128 VGPRs per SIMD) two of these waves fit on a SIMD instead of one.
+// IFSEG_LN_BWD_LEAN=1 selects it (laboratory: DESIGN.md round 5 (10)).
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_lean_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
+                                                          const float* mean, const float* rstd, const bf16_t* dx_add,
+                                                          bf16_t* dx, float* dgamma_part, float* dbeta_part, int rows, int C,
+                                                          RowMap mdy, RowMap mx, RowMap mdx, RowMap madd, DropArgs drop, int pf32) {
+  __shared__ float red[4 * (64 * 8 + 8)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  float gam[NCH][8], dg[NCH][8], db[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) ldp8(gamma, c, pf32, gam[i]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; if (c >= nch) gam[i][e] = 0.f; }
+  }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    const bf16_t* xp = x + mx.off(row);
+    const bf16_t* dyp = dy + mdy.off(row);
+    uint4 rx[NCH], rd[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        rx[i] = *reinterpret_cast<const uint4*>(xp + c * 8);
+        rd[i] = *reinterpret_cast<const uint4*>(dyp + c * 8);
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        float xr[8], d[8];
+        unpack8(rx[i], xr);
+        unpack8(rd[i], d);
+        if (drop.on) drop8(d, drop, (long long)row * nch + c, row);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xr[e] - mu) * rs;
+          const float g = d[e] * gam[i][e];
+          dg[i][e] += d[e] * xh; db[i][e] += d[e];
+          s1 += g; s2 += g * xh;
+        }
+      }
+    }
+    s1 = warp_sum(s1); s2 = warp_sum(s2);
+    s1 /= C; s2 /= C;
+    // (opaque to the optimiser: the second pass must RE-derive xhat and g from the packed row instead of keeping the first
+    // pass's 32 fp32 values alive across the reductions)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      asm volatile("" : "+v"(rx[i].x), "+v"(rx[i].y), "+v"(rx[i].z), "+v"(rx[i].w), "+v"(rd[i].x), "+v"(rd[i].y), "+v"(rd[i].z), "+v"(rd[i].w));
+    bf16_t* dxp = dx + mdx.off(row);
+    const bf16_t* ap = dx_add ? dx_add + madd.off(row) : nullptr;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        float xr[8], d[8], o[8];
+        unpack8(rx[i], xr);
+        unpack8(rd[i], d);
+        if (drop.on) drop8(d, drop, (long long)row * nch + c, row);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xr[e] - mu) * rs;
+          const float g = d[e] * gam[i][e];
+          o[e] = rs * (g - s1 - xh * s2) * 1.f;
+        }
+        if (ap) {
+          float r[8];
+          unpack8(*reinterpret_cast<const uint4*>(ap + c * 8), r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += r[e];
+        }
+        *reinterpret_cast<uint4*>(dxp + c * 8) = pack8(o);
+      }
+    }
+  }
+  if (!dgamma_part) return;
+  float (*r4)[64 * 8 + 8] = reinterpret_cast<float (*)[64 * 8 + 8]>(red);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r4[wave][lane * 8 + e] = pass ? db[i][e] : dg[i][e];
+      __syncthreads();
+      for (int t = threadIdx.x; t < 512; t += 256) {
+        const int c = (t >> 3) + i * 64;
+        if (c < nch) {
+          const float sum = r4[0][t] + r4[1][t] + r4[2][t] + r4[3][t];
+          (pass ? dbeta_part : dgamma_part)[(long long)blockIdx.x * C + c * 8 + (t & 7)] = sum;
         }
       }
     }
@@ -689,7 +798,11 @@ extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, co
   hipStream_t s = (hipStream_t)stream;
   const bf16_t *DY = (const bf16_t*)dy, *X = (const bf16_t*)x, *G = (const bf16_t*)gamma, *A = (const bf16_t*)dx_add;
   ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 8.0 : 6.0));
-  if (C <= 1024) launch_ln_bwd<2, 1>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd, dr);
+  static const bool lean = getenv("IFSEG_LN_BWD_LEAN") != nullptr;
+  if (C <= 1024 && lean && !(act_gelu & IFSEG_LN_GELU))
+    hipLaunchKernelGGL((ln_bwd_lean_kernel<2>), g, dim3(256), 0, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C,
+                       mdy, mx, mdx, madd, dr, (act_gelu & IFSEG_LN_PARAMS_F32) ? 1 : 0);
+  else if (C <= 1024) launch_ln_bwd<2, 1>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd, dr);
   else launch_ln_bwd<2, 4>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd, dr);
   ifseg_prof_end(IFSEG_K_LN_BWD, s);
   IFSEG_CHECK_LAUNCH();
