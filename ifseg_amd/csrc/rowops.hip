@@ -325,16 +325,20 @@ __global__ __launch_bounds__(256, LN_BWD_MINWAVES) void ln_bwd_kernel(const bf16
   }
 }
 
-// ln_bwd, narrow rows (C <= 1024, one wave per row, no GELU), register-lean: the row's dy / x stay PACKED (bf16) across the two
-// row reductions and the second pass recomputes g and xhat from them with the same statements (bit-identical results) instead of
-// holding two fp32 copies of the row; no software prefetch.  ~100 VGPRs instead of 146: next to the grouped weight-gradient
-// GEMM of the side stream (two workgroups per CU, 2 x 128 VGPRs per SIMD) two of these waves fit on a SIMD instead of one.
-// IFSEG_LN_BWD_LEAN=1 selects it (laboratory: DESIGN.md round 5 (10)).
-template <int NCH>
+// ln_bwd, narrow rows (C <= 1024, one wave per row, no GELU), register-lean (round 5): the row's dy / x stay PACKED (bf16)
+// across the two row reductions and the second pass re-derives g and xhat from them with the first pass's statements -- g by an
+// explicitly rounded multiply -- instead of holding two fp32 copies of the row; no software prefetch.  118 VGPRs instead of
+// 146 (4 waves per SIMD), 11-13 % faster alone (tools/ln_bench.py).  Against ln_bwd_kernel<2, false, 1> the per-block partial
+// sums are bit-identical and dx differs in ~1e-5 of its elements by one bf16 ulp (tools/ln_hash.py: the compiler fuses the
+// row sums' multiply-adds differently in the two kernels).  DX2: the second output of ifseg_ln_bwd_drop,
+// dx2 = drop2(dx as stored in bf16) -- the same instantiation as the plain call, so the pair stays bit-identical to
+// ifseg_ln_bwd followed by ifseg_dropout.  IFSEG_LN_BWD_CLASSIC=1 selects the former kernels.
+template <int NCH, bool DX2>
 __global__ __launch_bounds__(256) void ln_bwd_lean_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
                                                           const float* mean, const float* rstd, const bf16_t* dx_add,
                                                           bf16_t* dx, float* dgamma_part, float* dbeta_part, int rows, int C,
-                                                          RowMap mdy, RowMap mx, RowMap mdx, RowMap madd, DropArgs drop, int pf32) {
+                                                          RowMap mdy, RowMap mx, RowMap mdx, RowMap madd, DropArgs drop, int pf32,
+                                                          bf16_t* dx2, RowMap mdx2, DropArgs drop2) {
   __shared__ float red[4 * (64 * 8 + 8)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C >> 3;
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(256) void ln_bwd_lean_kernel(const bf16_t* dy, cons
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float xh = (xr[e] - mu) * rs;
-          const float g = d[e] * gam[i][e];
+          const float g = __fmul_rn(d[e], gam[i][e]);           // (rounded as the first pass's g was)
           o[e] = rs * (g - s1 - xh * s2) * 1.f;
         }
         if (ap) {
@@ -406,7 +410,14 @@ __global__ __launch_bounds__(256) void ln_bwd_lean_kernel(const bf16_t* dy, cons
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] += r[e];
         }
-        *reinterpret_cast<uint4*>(dxp + c * 8) = pack8(o);
+        const uint4 pk = pack8(o);
+        *reinterpret_cast<uint4*>(dxp + c * 8) = pk;
+        if (DX2) {
+          float d2[8];
+          unpack8(pk, d2);                               // the adjoint sees dx as stored
+          if (drop2.on) drop8(d2, drop2, (long long)row * nch + c, row);
+          *reinterpret_cast<uint4*>(dx2 + mdx2.off(row) + c * 8) = pack8(d2);
+        }
       }
     }
   }
@@ -798,10 +809,10 @@ extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, co
   hipStream_t s = (hipStream_t)stream;
   const bf16_t *DY = (const bf16_t*)dy, *X = (const bf16_t*)x, *G = (const bf16_t*)gamma, *A = (const bf16_t*)dx_add;
   ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 8.0 : 6.0));
-  static const bool lean = getenv("IFSEG_LN_BWD_LEAN") != nullptr;
+  static const bool lean = getenv("IFSEG_LN_BWD_CLASSIC") == nullptr;
   if (C <= 1024 && lean && !(act_gelu & IFSEG_LN_GELU))
-    hipLaunchKernelGGL((ln_bwd_lean_kernel<2>), g, dim3(256), 0, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C,
-                       mdy, mx, mdx, madd, dr, (act_gelu & IFSEG_LN_PARAMS_F32) ? 1 : 0);
+    hipLaunchKernelGGL((ln_bwd_lean_kernel<2, false>), g, dim3(256), 0, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C,
+                       mdy, mx, mdx, madd, dr, (act_gelu & IFSEG_LN_PARAMS_F32) ? 1 : 0, (bf16_t*)nullptr, RowMap{}, DropArgs{});
   else if (C <= 1024) launch_ln_bwd<2, 1>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd, dr);
   else launch_ln_bwd<2, 4>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd, dr);
   ifseg_prof_end(IFSEG_K_LN_BWD, s);
@@ -827,9 +838,15 @@ extern "C" int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamm
   RowMap mdy{rpb, dy_bs, lddy}, mx{rpb, x_bs, ldx}, mdx{rpb, dx_bs, lddx}, madd{rpb, add_bs, ldadd}, mdx2{rpb, dx2_bs, lddx2};
   hipStream_t s = (hipStream_t)stream;
   ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 10.0 : 8.0));
-  hipLaunchKernelGGL(ln_bwd_drop_kernel, dim3(nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
-                     (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, dgamma_part, dbeta_part,
-                     (bf16_t*)dx2, rows, C, mdy, mx, mdx, madd, mdx2, dr, (flags & IFSEG_LN_PARAMS_F32) ? 1 : 0);
+  static const bool lean = getenv("IFSEG_LN_BWD_CLASSIC") == nullptr;
+  if (lean)
+    hipLaunchKernelGGL((ln_bwd_lean_kernel<2, true>), dim3(nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
+                       (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C,
+                       mdy, mx, mdx, madd, DropArgs{}, (flags & IFSEG_LN_PARAMS_F32) ? 1 : 0, (bf16_t*)dx2, mdx2, dr);
+  else
+    hipLaunchKernelGGL(ln_bwd_drop_kernel, dim3(nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
+                       (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, dgamma_part, dbeta_part,
+                       (bf16_t*)dx2, rows, C, mdy, mx, mdx, madd, mdx2, dr, (flags & IFSEG_LN_PARAMS_F32) ? 1 : 0);
   ifseg_prof_end(IFSEG_K_LN_BWD, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
