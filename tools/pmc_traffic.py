@@ -7,7 +7,7 @@ FAM = [("attn_bwd_dkv", r"attn_(bwd|bi)_dkv_kernel"), ("attn_bwd_dq", r"attn_(bw
        ("attn_dense_bias", r"attn_dense_bias_kernel"), ("attn_dbias_grads", r"attn_dbias_grads_kernel"), ("attn_dbias_tables", r"attn_dbias_tables_kernel"),
        ("attn_bwd_reduce", r"attn_bwd_reduce_kernel"), ("gemm_nn_gln", r"gemm_nn_gln_kernel"),
        ("gemm_nt", r"gemm_kernel<0, false"), ("gemm_nn", r"gemm_kernel<0, true"), ("gemm_tn", r"gemm_kernel<1, true"), ("gemm_tn_group", r"gemm_tn_group_kernel"),
-       ("conv", r"gemm_kernel<2, "), ("ln_fwd", r"ln_fwd_kernel"), ("ln_bwd", r"ln_bwd(_drop)?_kernel"), ("adam", r"adam_kernel")]
+       ("conv", r"gemm_kernel<2, "), ("ln_fwd", r"ln_fwd_kernel"), ("ln_bwd", r"ln_bwd(_drop|_lean)?_kernel"), ("adam", r"adam_kernel")]
 
 def collect(d, counter):
     acc = collections.defaultdict(lambda: [0.0, 0])
