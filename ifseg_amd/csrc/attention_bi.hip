@@ -773,6 +773,7 @@ struct DenseArgs {
   const int* gcode;
   const float *rel2d, *rel1d, *relx;
   float* D;
+  int round_bf16;             // IFSEG_EXP_D_BF16 (measurement): every entry rounded to bf16 -- what a bf16 bias operand would hold
 };
 
 // D[h][i][j] = pos_q[i] . pos_k[j] + rel(i, j) as [H][Tp][Sp], -inf where (i, j) is masked (causal, "tail-first" order),
@@ -842,7 +843,11 @@ __global__ __launch_bounds__(512) void attn_dense_bias_kernel(DenseArgs a) {
       for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          dp[(long long)(8 * rg + e) * a.Sp] = dead ? NEG_INF : entry(i0 + 8 * rg + 4 * half + e, j0 + x, acc[rg * 4 + e]);
+          {
+            float v = dead ? NEG_INF : entry(i0 + 8 * rg + 4 * half + e, j0 + x, acc[rg * 4 + e]);
+            if (a.round_bf16) v = bf2f(f2bf(v));
+            dp[(long long)(8 * rg + e) * a.Sp] = v;
+          }
     }
   }
 }
@@ -1232,6 +1237,8 @@ extern "C" int ifseg_attn_dense_bias(const void* pos_q, const void* pos_k, int l
   a.H = H; a.T = T; a.S = S; a.Sp = Sp; a.Tp = Tp;
   a.rel_mode = rel_mode; a.P = (rel_mode || causal) ? P : S; a.code_bias = code_bias; a.n2d = rel_mode ? n2d : 0; a.Lt = rel_mode ? T - P : 0; a.causal = causal;
   a.gcode = gcode; a.rel2d = rel2d; a.rel1d = rel1d; a.relx = relx; a.D = D;
+  static const int round_bf16 = getenv("IFSEG_EXP_D_BF16") ? 1 : 0;
+  a.round_bf16 = round_bf16;
   const size_t lds = rel_mode ? ((((size_t)n2d + 3) & ~(size_t)3) + (((size_t)2 * a.Lt + 2) & ~(size_t)3) + (size_t)P) * 4 : 16;
   if (lds > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_dense_bias_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
