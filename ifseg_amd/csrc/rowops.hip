@@ -188,11 +188,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const bf16
 // WPR = waves per row: 1 (narrow rows: a wave owns a row, four rows per block in flight) or 4 (wide rows: the
 // block owns a row, a thread keeps NCH <= 2 chunks so the three per-column accumulators stay in registers).
 // The next row's x / dy are fetched (as packed bf16) while the current row is reduced.
-#ifndef LN_BWD_MINWAVES
-#define LN_BWD_MINWAVES 1
-#endif
 template <int NCH, bool GELU, int WPR>
-__global__ __launch_bounds__(256, LN_BWD_MINWAVES) void ln_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
                                                      const float* mean, const float* rstd, const bf16_t* dx_add,
                                                      bf16_t* dx, float* dgamma_part, float* dbeta_part, int rows, int C,
                                                      RowMap mdy, RowMap mx, RowMap mdx, RowMap madd, DropArgs drop, int pf32) {
