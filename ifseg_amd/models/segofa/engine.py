@@ -119,6 +119,7 @@ class HipEngine:
         # where the NEXT batch's frozen-trunk pass is launched: "fwd" = at the start of this step's forward, "e<k>" = when
         # the backward reaches encoder layer k, "end" = after the last backward kernel of the main stream
         self.trunk_at = os.environ.get("IFSEG_TRUNK_AT", "fwd")
+        self.tail_pos_main = os.environ.get("IFSEG_TAIL_POS_MAIN") == "1"
         self._bt = ""                    # tag of the backward block being processed (unique gradient buffers)
 
     # ------------------------------------------------------------------ packing
@@ -1908,6 +1909,11 @@ class HipEngine:
                                        ("%stoken_rel_pos_table_list.%d.weight" % (e, l), g["enc_idx1d"]),
                                        (None, None)], nxt=nx_f)
             dbr = nx_f["out"] if nx_f else None
+            if l == 0 and self.tail_pos_main and self.overlap:
+                # the abs-pos accumulators are complete once layer 0's bias-gradient kernels have run: an event on the side
+                # stream BEFORE that layer's weight-gradient group, for the main stream's abs-pos tail (below)
+                pos_ready = self._ev()
+                self._side_do(lambda ev=pos_ready: ev.record(self._side))
             self._side_do(lambda p=p: (self._flush_tables(), self._notify(p)))
             self._side_flush()
         # ---- encoder abs-pos operands
@@ -1917,6 +1923,14 @@ class HipEngine:
         if "tailsplit" in _EXP_SKIP:     # (measurement: the whole tail on the side stream, capped grid)
             self._side_do(lambda: (self._dw_flush(), self._enc_tail_pos_bwd(B, L, P, T, h, w, depq, depk, pos_all, dpos_all),
                                    self._enc_tail_emb_bwd(B, L, P, T, dx)))
+        elif self.tail_pos_main and self.overlap and cfg.enc_layers > 0:
+            # both halves of the tail on the main stream, NEXT TO the side stream's last weight-gradient group instead of behind it
+            # (the abs-pos half only waits for the bias-gradient kernels of layer 0: `pos_ready`)
+            self._side_do(lambda: self._dw_flush(wgs=0))
+            self._side_flush()
+            self._enc_tail_emb_bwd(B, L, P, T, dx)
+            torch.cuda.current_stream().wait_event(pos_ready)
+            self._enc_tail_pos_bwd(B, L, P, T, h, w, depq, depk, pos_all, dpos_all)
         else:
             self._side_do(lambda: (self._dw_flush(wgs=0), self._enc_tail_pos_bwd(B, L, P, T, h, w, depq, depk, pos_all, dpos_all)))
             self._side_flush()
