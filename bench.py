@@ -175,13 +175,19 @@ def main():
     ap.add_argument("--image-free", action="store_true",
                     help="the recipe's image-free step (SURVEY 8f row 1, coco_unseen.sh:51): loss on an artificial image "
                          "(EmbeddingBag patches, no trunk) + a no-grad pass over the real images for the metrics")
+    ap.add_argument("--lab", action="store_true",
+                    help="laboratory run: accept IFSEG_LAB=1 (the gate of every A/B switch, ifseg_amd/lab.py); the line is "
+                         "marked \"lab\": true and is not a record")
     a = ap.parse_args()
-    # a record must not come from a run that leaves work out: experiment switches (IFSEG_EXP_*: kernels skipped, bias work
-    # compiled out) abort the run, and every IFSEG_* variable that was set is printed into the line (config.env)
+    # a record must not come from a run that leaves work out or runs a non-default path: experiment switches (IFSEG_EXP_*:
+    # kernels skipped, bias work compiled out) and the laboratory gate (IFSEG_LAB=1, without --lab) abort the run, and every
+    # IFSEG_* variable that was set is printed into the line (config.env)
     env_seen = {k: v for k, v in sorted(os.environ.items()) if k.startswith("IFSEG_")}
     exp = [k for k in env_seen if k.startswith("IFSEG_EXP_") or k in ("IFSEG_RING_ABLATE",)]
+    if os.environ.get("IFSEG_LAB") == "1" and not a.lab:
+        exp.append("IFSEG_LAB")
     if exp:
-        sys.stderr.write("bench.py: experiment switch(es) %s set -- they leave work out of the step; refusing to report a number\n" % ", ".join(exp))
+        sys.stderr.write("bench.py: experiment / laboratory switch(es) %s set -- not the product's default step; refusing to report a number\n" % ", ".join(exp))
         sys.exit(3)
     C = CONFIGS[a.config]
     if a.batch is None:
@@ -412,6 +418,7 @@ def main():
                              PROF_STRIDE, " (on %d eagerly enqueued steps after the timed graph replays)" % min(10, a.steps) if graphed else ""),
                          "whole_step_frac": round(value / world * gf_img / 1e3 / MFMA_PEAK_TF, 4) if gf_img else None,
                          "gflop_per_image": gf_img},
+            **({"lab": True} if os.environ.get("IFSEG_LAB") == "1" else {}),
             "roofline_gemm_kernel": _group_roofline(grs, extra),
             "roofline_other_kernels": {r["kind"]: _one_roofline(r, extra) for r in ors},
             "kernel_families_ms_per_step": {f["kind"]: round(f["ms"], 3) for f in fam},

@@ -19,6 +19,9 @@ GEMM_RELU, GEMM_OUT_F32, GEMM_ACCUMULATE = 1, 2, 4
 c_void_p, c_int, c_float, c_ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 
 
+ABI_VERSION = 16          # == IFSEG_ABI_VERSION of include/ifseg_hip.h (checked at load time and by __graft_entry__.build)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -33,7 +36,7 @@ def lib():
         ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ifseg_abi_version.restype = c_int
-        if _lib.ifseg_abi_version() != 15:
+        if _lib.ifseg_abi_version() != ABI_VERSION:
             raise RuntimeError("ifseg_amd: ABI version mismatch")
     return _lib
 
@@ -168,6 +171,11 @@ def ffn_ln_param_grads(w2, dw2, db2, gamma, beta, dgamma, dbeta, dy=None, u=None
     if J > 1024:
         # the rescue kernel stages one fc2.weight column (J values) in LDS: embed dims above 1024 (segofa_huge: 1280) run without
         # it -- a gain of exactly 0 then yields a zero gradient instead of the value from the definition
+        if dy is not None and not _pg_ws.get("warned"):
+            _pg_ws["warned"] = True
+            import warnings
+            warnings.warn("ifseg_amd: ffn_layernorm gradients run without the small-gain rescue path for embed dims above 1024 "
+                          "(J = %d): a gain of exactly 0 yields a zero gradient there" % J)
         dy = None
     ws = _pg_ws.get((w2.device, N))
     if ws is None:
@@ -618,6 +626,24 @@ def ln_bwd_drop(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx2, dx_a
                                  c_int(_ln_flags(gamma)), c_int(rpb), c_ll(db_), c_int(dl), c_ll(xb), c_int(xl), c_ll(ob), c_int(ol), c_ll(ab),
                                  c_int(al), c_ll(o2b), c_int(o2l), _drop_ref(drop2, rpb or rows), _stream())
     _check(rc, "ln_bwd_drop")
+    return dx, dx2
+
+
+def ln_bwd_pair(dy, x, gamma, mean, rstd, dx, dg_part, db_part, x2, gamma2, mean2, rstd2, dx2, dg2_part, db2_part,
+                dx_add=None, drop2=None, rows_per_batch=None):
+    """dx = [dx_add +] LN1'(x; gamma)(dy), dx2 = LN2'(x2; gamma2)(drop2(dx)): a block's closing pre-LN backward and the next
+    block's opening post-LN backward of the same rows in one launch (all operands [rows, C], last dimension contiguous)"""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    for t in (dy, x, dx, x2, dx2) + ((dx_add,) if dx_add is not None else ()):
+        assert t.dim() == 2 and t.stride(1) == 1 and t.shape == (rows, C), (tuple(t.shape), t.stride())
+    rc = lib().ifseg_ln_bwd_pair(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx_add), _ptr(dx), _ptr(dg_part),
+                                 _ptr(db_part), _ptr(x2), _ptr(gamma2), _ptr(mean2), _ptr(rstd2), _ptr(dx2), _ptr(dg2_part),
+                                 _ptr(db2_part), c_int(LN_BWD_BLOCKS), c_int(rows), c_int(C), c_int(_ln_flags(gamma)),
+                                 c_int(dy.stride(0)), c_int(x.stride(0)), c_int(dx_add.stride(0) if dx_add is not None else 0),
+                                 c_int(dx.stride(0)), c_int(x2.stride(0)), c_int(dx2.stride(0)),
+                                 _drop_ref(drop2, rows_per_batch or rows), _stream())
+    _check(rc, "ln_bwd_pair")
     return dx, dx2
 
 

@@ -30,7 +30,7 @@ import time
 
 import torch
 
-from ... import hip
+from ... import hip, lab
 from .config import image_rp_bucket, token_bucket_of_delta
 
 BF = torch.bfloat16
@@ -115,6 +115,8 @@ class HipEngine:
         # the forward through the batch-inner kernel wherever the layer's dense bias exists (IFSEG_ATTN_BI_FWD=0: round-3 forward)
         self.bi_fwd = os.environ.get("IFSEG_ATTN_BI_FWD", "1") != "0"
         self._ffn_pg_tasks = []
+        # a block's closing pre-LN backward and the next block's opening post-LN backward in one launch (round 6)
+        self.ln_bwd_pairs = lab.get("NO_LN_BWD_PAIRS") is None
         self._train_fwd = False
         # where the NEXT batch's frozen-trunk pass is launched: "fwd" = at the start of this step's forward, "e<k>" = when
         # the backward reaches encoder layer k, "end" = after the last backward kernel of the main stream
@@ -1025,6 +1027,10 @@ class HipEngine:
                 nl = ("%slayers.%d.self_attn_layer_norm" % (e, l + 1), "e%d_ln1" % (l + 1), buf("e%d_xn" % (l + 1), (B * T, C)))
             else:
                 nl = (e + "layer_norm", "e_final_ln", buf("enc_out", (B, T, C)).view(B * T, C))
+            if l + 1 < cfg.enc_layers:
+                # the FFN's tail launch also computes layer l+1's pre-LN: it reads that layer's self_attn_layer_norm gain / bias
+                # (fp32 master) -- a deferred optimizer must be done with slice e<l+1> first
+                self._params_wait(["e%d" % (l + 1)])
             x, x_pre = self._ffn_fwd(tg, p, x, B * T, site=("e", l, 1), rpb=T, xn_pre=xn, next_ln=nl)
         enc_out = buf("enc_out", (B, T, C))
         if x_pre is None:
@@ -1448,6 +1454,40 @@ class HipEngine:
         self._ln_red_tasks.append((part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C, False))
         return dx
 
+    def _post_desc(self, tg, kind, p, rows, rpb):
+        """descriptor of the post-LN backward that OPENS block `kind` ("c": cross attention, "s": self attention) of layer `tg` in
+        the backward, for `_ln_bwd_closing` of the block before it: (saved LN input, parameter, statistics tag, dropout, output)"""
+        if kind == "c":
+            s, pname, tag, bt = self.saved[tg + "_ca"], p + "cross_attn_ln", tg + "_cln2", tg + "c"
+        else:
+            s, bt = self.saved[tg + "_sa"], tg + "s"
+            pname, tag = p + ("self_attn_ln" if tg[0] == "d" else "attn_ln"), tg + "_ln2"
+        drop = None
+        if self.drop_on and s["site"] is not None:
+            drop = self._dropargs(self._site_id(s["site"]), self._dp(*s["site"]), rpb)
+        prev, self._bt = self._bt, bt
+        out = self.gbuf("g_da_%d" % rows, (rows, self.cfg.embed_dim))
+        self._bt = prev
+        return dict(x=s["a"], pname=pname, tag=tag, drop=drop, out=out, rpb=rpb, done=False)
+
+    def _ln_bwd_closing(self, dy, x, pname, stats_tag, dx, dx_add, nxt, post):
+        """the pre-LN backward that closes a block of the backward.  With `post` (`_post_desc`) the post-LN backward that opens
+        the NEXT block runs in the same launch on the same rows (csrc/rowops.hip ln_bwd_pair_kernel: the residual-stream
+        gradient is written once and not read back); with `nxt` see `_ln_bwd_fused`."""
+        C = x.shape[-1]
+        rows = x.numel() // C
+        if post is None or nxt is not None or C > 1024 or not self.ln_bwd_pairs:
+            return self._ln_bwd_fused(dy, x, pname, stats_tag, dx, dx_add, nxt)
+        mu, rs = self._ln_stats(stats_tag, rows)
+        mu2, rs2 = self._ln_stats(post["tag"], rows)
+        part, part2 = self._ln_part(C, stats_tag), self._ln_part(C, post["tag"])
+        hip.ln_bwd_pair(dy, x, self.Wf(pname + ".weight"), mu, rs, dx, part[0], part[1], post["x"], self.Wf(post["pname"] + ".weight"),
+                        mu2, rs2, post["out"], part2[0], part2[1], dx_add=dx_add, drop2=post["drop"], rows_per_batch=post["rpb"])
+        self._ln_red_tasks.append((part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C, False))
+        self._ln_red_tasks.append((part2, self._fused(self.g16, post["pname"] + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C, False))
+        post["done"] = True
+        return dx
+
     def _next_drop(self, tg, rows):
         """descriptor of the fc2 dropout adjoint that opens the FFN block of layer `tg` in the backward (None if inactive)"""
         s = self.saved[tg + "_ffn"]
@@ -1482,7 +1522,7 @@ class HipEngine:
             return hip.linear_dx(dy, wname_or_view, out=dx_out, resid=dx_resid, accumulate=dx_accumulate)
         return None
 
-    def _ffn_bwd(self, tg, p, dx2, rows, dbr_pre=None, nxt=None):
+    def _ffn_bwd(self, tg, p, dx2, rows, dbr_pre=None, nxt=None, post=None):
         """dx2: grad of the block output [rows, C]; returns grad of x1 (block input).  dbr_pre: the fc2 dropout adjoint of
         dx2 if the previous block of the backward already produced it; nxt: see `_ln_bwd_fused`."""
         C, Fd = self.cfg.embed_dim, self.cfg.ffn_dim
@@ -1515,7 +1555,7 @@ class HipEngine:
         dxn = buf("g_dxn_%d" % rows, (rows, C))
         self._linear_bwd(du, s["xn"], W(p + "fc1.weight"), G(p + "fc1.weight"), G(p + "fc1.bias"), dx_out=dxn)
         dx1 = gbuf("g_dx1_%d" % rows, (rows, C))
-        self._ln_bwd_fused(dxn, s["x1"].view(rows, C), p + "final_layer_norm", tg + "_fln1", dx1, dx2, nxt)
+        self._ln_bwd_closing(dxn, s["x1"].view(rows, C), p + "final_layer_norm", tg + "_fln1", dx1, dx2, nxt, post)
         if self.dw_split:
             self._side_do(self._dw_flush)      # fc1 / fc2 dW as their own group: runs under the attention backward
         self._side_flush()
@@ -1758,7 +1798,7 @@ class HipEngine:
         return dx                # the caller flushes the side queue together with the layer's hook
 
     def _cross_block_bwd(self, tg, p, dy2, B, Td, Te, cpq, cpk, scaling, d_enc_out, first_cross, dcpq_acc, dcpk_acc,
-                         da_pre=None, nxt=None):
+                         da_pre=None, nxt=None, post=None):
         C = self.cfg.embed_dim
         s = self.saved[tg + "_ca"]
         W, Wf, G, buf = self.W, self.Wf, self.G, self.buf
@@ -1805,7 +1845,7 @@ class HipEngine:
         if self.kproj_fix:       # (every layer's K|V projection reads the same encoder output: one column sum per step)
             self._kfix_tasks.append((G(a_ + ".k_proj.weight"), G(a_ + ".k_proj.bias"), enc2d, "enc_out"))
         dy1 = gbuf("g_dy1c_%d" % rows, (rows, C))
-        self._ln_bwd_fused(dyn, s["x"].view(rows, C), p + "encoder_attn_layer_norm", tg + "_cln1", dy1, dy2, nxt)
+        self._ln_bwd_closing(dyn, s["x"].view(rows, C), p + "encoder_attn_layer_norm", tg + "_cln1", dy1, dy2, nxt, post)
         self._side_flush()
         return dy1
 
@@ -1858,15 +1898,18 @@ class HipEngine:
             first = l == cfg.dec_layers - 1
             # the self block's closing pre-LN backward also produces the fc2-dropout adjoint that opens layer l-1's FFN block
             nx_f = self._next_drop("d%d" % (l - 1), B * Td) if fuse and l > 0 else None
-            dy = self._ffn_bwd(tg, p, dy, B * Td, dbr_pre=dbr)
-            dy = self._cross_block_bwd(tg, p, dy, B, Td, T, ctx["d_cpq"], ctx["d_cpk"], scaling, d_enc_out, first, dcpq, dcpk)
+            # (each block's closing pre-LN backward also runs the post-LN backward that opens the next block: `_ln_bwd_closing`)
+            pc, ps = self._post_desc(tg, "c", p, B * Td, Td), self._post_desc(tg, "s", p, B * Td, Td)
+            dy = self._ffn_bwd(tg, p, dy, B * Td, dbr_pre=dbr, post=pc)
+            dy = self._cross_block_bwd(tg, p, dy, B, Td, T, ctx["d_cpq"], ctx["d_cpk"], scaling, d_enc_out, first, dcpq, dcpk,
+                                       da_pre=pc["out"] if pc["done"] else None, post=ps)
             tabn = "%sseg_rel_pos_table_list.%d.weight" % (d, l)
             dy = self._self_block_bwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", dy, B, Td,
                                       ctx["d_spq"], ctx["d_spk"], scaling, dspq, dspk, first,
-                                      [(tabn, g["dec_idx2d"]), (tabn, g["dec_idx1d"]), (tabn, g["dec_idxx"])], nxt=nx_f)
+                                      [(tabn, g["dec_idx2d"]), (tabn, g["dec_idx1d"]), (tabn, g["dec_idxx"])], nxt=nx_f,
+                                      da_pre=ps["out"] if ps["done"] else None)
             dbr = nx_f["out"] if nx_f else None
-            self._side_do(lambda p=p: (self._flush_tables(), self._notify(p)))   # final in side-stream order
-            self._side_flush()
+            self._layer_end(p)                       # final in side-stream order
         # ---- decoder embedding LN (input = [enc_out[:, :P] | embed(bos)])
         self.mark("dec_bwd_end")
         self._bt = "dtop"
@@ -1902,20 +1945,20 @@ class HipEngine:
             if self.trunk_at == "e%d" % l:
                 self._trunk_launch_point()
             nx_f = self._next_drop("e%d" % (l - 1), B * T) if fuse and l > 0 else None
-            dx = self._ffn_bwd(tg, p, dx, B * T, dbr_pre=dbr)
+            ps = self._post_desc(tg, "s", p, B * T, T)
+            dx = self._ffn_bwd(tg, p, dx, B * T, dbr_pre=dbr, post=ps)
             dx = self._self_block_bwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", dx, B, T, ctx["e_pq"],
                                       ctx["e_pk"], scaling, depq, depk, first,
                                       [("%simage_rel_pos_table_list.%d.weight" % (e, l), g["enc_idx2d"]),
                                        ("%stoken_rel_pos_table_list.%d.weight" % (e, l), g["enc_idx1d"]),
-                                       (None, None)], nxt=nx_f)
+                                       (None, None)], nxt=nx_f, da_pre=ps["out"] if ps["done"] else None)
             dbr = nx_f["out"] if nx_f else None
             if l == 0 and self.tail_pos_main and self.overlap:
                 # the abs-pos accumulators are complete once layer 0's bias-gradient kernels have run: an event on the side
                 # stream BEFORE that layer's weight-gradient group, for the main stream's abs-pos tail (below)
                 pos_ready = self._ev()
                 self._side_do(lambda ev=pos_ready: ev.record(self._side))
-            self._side_do(lambda p=p: (self._flush_tables(), self._notify(p)))
-            self._side_flush()
+            self._layer_end(p)
         # ---- encoder abs-pos operands
         self._bt = "etop"
         # the main stream has run out of work: the side stream gets the whole GPU for the last weight gradients (no workgroup
@@ -2110,6 +2153,14 @@ class HipEngine:
             setattr(self, attr, [])
             if red:
                 hip.reduce_parts_multi(red)
+
+    def _layer_end(self, p):
+        """(end of a layer's backward) the layer's weight-gradient group, its followers, the table casts and the gradient-ready
+        notification, in side-stream order.  (Round 6 measured holding the group back until a point inside the NEXT layer's
+        backward -- beside the attention backward instead of beside the LayerNorm pair: the LayerNorms got 15 us faster each and
+        the dK|dV kernel 70 us slower, +0.3 ms per step; profiles/round6_dw_release_ab.txt.)"""
+        self._side_do(lambda: (self._flush_tables(), self._notify(p)))
+        self._side_flush()
 
     def _flush_tables(self):
         self._dw_flush()

@@ -404,6 +404,8 @@ class SegOFAModel(ModelBase):
         if not eng.packed or eng.device != dev:
             eng.pack(dev)
         eng.refresh_frozen()
+        # (dropout / DropPath / attention and activation dropout follow `need_grad`, which requires model.training: an eval()
+        # forward -- with or without grad mode -- applies none of them, as the reference's dropout modules in eval)
         need_grad = torch.is_grad_enabled() and self.training
         params = eng.trainable_params() if (need_grad and self.autograd_mode == "inputs") else ()
         anchor = torch.zeros(1, device=dev, requires_grad=need_grad)
@@ -418,7 +420,9 @@ class SegOFAModel(ModelBase):
                 "image_embed_before_proj": [ctx["feat"]],
                 "position_embeddings": [eng.ws["e_pos_all"]],
                 "resized_grid": bool(ctx.get("resized", False)),
-                "encoder_padding_mask": [torch.zeros(B, T, dtype=torch.bool, device=logits.device)],
+                # (encoder_module.py:730-752,838: True at <pad> source tokens -- the P patch positions are never padding)
+                "encoder_padding_mask": [torch.cat([torch.zeros(B, ctx["P"], dtype=torch.bool, device=logits.device), ~ctx["nonpad"]], 1)
+                                         if ctx.get("nonpad") is not None else torch.zeros(B, T, dtype=torch.bool, device=logits.device)],
             },
             "attn": [None],
             "logits_padded": eng.ws["logits_pad"],

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 15
+#define IFSEG_ABI_VERSION 16
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -341,6 +341,17 @@ int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamma, const fl
                       const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, void* dx2, int nblocks, int rows,
                       int C, int flags, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx, long long dx_bs, int lddx,
                       long long add_bs, int ldadd, long long dx2_bs, int lddx2, const ifseg_drop_args* drop2, void* stream);
+/* Two LayerNorm backwards of one residual-stream row in one launch (C <= 1024, contiguous-k rows with the given leading
+ * dimensions): stage 1 is ifseg_ln_bwd of the pre-LN that closes a block of the backward (unify_transformer_layer.py:262-266,
+ * 463-470: dx = dx_add + LN'(x; gamma)(dy)), stage 2 the post-LN backward that opens the next block on the same row
+ * (attn_ln / cross_attn_ln / self_attn_ln followed by dropout + DropPath, :256-261, 529-545): dx2 = LN'(x2; gamma2)(drop2(dx as
+ * stored in bf16)).  dx is written once and not read back; both pairs of dgamma / dbeta partials [nblocks][C] are produced.
+ * Same arithmetic as ifseg_ln_bwd followed by ifseg_ln_bwd(drop = drop2) on its output. */
+int ifseg_ln_bwd_pair(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                      const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, const void* x2, const void* gamma2,
+                      const float* mean2, const float* rstd2, void* dx2, float* dgamma2_part, float* dbeta2_part, int nblocks,
+                      int rows, int C, int flags, int lddy, int ldx, int ldadd, int lddx, int ldx2, int lddx2,
+                      const ifseg_drop_args* drop2, void* stream);
 /* fp32 master copy <- bf16 arena wherever bf16(master[i]) != p16[i] (an optimizer outside this library stepped the bf16
  * parameters: fp16_optimizer.py:198-222 writes the model copy); agreeing entries keep their fp32 value. */
 int ifseg_sync_master(float* master, const void* p16, long long n, void* stream);

@@ -887,6 +887,47 @@ def test_ln_bwd_drop_is_bit_identical_to_two_calls():
     assert torch.equal(qg1, pg1) and torch.equal(qb1, pb1)
 
 
+@pytest.mark.parametrize("C,f32,with_add", [(768, True, True), (1024, False, True), (64, True, False)])
+def test_ln_bwd_pair_equals_the_two_launches(C, f32, with_add):
+    """ifseg_ln_bwd_pair: a block's closing pre-LN backward + the next block's opening post-LN backward (dropout + DropPath
+    adjoint on its input) on the same rows in one launch == ifseg_ln_bwd twice (same statements: bit-identical partial sums and
+    outputs up to the two kernels' different multiply-add contraction, at most one bf16 ulp on a few elements)."""
+    from ifseg_amd import hip
+    dev = _dev()
+    B, T, p, seed = 3, 257, 0.1, 4242
+    rows = B * T
+    dy, x, add, x2 = (_rand((rows, C), dev, 140 + i) for i in range(4))
+    mk = (lambda t: t.float() + 1e-3 * torch.rand(C, device=dev)) if f32 else (lambda t: t)
+    g1, g2 = mk(_rand((C,), dev, 146, 0.2) + 1), mk(_rand((C,), dev, 147, 0.2) + 1)
+    dp = torch.tensor([1 / 0.9, 0.0, 1 / 0.9], device=dev)
+    m1, m2 = torch.rand(rows, device=dev) - 0.5, torch.rand(rows, device=dev) - 0.5
+    r1, r2 = torch.rand(rows, device=dev) + 0.5, torch.rand(rows, device=dev) + 0.5
+    nb = hip.LN_BWD_BLOCKS
+    parts = lambda: (torch.zeros(nb, C, device=dev), torch.zeros(nb, C, device=dev))
+    a = add if with_add else None
+    dx_ref, da_ref = torch.empty_like(dy), torch.empty_like(dy)
+    pg1, pb1 = parts(); pg2, pb2 = parts()
+    hip.ln_bwd(dy, x, g1, m1, r1, dx_ref, pg1, pb1, dx_add=a)
+    hip.ln_bwd(dx_ref, x2, g2, m2, r2, da_ref, pg2, pb2, drop=(p, seed, dp, T))
+    dx, da = torch.empty_like(dy), torch.empty_like(dy)
+    qg1, qb1 = parts(); qg2, qb2 = parts()
+    hip.ln_bwd_pair(dy, x, g1, m1, r1, dx, qg1, qb1, x2, g2, m2, r2, da, qg2, qb2, dx_add=a, drop2=(p, seed, dp, T),
+                    rows_per_batch=T)
+    torch.cuda.synchronize()
+
+    def close(u, v, what):
+        diff = (u.float() - v.float()).abs()
+        bad = (diff > 0).float().mean().item()
+        ulp = (diff / v.float().abs().clamp_min(1e-6)).max().item()
+        assert bad < 1e-3 and ulp < 1.0 / 64, (what, bad, ulp)       # (a bf16 ulp is 2^-7 .. 2^-8 of the value)
+    close(dx, dx_ref, "dx")
+    close(da, da_ref, "da")
+    for q, r_, n in ((qg1, pg1, "dg1"), (qb1, pb1, "db1"), (qg2, pg2, "dg2"), (qb2, pb2, "db2")):
+        assert _rel(q.sum(0), r_.sum(0)) < 1e-4, (n, _rel(q.sum(0), r_.sum(0)))
+    # the sample dropped by DropPath passes no gradient through the second LayerNorm
+    assert da.view(B, T, C)[1].abs().max().item() == 0 and da.view(B, T, C)[0].abs().max().item() > 0
+
+
 def test_gemm_nn_rowdot_delta_epilogue():
     """ifseg_gemm_nn_rowdot: dO = da @ W and delta[b,h,t] = sum_c dO[b,t,64h+c] * O[b,t,64h+c] from the same epilogue."""
     from ifseg_amd import hip
