@@ -217,10 +217,8 @@ def main():
             dist.init_process_group(backend)                       # functional test on a 1-GPU box
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if os.environ.get("IFSEG_MAIN_PRIO"):       # laboratory: the step's main stream as a created stream of this priority
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["IFSEG_MAIN_PRIO"])))
 
-    from ifseg_amd import hip
+    from ifseg_amd import hip, lab
     from ifseg_amd.criterions import SegCriterion
     from ifseg_amd.tasks.mm_tasks import SegmentationTask
     from ifseg_amd.trainer import Trainer
@@ -388,7 +386,7 @@ def main():
     ors = [hip.prof_read(k) for k in ok_]
     hip.prof_enable(0)
     rccl_stats = trainer.reducer.stats()
-    if world > 1 and rccl_stats["mode"] != "direct" and os.environ.get("IFSEG_REDUCE_MODE") is None:
+    if world > 1 and rccl_stats["mode"] != "direct" and lab.get("REDUCE_MODE") is None:
         raise RuntimeError("bench.py: %d ranks but the gradient all-reduce did not run through the direct RCCL communicator (%r)"
                            % (world, rccl_stats))
     if world > 1 and rccl_stats["ranks"] != world:

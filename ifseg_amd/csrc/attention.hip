@@ -1411,19 +1411,9 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, const int bl
 template <bool HAS_POS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) { attn_bwd_dq_body<HAS_POS>(a, blockIdx.x); }
 
-// ONE launch for the whole attention backward: the dK/dV workgroups (key-stationary) followed by the dQ workgroups
-// (query-stationary) in one grid.  As two launches on two streams (round 2) the pair needed a cross-stream fork and join
-// around every attention (an event bubble on the main queue plus ~36 us of waiting for the dQ kernel, 18 x per step) and
-// a stream of its own -- and the GPU runs at most four queues concurrently, which the data-parallel step needs for RCCL.
-// The dQ workgroups are the shorter ones: dispatched last they fill the holes the last round of dK/dV workgroups leaves.
-// MEASURED (round 3): slower than the two kernels on two streams -- 447 us on the encoder shape against 189 + 125 us alone,
-// 18.82 vs 17.89 ms per step: one kernel = one register allocation for both bodies (75 spilled SGPRs, scratch in the loop).
-// Off by default (IFSEG_ATTN_BWD_ONE_LAUNCH=1 selects it).
-template <bool HAS_POS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a, int n_dkv) {
-  if ((int)blockIdx.x < n_dkv) attn_bwd_dkv_body<HAS_POS, 4>(a, blockIdx.x);
-  else attn_bwd_dq_body<HAS_POS>(a, (int)blockIdx.x - n_dkv);
-}
+// (Measured and removed: ONE launch for the whole attention backward -- the dK/dV workgroups followed by the dQ workgroups in one
+// grid.  Round 3: 447 us on the encoder shape against 189 + 125 us for the two kernels, 18.82 vs 17.89 ms per step: one kernel =
+// one register allocation for both bodies, 75 spilled SGPRs and scratch in the loop.)
 
 // delta[b,h,t] = sum_d dO[b,t,h,d] * O[b,t,h,d]   (8 lanes per (row, head))
 __global__ void attn_delta_kernel(const bf16_t* o, const bf16_t* dO, float* delta, int B, int H, int T,
@@ -1705,7 +1695,7 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
                              (rowseg_h ? (size_t)2 * nw * (4 + 3 * 64) * 4 : 0) : 0);      // exchange area: `rowseg` grids only
   };
   // 8-wave workgroups (one copy of the tables for twice the waves) when a 4-wave workgroup takes more than half a CU's LDS
-  const bool dkv8 = a.rel_mode && lds_kv_of(4) > 80 * 1024 && lds_kv_of(8) <= 160 * 1024 && !getenv("IFSEG_ATTN_DKV_4WAVES");
+  const bool dkv8 = a.rel_mode && lds_kv_of(4) > 80 * 1024 && lds_kv_of(8) <= 160 * 1024;
   const size_t lds_kv = lds_kv_of(dkv8 ? 8 : 4);
   const size_t lds_q = 2 * (KT_BYTES + VT_BYTES) + (a.rel_mode ? n2dp * 4 + (size_t)a.P * 4 : 0);
   if (lds_kv > 160 * 1024 || lds_q > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
@@ -1715,22 +1705,6 @@ extern "C" int ifseg_attn_bwd(const ifseg_attn_bwd_args* x, void* stream) {
 #else
   const bool has_pos = x->pos_q != nullptr;
 #endif
-  if (do_kv && do_q && !dkv8 && getenv("IFSEG_ATTN_BWD_ONE_LAUNCH")) {      // measured slower than the two launches: see the kernel
-    const size_t lds = lds_kv > lds_q ? lds_kv : lds_q;
-    const int n_dkv = nkt * a.H * a.B, n_dq = nq * a.H * a.B;
-    // (timed as the dK/dV family: 8 T S 64 flops per (b, h) = dV, dP, dK and dQ of the reference at head dim 64)
-    ifseg_prof_begin(IFSEG_K_ATTN_DKV, s, 8.0 * 64 * (double)a.T * a.S * a.B * a.H, 0);
-    if (x->pos_q) {
-      (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, dim3(n_dkv + n_dq), dim3(256), lds, s, a, n_dkv);
-    } else {
-      (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, dim3(n_dkv + n_dq), dim3(256), lds, s, a, n_dkv);
-    }
-    ifseg_prof_end(IFSEG_K_ATTN_DKV, s);
-    IFSEG_CHECK_LAUNCH();
-    return 0;
-  }
   if (has_pos) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);

@@ -8,7 +8,9 @@
 //     dV_b = gain P_b^T dO_b;  dS_b = P_b o (gain dO_b v_b^T - delta_b);  dQ_b = dS_b k_b;  dK_b = dS_b^T q_b
 //     dBias = sum_b dS_b      -> d abs-pos operands, d rel-pos tables (ifseg_attn_dbias_grads)
 //
-// MI355X formulation.  The bias is a dense fp32 operand D[h] ([Tp][Sp], padding and masked entries -inf) built once per layer and step by
+// MI355X formulation.  The bias is a dense bf16 operand D[h] ([Tp][Sp], padding and masked entries -inf; round 6: bf16 -- what the
+// reference itself holds under --fp16, unify_multihead_attention.py:464, encoder_module.py:757-771 -- half the bytes of the operand
+// in HBM and in every stage) built once per layer and step by
 // ifseg_attn_dense_bias from parameters only (side stream, start of the step).  A workgroup of 8 waves owns
 // (head, 64 stationary rows = 2 blocks of 32, 4 batch elements): wave = (row block, batch element).  The 4 batch waves of a
 // row block read the SAME 32 x 32 bias tile from LDS (one LDS-DMA per tile instead of four regenerations by MFMA + table
@@ -33,7 +35,8 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 struct BiArgs {
   const bf16_t *q, *k, *v, *dO;
-  const float *lse, *delta, *D, *gain;
+  const float *lse, *delta, *gain;
+  const bf16_t* D;
   float* dgain_rows;
   bf16_t *dq, *dk, *dv, *dbias;
   bf16_t* out; float* lse_out; long long o_bs; int ldo;      // forward
@@ -121,12 +124,32 @@ __device__ __forceinline__ void store_tile_bf16(bf16_t* rowp, const f32x16& acc,
 // row statistics
 constexpr int ST_A = 0;                 // dQ: K[4][32][64]   dK/dV: Q[4][32][64]       (bf16, 4 KiB each)
 constexpr int ST_B = 16384;             // dQ: V[4][32][64]   dK/dV: dO[4][32][64]
-constexpr int ST_D = 32768;             // bias tiles [2][32][32] fp32 (4 KiB each)
-constexpr int ST_L = 40960;             // dK/dV: [4][lse 32 | delta 32] fp32
-constexpr int STG_DQ = 40960, STG_DKV = 41984;
+constexpr int ST_D = 32768;             // bias tiles [2][32][32] bf16 (2 KiB each): 64-byte rows, 16-byte chunk ^= (row >> 2) & 3
+constexpr int ST_L = 36864;             // dK/dV: [4][lse 32 | delta 32] fp32
+constexpr int STG_DQ = 36864, STG_DKV = 37888;
 constexpr int SLOT = 4096;              // dQ kernel: one wave's fp32 dS tile [32][32], chunk XOR (row & 7)
-constexpr int LDS_DQ = 2 * STG_DQ + 2 * 8 * SLOT;      // 147456
-constexpr int LDS_DKV = 2 * STG_DKV;                    // 83968
+constexpr int LDS_DQ = 2 * STG_DQ + 2 * 8 * SLOT;      // 139264
+constexpr int LDS_DKV = 2 * STG_DKV;                    // 75776
+
+// bias tile image [32 rows][32 keys] bf16: row r at r * 64 bytes, its four 16-byte chunks XOR-ed with (r >> 2) & 3 (the LDS-DMA
+// granule is 16 bytes: the swizzle is applied on the source address).  Row-wise readers (lane = query: 8 bytes = the lane's four
+// consecutive keys of a register group) see a 2-way conflict = the cycles of the fp32 tile's 16-byte reads; the dK/dV kernel reads
+// four consecutive QUERIES of one key per lane with the hardware transpose (ds_read_b64_tr_b16): four rows x 64 bytes per
+// 32 lanes, every bank once.
+__device__ __forceinline__ int db_swz(int r) { return (r >> 2) & 3; }
+__device__ __forceinline__ int db_off(int r, int colbyte) { return r * 64 + ((((colbyte >> 4) ^ db_swz(r)) & 3) << 4) + (colbyte & 15); }
+// one LDS-DMA piece of a bias tile: rows 16 p .. 16 p + 15 (lane l: row 16 p + (l >> 2), position l & 3)
+__device__ __forceinline__ void db_stage(const bf16_t* dbase, int p, int row0, int rmax, int Sp, int col0, int lane, unsigned dst) {
+  const int row = p * 16 + (lane >> 2);
+  const int c = (lane & 3) ^ db_swz(row);
+  const int ir = min(row0 + row, rmax);
+  lds_dma16_gs(dbase, (ir * Sp + col0 + c * 8) * 2, dst + p * 1024);
+}
+// four bf16 seeds of register group rg (8 bytes, requested with the block's other LDS reads) -> fp32, right before the MFMAs:
+// between the request and the first MFMA a block holds 8 registers of raw seeds instead of 16 of fp32 ones
+__device__ __forceinline__ void db_expand(const uint2& w, f32x16& s, int rg) {
+  s[rg * 4] = bflo(w.x); s[rg * 4 + 1] = bfhi(w.x); s[rg * 4 + 2] = bflo(w.y); s[rg * 4 + 3] = bfhi(w.y);
+}
 
 // Block schedule of the streamed side under the causal mask ("tail-first" order: a grid row i sees grid columns j <= i and
 // every tail column; a tail row sees tail columns j <= i only).  The dense bias already holds -inf for every masked
@@ -194,7 +217,7 @@ __device__ __forceinline__ void attn_bi_fwd_body(const BiArgs& a) {
   }
   const bf16_t* kb_ = a.k + (long long)bc * a.k_bs + h * 64;
   const bf16_t* vb_ = a.v + (long long)bc * a.v_bs + h * 64;
-  const float* db_ = a.D + (long long)h * a.Tp * a.Sp;
+  const bf16_t* db_ = a.D + (long long)h * a.Tp * a.Sp;
   const unsigned lds0 = lds_addr(smem);
   const int r8 = lane >> 3, cp = lane & 7;
   const int kl = a.kv_len ? __builtin_amdgcn_readfirstlane(a.kv_len[bc]) : 0x7fffffff;
@@ -214,12 +237,7 @@ __device__ __forceinline__ void attn_bi_fwd_body(const BiArgs& a) {
       const int jr = min(j0 + row, a.S - 1);
       lds_dma16_gs(src, (jr * ld + c * 8) * 2, dst + piece * 1024);
     }
-    {
-      const int row = bl * 8 + r8;
-      const int c = cp ^ vx_swz(row);
-      const int ir = min(q0 + qb * 32 + row, a.T - 1);
-      lds_dma16_gs(db_, (ir * a.Sp + j0 + c * 4) * 4, base + ST_D + qb * 4096 + bl * 1024);
-    }
+    if (bl < 2) db_stage(db_, bl, q0 + qb * 32, a.T - 1, a.Sp, j0, lane, base + ST_D + qb * 2048);
   };
   f32x16 oacc[2];
 #pragma unroll
@@ -231,6 +249,7 @@ __device__ __forceinline__ void attn_bi_fwd_body(const BiArgs& a) {
   int oR[4], oT[2][2][2];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) oR[ks] = vx_off(lane & 31, half * 16) ^ (ks << 5);
+  const int oD = db_off(lane & 31, half * 8);            // register group rg: ^ (rg << 4)
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -246,16 +265,18 @@ __device__ __forceinline__ void attn_bi_fwd_body(const BiArgs& a) {
     const unsigned char* stg = smem + (it & 1) * STG_DQ;
     const unsigned char* sK = stg + ST_A + bl * 4096;
     const unsigned char* sV = stg + ST_B + bl * 4096;
-    const unsigned char* sD = stg + ST_D + qb * 4096;
+    const unsigned char* sD = stg + ST_D + qb * 2048;
     f32x16 s;
     bf16x8 kf[4];
     U128 vt[2][2];
+    uint2 wD[4];
+    {
+      int ll = lane;
+      asm volatile("" : "+v"(ll));                       // (re-derived per block: four hoisted offsets cost the kernel its second workgroup per CU)
+      const int oDl = db_off(ll & 31, (ll >> 5) * 8);
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const float4 d4 = *reinterpret_cast<const float4*>(sD + oR[rg]);
-      s[rg * 4] = d4.x; s[rg * 4 + 1] = d4.y; s[rg * 4 + 2] = d4.z; s[rg * 4 + 3] = d4.w;
+      for (int rg = 0; rg < 4; ++rg) wD[rg] = *reinterpret_cast<const uint2*>(sD + (oDl ^ (rg << 4)));
     }
-    if (sc.block(it) * 32 + 32 > kl) mask_padded_keys(s, sc.block(it) * 32, half, kl);      // (wave-uniform: no padding, no cost)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) kf[ks] = lds_read_b128(sK + oR[ks]);
 #pragma unroll
@@ -270,6 +291,9 @@ __device__ __forceinline__ void attn_bi_fwd_body(const BiArgs& a) {
     __builtin_amdgcn_sched_barrier(0);
     if (it + 1 < sc.n) issue(it + 1, (it + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) db_expand(wD[rg], s, rg);
+    if (sc.block(it) * 32 + 32 > kl) mask_padded_keys(s, sc.block(it) * 32, half, kl);      // (wave-uniform: no padding, no cost)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
     // element r <-> key j0 + (r&3) + 8*(r>>2) + 4*half ; query = lane.  Masked / padded entries are -inf in the bias.
@@ -379,7 +403,7 @@ __device__ __forceinline__ void attn_bi_dq_body(const BiArgs& a) {
 
   const bf16_t* kb_ = a.k + (long long)bc * a.k_bs + h * 64;
   const bf16_t* vb_ = a.v + (long long)bc * a.v_bs + h * 64;
-  const float* db_ = a.D + (long long)h * a.Tp * a.Sp;
+  const bf16_t* db_ = a.D + (long long)h * a.Tp * a.Sp;
   const unsigned lds0 = lds_addr(smem);
   // staging of block `it` into stage st: the four 1-KiB pieces of ONE operand tile of this wave's batch element (group 0:
   // V, group 1: K) and a quarter of this group's bias tile.  Lane l of a piece = row 8 p + (l >> 3), 16-byte position
@@ -398,12 +422,7 @@ __device__ __forceinline__ void attn_bi_dq_body(const BiArgs& a) {
       const int jr = min(j0 + row, a.S - 1);
       lds_dma16_gs(src, (jr * ld + c * 8) * 2, dst + piece * 1024);
     }
-    {
-      const int row = bl * 8 + r8;
-      const int c = cp ^ vx_swz(row);
-      const int ir = min(q0 + qb * 32 + row, a.T - 1);
-      lds_dma16_gs(db_, (ir * a.Sp + j0 + c * 4) * 4, base + ST_D + qb * 4096 + bl * 1024);
-    }
+    if (bl < 2) db_stage(db_, bl, q0 + qb * 32, a.T - 1, a.Sp, j0, lane, base + ST_D + qb * 2048);
   };
 
   f32x16 dq[2];
@@ -424,6 +443,7 @@ __device__ __forceinline__ void attn_bi_dq_body(const BiArgs& a) {
       const int colb = (db * 32 + g16 * 16 + (i16 & 3) * 4) * 2, r0 = 16 * s2 + 4 * half + (i16 >> 2);
       oT[s2][db][0] = vx_off(r0, colb); oT[s2][db][1] = vx_off(r0 + 8, colb);
     }
+  const int oD = db_off(lane & 31, half * 8);            // bias seeds of register group rg: ^ (rg << 4)
   const int oS = (lane & 31) * 128 + ((half ^ (lane & 7)) << 4);       // this wave's dS tile: row = query, chunk (half + 2 rg) ^ (row & 7)
 
   // quarter bl of query block qb's tile: row 8 bl + (lane >> 3), columns 4 (lane & 7) .. + 3
@@ -448,16 +468,13 @@ __device__ __forceinline__ void attn_bi_dq_body(const BiArgs& a) {
     const unsigned char* stg = smem + (it & 1) * STG_DQ;
     const unsigned char* sK = stg + ST_A + bl * 4096;
     const unsigned char* sV = stg + ST_B + bl * 4096;
-    const unsigned char* sD = stg + ST_D + qb * 4096;
+    const unsigned char* sD = stg + ST_D + qb * 2048;
     f32x16 s, dp;
     bf16x8 kf[4], vf[4];
     U128 f[2][2];
+    uint2 wD[4];
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const float4 d4 = *reinterpret_cast<const float4*>(sD + oR[rg]);
-      s[rg * 4] = d4.x; s[rg * 4 + 1] = d4.y; s[rg * 4 + 2] = d4.z; s[rg * 4 + 3] = d4.w;
-    }
-    if (sc.block(it) * 32 + 32 > kl) mask_padded_keys(s, sc.block(it) * 32, half, kl);      // (wave-uniform: no padding, no cost)
+    for (int rg = 0; rg < 4; ++rg) wD[rg] = *reinterpret_cast<const uint2*>(sD + (oD ^ (rg << 4)));
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) kf[ks] = lds_read_b128(sK + oR[ks]);
 #pragma unroll
@@ -476,6 +493,9 @@ __device__ __forceinline__ void attn_bi_dq_body(const BiArgs& a) {
     // pass while this block's LDS reads return (the other stage is free since the barrier)
     if (it + 1 < sc.n) issue(it + 1, (it + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) db_expand(wD[rg], s, rg);
+    if (sc.block(it) * 32 + 32 > kl) mask_padded_keys(s, sc.block(it) * 32, half, kl);      // (wave-uniform: no padding, no cost)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dp[e] = 0.f;
 #pragma unroll
@@ -590,7 +610,7 @@ __device__ __forceinline__ void attn_bi_dkv_body(const BiArgs& a) {
   const bf16_t* ob_ = a.dO + (long long)bc * a.do_bs + h * 64;
   const float* lb_ = a.lse + ((long long)bc * a.H + h) * a.T;
   const float* eb_ = a.delta + ((long long)bc * a.H + h) * a.T;
-  const float* db_ = a.D + (long long)h * a.Tp * a.Sp;
+  const bf16_t* db_ = a.D + (long long)h * a.Tp * a.Sp;
   const unsigned lds0 = lds_addr(smem);
   const int r8 = lane >> 3, cp = lane & 7;
   auto issue = [&](int it, int st) {
@@ -607,15 +627,12 @@ __device__ __forceinline__ void attn_bi_dkv_body(const BiArgs& a) {
       const int ir = min(i0 + row, a.T - 1);
       lds_dma16_gs(src, (ir * ld + c * 8) * 2, dst + piece * 1024);
     }
-    {
-      // bias tile [32 queries][32 keys of key block kbw], rows 8 bl .. 8 bl + 7.  The accumulators want four CONSECUTIVE
-      // QUERIES of one key per lane -- a column of this tile -- so the seeds are read one float at a time (a row of 32 lanes
-      // = 32 banks); rows r and r + 4 (the two lane halves of one read) sit at positions of opposite parity = opposite bank
-      // halves: position(r) = r ^ ((r >> 2) & 1) within each group of eight.  (An earlier version kept a second, transposed copy of the
-      // bias, which served this kernel with 16-byte reads; building it was half of the dense-bias kernel's HBM writes.)
-      const int row = bl * 8 + (r8 ^ ((r8 >> 2) & 1));
+    if (bl < 2) {
+      // bias tile [32 queries][32 keys of key block kbw].  The accumulators want four CONSECUTIVE QUERIES of one key per lane --
+      // a column of this tile: read with the hardware transpose (ds_read_b64_tr_b16), four 8-byte reads per block.  (The
+      // fp32 tile of round 4 served them with sixteen 4-byte reads; before that a second, transposed copy of the bias in HBM.)
       const int jc = min(k0 + kbw * 32, a.Sp - 32);          // (a key block entirely in the padding: any valid address)
-      lds_dma16_gs(db_, ((i0 + row) * a.Sp + jc + cp * 4) * 4, base + ST_D + kbw * 4096 + bl * 1024);
+      db_stage(db_, bl, i0, 0x7fffffff, a.Sp, jc, lane, base + ST_D + kbw * 2048);
     }
     if (kbw == 0) {
       // lanes 0..31: lse, lanes 32..63: delta of this wave's batch element (LDS-DMA places lane i at base + 4 i)
@@ -635,8 +652,11 @@ __device__ __forceinline__ void attn_bi_dkv_body(const BiArgs& a) {
   int oR[4], oT[2][2][2];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) oR[ks] = vx_off(lane & 31, half * 16) ^ (ks << 5);
-  // bias seeds: element e of row group rg <-> query 8 rg + 4 half + e at position 8 rg + ((4 half + e) ^ half)
-  const int oD0 = ((4 * half) ^ half) * 32 + (lane & 31), oD1 = ((4 * half + 1) ^ half) * 32 + (lane & 31);
+  // bias seeds: register group rg <-> queries 8 rg + 4 half .. + 3 of key (lane & 31): lane i of a 16-lane group passes the
+  // address of the 8-byte piece (row i >> 2, keys 4 (i & 3) ..) of the [4 queries][16 keys] block and receives its column i
+  int oDt[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) oDt[rg] = db_off(8 * rg + 4 * half + (i16 >> 2), (g16 * 16 + (i16 & 3) * 4) * 2);
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -656,23 +676,27 @@ __device__ __forceinline__ void attn_bi_dkv_body(const BiArgs& a) {
     const unsigned char* stg = smem + st * STG_DKV;
     const unsigned char* sQ = stg + ST_A + bl * 4096;
     const unsigned char* sO = stg + ST_B + bl * 4096;
-    const float* sD = reinterpret_cast<const float*>(stg + ST_D + kbw * 4096);
+    const unsigned char* sD = stg + ST_D + kbw * 2048;
     const float* sL = reinterpret_cast<const float*>(stg + ST_L + bl * 256);
     f32x16 s, dp;
+    uint2 wD[4];
     float ls[16], de[DROP ? 16 : 1];
     bf16x8 qf[4], of[4];
     U128 fo[2][2], fq[2][2];
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      s[rg * 4] = sD[oD0 + rg * 256]; s[rg * 4 + 1] = sD[oD1 + rg * 256];
-      s[rg * 4 + 2] = sD[oD0 + rg * 256 + 64]; s[rg * 4 + 3] = sD[oD1 + rg * 256 + 64];
+      {
+        int od = oDt[rg];
+        if (DROP) {       // (the dropping instantiation has no register left for four hoisted offsets: re-derived per block)
+          int ll = lane;
+          asm volatile("" : "+v"(ll));
+          od = db_off(8 * rg + 4 * (ll >> 5) + ((ll & 15) >> 2), (((ll >> 4) & 1) * 16 + (ll & 3) * 4) * 2);
+        }
+        U64 w; w.s = lds_read_tr(sD + od); wD[rg] = w.v;
+      }
       const float4 e4 = *reinterpret_cast<const float4*>(sL + 32 + 8 * rg + 4 * half);
       dp[rg * 4] = e4.x; dp[rg * 4 + 1] = e4.y; dp[rg * 4 + 2] = e4.z; dp[rg * 4 + 3] = e4.w;
       if (DROP) { de[rg * 4] = e4.x; de[rg * 4 + 1] = e4.y; de[rg * 4 + 2] = e4.z; de[rg * 4 + 3] = e4.w; }
-    }
-    if (anypad) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[e] = kpad ? NEG_INF : s[e];
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = lds_read_b128(sQ + oR[ks]);
@@ -699,6 +723,12 @@ __device__ __forceinline__ void attn_bi_dkv_body(const BiArgs& a) {
     // (the next block's staging is issued while this block's LDS reads return: see the dQ kernel)
     if (it + 1 < sc.n) issue(it + 1, (it + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) db_expand(wD[rg], s, rg);
+    if (anypad) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = kpad ? NEG_INF : s[e];
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s, 0, 0, 0);
@@ -772,8 +802,7 @@ struct DenseArgs {
   int rel_mode, P, code_bias, n2d, Lt, causal;
   const int* gcode;
   const float *rel2d, *rel1d, *relx;
-  float* D;
-  int round_bf16;             // IFSEG_EXP_D_BF16 (measurement): every entry rounded to bf16 -- what a bf16 bias operand would hold
+  bf16_t* D;
 };
 
 // D[h][i][j] = pos_q[i] . pos_k[j] + rel(i, j) as [H][Tp][Sp], -inf where (i, j) is masked (causal, "tail-first" order),
@@ -828,9 +857,9 @@ __global__ __launch_bounds__(512) void attn_dense_bias_kernel(DenseArgs a) {
       for (int ks = 0; ks < 4; ++ks) { U128 w; w.v = *reinterpret_cast<const uint4*>(kp + ks * 16); fk[ks] = w.b; }
     }
     f32x16 acc;
-    // lane = key j0 + x, element r <-> query i0 + (r&3) + 8*(r>>2) + 4*half: a store instruction writes two whole 128-byte
-    // row segments (the other orientation -- a lane owning a query row, 16-byte stores -- put 32-byte pieces of 32 rows into
-    // every store and measured 1.3 x the algorithmic HBM write bytes, profiles/round4_hbm_traffic.json)
+    // lane = key j0 + x, element r <-> query i0 + (r&3) + 8*(r>>2) + 4*half (the other orientation -- a lane owning a query
+    // row, 16-byte stores -- put 32-byte pieces of 32 rows into every store and measured 1.3 x the algorithmic HBM write
+    // bytes, profiles/round4_hbm_traffic.json)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     if (a.pq && !dead) {
@@ -838,16 +867,24 @@ __global__ __launch_bounds__(512) void attn_dense_bias_kernel(DenseArgs a) {
       for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[ks], fk[ks], acc, 0, 0, 0);
     }
     {
-      float* dp = a.D + ((long long)h * a.Tp + i0 + 4 * half) * a.Sp + j0 + x;
+      // bf16 pairs of neighbouring keys: lanes x and x ^ 1 exchange two of their four rows per register group (DPP quad_perm
+      // [1,0,3,2]) -- the even lane stores rows e = 0, 1 of the key pair, the odd lane rows e = 2, 3 -- so a store instruction
+      // writes 64-byte row pieces of four rows (dwords), not 2-byte elements
+      unsigned* dp = reinterpret_cast<unsigned*>(a.D + ((long long)h * a.Tp + i0 + 4 * half) * a.Sp + j0 + (x & ~1));
+      const bool odd = x & 1;
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg)
+      for (int rg = 0; rg < 4; ++rg) {
+        float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          {
-            float v = dead ? NEG_INF : entry(i0 + 8 * rg + 4 * half + e, j0 + x, acc[rg * 4 + e]);
-            if (a.round_bf16) v = bf2f(f2bf(v));
-            dp[(long long)(8 * rg + e) * a.Sp] = v;
-          }
+        for (int e = 0; e < 4; ++e) v[e] = dead ? NEG_INF : entry(i0 + 8 * rg + 4 * half + e, j0 + x, acc[rg * 4 + e]);
+        const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];
+        const float r0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0xB1, 0xf, 0xf, true));
+        const float r1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0xB1, 0xf, 0xf, true));
+        const unsigned w0 = odd ? pack2bf(r0, v[2]) : pack2bf(v[0], r0), w1 = odd ? pack2bf(r1, v[3]) : pack2bf(v[1], r1);
+        const int e0 = odd ? 2 : 0;
+        dp[((long long)(8 * rg + e0) * a.Sp) >> 1] = w0;
+        dp[((long long)(8 * rg + e0 + 1) * a.Sp) >> 1] = w1;
+      }
     }
   }
 }
@@ -1225,7 +1262,7 @@ __global__ __launch_bounds__(256) void attn_dbias_tables_kernel(DbArgs a) {
 
 extern "C" int ifseg_attn_dense_bias(const void* pos_q, const void* pos_k, int ldpq, int ldpk, int H, int T, int S,
                                      int rel_mode, int P, const int* gcode, int code_bias, int n2d, const float* rel2d,
-                                     const float* rel1d, const float* relx, int causal, float* D, int Sp, int Tp,
+                                     const float* rel1d, const float* relx, int causal, void* D, int Sp, int Tp,
                                      void* stream) {
   (void)hipGetLastError();
   if (!D || H <= 0 || T <= 0 || S <= 0 || (Sp & 31) || (Tp & 31) || Sp < S || Tp < T) return IFSEG_ERR_BAD_ARG;
@@ -1236,9 +1273,8 @@ extern "C" int ifseg_attn_dense_bias(const void* pos_q, const void* pos_k, int l
   a.pq = (const bf16_t*)pos_q; a.pk = (const bf16_t*)pos_k; a.ldpq = ldpq; a.ldpk = ldpk;
   a.H = H; a.T = T; a.S = S; a.Sp = Sp; a.Tp = Tp;
   a.rel_mode = rel_mode; a.P = (rel_mode || causal) ? P : S; a.code_bias = code_bias; a.n2d = rel_mode ? n2d : 0; a.Lt = rel_mode ? T - P : 0; a.causal = causal;
-  a.gcode = gcode; a.rel2d = rel2d; a.rel1d = rel1d; a.relx = relx; a.D = D;
-  static const int round_bf16 = getenv("IFSEG_EXP_D_BF16") ? 1 : 0;
-  a.round_bf16 = round_bf16;
+  a.gcode = gcode; a.rel2d = rel2d; a.rel1d = rel1d; a.relx = relx; a.D = (bf16_t*)D;
+  if ((size_t)D & 15) return IFSEG_ERR_BAD_ARG;
   const size_t lds = rel_mode ? ((((size_t)n2d + 3) & ~(size_t)3) + (((size_t)2 * a.Lt + 2) & ~(size_t)3) + (size_t)P) * 4 : 16;
   if (lds > 160 * 1024) return IFSEG_ERR_BAD_SHAPE;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_dense_bias_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1253,7 +1289,7 @@ extern "C" int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* x, void* stream) {
   if ((x->Sp & 31) || (x->Tp & 31) || x->Sp < x->S || x->Tp < x->T || !x->D) return IFSEG_ERR_BAD_ARG;
   BiArgs a{};
   a.q = (const bf16_t*)x->q; a.k = (const bf16_t*)x->k; a.v = (const bf16_t*)x->v; a.dO = (const bf16_t*)x->dout;
-  a.lse = x->lse; a.delta = x->delta; a.D = x->D; a.gain = (const float*)x->gain;
+  a.lse = x->lse; a.delta = x->delta; a.D = (const bf16_t*)x->D; a.gain = (const float*)x->gain;
   a.dq = (bf16_t*)x->dq; a.dk = (bf16_t*)x->dk; a.dv = (bf16_t*)x->dv; a.dbias = (bf16_t*)x->dbias; a.dgain_rows = x->dgain_rows;
   a.B = x->B; a.H = x->H; a.T = x->T; a.S = x->S; a.Sp = x->Sp; a.Tp = x->Tp;
   a.q_bs = x->q_bs; a.k_bs = x->k_bs; a.v_bs = x->v_bs; a.do_bs = x->do_bs; a.dq_bs = x->dq_bs; a.dk_bs = x->dk_bs; a.dv_bs = x->dv_bs;
@@ -1272,7 +1308,7 @@ extern "C" int ifseg_attn_bwd_bi(const ifseg_attn_bi_args* x, void* stream) {
     long long ldmax = a.ldq;
     for (long long l : {(long long)a.lddo, (long long)a.ldk, (long long)a.ldv}) ldmax = l > ldmax ? l : ldmax;
     const long long rows = a.T > a.S ? a.T : a.S;
-    if (rows * ldmax * 2 >= (1ll << 31) || (long long)a.Tp * a.Sp * 4 >= (1ll << 31))
+    if (rows * ldmax * 2 >= (1ll << 31) || (long long)a.Tp * a.Sp * 2 >= (1ll << 31))
       return IFSEG_ERR_BAD_SHAPE;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -1303,7 +1339,7 @@ extern "C" int ifseg_attn_fwd_bi(const ifseg_attn_bi_args* x, void* stream) {
   if (!x || x->B <= 0 || x->H <= 0 || x->T <= 0 || x->S <= 0 || !x->q || !x->k || !x->v || !x->out || !x->lse || !x->D) return IFSEG_ERR_BAD_ARG;
   if ((x->Sp & 31) || x->Sp < x->S || (x->Tp & 31) || x->Tp < x->T) return IFSEG_ERR_BAD_ARG;
   BiArgs a{};
-  a.q = (const bf16_t*)x->q; a.k = (const bf16_t*)x->k; a.v = (const bf16_t*)x->v; a.D = x->D; a.gain = (const float*)x->gain;
+  a.q = (const bf16_t*)x->q; a.k = (const bf16_t*)x->k; a.v = (const bf16_t*)x->v; a.D = (const bf16_t*)x->D; a.gain = (const float*)x->gain;
   a.out = (bf16_t*)x->out; a.lse_out = const_cast<float*>(x->lse); a.o_bs = x->out_bs; a.ldo = x->ldout;
   a.B = x->B; a.H = x->H; a.T = x->T; a.S = x->S; a.Sp = x->Sp; a.Tp = x->Tp;
   a.q_bs = x->q_bs; a.k_bs = x->k_bs; a.v_bs = x->v_bs; a.ldq = x->ldq; a.ldk = x->ldk; a.ldv = x->ldv;
@@ -1316,7 +1352,7 @@ extern "C" int ifseg_attn_fwd_bi(const ifseg_attn_bi_args* x, void* stream) {
   if (a.causal && ((a.P & 63) || a.P > a.T || a.P > a.S)) return IFSEG_ERR_BAD_SHAPE;
   {
     const long long ldmax = a.ldk > a.ldv ? a.ldk : a.ldv;
-    if ((long long)a.S * ldmax * 2 >= (1ll << 31) || (long long)a.Tp * a.Sp * 4 >= (1ll << 31)) return IFSEG_ERR_BAD_SHAPE;
+    if ((long long)a.S * ldmax * 2 >= (1ll << 31) || (long long)a.Tp * a.Sp * 2 >= (1ll << 31)) return IFSEG_ERR_BAD_SHAPE;
   }
   hipStream_t s = (hipStream_t)stream;
   const int lds = 2 * STG_DQ;

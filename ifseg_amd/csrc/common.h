@@ -26,6 +26,14 @@ typedef unsigned short bf16_t;  // raw storage type
     }                                                                                          \
   } while (0)
 
+// The laboratory gate of the host code (ifseg_amd/lab.py is the Python side): a measurement switch IFSEG_<NAME> is honoured only
+// when IFSEG_LAB=1 is set as well; bench.py refuses to report a number under IFSEG_LAB=1 unless started with --lab.  Callers keep
+// the result in a function-local static (one environment scan per process, not per launch).
+static inline const char* ifseg_lab_env(const char* name) {
+  const char* g = getenv("IFSEG_LAB");
+  return (g && g[0] == '1' && g[1] == 0) ? getenv(name) : nullptr;
+}
+
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
 
 // round-to-nearest-even float -> bf16 (NaN kept quiet)

@@ -18,7 +18,6 @@
 #include <cstdlib>
 #include "gemm_common.h"
 #include "prof.h"
-#include "gemm_ring.h"
 
 namespace {
 
@@ -455,18 +454,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(GroupArgs ga) {
 
 }  // namespace
 
-// tile configuration of the persistent ring kernel (gemm_ring.hip) for a problem, 0 = the one-tile-per-workgroup kernel of
-// this file.  IFSEG_GEMM_RING=<id> forces a configuration (A/B measurements), IFSEG_GEMM_RING=0 turns the ring kernel off.
-static int ring_cfg(int M, int N, int K, bool group) {
-  (void)M; (void)N; (void)K; (void)group;
-  const char* e = getenv(group ? "IFSEG_GEMM_RING_GROUP" : "IFSEG_GEMM_RING");
-  if (e) return atoi(e);
-  return 0;
-}
-
 static int two_stage_max() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("IFSEG_GEMM_TWO_STAGE_MAX"); v = e ? atoi(e) : TWO_STAGE_MAX_WGS; }
+  if (v < 0) { const char* e = ifseg_lab_env("IFSEG_GEMM_TWO_STAGE_MAX"); v = e ? atoi(e) : TWO_STAGE_MAX_WGS; }
   return v;
 }
 
@@ -513,8 +503,9 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, int M, i
   const bool narrow = layout == IFSEG_GEMM_NT && g.splitk == 1 && (N <= 64 || tiles128 < 384);
   const int tiles = narrow ? ((M + BM - 1) / BM) * ((N + 63) / 64) : tiles128;
   dim3 grid(tiles, batch > 0 ? batch : 1, g.splitk), block(256);
+  static const bool no_xcd_slices = ifseg_lab_env("IFSEG_GEMM_NO_XCD_SLICES") != nullptr;
   if (layout == IFSEG_GEMM_TN && g.splitk > 1 && batch <= 1 && (8 % g.splitk) == 0 && tiles % (8 / g.splitk) == 0 &&
-      !getenv("IFSEG_GEMM_NO_XCD_SLICES")) {
+      !no_xcd_slices) {
     g.xcd_groups = 8 / g.splitk;
     grid = dim3(tiles * g.splitk, 1, 1);
   }
@@ -523,16 +514,6 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, int M, i
   if ((flags & IFSEG_GEMM_COLSUM) && layout != IFSEG_GEMM_TN) return IFSEG_ERR_BAD_ARG;
   const double nb = batch > 0 ? batch : 1;
   ifseg_prof_begin(IFSEG_K_GEMM_NT + layout, s, 2.0 * M * N * K * nb, 2.0 * nb * ((double)M * K + (double)N * K + (double)M * N));
-  if (g.splitk == 1 && batch <= 1 && !narrow && layout != IFSEG_GEMM_TN) {
-    const int cfg = ring_cfg(M, N, K, false);
-    if (cfg > 0) {
-      const int rc = gemm_ring_launch(&g, A_KC, layout == IFSEG_GEMM_NN, 0, cfg, stream);
-      ifseg_prof_end(IFSEG_K_GEMM_NT + layout, s);
-      if (rc) return rc;
-      IFSEG_CHECK_LAUNCH();
-      return 0;
-    }
-  }
   const bool two_stage = (long long)tiles * g.splitk * (batch > 0 ? batch : 1) <= two_stage_max();
 #define LAUNCH2(AM, BKS, BNV)                                                                        \
   do {                                                                                               \
@@ -599,20 +580,10 @@ extern "C" int ifseg_gemm_tn_group(int n, const ifseg_gemm_tn_problem* probs, in
   ga.total = total;
   hipStream_t s = (hipStream_t)stream;
   ifseg_prof_begin(IFSEG_K_GEMM_TN, s, flops, bytes);
-  if (const int cfg = ring_cfg(0, 0, 0, true)) {
-    const int rc = gemm_ring_group_launch(&ga, cfg, max_workgroups, stream);
-    if (rc <= 0) {
-      ifseg_prof_end(IFSEG_K_GEMM_TN, s);
-      if (rc) return rc;
-      IFSEG_CHECK_LAUNCH();
-      return 0;
-    }
-    // (rc > 0: the configuration does not take this group -- the tile kernel below does)
-  }
   int grid = total;
   if (max_workgroups > 0 && max_workgroups < total) grid = max_workgroups >= 8 ? (max_workgroups & ~7) : max_workgroups;
-  if (getenv("IFSEG_GEMM_GROUP_ONE_STAGE")) hipLaunchKernelGGL(gemm_tn_group_kernel<1>, dim3(grid), dim3(256), 0, s, ga);
-  else hipLaunchKernelGGL(gemm_tn_group_kernel<2>, dim3(grid), dim3(256), 0, s, ga);
+  // (two LDS stages; one stage -- half the footprint, four workgroups per CU -- measured 17.46 against 16.96 ms per step, round 5)
+  hipLaunchKernelGGL(gemm_tn_group_kernel<2>, dim3(grid), dim3(256), 0, s, ga);
   ifseg_prof_end(IFSEG_K_GEMM_TN, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
@@ -643,13 +614,6 @@ extern "C" int ifseg_gemm_nn_gelu_ln_bwd(const void* A, const void* B, void* C, 
   hipStream_t s = (hipStream_t)stream;
   // (timed with the NN family; flops of the GEMM only)
   ifseg_prof_begin(IFSEG_K_GEMM_NT + IFSEG_GEMM_NN, s, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + 2.0 * M * N));
-  if (const int cfg = ring_cfg(M, N, K, false)) {
-    const int rc = gemm_ring_launch(&g, A_KC, 1, 1, cfg, stream);
-    ifseg_prof_end(IFSEG_K_GEMM_NT + IFSEG_GEMM_NN, s);
-    if (rc) return rc;
-    IFSEG_CHECK_LAUNCH();
-    return 0;
-  }
   if (tiles <= two_stage_max()) hipLaunchKernelGGL(gemm_nn_gln_kernel<2>, dim3(tiles), dim3(256), 0, s, g);
   else hipLaunchKernelGGL(gemm_nn_gln_kernel<1>, dim3(tiles), dim3(256), 0, s, g);
   ifseg_prof_end(IFSEG_K_GEMM_NT + IFSEG_GEMM_NN, s);
@@ -681,15 +645,6 @@ extern "C" int ifseg_conv2d_nhwc_bf16(const void* in, const void* w, const void*
   const bool narrow = g.N <= 64 || tiles128 < 384;
   const int tiles = narrow ? ((g.M + BM - 1) / BM) * ((g.N + 63) / 64) : tiles128;
   ifseg_prof_begin(IFSEG_K_CONV, (hipStream_t)stream, 2.0 * g.M * g.N * g.K, 2.0 * ((double)B * H * W * Cin + (double)g.N * g.K + (double)g.M * g.N));
-  if (!narrow) {
-    if (const int cfg = ring_cfg(g.M, g.N, g.K, false)) {
-      const int rc = gemm_ring_launch(&g, A_CONV, 0, 0, cfg, stream);
-      ifseg_prof_end(IFSEG_K_CONV, (hipStream_t)stream);
-      if (rc) return rc;
-      IFSEG_CHECK_LAUNCH();
-      return 0;
-    }
-  }
   const bool two_stage = tiles <= two_stage_max();
   const dim3 grid(tiles, 1), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -703,5 +658,4 @@ extern "C" int ifseg_conv2d_nhwc_bf16(const void* in, const void* w, const void*
 extern "C" int ifseg_abi_version(void) { return IFSEG_ABI_VERSION; }
 // every object of the library reports its own measurement switches; any one of them marks the build
 int ifseg_exp_attention();
-int ifseg_exp_gemm_ring();
-extern "C" int ifseg_experimental_build(void) { return ifseg_exp_attention() | (ifseg_exp_gemm_ring() << 1); }
+extern "C" int ifseg_experimental_build(void) { return ifseg_exp_attention(); }

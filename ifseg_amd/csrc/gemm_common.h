@@ -1,5 +1,5 @@
-// Shared definitions of the GEMM kernels (gemm.hip: one tile per workgroup, split-K; gemm_ring.hip: persistent workgroups
-// with a ring of LDS stages): argument block, LDS tile images, LDS-DMA pieces.
+// Shared definitions of the GEMM kernels (gemm.hip: one tile per workgroup, split-K; conv.hip; tools/gemm_ring/: the persistent
+// ring-of-stages laboratory of round 5, not part of the library): argument block, LDS tile images, LDS-DMA pieces.
 #pragma once
 #include "common.h"
 #include "../../include/ifseg_hip.h"

@@ -61,14 +61,3 @@ extern "C" int ifseg_prof_read(int kind, double* ms, double* flops, double* byte
   return 0;
 }
 
-// A HIP stream restricted to a set of compute units (hipExtStreamCreateWithCUMask; bit i of the mask = CU i in the runtime's
-// enumeration): the laboratory switch IFSEG_CUMASK_* gives the engine's side streams (weight gradients, dQ, trunk) a part of
-// the chip of their own instead of letting the four queues share every CU.  Results do not depend on it.
-extern "C" int ifseg_stream_create_cumask(const unsigned* mask, int nwords, void** stream) {
-  (void)hipGetLastError();
-  if (!mask || nwords <= 0 || !stream) return IFSEG_ERR_BAD_ARG;
-  hipStream_t s = nullptr;
-  if (hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask) != hipSuccess) { (void)hipGetLastError(); return IFSEG_ERR_BAD_ARG; }
-  *stream = (void*)s;
-  return 0;
-}

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
 // sums are bit-identical and dx differs in ~1e-5 of its elements by one bf16 ulp (tools/ln_hash.py: the compiler fuses the
 // row sums' multiply-adds differently in the two kernels).  DX2: the second output of ifseg_ln_bwd_drop,
 // dx2 = drop2(dx as stored in bf16) -- the same instantiation as the plain call, so the pair stays bit-identical to
-// ifseg_ln_bwd followed by ifseg_dropout.  IFSEG_LN_BWD_CLASSIC=1 selects the former kernels.
+// ifseg_ln_bwd followed by ifseg_dropout.  (ln_bwd_kernel remains for the GELU / wide rows.)
 template <int NCH, bool DX2>
 __global__ __launch_bounds__(256) void ln_bwd_lean_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
                                                           const float* mean, const float* rstd, const bf16_t* dx_add,
@@ -433,287 +433,6 @@ __global__ __launch_bounds__(256) void ln_bwd_lean_kernel(const bf16_t* dy, cons
         if (c < nch) {
           const float sum = r4[0][t] + r4[1][t] + r4[2][t] + r4[3][t];
           (pass ? dbeta_part : dgamma_part)[(long long)blockIdx.x * C + c * 8 + (t & 7)] = sum;
-        }
-      }
-    }
-  }
-}
-
-// ln_bwd (C <= 1024, one wave per row) with a second output dx2 = drop2(dx as stored in bf16): the pre-LN backward that
-// closes a block of the backward and the fc2-dropout adjoint that opens the next one in one launch (bit-identical to
-// ifseg_ln_bwd followed by ifseg_dropout: the arithmetic of stage 1 is ln_bwd_kernel's, statement for statement).
-__global__ __launch_bounds__(256) void ln_bwd_drop_kernel(
-    const bf16_t* dy, const bf16_t* x, const bf16_t* gamma, const float* mean, const float* rstd, const bf16_t* dx_add,
-    bf16_t* dx, float* dgamma_part, float* dbeta_part, bf16_t* dx2, int rows, int C, RowMap mdy, RowMap mx, RowMap mdx,
-    RowMap madd, RowMap mdx2, DropArgs drop2, int pf32) {
-  constexpr int NCH = 2;
-  __shared__ float red[4 * (64 * 8 + 8)];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nch = C >> 3;
-  float gam[NCH][8], dg[NCH][8], db[NCH][8];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + i * 64;
-    if (c < nch) ldp8(gamma, c, pf32, gam[i]);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; if (c >= nch) gam[i][e] = 0.f; }
-  }
-  const int row0 = blockIdx.x * 4 + wave, rstep = gridDim.x * 4;
-  uint4 rx[NCH], rd[NCH];
-  auto fetch = [&](int row) {
-    const bf16_t* xp = x + mx.off(row);
-    const bf16_t* dyp = dy + mdy.off(row);
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane + i * 64;
-      if (c < nch) {
-        rx[i] = *reinterpret_cast<const uint4*>(xp + c * 8);
-        rd[i] = *reinterpret_cast<const uint4*>(dyp + c * 8);
-      }
-    }
-  };
-  if (row0 < rows) fetch(row0);
-  for (int row = row0; row < rows; row += rstep) {
-    const float mu = mean[row], rs = rstd[row];
-    float xr[NCH][8], gv[NCH][8], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane + i * 64;
-      if (c < nch) {
-        float d[8];
-        unpack8(rx[i], xr[i]);
-        unpack8(rd[i], d);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float a = xr[i][e];
-          const float xh = (a - mu) * rs;
-          const float g = d[e] * gam[i][e];
-          dg[i][e] += d[e] * xh; db[i][e] += d[e];
-          s1 += g; s2 += g * xh;
-          gv[i][e] = g;
-          xr[i][e] = xh;
-        }
-      }
-    }
-    if (row + rstep < rows) fetch(row + rstep);      // in flight under the reduction and the stores below
-    s1 = warp_sum(s1); s2 = warp_sum(s2);
-    s1 /= C; s2 /= C;
-    bf16_t* dxp = dx + mdx.off(row);
-    bf16_t* dx2p = dx2 + mdx2.off(row);
-    const bf16_t* ap = dx_add ? dx_add + madd.off(row) : nullptr;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane + i * 64;
-      if (c < nch) {
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xh = xr[i][e], dact = 1.f;
-          o[e] = rs * (gv[i][e] - s1 - xh * s2) * dact;
-        }
-        if (ap) {
-          float r[8];
-          unpack8(*reinterpret_cast<const uint4*>(ap + c * 8), r);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] += r[e];
-        }
-        const uint4 pk = pack8(o);
-        *reinterpret_cast<uint4*>(dxp + c * 8) = pk;
-        float d2[8];
-        unpack8(pk, d2);                               // the adjoint sees dx as stored
-        if (drop2.on) drop8(d2, drop2, (long long)row * nch + c, row);
-        *reinterpret_cast<uint4*>(dx2p + c * 8) = pack8(d2);
-      }
-    }
-  }
-  if (!dgamma_part) return;
-  // cross-wave reduction of the four rows' partials (chunk by chunk through LDS)
-  float (*r4)[64 * 8 + 8] = reinterpret_cast<float (*)[64 * 8 + 8]>(red);
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      __syncthreads();
-#pragma unroll
-      for (int e = 0; e < 8; ++e) r4[wave][lane * 8 + e] = pass ? db[i][e] : dg[i][e];
-      __syncthreads();
-      for (int t = threadIdx.x; t < 512; t += 256) {
-        const int c = (t >> 3) + i * 64;
-        if (c < nch) {
-          const float sum = r4[0][t] + r4[1][t] + r4[2][t] + r4[3][t];
-          (pass ? dbeta_part : dgamma_part)[(long long)blockIdx.x * C + c * 8 + (t & 7)] = sum;
-        }
-      }
-    }
-  }
-}
-
-// Two LayerNorm backwards of one row in one launch (round 6): the pre-LN backward that closes a block of the backward,
-//     dx = dx_add + LN1'(x; gamma)(dy)                           (unify_transformer_layer.py:262-266 / 463-470 under autograd)
-// followed by the post-LN backward that opens the next block on that very row,
-//     dx2 = LN2'(x2; gamma2)(drop2(dx as stored in bf16))        (attn_ln / cross_attn_ln / self_attn_ln + dropout + DropPath)
-// -- the residual-stream gradient dx is written once and not read back, one launch boundary less per pair.  Stage 1 is
-// ln_bwd_lean_kernel's stage statement for statement, stage 2 the same statements on the second operand set.
-struct LnPairArgs {
-  const bf16_t *dy, *x, *gamma; const float *mean, *rstd; const bf16_t* dx_add; bf16_t* dx; float *dg_part, *db_part;
-  const bf16_t *x2, *gamma2; const float *mean2, *rstd2; bf16_t* dx2; float *dg2_part, *db2_part;
-  int rows, C, lddy, ldx, ldadd, lddx, ldx2, lddx2, pf32;
-  DropArgs drop2;
-};
-template <int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_pair_kernel(LnPairArgs a) {
-  __shared__ float red[4 * (64 * 8 + 8)];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nch = a.C >> 3, C = a.C;
-  // the two gain vectors live in LDS as fp32 (32 registers less: three waves per SIMD instead of two)
-  __shared__ __attribute__((aligned(16))) float sgam[2][NCH * 64 * 8];
-  float dg[NCH][8], db[NCH][8], dg2[NCH][8], db2[NCH][8];
-  for (int c = threadIdx.x; c < NCH * 64; c += 256) {
-    float g1[8], g2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { g1[e] = 0.f; g2[e] = 0.f; }
-    if (c < nch) { ldp8(a.gamma, c, a.pf32, g1); ldp8(a.gamma2, c, a.pf32, g2); }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { sgam[0][c * 8 + e] = g1[e]; sgam[1][c * 8 + e] = g2[e]; }
-  }
-#pragma unroll
-  for (int i = 0; i < NCH; ++i)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; dg2[i][e] = 0.f; db2[i][e] = 0.f; }
-  __syncthreads();
-  auto ldg = [&](int which, int i, float* o) {
-    const float4* q = reinterpret_cast<const float4*>(&sgam[which][(lane + i * 64) * 8]);
-    const float4 u = q[0], v = q[1];
-    o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = u.w; o[4] = v.x; o[5] = v.y; o[6] = v.z; o[7] = v.w;
-  };
-  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
-    const float mu = a.mean[row], rs = a.rstd[row];
-    const bf16_t* xp = a.x + (long long)row * a.ldx;
-    const bf16_t* dyp = a.dy + (long long)row * a.lddy;
-    const bf16_t* x2p = a.x2 + (long long)row * a.ldx2;
-    uint4 rx[NCH], rd[NCH], rx2[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane + i * 64;
-      if (c < nch) {
-        rx[i] = *reinterpret_cast<const uint4*>(xp + c * 8);
-        rd[i] = *reinterpret_cast<const uint4*>(dyp + c * 8);
-        rx2[i] = *reinterpret_cast<const uint4*>(x2p + c * 8);       // (stage 2's operand: in flight under stage 1)
-      }
-    }
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane + i * 64;
-      if (c < nch) {
-        float xr[8], d[8], gm[8];
-        unpack8(rx[i], xr);
-        unpack8(rd[i], d);
-        ldg(0, i, gm);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xh = (xr[e] - mu) * rs;
-          const float g = d[e] * gm[e];
-          dg[i][e] += d[e] * xh; db[i][e] += d[e];
-          s1 += g; s2 += g * xh;
-        }
-      }
-    }
-    s1 = warp_sum(s1); s2 = warp_sum(s2);
-    s1 /= C; s2 /= C;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-      asm volatile("" : "+v"(rx[i].x), "+v"(rx[i].y), "+v"(rx[i].z), "+v"(rx[i].w), "+v"(rd[i].x), "+v"(rd[i].y), "+v"(rd[i].z), "+v"(rd[i].w));
-    bf16_t* dxp = a.dx + (long long)row * a.lddx;
-    const bf16_t* ap = a.dx_add ? a.dx_add + (long long)row * a.ldadd : nullptr;
-    uint4 pk[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane + i * 64;
-      if (c < nch) {
-        float xr[8], d[8], o[8], gm[8];
-        unpack8(rx[i], xr);
-        unpack8(rd[i], d);
-        ldg(0, i, gm);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xh = (xr[e] - mu) * rs;
-          const float g = __fmul_rn(d[e], gm[e]);
-          o[e] = rs * (g - s1 - xh * s2) * 1.f;
-        }
-        if (ap) {
-          float r[8];
-          unpack8(*reinterpret_cast<const uint4*>(ap + c * 8), r);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] += r[e];
-        }
-        pk[i] = pack8(o);
-        *reinterpret_cast<uint4*>(dxp + c * 8) = pk[i];
-      }
-    }
-    // ---- stage 2: the post-LN backward of drop2(dx), dx exactly as stored
-    const float mu2 = a.mean2[row], rs2 = a.rstd2[row];
-    float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane + i * 64;
-      if (c < nch) {
-        float xr[8], d[8];
-        unpack8(rx2[i], xr);
-        unpack8(pk[i], d);
-        if (a.drop2.on) drop8(d, a.drop2, (long long)row * nch + c, row);
-        float gm[8];
-        ldg(1, i, gm);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xh = (xr[e] - mu2) * rs2;
-          const float g = d[e] * gm[e];
-          dg2[i][e] += d[e] * xh; db2[i][e] += d[e];
-          t1 += g; t2 += g * xh;
-        }
-      }
-    }
-    t1 = warp_sum(t1); t2 = warp_sum(t2);
-    t1 /= C; t2 /= C;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-      asm volatile("" : "+v"(rx2[i].x), "+v"(rx2[i].y), "+v"(rx2[i].z), "+v"(rx2[i].w), "+v"(pk[i].x), "+v"(pk[i].y), "+v"(pk[i].z), "+v"(pk[i].w));
-    bf16_t* dx2p = a.dx2 + (long long)row * a.lddx2;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = lane + i * 64;
-      if (c < nch) {
-        float xr[8], d[8], o[8];
-        unpack8(rx2[i], xr);
-        unpack8(pk[i], d);
-        if (a.drop2.on) drop8(d, a.drop2, (long long)row * nch + c, row);
-        float gm[8];
-        ldg(1, i, gm);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xh = (xr[e] - mu2) * rs2;
-          const float g = __fmul_rn(d[e], gm[e]);
-          o[e] = rs2 * (g - t1 - xh * t2) * 1.f;
-        }
-        *reinterpret_cast<uint4*>(dx2p + c * 8) = pack8(o);
-      }
-    }
-  }
-  float (*r4)[64 * 8 + 8] = reinterpret_cast<float (*)[64 * 8 + 8]>(red);
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      __syncthreads();
-#pragma unroll
-      for (int e = 0; e < 8; ++e) r4[wave][lane * 8 + e] = pass == 0 ? dg[i][e] : pass == 1 ? db[i][e] : pass == 2 ? dg2[i][e] : db2[i][e];
-      __syncthreads();
-      float* outp = pass == 0 ? a.dg_part : pass == 1 ? a.db_part : pass == 2 ? a.dg2_part : a.db2_part;
-      for (int t = threadIdx.x; t < 512; t += 256) {
-        const int c = (t >> 3) + i * 64;
-        if (c < nch) {
-          const float sum = r4[0][t] + r4[1][t] + r4[2][t] + r4[3][t];
-          outp[(long long)blockIdx.x * C + c * 8 + (t & 7)] = sum;
         }
       }
     }
@@ -978,8 +697,7 @@ extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, co
   hipStream_t s = (hipStream_t)stream;
   const bf16_t *DY = (const bf16_t*)dy, *X = (const bf16_t*)x, *G = (const bf16_t*)gamma, *A = (const bf16_t*)dx_add;
   ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 8.0 : 6.0));
-  static const bool lean = getenv("IFSEG_LN_BWD_CLASSIC") == nullptr;
-  if (C <= 1024 && lean && !(act_gelu & IFSEG_LN_GELU))
+  if (C <= 1024 && !(act_gelu & IFSEG_LN_GELU))
     hipLaunchKernelGGL((ln_bwd_lean_kernel<2, false>), g, dim3(256), 0, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C,
                        mdy, mx, mdx, madd, dr, (act_gelu & IFSEG_LN_PARAMS_F32) ? 1 : 0, (bf16_t*)nullptr, RowMap{}, DropArgs{});
   else if (C <= 1024) launch_ln_bwd<2, 1>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd, dr);
@@ -1007,48 +725,9 @@ extern "C" int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamm
   RowMap mdy{rpb, dy_bs, lddy}, mx{rpb, x_bs, ldx}, mdx{rpb, dx_bs, lddx}, madd{rpb, add_bs, ldadd}, mdx2{rpb, dx2_bs, lddx2};
   hipStream_t s = (hipStream_t)stream;
   ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 10.0 : 8.0));
-  static const bool lean = getenv("IFSEG_LN_BWD_CLASSIC") == nullptr;
-  if (lean)
-    hipLaunchKernelGGL((ln_bwd_lean_kernel<2, true>), dim3(nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
-                       (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C,
-                       mdy, mx, mdx, madd, DropArgs{}, (flags & IFSEG_LN_PARAMS_F32) ? 1 : 0, (bf16_t*)dx2, mdx2, dr);
-  else
-    hipLaunchKernelGGL(ln_bwd_drop_kernel, dim3(nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
-                       (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, dgamma_part, dbeta_part,
-                       (bf16_t*)dx2, rows, C, mdy, mx, mdx, madd, mdx2, dr, (flags & IFSEG_LN_PARAMS_F32) ? 1 : 0);
-  ifseg_prof_end(IFSEG_K_LN_BWD, s);
-  IFSEG_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int ifseg_ln_bwd_pair(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
-                                 const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part,
-                                 const void* x2, const void* gamma2, const float* mean2, const float* rstd2, void* dx2,
-                                 float* dgamma2_part, float* dbeta2_part, int nblocks, int rows, int C, int flags,
-                                 int lddy, int ldx, int ldadd, int lddx, int ldx2, int lddx2,
-                                 const ifseg_drop_args* drop2, void* stream) {
-  (void)hipGetLastError();
-  if (rows <= 0) return 0;
-  if ((C & 7) || C > 1024 || nblocks <= 0) return IFSEG_ERR_BAD_SHAPE;
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma_part || !dbeta_part || !x2 || !gamma2 || !mean2 || !rstd2 || !dx2 ||
-      !dgamma2_part || !dbeta2_part)
-    return IFSEG_ERR_BAD_ARG;
-  if (((lddy | ldx | lddx | ldx2 | lddx2) & 7) || (dx_add && (ldadd & 7))) return IFSEG_ERR_BAD_SHAPE;
-  if (flags & IFSEG_LN_GELU) return IFSEG_ERR_BAD_ARG;
-  LnPairArgs a{};
-  if (drop2) {
-    if (drop2->p < 0.f || drop2->p >= 1.f || drop2->rows_per_batch <= 0) return IFSEG_ERR_BAD_ARG;
-    a.drop2 = DropArgs{1, drop2->p, drop2->seed, drop2->drop_path_scale, drop2->rows_per_batch, drop2->seed_add};
-  }
-  a.dy = (const bf16_t*)dy; a.x = (const bf16_t*)x; a.gamma = (const bf16_t*)gamma; a.mean = mean; a.rstd = rstd;
-  a.dx_add = (const bf16_t*)dx_add; a.dx = (bf16_t*)dx; a.dg_part = dgamma_part; a.db_part = dbeta_part;
-  a.x2 = (const bf16_t*)x2; a.gamma2 = (const bf16_t*)gamma2; a.mean2 = mean2; a.rstd2 = rstd2; a.dx2 = (bf16_t*)dx2;
-  a.dg2_part = dgamma2_part; a.db2_part = dbeta2_part;
-  a.rows = rows; a.C = C; a.lddy = lddy; a.ldx = ldx; a.ldadd = ldadd; a.lddx = lddx; a.ldx2 = ldx2; a.lddx2 = lddx2;
-  a.pf32 = (flags & IFSEG_LN_PARAMS_F32) ? 1 : 0;
-  hipStream_t s = (hipStream_t)stream;
-  ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 12.0 : 10.0));
-  hipLaunchKernelGGL((ln_bwd_pair_kernel<2>), dim3(nblocks), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((ln_bwd_lean_kernel<2, true>), dim3(nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
+                     (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C,
+                     mdy, mx, mdx, madd, DropArgs{}, (flags & IFSEG_LN_PARAMS_F32) ? 1 : 0, (bf16_t*)dx2, mdx2, dr);
   ifseg_prof_end(IFSEG_K_LN_BWD, s);
   IFSEG_CHECK_LAUNCH();
   return 0;

@@ -9,6 +9,8 @@ import os
 
 import torch
 
+from . import lab
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IFSEG_LIB", os.path.join(_HERE, "lib", "libifseg_hip.so"))
 _lib = None
@@ -19,7 +21,7 @@ GEMM_RELU, GEMM_OUT_F32, GEMM_ACCUMULATE = 1, 2, 4
 c_void_p, c_int, c_float, c_ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 
 
-ABI_VERSION = 16          # == IFSEG_ABI_VERSION of include/ifseg_hip.h (checked at load time and by __graft_entry__.build)
+ABI_VERSION = 17          # == IFSEG_ABI_VERSION of include/ifseg_hip.h (checked at load time and by __graft_entry__.build)
 
 
 def lib():
@@ -63,16 +65,6 @@ def set_stream(handle):
     prev = _stream_handle
     _stream_handle = handle
     return prev
-
-
-def cumask_stream(mask_hex, device):
-    """torch.cuda.ExternalStream over a HIP stream restricted to the CUs of `mask_hex` (bit i = CU i; IFSEG_CUMASK_* switches)"""
-    v = int(mask_hex, 16)
-    words = [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
-    arr = (ctypes.c_uint32 * 8)(*words)
-    out = c_void_p()
-    _check(lib().ifseg_stream_create_cumask(arr, c_int(8), ctypes.byref(out)), "stream_create_cumask")
-    return torch.cuda.ExternalStream(out.value, device=device)
 
 
 def _stream():
@@ -194,12 +186,12 @@ _splitk_ws = {}
 GEMM_COLSUM = 8
 # workgroups a dW GEMM is split over: it runs on the side stream next to the dX chain, so filling the chip alone is not
 # the goal (256 / 512 / 128 measured within 1% of each other; fewer slabs = less fp32 workspace traffic)
-DW_TARGET_WGS = int(os.environ.get("IFSEG_DW_WGS", "256"))
-DW_XCD_SLICES = os.environ.get("IFSEG_DW_NO_XCD_SLICES") is None
+DW_TARGET_WGS = int(lab.get("DW_WGS", "256"))
+DW_XCD_SLICES = lab.get("DW_NO_XCD_SLICES") is None
 # dW GEMMs with at least this many 128x128 tiles run without split-K (bf16 dW and db written once, no slabs, no
 # reduction).  Off by default: measured on the Base step, 144-tile GEMMs that walk all 8480 tokens per workgroup make the
 # weight-gradient stream lag (372-382 img/s vs 388 with split-K 2); the path is kept for models with wider layers.
-DW_DIRECT_TILES = int(os.environ.get("IFSEG_DW_DIRECT", "1000000"))
+DW_DIRECT_TILES = int(lab.get("DW_DIRECT", "1000000"))
 
 
 def linear_dw(dy, x, out, accumulate=False, bias_out=None):
@@ -255,7 +247,7 @@ class _TnProblem(ctypes.Structure):
 
 
 GEMM_GROUP_MAX = 8
-DW_GROUP_WGS = int(os.environ.get("IFSEG_DW_GROUP_WGS", "512"))     # grid cap of the grouped dW GEMM: two workgroups per CU (in-step sweep, round 3: 256: 17.49, 384: 17.46, 512: 17.23 / 17.39, 768: 17.28, uncapped: 17.36 ms)
+DW_GROUP_WGS = int(lab.get("DW_GROUP_WGS", "512"))     # grid cap of the grouped dW GEMM: two workgroups per CU (in-step sweep, round 3: 256: 17.49, 384: 17.46, 512: 17.23 / 17.39, 768: 17.28, uncapped: 17.36 ms)
 
 
 def dw_groupable(dy, x, out, bias_out):
@@ -399,12 +391,12 @@ def _pad32(n):
 
 
 class DenseBias:
-    """The batch-invariant attention bias of one layer as a dense fp32 operand D [H, Tp, Sp] (-inf = masked or padding),
-    built from parameters only by ifseg_attn_dense_bias."""
+    """The batch-invariant attention bias of one layer as a dense bf16 operand D [H, Tp, Sp] (-inf = masked or padding),
+    built from parameters only by ifseg_attn_dense_bias (fp32 arithmetic, one rounding)."""
 
     def __init__(self, H, T, S, device):
         self.H, self.T, self.S, self.Sp, self.Tp = H, T, S, _pad32(S), _pad32(T)
-        self.D = torch.empty(H, self.Tp, self.Sp, dtype=torch.float32, device=device)
+        self.D = torch.empty(H, self.Tp, self.Sp, dtype=torch.bfloat16, device=device)
 
 
 def attn_dense_bias(dense, pos_q, pos_k, rel=None, causal=False, P=None):
@@ -607,7 +599,7 @@ def ln_fwd_pair(x, gamma, beta, y, mean, rstd, gamma2, beta2, y2, mean2, rstd2, 
     return y, y2
 
 
-LN_BWD_BLOCKS = int(os.environ.get("IFSEG_LN_BWD_BLOCKS", "768"))   # three resident blocks per CU (146-162 VGPRs): best of a 256..2048 sweep on MI355X
+LN_BWD_BLOCKS = int(lab.get("LN_BWD_BLOCKS", "768"))   # three resident blocks per CU (146-162 VGPRs): best of a 256..2048 sweep on MI355X
 
 
 def ln_bwd_drop(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx2, dx_add=None, drop2=None):
@@ -626,24 +618,6 @@ def ln_bwd_drop(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx2, dx_a
                                  c_int(_ln_flags(gamma)), c_int(rpb), c_ll(db_), c_int(dl), c_ll(xb), c_int(xl), c_ll(ob), c_int(ol), c_ll(ab),
                                  c_int(al), c_ll(o2b), c_int(o2l), _drop_ref(drop2, rpb or rows), _stream())
     _check(rc, "ln_bwd_drop")
-    return dx, dx2
-
-
-def ln_bwd_pair(dy, x, gamma, mean, rstd, dx, dg_part, db_part, x2, gamma2, mean2, rstd2, dx2, dg2_part, db2_part,
-                dx_add=None, drop2=None, rows_per_batch=None):
-    """dx = [dx_add +] LN1'(x; gamma)(dy), dx2 = LN2'(x2; gamma2)(drop2(dx)): a block's closing pre-LN backward and the next
-    block's opening post-LN backward of the same rows in one launch (all operands [rows, C], last dimension contiguous)"""
-    C = x.shape[-1]
-    rows = x.numel() // C
-    for t in (dy, x, dx, x2, dx2) + ((dx_add,) if dx_add is not None else ()):
-        assert t.dim() == 2 and t.stride(1) == 1 and t.shape == (rows, C), (tuple(t.shape), t.stride())
-    rc = lib().ifseg_ln_bwd_pair(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx_add), _ptr(dx), _ptr(dg_part),
-                                 _ptr(db_part), _ptr(x2), _ptr(gamma2), _ptr(mean2), _ptr(rstd2), _ptr(dx2), _ptr(dg2_part),
-                                 _ptr(db2_part), c_int(LN_BWD_BLOCKS), c_int(rows), c_int(C), c_int(_ln_flags(gamma)),
-                                 c_int(dy.stride(0)), c_int(x.stride(0)), c_int(dx_add.stride(0) if dx_add is not None else 0),
-                                 c_int(dx.stride(0)), c_int(x2.stride(0)), c_int(dx2.stride(0)),
-                                 _drop_ref(drop2, rows_per_batch or rows), _stream())
-    _check(rc, "ln_bwd_pair")
     return dx, dx2
 
 

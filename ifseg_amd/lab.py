@@ -6,12 +6,13 @@ number under `IFSEG_LAB=1` unless it is started with `--lab` (the line is then m
 refuses `IFSEG_EXP_*` builds.  (csrc/common.h `lab_env` is the same gate for the C++ host code.)"""
 import os
 
-ON = os.environ.get("IFSEG_LAB") == "1"
+def on():
+    return os.environ.get("IFSEG_LAB") == "1"
 
 
 def get(name, default=None):
     """value of the laboratory switch IFSEG_<name> (a string), or `default` outside the laboratory"""
-    if not ON:
+    if not on():
         return default
     return os.environ.get("IFSEG_" + name, default)
 

@@ -31,13 +31,14 @@ import time
 import torch
 
 from ... import hip, lab
+from . import resized as R
 from .config import image_rp_bucket, token_bucket_of_delta
 
 BF = torch.bfloat16
 # TIMING EXPERIMENTS ONLY (wrong results): kernels left out of the step to bound what optimising them could return,
 # e.g. IFSEG_EXP_SKIP=lnwide,dq (tools/skip_bound.sh; DESIGN section 4 "Round 3")
-_POISON = os.environ.get("IFSEG_POISON_WS", "") == "1"
-_EXP_SKIP = set(filter(None, os.environ.get("IFSEG_EXP_SKIP", "").split(",")))
+_POISON = lab.get("POISON_WS", "") == "1"
+_EXP_SKIP = set(filter(None, lab.get("EXP_SKIP", "").split(",")))
 
 
 def _pad8(n):
@@ -73,12 +74,12 @@ class HipEngine:
         # reductions) is enqueued on a second HIP stream and overlaps the dX chain on the main stream
         self._pending_checks, self._checked_kinds = [], set()
         self.master_owned = False        # True once the bundled Trainer updates `master` and `p16` together
-        self.overlap = os.environ.get("IFSEG_NO_OVERLAP") is None
-        self.delta_fused = os.environ.get("IFSEG_NO_DELTA_FUSE") is None     # delta from the out_proj dX GEMM's epilogue
+        self.overlap = lab.get("NO_OVERLAP") is None
+        self.delta_fused = lab.get("NO_DELTA_FUSE") is None     # delta from the out_proj dX GEMM's epilogue
         self._side = None
         self._trunk_stream, self._pf, self._pf_slot = None, None, 0
         self._pf_more = []               # features of the batches AFTER the next one (one trunk pass over several batches)
-        self.trunk_lookahead = max(1, int(os.environ.get("IFSEG_TRUNK_LOOKAHEAD", "2")))
+        self.trunk_lookahead = max(1, int(lab.get("TRUNK_LOOKAHEAD", "2")))
         self._pf_request = None          # images of the next batch (set by the trainer; consumed by the next forward)
         self._pending, self._in_flush = [], False
         # weight-gradient GEMMs of a layer are collected and launched as ONE grouped GEMM at the end of the layer's
@@ -86,21 +87,20 @@ class HipEngine:
         self._dw_tasks = []
         self._kfix_tasks = []       # (k_proj dW [C, C], k_proj db [C], projection input x [rows, C], tag of a shared column-sum workspace or None)
         self._ln_red_tasks, self._ln_red_acc = [], []    # (partials, [2, C] gradient view, ...) of LayerNorm backward launches
-        self.dw_grouped = os.environ.get("IFSEG_NO_DW_GROUP") is None
-        self.dw_split = os.environ.get("IFSEG_DW_SPLIT", "0") == "1"
+        self.dw_grouped = lab.get("NO_DW_GROUP") is None
         # IFSEG_DRAIN_TIMING=1: event pair around the end-of-backward join (bench.py reports `end_of_backward_wait_ms`).
         # Measured 0.49 ms per C2 step.  Moving the attentions' bias-gradient reductions to the third stream shortened it to
         # 0.41 ms and made the step 0.45 ms SLOWER (a third busy queue under the dX chain); for the last layer only: 0.42 ms,
         # step unchanged.  Not adopted.
-        self.drain_timing = [] if os.environ.get("IFSEG_DRAIN_TIMING") else None
+        self.drain_timing = [] if lab.get("DRAIN_TIMING") else None
         # IFSEG_PHASE_TIMING=1: a few timing events per step on the main stream (`mark`, with the host's clock next to each);
         # bench.py reports the phases' GPU and host durations over the timed region (`phase_ms`, `phase_host_ms`)
-        self.marks = [] if os.environ.get("IFSEG_PHASE_TIMING") else None
+        self.marks = [] if lab.get("PHASE_TIMING") else None
         self.attn_bwd_timing = None      # {"stride": n, "seen": 0, "pairs": []} while bench.py times the attention backward
         self._rb_cache, self._wver = {}, 0   # dense resized rel-pos biases (eval on other aspect ratios), weights version
         # ffn_layernorm(gelu(fc1)) backward folded into the fc2 dX GEMM's epilogue (csrc/rowops.hip "FFN's ffn_layernorm",
         # csrc/gemm.hip EPI_GLN): no 3072-wide LayerNorm-backward pass.  IFSEG_NO_FFN_LN_FUSE=1: the stand-alone kernel.
-        self.ffn_ln_fused = os.environ.get("IFSEG_NO_FFN_LN_FUSE") is None
+        self.ffn_ln_fused = lab.get("NO_FFN_LN_FUSE") is None
         # attention backward with the batch inside the workgroup (csrc/attention_bi.hip): the bias is a dense batch-invariant
         # operand built once per layer from parameters, sum_b dS leaves the dQ kernel once per tile.  IFSEG_ATTN_BI=0: the
         # round-3 kernels (one workgroup per (batch, head, tile), bias regenerated per batch element).
@@ -108,20 +108,17 @@ class HipEngine:
         # 8 and <= 64 (measured in the step, DESIGN round 4, same box: Base C2 17.44 vs 18.03 ms with the round-3 kernels;
         # SegOFA-Large at 640^2 83.4 vs 101.7 ms).  Until the dense bias lost its transposed copy the causal decoder
         # self-attention was 0.1 ms better off on the round-3 kernels' 32-wide fast path; now it is 0.06 ms worse.  "0": nowhere.
-        self.attn_bi = os.environ.get("IFSEG_ATTN_BI", "auto")
+        self.attn_bi = lab.get("ATTN_BI", "auto")
         # k_proj.weight gradients without the product of dK's spurious column sum and the token mean of the projection's input
         # (an exact identity: sum_j dK_j = 0; csrc/rowops.hip ifseg_kproj_common_mode).  IFSEG_NO_KPROJ_FIX=1: as computed.
-        self.kproj_fix = os.environ.get("IFSEG_NO_KPROJ_FIX") is None
+        self.kproj_fix = lab.get("NO_KPROJ_FIX") is None
         # the forward through the batch-inner kernel wherever the layer's dense bias exists (IFSEG_ATTN_BI_FWD=0: round-3 forward)
-        self.bi_fwd = os.environ.get("IFSEG_ATTN_BI_FWD", "1") != "0"
+        self.bi_fwd = lab.get("ATTN_BI_FWD", "1") != "0"
         self._ffn_pg_tasks = []
-        # a block's closing pre-LN backward and the next block's opening post-LN backward in one launch (round 6)
-        self.ln_bwd_pairs = lab.get("NO_LN_BWD_PAIRS") is None
         self._train_fwd = False
         # where the NEXT batch's frozen-trunk pass is launched: "fwd" = at the start of this step's forward, "e<k>" = when
         # the backward reaches encoder layer k, "end" = after the last backward kernel of the main stream
-        self.trunk_at = os.environ.get("IFSEG_TRUNK_AT", "fwd")
-        self.tail_pos_main = os.environ.get("IFSEG_TAIL_POS_MAIN") == "1"
+        self.trunk_at = lab.get("TRUNK_AT", "fwd")
         self._bt = ""                    # tag of the backward block being processed (unique gradient buffers)
 
     # ------------------------------------------------------------------ packing
@@ -311,7 +308,7 @@ class HipEngine:
         self.stem_w = w.permute(2, 3, 1, 0).contiguous().to(dev)          # [7][7][3][64] fp32
         # (the matrix-core stem kernel takes bf16 weights, like every other convolution of the trunk; IFSEG_STEM_DIRECT=1: the
         # round-1 direct fp32 kernel)
-        if os.environ.get("IFSEG_STEM_DIRECT") is None:
+        if lab.get("STEM_DIRECT") is None:
             self.stem_w = hip.stem_weights_mfma(self.stem_w)
         self.stem_shift = sh.contiguous().to(dev)
         self.rn_blocks = []
@@ -378,10 +375,8 @@ class HipEngine:
         return e
 
     def _new_stream(self, which, priority=0):
-        """a side stream; IFSEG_CUMASK_<which>=<hex> (laboratory) restricts it to those compute units"""
-        m = os.environ.get("IFSEG_CUMASK_" + which)
-        if m:
-            return hip.cumask_stream(m, self.device)
+        """a side stream.  (Round 5 measured CU-masked streams for the weight-gradient / dQ / trunk work: a masked stream is one
+        more hardware queue, 25-31 ms per step -- profiles/round5_cumask_ab.txt; removed.)"""
         return torch.cuda.Stream(device=self.device, priority=priority)
 
     def _wgrad_init(self):
@@ -432,7 +427,7 @@ class HipEngine:
     def _dq_stream_get(self):
         if getattr(self, "_dqs", None) is None:
             self._wgrad_init()
-            self._dqs = self._new_stream("DQ", int(os.environ.get("IFSEG_DQ_PRIO", "0")))
+            self._dqs = self._new_stream("DQ")
         return self._dqs
 
     @contextlib.contextmanager
@@ -463,6 +458,17 @@ class HipEngine:
             d = hip.DenseBias(H, T, S, self.device)
             self.ws[key] = d
         hip.attn_dense_bias(d, pq, pk, rel=rel, causal=causal, P=P)
+        return d
+
+    def _dense_from(self, tag, H, T, S, bias):
+        """a dense bias operand from a ready fp32 [H, T, S] tensor (training on a resized grid: models/segofa/resized.py)"""
+        key = "dense_" + tag
+        d = self.ws.get(key)
+        if d is None or (d.H, d.T, d.S) != (H, T, S):
+            d = hip.DenseBias(H, T, S, self.device)
+            d.D.fill_(float("-inf"))              # rows / columns of the padding stay masked
+            self.ws[key] = d
+        d.D[:, :T, :S].copy_(bias)
         return d
 
     def _dense_built(self, ctx, tag):
@@ -534,7 +540,7 @@ class HipEngine:
         if self._trunk_stream is None:
             # high priority: the ~100 small convolutions must finish within the step they run under -- at normal priority
             # they were starved by the main / weight-gradient queues and the NEXT forward waited 2.6 ms for its features
-            self._trunk_stream = self._new_stream("TRUNK", int(os.environ.get("IFSEG_TRUNK_PRIO", "-1")))
+            self._trunk_stream = self._new_stream("TRUNK", -1)
         cur = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(cur)                                   # the images were produced on the caller's stream
@@ -830,7 +836,7 @@ class HipEngine:
         real data iterator).  The first call of a process checks synchronously."""
         if torch.cuda.is_current_stream_capturing():
             return                                 # a captured forward replays validated inputs (checked at warm-up)
-        if os.environ.get("IFSEG_SYNC_CHECKS"):
+        if lab.get("SYNC_CHECKS"):
             if bool(bad(tensor)):
                 raise exc(message)
             return
@@ -884,7 +890,7 @@ class HipEngine:
         dev = src_tokens.device if bag is not None else patch_images.device
         if not self.packed or self.device != dev:
             self.pack(dev)
-        pads = bool(getattr(cfg, "padded_prompts", False)) or os.environ.get("IFSEG_PADDED_PROMPTS") == "1"
+        pads = bool(getattr(cfg, "padded_prompts", False))
         if pads:
             if bag is not None:
                 raise NotImplementedError("ifseg_amd HIP engine: padded prompts in the image-free branch are not supported")
@@ -894,8 +900,7 @@ class HipEngine:
                                 exc=ValueError)
         else:
             self.deferred_check(src_tokens, lambda t: t.eq(1).any(),
-                                "ifseg_amd HIP engine: padded source tokens need cfg.padded_prompts = True "
-                                "(or IFSEG_PADDED_PROMPTS=1): every IFSeg sample carries the same unpadded prompt, so by "
+                                "ifseg_amd HIP engine: padded source tokens need cfg.padded_prompts = True: every IFSeg sample carries the same unpadded prompt, so by "
                                 "default a step carries no per-sample key counts")
         B, L = src_tokens.shape
         C, Fd, H = cfg.embed_dim, cfg.ffn_dim, cfg.heads
@@ -920,21 +925,25 @@ class HipEngine:
         oh = cfg.orig_patch_image_size // 16
         slow = (h, w) != (oh, oh) or (h, w) != (cfg.seg_bucket_size,) * 2 or P % 64 != 0
         if slow:
-            # eval-time images whose feature grid differs from the trained one (seg_criterion.py:194-217,
-            # batch 1, native aspect ratio): position tables / rel-pos biases are bilinear-resized exactly
-            # like the reference and handed to the attention kernel as a dense fp32 bias.  Forward only.
+            # images whose feature grid differs from the trained one (seg_criterion.py:194-217 at evaluation: batch 1, native
+            # aspect ratio; `--patch-image-size 640` on a 512-grid checkpoint in training): position tables / rel-pos biases are
+            # bilinear-resized exactly like the reference.  Evaluation: the dense fp32 bias of csrc/resize.hip, cached per shape.
+            # Training (round 6): the standard step below with dense biases from models/segofa/resized.py and their adjoints.
             if pads:
                 raise NotImplementedError("ifseg_amd HIP engine: padded prompts on a resized feature grid are not supported")
-            if need_grad:
-                raise NotImplementedError("ifseg_amd HIP engine: training on a feature grid (%dx%d) other than the "
-                                          "trained one (%dx%d) is not supported (eval-only slow path)" % (h, w, oh, oh))
-            return self._forward_resized(src_tokens, feat, h, w, prev_output_tokens, full_context_alignment)
+            if bag is not None:
+                raise NotImplementedError("ifseg_amd HIP engine: the image-free entry on a resized feature grid is not supported")
+            if not need_grad:
+                return self._forward_resized(src_tokens, feat, h, w, prev_output_tokens, full_context_alignment)
+        resized = bool(slow)
         g = self._geometry(h, w, L)
         T, Td = P + L, P + 1
         self._drop_setup(B, need_grad)
         self._train_fwd = bool(need_grad)
         ctx = {"B": B, "L": L, "P": P, "T": T, "Td": Td, "h": h, "w": w, "full": bool(full_context_alignment),
                "src_tokens": src_tokens, "feat": feat}
+        if resized:
+            ctx["resized"] = True
         if pads:
             # encoder_padding_mask as valid key counts: the P patch tokens + the prompt tokens in front of the padding
             nonpad = src_tokens.ne(1)
@@ -975,10 +984,16 @@ class HipEngine:
             x[:, P:].mul_(ctx["nonpad"].unsqueeze(-1).to(x.dtype))      # x = x * (1 - encoder_padding_mask), encoder_module.py:738-742
         # ---- abs-pos operands (encoder_module.py:757-771): LN over the table rows in place
         bsz = cfg.image_bucket_size
-        img_pos_view = W(e + "embed_image_positions.weight")[1:1 + bsz * h].view(h, bsz, C)[:, :w]
         pos_all = buf("e_pos_all", (T, C))
         mu, rs = self._ln_stats("ipos_ln", P)
-        hip.ln_fwd(img_pos_view, Wf(e + "image_pos_ln.weight"), Wf(e + "image_pos_ln.bias"), pos_all[:P].view(h, w, C), mu, rs)
+        if resized and P > oh * oh:
+            # more patches than the trained grid: the trained grid's rows resized (get_patch_images_info, encoder_module.py:358-370)
+            ipos = buf("e_ipos_resized", (P, C))
+            hip.resize_rows_bilinear(W(e + "embed_image_positions.weight"), ipos, h, w, oh, oh, bsz, 1)
+            hip.ln_fwd(ipos, Wf(e + "image_pos_ln.weight"), Wf(e + "image_pos_ln.bias"), pos_all[:P], mu, rs)
+        else:
+            img_pos_view = W(e + "embed_image_positions.weight")[1:1 + bsz * h].view(h, bsz, C)[:, :w]
+            hip.ln_fwd(img_pos_view, Wf(e + "image_pos_ln.weight"), Wf(e + "image_pos_ln.bias"), pos_all[:P].view(h, w, C), mu, rs)
         mu, rs = self._ln_stats("tpos_ln", L)
         hip.ln_fwd(W(e + "embed_positions.weight")[:L], Wf(e + "pos_ln.weight"), Wf(e + "pos_ln.bias"), pos_all[P:], mu, rs)
         pqk = buf("e_pqk", (T, 2 * C))
@@ -993,14 +1008,25 @@ class HipEngine:
         (e_rx,) = self._rel_tables_all("e_x", [None] * cfg.enc_layers, [(False, g["enc_idxx"])])
         self.mark("enc_layers_start")
         x_pre = None
-        bi = (need_grad or pads) and w <= 64 and w % 8 == 0 and self.attn_bi in ("1", "auto")
+        bi = resized or ((need_grad or pads) and w <= 64 and w % 8 == 0 and self.attn_bi in ("1", "auto"))
         # which attentions: e(ncoder self), d(ecoder self), c(ross); IFSEG_ATTN_BI_WHICH overrides
-        bi_which = os.environ.get("IFSEG_ATTN_BI_WHICH", "e+d+c").split("+") if bi else []
+        bi_which = lab.get("ATTN_BI_WHICH", "e+d+c").split("+") if bi else []
         if pads and not (bi and "e" in bi_which and "c" in bi_which and self.bi_fwd):
             raise NotImplementedError("ifseg_amd HIP engine: key padding is implemented by the batch-inner attention kernels "
-                                      "(grids up to 64 wide, a multiple of 8; IFSEG_ATTN_BI / _WHICH / _FWD at their defaults)")
+                                      "(grids up to 64 wide, a multiple of 8)")
         ctx["dense"] = {}
-        if bi and "e" in bi_which:
+        if resized:
+            bi_which = ["e", "d", "c"]
+            with self._wgrad():          # parameters only: torch ops on [H, T, T] tensors (models/segofa/resized.py), side stream
+                bufs = dict(self.model.named_buffers())
+                absb = R.abs_bias(ctx["e_pq"], ctx["e_pk"], H)
+                for l in range(cfg.enc_layers):
+                    relb = R.encoder_rel_bias(W("%stoken_rel_pos_table_list.%d.weight" % (e, l)).float(),
+                                              W("%simage_rel_pos_table_list.%d.weight" % (e, l)).float(),
+                                              bufs["encoder.token_rp_bucket"], bufs["encoder.image_rp_bucket"], (h, w), oh, bsz, L)
+                    ctx["dense"]["e%d" % l] = self._dense_from(("e%d" % l), H, T, T, absb + relb)
+                    self._dense_built(ctx, "e%d" % l)
+        elif bi and "e" in bi_which:
             # parameters only: every layer's dense bias on the side stream, under the first blocks of the forward
             with self._wgrad():
                 for l in range(cfg.enc_layers):
@@ -1019,7 +1045,7 @@ class HipEngine:
             p = "%slayers.%d." % (e, l)
             tg = "e%d" % l
             self._params_wait([tg])
-            rel = hip.RelBias(P, g["gcode"], g["code_bias"], e_r2[l], e_r1[l], e_rx[l], grid_w=w)
+            rel = None if resized else hip.RelBias(P, g["gcode"], g["code_bias"], e_r2[l], e_r1[l], e_rx[l], grid_w=w)
             x, xn = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", x, B, T,
                                          ctx["e_pq"], ctx["e_pk"], rel, False, scaling, site=("e", l, 0), xn_pre=x_pre,
                                          next_ln=(p + "final_layer_norm", tg + "_fln1", buf(tg + "_fxn", (B * T, C))))
@@ -1073,10 +1099,16 @@ class HipEngine:
         sb = cfg.seg_bucket_size
         segtab = W(d + "embed_seg_positions.weight")
         tp = buf("d_tp", (Td, C))
+        seg_rows, seg_bos = segtab[1:1 + P], segtab[:1]
+        if resized:      # the sb x sb grid's rows resized to (h, w) (decoder_module.py:541-550); the bos slot as it is
+            tgt = buf("d_spos_resized", (Td, C))
+            hip.resize_rows_bilinear(segtab, tgt[:P], h, w, sb, sb, sb, 1)
+            tgt[P:].copy_(segtab[:1])
+            seg_rows, seg_bos = tgt[:P], tgt[P:]
         mu, rs = self._ln_stats("d_tp_ln_p", P)
-        hip.ln_fwd(segtab[1:1 + P], Wf(d + "seg_pos_ln.weight"), Wf(d + "seg_pos_ln.bias"), tp[:P], mu, rs)
+        hip.ln_fwd(seg_rows, Wf(d + "seg_pos_ln.weight"), Wf(d + "seg_pos_ln.bias"), tp[:P], mu, rs)
         mu, rs = self._ln_stats("d_tp_ln_b", 1)
-        hip.ln_fwd(segtab[:1], Wf(d + "seg_pos_ln.weight"), Wf(d + "seg_pos_ln.bias"), tp[P:], mu, rs)
+        hip.ln_fwd(seg_bos, Wf(d + "seg_pos_ln.weight"), Wf(d + "seg_pos_ln.bias"), tp[P:], mu, rs)
         spqk = buf("d_spqk", (Td, 2 * C))
         hip.linear_fwd(tp, self._fused(self.p16, d + "self_pos_q_linear.weight", 2 * C, C),
                        self._fused(self.p16, d + "self_pos_q_linear.bias", 2 * C), out=spqk, alpha=scaling, alpha_ncols=C)
@@ -1090,7 +1122,25 @@ class HipEngine:
             "d_seg", ["%sseg_rel_pos_table_list.%d.weight" % (d, l) for l in range(cfg.dec_layers)],
             [(True, g["dec_idx2d"]), (True, g["dec_idx1d"]), (True, g["dec_idxx"])])
         y_pre = None
-        if bi:
+        if resized:
+            with self._wgrad():
+                bufs = dict(self.model.named_buffers())
+                absb = R.abs_bias(ctx["d_spq"], ctx["d_spk"], H)
+                if causal:
+                    absb = absb.masked_fill(R.causal_mask(P, dev)[None], float("-inf"))
+                for l in range(cfg.dec_layers):
+                    relb = R.decoder_rel_bias(W("%sseg_rel_pos_table_list.%d.weight" % (d, l)).float(), bufs["decoder.seg_rp_bucket"], (h, w), sb)
+                    ctx["dense"]["d%d" % l] = self._dense_from("d%d" % l, H, Td, Td, absb + relb)
+                    self._dense_built(ctx, "d%d" % l)
+                    if l == 0:
+                        ctx["dense"]["dc"] = self._dense_bias("dc", H, Td, T, cpq, cpk, None, False, None)
+                        self._dense_built(ctx, "dc")
+                if self.overlap:
+                    if getattr(self, "_dense_ev", None) is None:
+                        self._dense_ev = torch.cuda.Event()
+                    self._dense_ev.record(self._side)
+                    ctx["dense_ready"] = self._dense_ev
+        elif bi:
             with self._wgrad():
                 for l in range(cfg.dec_layers if "d" in bi_which else 0):
                     rel = hip.RelBias(P, g["gcode"], g["code_bias"], d_r2[l], d_r1[l], d_rx[l], grid_w=w)
@@ -1111,9 +1161,10 @@ class HipEngine:
         for l in range(cfg.dec_layers):
             p = "%slayers.%d." % (d, l)
             tg = "d%d" % l
-            rel = hip.RelBias(P, g["gcode"], g["code_bias"], d_r2[l], d_r1[l], d_rx[l], grid_w=w)
+            # (resized grid: the causal mask is inside the dense operand, the kernels walk every block)
+            rel = None if resized else hip.RelBias(P, g["gcode"], g["code_bias"], d_r2[l], d_r1[l], d_rx[l], grid_w=w)
             y, yn = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", y, B, Td,
-                                         ctx["d_spq"], ctx["d_spk"], rel, causal, scaling, site=("d", l, 0), xn_pre=y_pre,
+                                         ctx["d_spq"], ctx["d_spk"], rel, causal and not resized, scaling, site=("d", l, 0), xn_pre=y_pre,
                                          next_ln=(p + "encoder_attn_layer_norm", tg + "_cln1", buf(tg + "_cyn", (B * Td, C))))
             y, yn = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling, site=("d", l, 1), yn_pre=yn,
                                           next_ln=(p + "final_layer_norm", tg + "_fln1", buf(tg + "_fxn", (B * Td, C))))
@@ -1297,7 +1348,7 @@ class HipEngine:
             self._dense_wait(tg)
             # (measured and dropped: the round-3 kernel seeded from the dense bias by global loads, 94.2 vs 91.3 ms on C4)
             hip.attn_fwd_bi(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], dd, o, lse, B, H, T, T, causal=causal,
-                            P=rel.P, gain=gain, kv_len=self.ctx_building.get("klen") if tg[0] == "e" else None,
+                            P=rel.P if rel is not None else None, gain=gain, kv_len=self.ctx_building.get("klen") if tg[0] == "e" else None,
                             drop=self._attn_drop(tg, self.attn_drop_p))
         elif self.attn_drop_p:
             raise NotImplementedError("ifseg_amd HIP engine: attention dropout needs the batch-inner attention kernels")
@@ -1454,40 +1505,6 @@ class HipEngine:
         self._ln_red_tasks.append((part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C, False))
         return dx
 
-    def _post_desc(self, tg, kind, p, rows, rpb):
-        """descriptor of the post-LN backward that OPENS block `kind` ("c": cross attention, "s": self attention) of layer `tg` in
-        the backward, for `_ln_bwd_closing` of the block before it: (saved LN input, parameter, statistics tag, dropout, output)"""
-        if kind == "c":
-            s, pname, tag, bt = self.saved[tg + "_ca"], p + "cross_attn_ln", tg + "_cln2", tg + "c"
-        else:
-            s, bt = self.saved[tg + "_sa"], tg + "s"
-            pname, tag = p + ("self_attn_ln" if tg[0] == "d" else "attn_ln"), tg + "_ln2"
-        drop = None
-        if self.drop_on and s["site"] is not None:
-            drop = self._dropargs(self._site_id(s["site"]), self._dp(*s["site"]), rpb)
-        prev, self._bt = self._bt, bt
-        out = self.gbuf("g_da_%d" % rows, (rows, self.cfg.embed_dim))
-        self._bt = prev
-        return dict(x=s["a"], pname=pname, tag=tag, drop=drop, out=out, rpb=rpb, done=False)
-
-    def _ln_bwd_closing(self, dy, x, pname, stats_tag, dx, dx_add, nxt, post):
-        """the pre-LN backward that closes a block of the backward.  With `post` (`_post_desc`) the post-LN backward that opens
-        the NEXT block runs in the same launch on the same rows (csrc/rowops.hip ln_bwd_pair_kernel: the residual-stream
-        gradient is written once and not read back); with `nxt` see `_ln_bwd_fused`."""
-        C = x.shape[-1]
-        rows = x.numel() // C
-        if post is None or nxt is not None or C > 1024 or not self.ln_bwd_pairs:
-            return self._ln_bwd_fused(dy, x, pname, stats_tag, dx, dx_add, nxt)
-        mu, rs = self._ln_stats(stats_tag, rows)
-        mu2, rs2 = self._ln_stats(post["tag"], rows)
-        part, part2 = self._ln_part(C, stats_tag), self._ln_part(C, post["tag"])
-        hip.ln_bwd_pair(dy, x, self.Wf(pname + ".weight"), mu, rs, dx, part[0], part[1], post["x"], self.Wf(post["pname"] + ".weight"),
-                        mu2, rs2, post["out"], part2[0], part2[1], dx_add=dx_add, drop2=post["drop"], rows_per_batch=post["rpb"])
-        self._ln_red_tasks.append((part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C, False))
-        self._ln_red_tasks.append((part2, self._fused(self.g16, post["pname"] + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C, False))
-        post["done"] = True
-        return dx
-
     def _next_drop(self, tg, rows):
         """descriptor of the fc2 dropout adjoint that opens the FFN block of layer `tg` in the backward (None if inactive)"""
         s = self.saved[tg + "_ffn"]
@@ -1522,7 +1539,7 @@ class HipEngine:
             return hip.linear_dx(dy, wname_or_view, out=dx_out, resid=dx_resid, accumulate=dx_accumulate)
         return None
 
-    def _ffn_bwd(self, tg, p, dx2, rows, dbr_pre=None, nxt=None, post=None):
+    def _ffn_bwd(self, tg, p, dx2, rows, dbr_pre=None, nxt=None):
         """dx2: grad of the block output [rows, C]; returns grad of x1 (block input).  dbr_pre: the fc2 dropout adjoint of
         dx2 if the previous block of the backward already produced it; nxt: see `_ln_bwd_fused`."""
         C, Fd = self.cfg.embed_dim, self.cfg.ffn_dim
@@ -1555,9 +1572,7 @@ class HipEngine:
         dxn = buf("g_dxn_%d" % rows, (rows, C))
         self._linear_bwd(du, s["xn"], W(p + "fc1.weight"), G(p + "fc1.weight"), G(p + "fc1.bias"), dx_out=dxn)
         dx1 = gbuf("g_dx1_%d" % rows, (rows, C))
-        self._ln_bwd_closing(dxn, s["x1"].view(rows, C), p + "final_layer_norm", tg + "_fln1", dx1, dx2, nxt, post)
-        if self.dw_split:
-            self._side_do(self._dw_flush)      # fc1 / fc2 dW as their own group: runs under the attention backward
+        self._ln_bwd_fused(dxn, s["x1"].view(rows, C), p + "final_layer_norm", tg + "_fln1", dx1, dx2, nxt)
         self._side_flush()
         return dx1
 
@@ -1620,13 +1635,7 @@ class HipEngine:
             else:       # one event pair on the main stream around delta + dK/dV + dQ (bench.py's roofline object)
                 t0 = torch.cuda.Event(enable_timing=True)
                 t0.record()
-        if os.environ.get("IFSEG_ATTN_BWD_ONE_LAUNCH"):
-            # one launch: dK/dV workgroups followed by the dQ workgroups in one grid (csrc/attention.hip,
-            # attn_bwd_fused_kernel).  Measured SLOWER than the two kernels side by side on two streams (round 3: 18.82 vs
-            # 17.89 ms per step; encoder shape alone 447 us vs 189 + 125 us): compiled as one kernel the two bodies share a
-            # register allocation (75 spilled SGPRs, 36 bytes of scratch per lane in the loop).  Kept selectable.
-            hip.attn_bwd(*args, phases=(hip.ATTN_BWD_DKV | hip.ATTN_BWD_DQ) if have_delta else 0, **kw)
-        elif self.overlap and not os.environ.get("IFSEG_DQ_SERIAL"):
+        if self.overlap and not lab.get("DQ_SERIAL"):
             # dK/dV and dQ are independent once delta exists; each leaves its last round of workgroups partly
             # empty (864 workgroups on 512 slots), so they run on two streams and fill each other's holes
             if not have_delta:
@@ -1699,18 +1708,7 @@ class HipEngine:
             ph = hip.ATTN_BWD_DKV
         if "dkv" in _EXP_SKIP:
             ph = hip.ATTN_BWD_DQ if not ph else -1
-        if ph == 0 and self.overlap and os.environ.get("IFSEG_BI_DQ_STREAM"):
-            # (experiment) the dQ kernel on its own stream beside the dK/dV kernel: neither fits a CU next to the other, but
-            # the second, partly filled round of workgroups of one leaves CUs to the other
-            with self._fork(self._dq_stream_get()):
-                hip.attn_bwd_bi(q, k, v, do, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain,
-                                dq_scale=scaling, phases=hip.ATTN_BWD_DQ, dgain_rows=dgr, kv_len=kv_len, drop=adrop)
-                dq_done = self._ev()
-                dq_done.record(self._dqs)
-            hip.attn_bwd_bi(q, k, v, do, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain,
-                            dq_scale=scaling, phases=hip.ATTN_BWD_DKV, kv_len=kv_len, drop=adrop)
-            torch.cuda.current_stream().wait_event(dq_done)
-        elif ph >= 0:
+        if ph >= 0:
             hip.attn_bwd_bi(q, k, v, do, lse, delta, dense, dq, dk, dv, dbias, B, H, T, S, causal=causal, P=P, gain=gain,
                             dq_scale=scaling, phases=ph, dgain_rows=dgr, kv_len=kv_len, drop=adrop)
         if timing is not None:
@@ -1737,8 +1735,34 @@ class HipEngine:
             # (d c_attn[h] = sum of the dQ kernel's row terms: `ones` stands in for the gain the round-3 formula divides by)
             hip.attn_bwd_reduce(B, H, T, S, C, None, None, dpq_acc, dpk_acc, True, dgr, ones, self.G(gain_name),
                                 hip.dbias_nparts(), tables)
+            if self.ctx.get("resized") and rel_grads is not None:
+                self._resized_rel_grads(rel_grads, dbias, T)
         if "reduce" not in _EXP_SKIP:
             self._side_do(reductions)
+
+    def _resized_rel_grads(self, rel_grads, dbias, T):
+        """(side stream) training on a resized grid: the rel-pos bucket tables' gradients = the adjoint of
+        models/segofa/resized.py's bias map applied to sum_b dS [ng, H, T, Sp] (bf16, from the dQ kernel)"""
+        cfg, ctx = self.cfg, self.ctx
+        h, w, L = ctx["h"], ctx["w"], ctx["L"]
+        names = []
+        for n, _ in rel_grads:
+            if n is not None and n not in names:
+                names.append(n)
+        dB = dbias[:, :, :, :T].float().sum(0)
+        bufs = dict(self.model.named_buffers())
+        if names[0].startswith("encoder."):
+            img_n = [n for n in names if "image_rel" in n][0]
+            tok_n = [n for n in names if "token_rel" in n][0]
+            oh = cfg.orig_patch_image_size // 16
+            fn = lambda tt, it: R.encoder_rel_bias(tt, it, bufs["encoder.token_rp_bucket"], bufs["encoder.image_rp_bucket"], (h, w), oh,
+                                                   cfg.image_bucket_size, L)
+            order = [tok_n, img_n]
+        else:
+            fn = lambda st: R.decoder_rel_bias(st, bufs["decoder.seg_rp_bucket"], (h, w), cfg.seg_bucket_size)
+            order = names[:1]
+        for n, gv in zip(order, R.table_grads(fn, [self.W(n) for n in order], dB)):
+            self.G(n).copy_(gv)
 
     def _table_acc(self, tabname):
         """fp32 accumulator of one rel-pos bucket table's gradient.  All of them are views of ONE flat buffer that the backward
@@ -1798,7 +1822,7 @@ class HipEngine:
         return dx                # the caller flushes the side queue together with the layer's hook
 
     def _cross_block_bwd(self, tg, p, dy2, B, Td, Te, cpq, cpk, scaling, d_enc_out, first_cross, dcpq_acc, dcpk_acc,
-                         da_pre=None, nxt=None, post=None):
+                         da_pre=None, nxt=None):
         C = self.cfg.embed_dim
         s = self.saved[tg + "_ca"]
         W, Wf, G, buf = self.W, self.Wf, self.G, self.buf
@@ -1845,7 +1869,7 @@ class HipEngine:
         if self.kproj_fix:       # (every layer's K|V projection reads the same encoder output: one column sum per step)
             self._kfix_tasks.append((G(a_ + ".k_proj.weight"), G(a_ + ".k_proj.bias"), enc2d, "enc_out"))
         dy1 = gbuf("g_dy1c_%d" % rows, (rows, C))
-        self._ln_bwd_closing(dyn, s["x"].view(rows, C), p + "encoder_attn_layer_norm", tg + "_cln1", dy1, dy2, nxt, post)
+        self._ln_bwd_fused(dyn, s["x"].view(rows, C), p + "encoder_attn_layer_norm", tg + "_cln1", dy1, dy2, nxt)
         self._side_flush()
         return dy1
 
@@ -1890,7 +1914,7 @@ class HipEngine:
         d_enc_out = buf("g_d_enc_out", (B, T, C))
         dspq, dspk = buf("g_dspq", (Td, C), torch.float32), buf("g_dspk", (Td, C), torch.float32)
         dcpq, dcpk = buf("g_dcpq", (Td, C), torch.float32), buf("g_dcpk", (T, C), torch.float32)
-        fuse = os.environ.get("IFSEG_NO_LN_BWD_DROP") is None
+        fuse = lab.get("NO_LN_BWD_DROP") is None
         dbr = None
         for l in reversed(range(cfg.dec_layers)):
             p = "%slayers.%d." % (d, l)
@@ -1898,16 +1922,14 @@ class HipEngine:
             first = l == cfg.dec_layers - 1
             # the self block's closing pre-LN backward also produces the fc2-dropout adjoint that opens layer l-1's FFN block
             nx_f = self._next_drop("d%d" % (l - 1), B * Td) if fuse and l > 0 else None
-            # (each block's closing pre-LN backward also runs the post-LN backward that opens the next block: `_ln_bwd_closing`)
-            pc, ps = self._post_desc(tg, "c", p, B * Td, Td), self._post_desc(tg, "s", p, B * Td, Td)
-            dy = self._ffn_bwd(tg, p, dy, B * Td, dbr_pre=dbr, post=pc)
-            dy = self._cross_block_bwd(tg, p, dy, B, Td, T, ctx["d_cpq"], ctx["d_cpk"], scaling, d_enc_out, first, dcpq, dcpk,
-                                       da_pre=pc["out"] if pc["done"] else None, post=ps)
+            # (measured and dropped in round 6: each block's closing pre-LN backward together with the post-LN backward that opens
+            # the next block in one launch -- +0.11 ms per step, profiles/round6_ln_bwd_pair_ab.txt)
+            dy = self._ffn_bwd(tg, p, dy, B * Td, dbr_pre=dbr)
+            dy = self._cross_block_bwd(tg, p, dy, B, Td, T, ctx["d_cpq"], ctx["d_cpk"], scaling, d_enc_out, first, dcpq, dcpk)
             tabn = "%sseg_rel_pos_table_list.%d.weight" % (d, l)
             dy = self._self_block_bwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", dy, B, Td,
                                       ctx["d_spq"], ctx["d_spk"], scaling, dspq, dspk, first,
-                                      [(tabn, g["dec_idx2d"]), (tabn, g["dec_idx1d"]), (tabn, g["dec_idxx"])], nxt=nx_f,
-                                      da_pre=ps["out"] if ps["done"] else None)
+                                      [(tabn, g["dec_idx2d"]), (tabn, g["dec_idx1d"]), (tabn, g["dec_idxx"])], nxt=nx_f)
             dbr = nx_f["out"] if nx_f else None
             self._layer_end(p)                       # final in side-stream order
         # ---- decoder embedding LN (input = [enc_out[:, :P] | embed(bos)])
@@ -1945,19 +1967,13 @@ class HipEngine:
             if self.trunk_at == "e%d" % l:
                 self._trunk_launch_point()
             nx_f = self._next_drop("e%d" % (l - 1), B * T) if fuse and l > 0 else None
-            ps = self._post_desc(tg, "s", p, B * T, T)
-            dx = self._ffn_bwd(tg, p, dx, B * T, dbr_pre=dbr, post=ps)
+            dx = self._ffn_bwd(tg, p, dx, B * T, dbr_pre=dbr)
             dx = self._self_block_bwd(tg, p, "self_attn", "self_attn_layer_norm", "attn_ln", dx, B, T, ctx["e_pq"],
                                       ctx["e_pk"], scaling, depq, depk, first,
                                       [("%simage_rel_pos_table_list.%d.weight" % (e, l), g["enc_idx2d"]),
                                        ("%stoken_rel_pos_table_list.%d.weight" % (e, l), g["enc_idx1d"]),
-                                       (None, None)], nxt=nx_f, da_pre=ps["out"] if ps["done"] else None)
+                                       (None, None)], nxt=nx_f)
             dbr = nx_f["out"] if nx_f else None
-            if l == 0 and self.tail_pos_main and self.overlap:
-                # the abs-pos accumulators are complete once layer 0's bias-gradient kernels have run: an event on the side
-                # stream BEFORE that layer's weight-gradient group, for the main stream's abs-pos tail (below)
-                pos_ready = self._ev()
-                self._side_do(lambda ev=pos_ready: ev.record(self._side))
             self._layer_end(p)
         # ---- encoder abs-pos operands
         self._bt = "etop"
@@ -1966,14 +1982,6 @@ class HipEngine:
         if "tailsplit" in _EXP_SKIP:     # (measurement: the whole tail on the side stream, capped grid)
             self._side_do(lambda: (self._dw_flush(), self._enc_tail_pos_bwd(B, L, P, T, h, w, depq, depk, pos_all, dpos_all),
                                    self._enc_tail_emb_bwd(B, L, P, T, dx)))
-        elif self.tail_pos_main and self.overlap and cfg.enc_layers > 0:
-            # both halves of the tail on the main stream, NEXT TO the side stream's last weight-gradient group instead of behind it
-            # (the abs-pos half only waits for the bias-gradient kernels of layer 0: `pos_ready`)
-            self._side_do(lambda: self._dw_flush(wgs=0))
-            self._side_flush()
-            self._enc_tail_emb_bwd(B, L, P, T, dx)
-            torch.cuda.current_stream().wait_event(pos_ready)
-            self._enc_tail_pos_bwd(B, L, P, T, h, w, depq, depk, pos_all, dpos_all)
         else:
             self._side_do(lambda: (self._dw_flush(wgs=0), self._enc_tail_pos_bwd(B, L, P, T, h, w, depq, depk, pos_all, dpos_all)))
             self._side_flush()
@@ -2057,9 +2065,16 @@ class HipEngine:
                          self._fused(self.g16, e + "pos_q_linear.weight", 2 * C, C),
                          self._fused(self.g16, e + "pos_q_linear.bias", 2 * C), dx_out=dpos_all, dx_accumulate=True)
         bsz = cfg.image_bucket_size
-        ipos_view = W(e + "embed_image_positions.weight")[1:1 + bsz * h].view(h, bsz, C)[:, :w]
-        ipos_grad = G(e + "embed_image_positions.weight")[1:1 + bsz * h].view(h, bsz, C)[:, :w]
-        self._ln_bwd(dpos_all[:P].view(h, w, C), ipos_view, e + "image_pos_ln", "ipos_ln", ipos_grad)
+        oh = cfg.orig_patch_image_size // 16
+        if self.ctx.get("resized") and P > oh * oh:
+            dipos = buf("g_dipos", (P, C))
+            self._ln_bwd(dpos_all[:P], self.ws["e_ipos_resized"], e + "image_pos_ln", "ipos_ln", dipos)
+            G(e + "embed_image_positions.weight")[1:1 + bsz * oh].view(oh, bsz, C)[:, :oh].copy_(
+                R.rows_resize_adjoint(dipos, (oh, oh), (h, w)).view(oh, oh, C))
+        else:
+            ipos_view = W(e + "embed_image_positions.weight")[1:1 + bsz * h].view(h, bsz, C)[:, :w]
+            ipos_grad = G(e + "embed_image_positions.weight")[1:1 + bsz * h].view(h, bsz, C)[:, :w]
+            self._ln_bwd(dpos_all[:P].view(h, w, C), ipos_view, e + "image_pos_ln", "ipos_ln", ipos_grad)
         self._ln_bwd(dpos_all[P:], W(e + "embed_positions.weight")[:L], e + "pos_ln", "tpos_ln",
                      G(e + "embed_positions.weight")[:L])
         self._dw_flush()                 # the LayerNorm partials of this half
@@ -2120,8 +2135,17 @@ class HipEngine:
                          G(d + "cross_pos_q_linear.bias"), dx_out=dtp, dx_accumulate=True)
         segG = G(d + "embed_seg_positions.weight")
         segtab = W(d + "embed_seg_positions.weight")
-        self._ln_bwd(dtp[:P], segtab[1:1 + P], d + "seg_pos_ln", "d_tp_ln_p", segG[1:1 + P])
-        self._ln_bwd(dtp[P:], segtab[:1], d + "seg_pos_ln", "d_tp_ln_b", segG[:1], accumulate=True)
+        if self.ctx.get("resized"):
+            # the LayerNorm saw the resized rows: its backward, then the adjoint of the bilinear resize into the sb x sb grid's rows
+            sb = cfg.seg_bucket_size
+            tgt, dtgt = self.ws["d_spos_resized"], buf("g_dtgt", (Td, C))
+            self._ln_bwd(dtp[:P], tgt[:P], d + "seg_pos_ln", "d_tp_ln_p", dtgt[:P])
+            self._ln_bwd(dtp[P:], tgt[P:], d + "seg_pos_ln", "d_tp_ln_b", dtgt[P:], accumulate=True)
+            segG[1:1 + sb * sb].copy_(R.rows_resize_adjoint(dtgt[:P], (sb, sb), (self.ctx["h"], self.ctx["w"])))
+            segG[:1].copy_(dtgt[P:])
+        else:
+            self._ln_bwd(dtp[:P], segtab[1:1 + P], d + "seg_pos_ln", "d_tp_ln_p", segG[1:1 + P])
+            self._ln_bwd(dtp[P:], segtab[:1], d + "seg_pos_ln", "d_tp_ln_b", segG[:1], accumulate=True)
         dcpk16 = buf("g_dcpk16", (T, C))
         hip.cast_f32_bf16(dcpk, dcpk16)
         self._linear_bwd(dcpk16, pos_all, W(d + "cross_pos_k_linear.weight"), G(d + "cross_pos_k_linear.weight"),

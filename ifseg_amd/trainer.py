@@ -15,12 +15,11 @@ bf16 write-back are ONE kernel over the arena with the norm kept on the device.
 """
 import contextlib
 import math
-import os
 
 import torch
 import torch.distributed as dist
 
-from . import hip
+from . import hip, lab
 
 
 def layer_slices(eng):
@@ -94,8 +93,7 @@ class ArenaReducer:
         # 213 MB for SegOFA-Base, ~0.7 ms over the full xGMI mesh) and is rounded to bf16 ONCE, after the sum.  The
         # default stays the reference's own behaviour under --bf16 (DDP reduces the bf16 gradients as they are).
         if fp32_accumulate is None:
-            import os
-            fp32_accumulate = os.environ.get("IFSEG_REDUCE_FP32") == "1"
+            fp32_accumulate = lab.get("REDUCE_FP32") == "1"
         self.fp32 = bool(fp32_accumulate) and flat.dtype != torch.float32
         self._wide = []
         # Buckets: layer slices become final in reverse arena order, so adjacent ones are merged until a bucket holds
@@ -103,13 +101,12 @@ class ArenaReducer:
         # of 14.  Every torch.distributed call costs the enqueueing host thread ~0.1-0.3 ms in the middle of the backward
         # (measured on the RCCL world-1 leg: +4 ms per step with one call per layer) and xGMI rings are per-link bound:
         # fewer, larger collectives.  (torch DDP: 25 MB buckets, distributed_fairseq_model.py:57-67.)
-        import os
-        self.bucket = int(float(os.environ.get("IFSEG_BUCKET_MB", "48")) * (1 << 20)) // max(1, flat.element_size())
+        self.bucket = int(float(lab.get("BUCKET_MB", "48")) * (1 << 20)) // max(1, flat.element_size())
         self._open = None               # [lo, hi) of the bucket being filled
         # IFSEG_REDUCE_MODE: "direct" (default on the nccl backend: ifseg_amd/rccl.py, collectives enqueued in the calling
         # stream), "c10d" (torch.distributed's async all_reduce on its internal stream), and for measurements "none",
         # "fake-extra-stream", "fake-same-stream"
-        self.mode = os.environ.get("IFSEG_REDUCE_MODE", "direct")
+        self.mode = lab.get("REDUCE_MODE", "direct")
         self.direct = None
         if self.mode == "direct" and dist.is_initialized() and dist.get_backend() == "nccl" and flat.is_cuda:
             from .rccl import RcclComm
@@ -265,8 +262,7 @@ class Trainer:
         # IFSEG_FORCE_GRAD_HOOK=1 with an initialised process group of ONE rank: the whole data-parallel leg (per-layer
         # all-reduce issued from the weight-gradient stream, finish()'s waits, the log all-reduce) runs through the real
         # backend -- how the RCCL path is exercised on a one-GPU box (tests/test_configs_gpu.py)
-        import os
-        self.dist_on = self.world > 1 or (dist.is_initialized() and os.environ.get("IFSEG_FORCE_GRAD_HOOK") == "1")
+        self.dist_on = self.world > 1 or (dist.is_initialized() and lab.get("FORCE_GRAD_HOOK") == "1")
         if self.dist_on:
             eng.grad_ready_hook = self._on_grads_ready
         if self.world > 1:
@@ -521,7 +517,7 @@ class Trainer:
         # defer_optimizer (default: IFSEG_DEFER_OPTIMIZER, off): clip + Adam run on their own stream underneath the NEXT
         # forward, which waits per parameter slice; the caller must not read parameters / optimizer state from another
         # stream without `params_ready()` (valid_step, close and grad_norm call it)
-        self._defer = (os.environ.get("IFSEG_DEFER_OPTIMIZER", "0") == "1") if defer_optimizer is None else bool(defer_optimizer)
+        self._defer = (lab.get("DEFER_OPTIMIZER", "0") == "1") if defer_optimizer is None else bool(defer_optimizer)
         eng = self.eng
         if not self.model.training:
             self.model.train()
@@ -530,7 +526,7 @@ class Trainer:
         if graph and self.world == 1 and len(samples) == 1:
             logs = self._graph_step(samples[0], prefetch[0] if prefetch else None)
         else:
-            if prefetch and "trunkpf" not in __import__("os").environ.get("IFSEG_EXP_SKIP", ""):
+            if prefetch and "trunkpf" not in lab.get("EXP_SKIP", ""):
                 self._ahead = list(prefetch)
             logs = self._step_body(samples)
         self.num_updates += 1

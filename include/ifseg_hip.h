@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 16
+#define IFSEG_ABI_VERSION 17
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -213,14 +213,15 @@ int ifseg_attn_bwd_reduce(const ifseg_attn_reduce_args* args, void* stream);
  * (encoder_module.py:757-771,790-809 with the expand at :317,791; decoder_module.py:553-558,603-627;
  * unify_multihead_attention.py:459-465).  These three entry points keep that structure:
  *
- * ifseg_attn_dense_bias: D[h][i][j] = pos_q[i].pos_k[j] + rel(i,j) as fp32 [H,Tp,Sp] (Sp / Tp = S / T rounded up
- *   to 32); -inf where the causal mask ("tail-first" order of ifseg_attn_fwd) hides (i,j), for padded columns j >= S
+ * ifseg_attn_dense_bias: D[h][i][j] = pos_q[i].pos_k[j] + rel(i,j) as bf16 [H,Tp,Sp] (computed in fp32, rounded once; the
+ *   reference holds this tensor in half precision under --fp16, unify_multihead_attention.py:464; Sp / Tp = S / T rounded up
+ *   to 32; D 16-byte aligned); -inf where the causal mask ("tail-first" order of ifseg_attn_fwd) hides (i,j), for padded columns j >= S
  *   and padded rows i >= T.  Parameters only: built once per layer and step.  (Causal: 32 x 32 tiles no kernel's block
  *   schedule reaches are not written.)
  *   rel(i,j) as documented at ifseg_attn_fwd (rel_mode = 1), pos_q / pos_k may be NULL (no abs-pos term). */
 int ifseg_attn_dense_bias(const void* pos_q, const void* pos_k, int ldpq, int ldpk, int H, int T, int S, int rel_mode,
                           int P, const int* gcode, int code_bias, int n2d, const float* rel2d, const float* rel1d,
-                          const float* relx, int causal, float* D, int Sp, int Tp, void* stream);
+                          const float* relx, int causal, void* D, int Sp, int Tp, void* stream);
 
 /* ifseg_attn_bwd_bi: dq (x dq_scale), dk, dv of S_b = q_b k_b^T + D (autograd of unify_multihead_attention.py:459-512)
  *   and dbias[g][h][i][j] = sum over the batch elements 4g .. 4g+3 of dS_b[h][i][j] (bf16 [ceil(B/4), H, T, Sp]).
@@ -230,7 +231,8 @@ int ifseg_attn_dense_bias(const void* pos_q, const void* pos_k, int ldpq, int ld
  *   the caller zero-fills the buffer once (the set of skipped blocks depends only on the shape).  No atomics. */
 typedef struct ifseg_attn_bi_args {
   const void *q, *k, *v, *dout;
-  const float *lse, *delta, *D;
+  const float *lse, *delta;
+  const void* D;                /* bf16 [H, Tp, Sp] (ifseg_attn_dense_bias) */
   const void* gain;            /* fp32 [H] or NULL */
   void *dq, *dk, *dv, *dbias;
   int B, H, T, S, Sp, Tp;
@@ -341,17 +343,6 @@ int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamma, const fl
                       const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, void* dx2, int nblocks, int rows,
                       int C, int flags, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx, long long dx_bs, int lddx,
                       long long add_bs, int ldadd, long long dx2_bs, int lddx2, const ifseg_drop_args* drop2, void* stream);
-/* Two LayerNorm backwards of one residual-stream row in one launch (C <= 1024, contiguous-k rows with the given leading
- * dimensions): stage 1 is ifseg_ln_bwd of the pre-LN that closes a block of the backward (unify_transformer_layer.py:262-266,
- * 463-470: dx = dx_add + LN'(x; gamma)(dy)), stage 2 the post-LN backward that opens the next block on the same row
- * (attn_ln / cross_attn_ln / self_attn_ln followed by dropout + DropPath, :256-261, 529-545): dx2 = LN'(x2; gamma2)(drop2(dx as
- * stored in bf16)).  dx is written once and not read back; both pairs of dgamma / dbeta partials [nblocks][C] are produced.
- * Same arithmetic as ifseg_ln_bwd followed by ifseg_ln_bwd(drop = drop2) on its output. */
-int ifseg_ln_bwd_pair(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
-                      const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, const void* x2, const void* gamma2,
-                      const float* mean2, const float* rstd2, void* dx2, float* dgamma2_part, float* dbeta2_part, int nblocks,
-                      int rows, int C, int flags, int lddy, int ldx, int ldadd, int lddx, int ldx2, int lddx2,
-                      const ifseg_drop_args* drop2, void* stream);
 /* fp32 master copy <- bf16 arena wherever bf16(master[i]) != p16[i] (an optimizer outside this library stepped the bf16
  * parameters: fp16_optimizer.py:198-222 writes the model copy); agreeing entries keep their fp32 value. */
 int ifseg_sync_master(float* master, const void* p16, long long n, void* stream);
@@ -527,8 +518,6 @@ int ifseg_crf_norm(const float* k1, float* n, int N, void* stream);
  * 5 ATTN_BWD_DKV, 6 ATTN_BWD_DQ, 7 LN_FWD, 8 LN_BWD.  ifseg_prof_read returns the summed
  * kernel time and the summed ALGORITHMIC flops / bytes of the recorded launches. */
 int ifseg_prof_enable(unsigned mask);
-/* laboratory: a HIP stream restricted to the compute units of `mask` (nwords x 32 bits; hipExtStreamCreateWithCUMask) */
-int ifseg_stream_create_cumask(const unsigned* mask, int nwords, void** stream);
 int ifseg_prof_stride(int stride); /* time only every stride-th launch of an enabled family (default 1) */
 int ifseg_prof_reset(void);
 int ifseg_prof_read(int kind, double* ms, double* flops, double* bytes, int* launches);

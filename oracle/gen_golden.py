@@ -56,6 +56,10 @@ GRAD_KEYS = [
     "decoder.layer_norm.weight",
     "decoder.embed_seg_positions.weight",
 ]
+# the tensors whose gradients pass through the resizes of a non-trained grid (case resize_train)
+RESIZE_KEYS = ["encoder.embed_image_positions.weight", "encoder.image_rel_pos_table_list.1.weight",
+               "decoder.seg_rel_pos_table_list.1.weight", "encoder.embed_positions.weight"]
+
 
 
 def build_reference(cfg, arch, overrides=None):
@@ -139,7 +143,7 @@ def sub_index(name, numel, n=SUB_N):
 
 
 def case_train(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys, full_grads=True, diversify=False, sub_all=False,
-               bf16_weights=False, pad_tail=None):
+               bf16_weights=False, pad_tail=None, image_hw=None):
     """bf16_weights: the procedural weights are rounded to bf16-representable values on both sides (identical weights);
     diversify: the (frozen, tied) seg projection is replaced by O.diversify_seg_projection(...) (measured in round 3: it
     removes the dominant common component of the logits, so the relative error of the HIP path grows by the same factor
@@ -148,7 +152,9 @@ def case_train(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys, f
     t0 = time.time()
     model, sd = build_reference(cfg, arch, overrides)
     crit = build_criterion(cfg)
-    batch = O.synthetic_batch(cfg, batch_size, src_len)
+    # image_hw: an image whose feature grid differs from the trained one -- TRAINING through the bilinear resizes of the position
+    # rows and of every layer's relative-position bias (encoder_module.py:356-372,798-809; decoder_module.py:541-550,603-627)
+    batch = O.synthetic_batch(cfg, batch_size, src_len, image_hw=image_hw) if image_hw else O.synthetic_batch(cfg, batch_size, src_len)
     if pad_tail is not None:
         # padded prompts (collate pads shorter prompts on the right, data/mm_data/segmentation_dataset.py collate ->
         # data_utils.collate_tokens): sample b ends with pad_tail[b] pad tokens, eos in front of them; the reference then
@@ -191,6 +197,8 @@ def case_train(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys, f
     save = {"logits_causal": ref_logits.numpy(), "logits_full": ref_full.numpy(),
             "loss": np.float64(loss.item()),
             "batch_size": batch_size, "src_len": src_len, "diversified": int(diversify), "bf16_weights": int(bf16_weights)}
+    if image_hw:
+        save["image_hw"] = np.array(image_hw)
     if pad_tail is not None:
         save["src_tokens"] = batch["src_tokens"].numpy()
     if sub_all:
@@ -465,7 +473,7 @@ def main():
     ap.add_argument("--skip-base", action="store_true")
     ap.add_argument("--only-imfree", action="store_true")
     ap.add_argument("--only-eval", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of: optim, upgrade, lazy, base_b2, base_c3, padded, base_padded")
+    ap.add_argument("--only", default="", help="comma list of: optim, upgrade, lazy, base_b2, base_c3, padded, base_padded, resize_train")
     a = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -485,6 +493,8 @@ def main():
         if "base_padded" in only:  # configs[0] geometry with prompts of different lengths (sample 1 ends in 9 <pad>): key padding at Base size
             case_train(O.base_config(), "base", None, 2, 36, "base_c1_padded.npz", GRAD_KEYS, full_grads=False, sub_all=True, bf16_weights=True,
                        pad_tail=[0, 9])
+        if "resize_train" in only:  # training on a 128 x 192 image (grid 8 x 12, P = 96 > the trained 64): VERDICT r5 item 5
+            case_train(fx, "tiny", ov, 2, 12, "fixture_resize_train.npz", GRAD_KEYS + RESIZE_KEYS, sub_all=True, image_hw=(128, 192))
         if "base_b2" in only:      # BASELINE config 1 as written: B = 2
             case_train(O.base_config(), "base", None, 2, 36, "base_c1_b2.npz", GRAD_KEYS, full_grads=False, sub_all=True, bf16_weights=True)
         if "base_c3" in only:      # BASELINE config 3 geometry on one device: Base width, 150 classes, L = 215 (T_enc 1239)

@@ -34,6 +34,7 @@ for j in range(2):
 
 def run(forced, nsteps=6, timed=30):
     if forced:
+        os.environ["IFSEG_LAB"] = "1"                 # (the gate of every laboratory switch: ifseg_amd/lab.py)
         os.environ["IFSEG_FORCE_GRAD_HOOK"] = "1"
     else:
         os.environ.pop("IFSEG_FORCE_GRAD_HOOK", None)

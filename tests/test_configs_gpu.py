@@ -202,6 +202,7 @@ def test_base_config1_default_is_the_batch_inner_attention_everywhere(golden_dir
 def test_base_config1_with_mixed_attention_kernels(golden_dir, monkeypatch):
     """... with the causal decoder self-attention on the round-3 kernels and the other two on the batch-inner ones
     (IFSEG_ATTN_BI_WHICH=e+c, the default until the dense bias lost its transposed copy): both families in one step."""
+    monkeypatch.setenv("IFSEG_LAB", "1")
     monkeypatch.setenv("IFSEG_ATTN_BI_WHICH", "e+c")
     m, _, _, _ = _golden_case(golden_dir, "base_c1_b2.npz", O.base_config(), 2)
     assert len(m.engine.ctx.get("dense", {})) == 7
@@ -209,6 +210,7 @@ def test_base_config1_with_mixed_attention_kernels(golden_dir, monkeypatch):
 
 def test_base_config1_with_the_round3_attention_kernels(golden_dir, monkeypatch):
     """... and with none of them on that path (IFSEG_ATTN_BI=0): the round-3 kernels stay covered at Base size."""
+    monkeypatch.setenv("IFSEG_LAB", "1")
     monkeypatch.setenv("IFSEG_ATTN_BI", "0")
     m, _, _, _ = _golden_case(golden_dir, "base_c1_b2.npz", O.base_config(), 2)
     assert not m.engine.ctx.get("dense")

@@ -168,6 +168,7 @@ def test_bucket_plan_covers_the_gradient_arena_exactly_once(arch, nseg, size, mo
         Layout.offs[n] = off
         off += _pad8(names[n].numel())
     n_train = Layout.offs[order[ntn]] if ntn < len(order) else off
+    monkeypatch.setenv("IFSEG_LAB", "1")
     monkeypatch.setenv("IFSEG_REDUCE_MODE", "none")
     flat = torch.empty(n_train, dtype=torch.bfloat16, device="meta")
     red = ArenaReducer(flat, layer_slices(Layout), n_train)

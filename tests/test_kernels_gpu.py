@@ -440,7 +440,7 @@ def test_attn_bwd_batch_inner(case):
             want = want + _dense_rel(H, T, S, P, gcode.long(), code_bias, *tabs).to(dev)
         if mask is not None:
             want = want.masked_fill(mask, float("-inf"))
-    got = dense.D[:, :T, :S]
+    got = dense.D[:, :T, :S].float()                 # the operand is bf16 (round 6): fp32 arithmetic, one rounding
     fin = torch.isfinite(want)
     if causal:
         # causal tiles no block schedule of the backward kernels reaches (more than one 32-column block beyond a 32-row block's
@@ -450,7 +450,9 @@ def test_attn_bwd_batch_inner(case):
         assert not fin[:, unread].any()
         got = torch.where(unread[None], want, got)
     assert torch.equal(torch.isfinite(got), fin)
-    assert (got[fin] - want[fin]).abs().max().item() < 2e-5 * max(1.0, want[fin].abs().max().item())
+    assert ((got[fin] - want[fin]).abs() <= want[fin].abs() * 2.0 ** -8 + 2e-5).all()
+    # the checks below that isolate the kernels' own arithmetic (lse, sum_b dS) use the bias AS STORED
+    want = torch.where(fin, got, want)
     # padding: -inf (causal: the grid columns of tail rows -- padded ones too -- belong to tiles no schedule reads)
     assert torch.isinf(dense.D[:, :T, S:]).all() and torch.isinf(dense.D[:, T:, (P if causal else 0):]).all()
     # ---- forward: the round-3 kernel (bias regenerated per batch element) and the batch-inner one (dense bias tile shared by
@@ -466,7 +468,9 @@ def test_attn_bwd_batch_inner(case):
     with torch.no_grad():
         sref = (q.float().view(B, T, H, 64).transpose(1, 2) @ k.float().view(B, S, H, 64).transpose(1, 2).transpose(2, 3)) + want
         lse_ref = torch.logsumexp(sref, -1) * 1.4426950408889634          # log2 units
-    assert (lse - lse_ref).abs().max().item() < 2e-3 and (lse - lse3).abs().max().item() < 2e-3
+    assert (lse - lse_ref).abs().max().item() < 2e-3
+    # (the round-3 kernel regenerates the bias in fp32; the dense operand is its bf16 rounding: one ulp of the largest entry)
+    assert (lse - lse3).abs().max().item() < 2e-3 + 2.0 ** -8 * 1.4427 * want[fin].abs().max().item()
     delta = (dout.float() * out.float()).view(B, T, H, 64).sum(-1).permute(0, 2, 1).contiguous()
     dq, dk, dv = torch.full_like(q, 3.0), torch.full_like(k, 3.0), torch.full_like(v, 3.0)
     ng = (B + 3) // 4
@@ -887,47 +891,6 @@ def test_ln_bwd_drop_is_bit_identical_to_two_calls():
     assert torch.equal(qg1, pg1) and torch.equal(qb1, pb1)
 
 
-@pytest.mark.parametrize("C,f32,with_add", [(768, True, True), (1024, False, True), (64, True, False)])
-def test_ln_bwd_pair_equals_the_two_launches(C, f32, with_add):
-    """ifseg_ln_bwd_pair: a block's closing pre-LN backward + the next block's opening post-LN backward (dropout + DropPath
-    adjoint on its input) on the same rows in one launch == ifseg_ln_bwd twice (same statements: bit-identical partial sums and
-    outputs up to the two kernels' different multiply-add contraction, at most one bf16 ulp on a few elements)."""
-    from ifseg_amd import hip
-    dev = _dev()
-    B, T, p, seed = 3, 257, 0.1, 4242
-    rows = B * T
-    dy, x, add, x2 = (_rand((rows, C), dev, 140 + i) for i in range(4))
-    mk = (lambda t: t.float() + 1e-3 * torch.rand(C, device=dev)) if f32 else (lambda t: t)
-    g1, g2 = mk(_rand((C,), dev, 146, 0.2) + 1), mk(_rand((C,), dev, 147, 0.2) + 1)
-    dp = torch.tensor([1 / 0.9, 0.0, 1 / 0.9], device=dev)
-    m1, m2 = torch.rand(rows, device=dev) - 0.5, torch.rand(rows, device=dev) - 0.5
-    r1, r2 = torch.rand(rows, device=dev) + 0.5, torch.rand(rows, device=dev) + 0.5
-    nb = hip.LN_BWD_BLOCKS
-    parts = lambda: (torch.zeros(nb, C, device=dev), torch.zeros(nb, C, device=dev))
-    a = add if with_add else None
-    dx_ref, da_ref = torch.empty_like(dy), torch.empty_like(dy)
-    pg1, pb1 = parts(); pg2, pb2 = parts()
-    hip.ln_bwd(dy, x, g1, m1, r1, dx_ref, pg1, pb1, dx_add=a)
-    hip.ln_bwd(dx_ref, x2, g2, m2, r2, da_ref, pg2, pb2, drop=(p, seed, dp, T))
-    dx, da = torch.empty_like(dy), torch.empty_like(dy)
-    qg1, qb1 = parts(); qg2, qb2 = parts()
-    hip.ln_bwd_pair(dy, x, g1, m1, r1, dx, qg1, qb1, x2, g2, m2, r2, da, qg2, qb2, dx_add=a, drop2=(p, seed, dp, T),
-                    rows_per_batch=T)
-    torch.cuda.synchronize()
-
-    def close(u, v, what):
-        diff = (u.float() - v.float()).abs()
-        bad = (diff > 0).float().mean().item()
-        ulp = (diff / v.float().abs().clamp_min(1e-6)).max().item()
-        assert bad < 1e-3 and ulp < 1.0 / 64, (what, bad, ulp)       # (a bf16 ulp is 2^-7 .. 2^-8 of the value)
-    close(dx, dx_ref, "dx")
-    close(da, da_ref, "da")
-    for q, r_, n in ((qg1, pg1, "dg1"), (qb1, pb1, "db1"), (qg2, pg2, "dg2"), (qb2, pb2, "db2")):
-        assert _rel(q.sum(0), r_.sum(0)) < 1e-4, (n, _rel(q.sum(0), r_.sum(0)))
-    # the sample dropped by DropPath passes no gradient through the second LayerNorm
-    assert da.view(B, T, C)[1].abs().max().item() == 0 and da.view(B, T, C)[0].abs().max().item() > 0
-
-
 def test_gemm_nn_rowdot_delta_epilogue():
     """ifseg_gemm_nn_rowdot: dO = da @ W and delta[b,h,t] = sum_c dO[b,t,64h+c] * O[b,t,64h+c] from the same epilogue."""
     from ifseg_amd import hip
@@ -1272,78 +1235,6 @@ def test_ffn_layernorm_gains_of_zero_small_and_negative_values():
     hip.ffn_ln_param_grads(w2, dw2, db2, gamma, beta, dgam, dbet)
     torch.cuda.synchronize()
     assert torch.isfinite(dgam.float()).all() and dgam[0].item() == 0.0
-
-
-# ----------------------------------------------------------------------------- persistent ring GEMM (opt-in, csrc/gemm_ring.hip)
-@pytest.mark.parametrize("cfg", [1, 3, 5, 6])
-def test_ring_gemm_is_bit_equal_to_the_tile_kernel(cfg, monkeypatch):
-    """IFSEG_GEMM_RING=<cfg> routes NT / NN / GELU+LN-backward / row-dot / convolution launches through the persistent ring
-    kernel (tile shapes 128x128 .. 256x256, k-tails, ragged M / N, every epilogue): the same MFMA sequence per output element
-    as the tile kernel => identical bits."""
-    from ifseg_amd import hip
-    dev = _dev()
-
-    def both(fn):
-        monkeypatch.delenv("IFSEG_GEMM_RING", raising=False)
-        a = fn()
-        monkeypatch.setenv("IFSEG_GEMM_RING", str(cfg))
-        b = fn()
-        monkeypatch.delenv("IFSEG_GEMM_RING", raising=False)
-        torch.cuda.synchronize()
-        for x, y in zip(a, b):
-            assert torch.equal(x, y)
-
-    for (M, N, K) in [(1000, 776, 136), (2120, 768, 768), (300, 2304, 64)]:
-        x, w, wT = _rand((M, K), dev, 1, 0.5), _rand((N, K), dev, 2, 0.5), _rand((K, N), dev, 5, 0.5)
-        bias, res = _rand((N,), dev, 3), _rand((M, N), dev, 4)
-        both(lambda: [hip.linear_fwd(x, w, bias, alpha=0.37, alpha_ncols=(N // 16) * 8, resid=res), hip.linear_fwd(x, w)])
-        both(lambda: [hip.linear_dx(x, wT), hip.linear_dx(x, wT, resid=res)])
-        acc = _rand((M, N), dev, 6)
-        both(lambda: [hip.linear_dx(x, wT, out=acc.clone(), accumulate=True)])
-    # row-dot epilogue (attention backward's delta)
-    B, T, C = 2, 530, 768
-    da, wo, o = _rand((B * T, C), dev, 7, 0.5), _rand((C, C), dev, 8, 0.1), _rand((B * T, C), dev, 9)
-    def rowdot():
-        out = torch.empty(B * T, C, dtype=torch.bfloat16, device=dev)
-        delta = torch.zeros(B, C // 64, T, dtype=torch.float32, device=dev)
-        hip.linear_dx_rowdot(da, wo, out, o, delta, T)
-        return [out, delta]
-    both(rowdot)
-    # convolution (implicit GEMM)
-    Bc, H, W, Cin, Cout = 2, 20, 24, 128, 256
-    xi, wc = _rand((Bc, H, W, Cin), dev, 10), _rand((Cout, 3, 3, Cin), dev, 11, 1.0 / math.sqrt(Cin * 9))
-    sh, rs = _rand((Cout,), dev, 12), _rand((Bc, H, W, Cout), dev, 13)
-    def conv():
-        out = torch.empty(Bc, H, W, Cout, dtype=torch.bfloat16, device=dev)
-        hip.conv2d_nhwc(xi, wc, sh, rs, out, Bc, H, W, Cin, Cout, 3, 3, 1, 1, True)
-        return [out]
-    both(conv)
-
-
-@pytest.mark.parametrize("cfg", [1, 3, 4])
-def test_ring_grouped_weight_gradients_are_bit_equal(cfg, monkeypatch):
-    """IFSEG_GEMM_RING_GROUP=<cfg>: the grouped dW (+ db) launch through the ring kernel (k-tail of the token count, strided
-    dY, problems of different K) against the tile kernel's grouped launch."""
-    from ifseg_amd import hip
-    dev = _dev()
-    shapes = [(768, 3072, 1060 * 2 + 8), (2304, 768, 1060 * 2 + 8), (768, 768, 2056)]
-    def run():
-        flats, tasks = [], []
-        for i, (N, K, Mi) in enumerate(shapes):
-            dy, x = _rand((Mi, N + 8), dev, 300 + i, 0.5)[:, :N], _rand((Mi, K), dev, 320 + i, 0.5)
-            flat = torch.full((N * K + N + 8,), 7.0, dtype=torch.bfloat16, device=dev)
-            tasks.append((dy, x, flat[: N * K].view(N, K), flat[N * K: N * K + N] if i != 2 else None))
-            flats.append(flat)
-        hip.linear_dw_group(tasks)
-        torch.cuda.synchronize()
-        return flats
-    monkeypatch.delenv("IFSEG_GEMM_RING_GROUP", raising=False)
-    a = run()
-    monkeypatch.setenv("IFSEG_GEMM_RING_GROUP", str(cfg))
-    monkeypatch.setenv("IFSEG_GEMM_RING_GROUP_ANY", "1")      # (by default a group of more tiles than CUs stays on the tile kernel)
-    b = run()
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)
 
 
 @pytest.mark.parametrize("case", ["enc_rel", "cross", "enc_b5", "big_enc"])

@@ -890,6 +890,73 @@ def test_padded_prompts_vs_reference_golden(golden_dir):
     assert _rel(lf, torch.from_numpy(g["logits_full"])) <= 2e-2
 
 
+def test_training_on_a_resized_grid_vs_reference_golden(golden_dir):
+    """Training on an image whose feature grid (8 x 12, P = 96) is not the trained one (8 x 8): the reference resizes the image
+    rows of both position tables (encoder_module.py:356-372, decoder_module.py:541-550) and every layer's relative-position
+    bias (encoder_module.py:798-809, decoder_module.py:603-627) under autograd.  tests/golden/fixture_resize_train.npz is the
+    REFERENCE's output (oracle/gen_golden.py --only resize_train: logits, loss, and its gradients of the position tables, the
+    rel-pos bucket tables and the rest); the engine takes the standard training step with dense biases from
+    models/segofa/resized.py and the adjoints of the resizes (this configuration used to be refused)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ifseg_amd.criterions import SegCriterion
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    g = np.load(os.path.join(golden_dir, "fixture_resize_train.npz"))
+    B, hw = int(g["batch_size"]), tuple(int(v) for v in g["image_hw"])
+    batch = O.synthetic_batch(ocfg, B, int(g["src_len"]), image_hw=hw)
+    o_logits, o_loss, o_grads, _ = _oracle_all_grads(ocfg, sd, batch, hw)
+    assert np.abs(o_logits.numpy() - g["logits_causal"]).max() <= 1e-5 and abs(o_loss.item() - float(g["loss"])) <= 1e-5
+    crit = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+    sample = {"net_input": {k: batch[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks", "prev_output_tokens")},
+              "target": batch["target"].to(dev), "ntokens": 1, "nsentences": B}
+    m = _build(ocfg, sd, dev)
+    m.train()
+    loss, _, logs = crit(m, sample)
+    logits = m.engine.ws["logits_pad"][:, :, : ocfg.num_seg_tokens].float().cpu()
+    ref = torch.from_numpy(g["logits_causal"])
+    print("resized-grid training: logits rel-L2 %.4f, loss %.5f vs %.5f" % (_rel(logits, ref), loss.item(), float(g["loss"])))
+    assert logits.shape == ref.shape and _rel(logits, ref) <= 2e-2 and abs(loss.item() - float(g["loss"])) <= 1e-2
+    assert (logits.argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.99
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(m.named_parameters())
+    gain_scale = max(v.abs().max().item() for k, v in o_grads.items() if k.endswith("c_attn"))
+    bad, n = [], 0
+    for k, og in sorted(o_grads.items()):
+        if k not in named or not named[k].requires_grad or og.norm() == 0 or k.endswith(("k_proj.bias", "pos_k_linear.bias")):
+            continue
+        hg = named[k].grad
+        if k.endswith("c_attn"):
+            assert (hg.float().cpu() - og).abs().max().item() <= 5e-2 * gain_scale, k
+            continue
+        n += 1
+        if _rel(hg, og) > 6e-2:
+            bad.append((round(_rel(hg, og), 4), k))
+    assert n > 100 and not bad, bad[:10]
+    # the reference's own gradients of the tensors behind the resizes
+    shown = {}
+    for k in g.files:
+        if k.startswith("grad:") and not k.endswith("c_attn"):
+            shown[k[5:]] = _rel(named[k[5:]].grad, torch.from_numpy(g[k]))
+            assert shown[k[5:]] <= 6e-2, (k, shown[k[5:]])
+    for k in ("encoder.embed_image_positions.weight", "decoder.embed_seg_positions.weight", "encoder.image_rel_pos_table_list.0.weight",
+              "encoder.image_rel_pos_table_list.1.weight", "decoder.seg_rel_pos_table_list.0.weight", "decoder.seg_rel_pos_table_list.1.weight",
+              "encoder.token_rel_pos_table_list.1.weight"):
+        assert k in shown, k
+    print("  gradients behind the resizes:", {k.split(".")[1] + "." + k.split(".")[-2]: round(v, 4) for k, v in shown.items() if "pos" in k})
+    # a second step on the trained grid afterwards (the engine switches paths per batch), then evaluation on the resized one
+    sq = O.synthetic_batch(ocfg, B, int(g["src_len"]))
+    loss2, _, _ = crit(m, {"net_input": {k: sq[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks", "prev_output_tokens")},
+                           "target": sq["target"].to(dev), "ntokens": 1, "nsentences": B})
+    loss2.backward()
+    m.eval()
+    with torch.no_grad():
+        lf, _ = m(**sample["net_input"], full_context_alignment=True)
+    assert _rel(lf, torch.from_numpy(g["logits_full"])) <= 2e-2
+
+
 def test_label_smoothing_runs_in_the_fused_criterion():
     """--label-smoothing > 0 (seg_criterion.py:142,265: F.cross_entropy(label_smoothing=eps)) stays on the fused loss kernel:
     loss, metrics and the gradient handed to the decoder equal the torch composition of the reference ops on the same logits."""

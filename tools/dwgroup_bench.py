@@ -22,3 +22,4 @@ for cap in (256, 384, 512, 768, 1024):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 10
     print("cap %4d: %7.1f us  %6.1f TF/s" % (cap, us, flops / us / 1e6))
+

@@ -567,6 +567,9 @@ using C4 = RingCfg<128, 256, 64, 2, 4, 2>;    // 128 KiB, 8 waves of 64 x 64
 using C5 = RingCfg<256, 256, 32, 2, 4, 4>;    // 160 KiB, 8 waves of 128 x 64, 32-deep k-steps
 using C6 = RingCfg<128, 128, 64, 2, 2, 2>;    //  80 KiB: two workgroups per CU
 using C7 = RingCfg<256, 256, 64, 2, 4, 2>;    // 160 KiB, 8 waves of 128 x 64
+using C8 = RingCfg<256, 128, 32, 4, 2, 2>;    //  80 KiB, 8 waves of 64 x 64, 32-deep k-steps (round 6: VERDICT r5 item 1 b)
+using C9 = RingCfg<256, 128, 32, 4, 2, 3>;    // 104 KiB
+using C10 = RingCfg<128, 256, 32, 2, 4, 2>;   //  80 KiB
 
 template <class C, int AMODE, bool B_KS, bool EPI_GLN>
 int launch1(const GemmArgs& g, int wgs_per_cu, hipStream_t s) {
@@ -621,6 +624,9 @@ int gemm_ring_group_launch(const void* group_args, int cfg, int max_workgroups, 
     case 1: return launch_group<C1>(ga, max_workgroups, s);
     case 3: return launch_group<C3>(ga, max_workgroups, s);
     case 4: return launch_group<C4>(ga, max_workgroups, s);
+    case 8: return launch_group<C8>(ga, max_workgroups, s);
+    case 9: return launch_group<C9>(ga, max_workgroups, s);
+    case 10: return launch_group<C10>(ga, max_workgroups, s);
   }
   return IFSEG_ERR_BAD_ARG;
 }

@@ -40,13 +40,5 @@ for nb in [int(v) for v in os.environ.get("BLOCKS", "256,512,768,1024,2048").spl
     line("ln_bwd blocks=%d (read dy, x, write dx)" % nb, timeit(lambda i: hip.ln_bwd(DY[i % nbuf], X[i % nbuf], gam, mu, rs, OUT[i % nbuf], part[0], part[1])), 3 * T)
     line("ln_bwd blocks=%d + dx_add" % nb, timeit(lambda i: hip.ln_bwd(DY[i % nbuf], X[i % nbuf], gam, mu, rs, OUT[i % nbuf], part[0], part[1], dx_add=ADD[i % nbuf])), 4 * T)
     line("ln_bwd_drop blocks=%d + dx_add (2 outputs)" % nb, timeit(lambda i: hip.ln_bwd_drop(DY[i % nbuf], X[i % nbuf], gam, mu, rs, OUT[i % nbuf], part[0], part[1], OUT2[i % nbuf], dx_add=ADD[i % nbuf])), 5 * T)
-hip.LN_BWD_BLOCKS = 768
-part = torch.empty(4, 768, C, device=dev)
-line("ln_bwd + dx_add THEN ln_bwd(drop) on its output (two launches)", timeit(lambda i: (
-    hip.ln_bwd(DY[i % nbuf], X[i % nbuf], gam, mu, rs, OUT[i % nbuf], part[0], part[1], dx_add=ADD[i % nbuf]),
-    hip.ln_bwd(OUT[i % nbuf], X[(i + 1) % nbuf], gam, mu, rs, OUT2[i % nbuf], part[2], part[3], drop=(0.1, 7, None, rows)))), 7 * T)
-line("ln_bwd_pair (the same in one launch)", timeit(lambda i: hip.ln_bwd_pair(
-    DY[i % nbuf], X[i % nbuf], gam, mu, rs, OUT[i % nbuf], part[0], part[1], X[(i + 1) % nbuf], gam, mu, rs, OUT2[i % nbuf], part[2], part[3],
-    dx_add=ADD[i % nbuf], drop2=(0.1, 7, None, rows))), 6 * T)
 cp = lambda i: OUT[i % nbuf].copy_(X[i % nbuf])
 line("torch copy_ (read + write)", timeit(cp), 2 * T)
