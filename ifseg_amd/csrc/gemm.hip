@@ -49,7 +49,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   } else {
     t = remapped ? bx : xcd_remap(bx, tiles_m * tiles_n);
   }
-  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+  // tile order: column tiles fastest -- or (grouped weight gradients of a problem with fewer row than column tiles, fc2's
+  // 6 x 24) row tiles fastest: the XCD's run of consecutive tiles then shares the FEW panels of the short side and streams
+  // only its own part of the long side, instead of every XCD reading all of the long operand
+  // (round 6: -0.02 ... -0.08 ms per step, profiles/round6_dw_small_experiments.txt)
+  const bool mfast = COLSUM && (g.flags & GEMM_FLAG_MFAST) && tiles_m < tiles_n;
+  const int m0 = (mfast ? t % tiles_m : t / tiles_n) * BM, n0 = (mfast ? t / tiles_m : t % tiles_n) * BN;
   const v4i32 rsA = make_rsrc(g.A + (long long)by * g.sA, g.nrecA);
   const v4i32 rsB = make_rsrc(g.B + (long long)by * g.sB, g.nrecB);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -567,7 +572,7 @@ extern "C" int ifseg_gemm_tn_group(int n, const ifseg_gemm_tn_problem* probs, in
     g.A = (const bf16_t*)q.A; g.B = (const bf16_t*)q.B; g.C = q.C;
     g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.N;
     g.alpha = 1.f; g.splitk = 1;
-    g.flags = (q.colsum ? IFSEG_GEMM_COLSUM : 0) | (q.accumulate ? IFSEG_GEMM_ACCUMULATE : 0);
+    g.flags = (q.colsum ? IFSEG_GEMM_COLSUM : 0) | (q.accumulate ? IFSEG_GEMM_ACCUMULATE : 0) | GEMM_FLAG_MFAST;
     const long long nrA = ((long long)(q.K - 1) * q.lda + q.M) * 2, nrB = ((long long)(q.K - 1) * q.ldb + q.N) * 2;
     if (nrA >= (1ll << 31) || nrB >= (1ll << 31)) return IFSEG_ERR_BAD_SHAPE;
     g.nrecA = (unsigned)nrA; g.nrecB = (unsigned)nrB;

@@ -13,6 +13,7 @@ constexpr int GBK = 64;
 constexpr int TWO_STAGE_MAX_WGS = 1024;
 constexpr int BM = 128;   // BN, BK and the LDS stage count are template parameters
 enum { A_KC = 0, A_KS = 1, A_CONV = 2 };
+constexpr int GEMM_FLAG_MFAST = 0x100;  // (internal, grouped dW) row tiles fastest in the tile order of a wide problem
 constexpr unsigned OOB = 0x80000000u;   // byte offset beyond every buffer (< 2 GiB each): the load returns zeros
 
 struct GemmArgs {

@@ -2182,7 +2182,8 @@ class HipEngine:
         """(end of a layer's backward) the layer's weight-gradient group, its followers, the table casts and the gradient-ready
         notification, in side-stream order.  (Round 6 measured holding the group back until a point inside the NEXT layer's
         backward -- beside the attention backward instead of beside the LayerNorm pair: the LayerNorms got 15 us faster each and
-        the dK|dV kernel 70 us slower, +0.3 ms per step; profiles/round6_dw_release_ab.txt.)"""
+        the dK|dV kernel 70 us slower, +0.3 ms per step; profiles/round6_dw_release_ab.txt.  And the group on the MAIN queue,
+        alone on the chip: +0.8 ms; profiles/round6_dw_small_experiments.txt.)"""
         self._side_do(lambda: (self._flush_tables(), self._notify(p)))
         self._side_flush()
 
