@@ -495,6 +495,40 @@ __global__ __launch_bounds__(256) void reduce_parts2d_kernel(const float* in, vo
   }
 }
 
+// the same for MANY parts and few columns (the loss kernel's 8192 per-tile statistics rows of 2 + 3 nseg floats): one block per
+// output element, a thread sums every 256th part (its loads independent, in flight together), fixed-order tree over the block.
+// (The 32-column kernel above gave each thread 1024 dependent strided loads here: 49 us on the main queue between the forward
+// and the backward of every step; this one takes ~6.)
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void reduce_parts_tall_kernel(const float* in, void* out, int outer, int parts, long long n,
+                                                                int accumulate, float scale) {
+  __shared__ float red[256];
+  const long long o = blockIdx.x / n, i = blockIdx.x % n;
+  const float* p = in + o * parts * n + i;
+  float s = 0.f;
+#pragma unroll 8
+  for (int k = threadIdx.x; k < parts; k += 256) s += p[(long long)k * n];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float t = red[0] * scale;
+    const long long gid = o * n + i;
+    if (OUT_BF16) {
+      bf16_t* op = reinterpret_cast<bf16_t*>(out) + gid;
+      if (accumulate) t += bf2f(*op);
+      *op = f2bf(t);
+    } else {
+      float* op = reinterpret_cast<float*>(out) + gid;
+      if (accumulate) t += *op;
+      *op = t;
+    }
+  }
+}
+
 // several reductions in one launch: block ranges by task
 struct ReduceTasks { ifseg_reduce_task t[16]; int start[17]; int n; };
 __global__ __launch_bounds__(256) void reduce_parts_multi_kernel(ReduceTasks ts) {
@@ -758,6 +792,12 @@ extern "C" int ifseg_reduce_parts(const float* in, void* out, int outer, int par
   (void)hipGetLastError();
   const long long total = (long long)outer * n;
   if (total <= 0) return 0;
+  if (parts >= 2048 && total <= 4096) {
+    if (out_bf16) hipLaunchKernelGGL(reduce_parts_tall_kernel<true>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, in, out, outer, parts, n, accumulate, scale);
+    else hipLaunchKernelGGL(reduce_parts_tall_kernel<false>, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, in, out, outer, parts, n, accumulate, scale);
+    IFSEG_CHECK_LAUNCH();
+    return 0;
+  }
   if (parts >= 32) {
     dim3 g2((unsigned)(outer * ((n + 31) / 32)));
     if (out_bf16) hipLaunchKernelGGL(reduce_parts2d_kernel<true>, g2, dim3(256), 0, (hipStream_t)stream, in, out, outer, parts, n, accumulate, scale);

@@ -1033,6 +1033,9 @@ class HipEngine:
                     rel = hip.RelBias(P, g["gcode"], g["code_bias"], e_r2[l], e_r1[l], e_rx[l], grid_w=w)
                     ctx["dense"]["e%d" % l] = self._dense_bias("e%d" % l, H, T, T, ctx["e_pq"], ctx["e_pk"], rel, False, P)
                     self._dense_built(ctx, "e%d" % l)
+        # (profiles/round6_early_decoder_dense_ab.txt: -0.11 ms per step; a pending deferred optimizer keeps the late place)
+        if need_grad and bi and self.overlap and not self._popt:
+            self._dec_pos_dense(ctx, g, pos_all, scaling, bi, bi_which, resized)
         if need_grad and self.overlap and not torch.cuda.is_current_stream_capturing() and "g16fwd" not in _EXP_SKIP:
             with self._wgrad():          # (behind the encoder's dense biases, which the forward waits for; the previous step's Adam read g16)
                 self._params_wait(None, stream=self._side)      # (a deferred optimizer is still reading the gradients)
@@ -1076,13 +1079,15 @@ class HipEngine:
             self._ffn_ln_coefs()        # one small launch for all layers, main stream (read again by the backward)
         if self.overlap and need_grad:
             with self._wgrad():
+                ctx["ckv_ready"] = []
                 for l in range(cfg.dec_layers):
                     a_ = "%slayers.%d.encoder_attn" % (d, l)
                     kv = buf("d%d_ckv" % l, (B, T, 2 * C))
                     hip.linear_fwd(enc_out.view(B * T, C), self._fused(self.p16, a_ + ".k_proj.weight", 2 * C, C),
                                    self._fused(self.p16, a_ + ".k_proj.bias", 2 * C), out=kv.view(B * T, 2 * C))
-                ctx["ckv_ready"] = self._ev()
-                ctx["ckv_ready"].record(self._side)
+                    ev = self._ev()              # one event per layer: a cross attention waits for ITS projection only
+                    ev.record(self._side)
+                    ctx["ckv_ready"].append(ev)
         y0b = buf("d_bos", (B, 1, C))
         bos = (prev_output_tokens[:, :1] if prev_output_tokens is not None
                else torch.zeros(B, 1, dtype=torch.long, device=dev))
@@ -1095,6 +1100,50 @@ class HipEngine:
         mu, rs = self._ln_stats("d_emb_ln_b", B)
         hip.ln_fwd(y0b, Wf(d + "layernorm_embedding.weight"), Wf(d + "layernorm_embedding.bias"), y[:, P:], mu, rs,
                    drop=self._dropargs(4))
+        if "d_cpq" not in ctx:       # (not already done ahead of the encoder layers)
+            self._dec_pos_dense(ctx, g, pos_all, scaling, bi, bi_which, resized)
+        cpq, cpk, causal = ctx["d_cpq"], ctx["d_cpk"], ctx["d_causal"]
+        d_r2, d_r1, d_rx = ctx["d_rel"]
+        y_pre = None
+        for l in range(cfg.dec_layers):
+            p = "%slayers.%d." % (d, l)
+            tg = "d%d" % l
+            # (resized grid: the causal mask is inside the dense operand, the kernels walk every block)
+            rel = None if resized else hip.RelBias(P, g["gcode"], g["code_bias"], d_r2[l], d_r1[l], d_rx[l], grid_w=w)
+            y, yn = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", y, B, Td,
+                                         ctx["d_spq"], ctx["d_spk"], rel, causal and not resized, scaling, site=("d", l, 0), xn_pre=y_pre,
+                                         next_ln=(p + "encoder_attn_layer_norm", tg + "_cln1", buf(tg + "_cyn", (B * Td, C))))
+            y, yn = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling, site=("d", l, 1), yn_pre=yn,
+                                          next_ln=(p + "final_layer_norm", tg + "_fln1", buf(tg + "_fxn", (B * Td, C))))
+            nl = (("%slayers.%d.self_attn_layer_norm" % (d, l + 1), "d%d_ln1" % (l + 1), buf("d%d_xn" % (l + 1), (B * Td, C)))
+                  if l + 1 < cfg.dec_layers else None)
+            y, y_pre = self._ffn_fwd(tg, p, y, B * Td, site=("d", l, 2), rpb=Td, xn_pre=yn, next_ln=nl)
+        ctx["d_y_final"] = y
+        # final LN written in reference order [bos, patches] (decoder_module.py:668-675)
+        featb = buf("d_feat", (B, Td, C))
+        mu, rs = self._ln_stats("d_final_ln_p", B * P)
+        hip.ln_fwd(y[:, :P], Wf(d + "layer_norm.weight"), Wf(d + "layer_norm.bias"), featb[:, 1:], mu, rs)
+        mu, rs = self._ln_stats("d_final_ln_b", B)
+        hip.ln_fwd(y[:, P:], Wf(d + "layer_norm.weight"), Wf(d + "layer_norm.bias"), featb[:, :1], mu, rs)
+        logits = buf("logits_pad", (B, Td, self.npad))
+        if self.train_seg:      # the tied projection follows the (trainable) seg embeddings: the padded copy is rebuilt per forward
+            self.wseg_pad[: cfg.num_seg_tokens].copy_(W("encoder.seg_embed_tokens.weight"))
+        hip.linear_fwd(featb.view(B * Td, C), self.wseg_pad, out=logits.view(B * Td, self.npad))   # :290-294
+        self.ctx = ctx
+        return logits, ctx
+
+    def _dec_pos_dense(self, ctx, g, pos_all, scaling, bi, bi_which, resized):
+        """The decoder's position operands (seg positions -> seg_pos_ln -> self / cross abs-pos projections, decoder_module.py:
+        541-558), its rel-pos delta tables and every decoder layer's dense bias operand (side stream).  All of it depends on
+        PARAMETERS only (and on the encoder's position rows): a training forward runs it ahead of the encoder layers, so the
+        decoder's dense biases are built under the encoder instead of at the encoder -> decoder hand-over, where the main queue
+        waited for them behind the six cross-attention K|V projections (round 6)."""
+        cfg = self.cfg
+        B, L, P, T, Td, h, w = (ctx[k] for k in ("B", "L", "P", "T", "Td", "h", "w"))
+        C, H = cfg.embed_dim, cfg.heads
+        W, Wf, buf = self.W, self.Wf, self.buf
+        d = "decoder."
+        dev = self.device
         # positions: internal order [grid cells 1..P | slot 0]
         sb = cfg.seg_bucket_size
         segtab = W(d + "embed_seg_positions.weight")
@@ -1117,11 +1166,10 @@ class HipEngine:
         cpk = buf("d_cpk", (T, C))
         hip.linear_fwd(pos_all, W(d + "cross_pos_k_linear.weight"), W(d + "cross_pos_k_linear.bias"), out=cpk)
         ctx.update(d_spq=spqk[:, :C], d_spk=spqk[:, C:], d_cpq=cpq, d_cpk=cpk)
-        causal = not full_context_alignment
+        causal = not ctx["full"]
         d_r2, d_r1, d_rx = self._rel_tables_all(
             "d_seg", ["%sseg_rel_pos_table_list.%d.weight" % (d, l) for l in range(cfg.dec_layers)],
             [(True, g["dec_idx2d"]), (True, g["dec_idx1d"]), (True, g["dec_idxx"])])
-        y_pre = None
         if resized:
             with self._wgrad():
                 bufs = dict(self.model.named_buffers())
@@ -1158,32 +1206,7 @@ class HipEngine:
                         self._dense_ev = torch.cuda.Event()
                     self._dense_ev.record(self._side)
                     ctx["dense_ready"] = self._dense_ev
-        for l in range(cfg.dec_layers):
-            p = "%slayers.%d." % (d, l)
-            tg = "d%d" % l
-            # (resized grid: the causal mask is inside the dense operand, the kernels walk every block)
-            rel = None if resized else hip.RelBias(P, g["gcode"], g["code_bias"], d_r2[l], d_r1[l], d_rx[l], grid_w=w)
-            y, yn = self._self_block_fwd(tg, p, "self_attn", "self_attn_layer_norm", "self_attn_ln", y, B, Td,
-                                         ctx["d_spq"], ctx["d_spk"], rel, causal and not resized, scaling, site=("d", l, 0), xn_pre=y_pre,
-                                         next_ln=(p + "encoder_attn_layer_norm", tg + "_cln1", buf(tg + "_cyn", (B * Td, C))))
-            y, yn = self._cross_block_fwd(tg, p, y, enc_out, B, Td, T, cpq, cpk, scaling, site=("d", l, 1), yn_pre=yn,
-                                          next_ln=(p + "final_layer_norm", tg + "_fln1", buf(tg + "_fxn", (B * Td, C))))
-            nl = (("%slayers.%d.self_attn_layer_norm" % (d, l + 1), "d%d_ln1" % (l + 1), buf("d%d_xn" % (l + 1), (B * Td, C)))
-                  if l + 1 < cfg.dec_layers else None)
-            y, y_pre = self._ffn_fwd(tg, p, y, B * Td, site=("d", l, 2), rpb=Td, xn_pre=yn, next_ln=nl)
-        ctx["d_y_final"] = y
-        # final LN written in reference order [bos, patches] (decoder_module.py:668-675)
-        featb = buf("d_feat", (B, Td, C))
-        mu, rs = self._ln_stats("d_final_ln_p", B * P)
-        hip.ln_fwd(y[:, :P], Wf(d + "layer_norm.weight"), Wf(d + "layer_norm.bias"), featb[:, 1:], mu, rs)
-        mu, rs = self._ln_stats("d_final_ln_b", B)
-        hip.ln_fwd(y[:, P:], Wf(d + "layer_norm.weight"), Wf(d + "layer_norm.bias"), featb[:, :1], mu, rs)
-        logits = buf("logits_pad", (B, Td, self.npad))
-        if self.train_seg:      # the tied projection follows the (trainable) seg embeddings: the padded copy is rebuilt per forward
-            self.wseg_pad[: cfg.num_seg_tokens].copy_(W("encoder.seg_embed_tokens.weight"))
-        hip.linear_fwd(featb.view(B * Td, C), self.wseg_pad, out=logits.view(B * Td, self.npad))   # :290-294
-        self.ctx = ctx
-        return logits, ctx
+        ctx["d_causal"], ctx["d_rel"] = causal, (d_r2, d_r1, d_rx)
 
     # ---------------------------------------------------------- resized-grid slow path (eval)
     def _resized_biases(self, kind, h, w, Lt, causal):
@@ -1378,8 +1401,7 @@ class HipEngine:
         kv = buf(tg + "_ckv", (B, Te, 2 * C))
         ready = self.ctx_building.get("ckv_ready") if self.ctx_building is not None else None
         if ready is not None:
-            if tg == "d0":
-                torch.cuda.current_stream().wait_event(ready)      # all layers' K|V were projected on the side stream
+            torch.cuda.current_stream().wait_event(ready[int(tg[1:])])      # this layer's K|V were projected on the side stream
         else:
             hip.linear_fwd(enc_out.view(B * Te, C), self._fused(self.p16, a_ + ".k_proj.weight", 2 * C, C),
                            self._fused(self.p16, a_ + ".k_proj.bias", 2 * C), out=kv.view(B * Te, 2 * C))
@@ -1896,8 +1918,10 @@ class HipEngine:
             torch.cuda.current_stream().wait_event(ctx["dense_ready"])
         e, d = "encoder.", "decoder."
         # ---- seg projection (frozen, tied to seg_embed_tokens: no weight grad)
+        fresh = "g_dlogits" not in self.ws or self.ws["g_dlogits"].shape != (B * Td, self.npad)
         dl = buf("g_dlogits", (B * Td, self.npad))
-        dl.zero_()
+        if fresh or _POISON:
+            dl.zero_()               # the padding columns: written once per allocation (nothing else writes them)
         dl.view(B, Td, self.npad)[:, :, : cfg.num_seg_tokens].copy_(dlogits)
         dfeat = buf("g_dfeat", (B, Td, C))
         hip.linear_dx(dl, self.wseg_pad, out=dfeat.view(B * Td, C))
@@ -1978,7 +2002,10 @@ class HipEngine:
         # ---- encoder abs-pos operands
         self._bt = "etop"
         # the main stream has run out of work: the side stream gets the whole GPU for the last weight gradients (no workgroup
-        # cap) and the abs-pos half of the tail, the main stream takes the embedding half, which only reads its own dx
+        # cap) and the abs-pos half of the tail, the main stream takes the embedding half, which only reads its own dx.
+        # (Round 6 measured the last layer's fc1 / fc2 weight gradients started under its attention backward and its bias-gradient
+        # kernels on the main stream at the end: the wait for the side stream shrank from 0.44 to 0.17 ms and the step grew by
+        # 0.04 ms -- profiles/round6_tail_ab.txt: the exposed end is resource-time, not slack.)
         if "tailsplit" in _EXP_SKIP:     # (measurement: the whole tail on the side stream, capped grid)
             self._side_do(lambda: (self._dw_flush(), self._enc_tail_pos_bwd(B, L, P, T, h, w, depq, depk, pos_all, dpos_all),
                                    self._enc_tail_emb_bwd(B, L, P, T, dx)))

@@ -591,6 +591,14 @@ def test_colsum_embed_cast_add():
     out = torch.zeros(768, device=dev)
     hip.reduce_parts(part, out, 1, hip.COLSUM_BLOCKS, 768)
     assert _rel(out, x.float().sum(0)) < 1e-5
+    # many parts, few columns (the loss kernel's per-tile statistics): the tall reduction, also accumulating / scaled / bf16
+    pt = torch.randn(2, 8192, 47, device=dev)
+    o32 = torch.full((2, 47), 3.0, device=dev)
+    hip.reduce_parts(pt, o32, 2, 8192, 47, accumulate=True, scale=0.5)
+    assert _rel(o32, 3.0 + 0.5 * pt.double().sum(1).float()) < 1e-5
+    o16 = torch.zeros(2, 47, dtype=torch.bfloat16, device=dev)
+    hip.reduce_parts(pt, o16, 2, 8192, 47)
+    assert _rel(o16, pt.double().sum(1).float()) < 5e-3
     table = _rand((101, 128), dev, 51)
     ids = torch.randint(0, 101, (2, 12), device=dev)
     addv = _rand((128,), dev, 52)
