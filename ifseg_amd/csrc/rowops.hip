@@ -1111,6 +1111,8 @@ extern "C" int ifseg_dropout(const void* x, const void* resid, void* out, long l
 // that recomputes gelu(u) -- LayerNorm forward / backward, the fused GEMM epilogue, the ffn_ln gradient kernels -- sees
 // a = keep * gelu(u) and da/du = keep * gelu'(u) without knowing about the mask.  The missing factor 1 / (1 - p) cancels in the
 // LayerNorm that follows: LN(a / (1 - p); eps) == LN(a; eps (1 - p)^2), forward and backward (the caller passes that eps).
+// (A pre-activation that is LEGITIMATELY <= -30 is indistinguishable from a dropped one -- and needs no distinction: both give
+// gelu = gelu' = 0 exactly, which is all any consumer reads from u.)
 namespace {
 __global__ void dropout_fill_kernel(const bf16_t* x, bf16_t* out, long long nchunks, float p, unsigned long long seed,
                                     const unsigned long long* seed_add, float fill) {

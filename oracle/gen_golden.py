@@ -473,7 +473,7 @@ def main():
     ap.add_argument("--skip-base", action="store_true")
     ap.add_argument("--only-imfree", action="store_true")
     ap.add_argument("--only-eval", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of: optim, upgrade, lazy, base_b2, base_c3, padded, base_padded, resize_train")
+    ap.add_argument("--only", default="", help="comma list of: train, optim, upgrade, lazy, base_b2, base_c3, padded, base_padded, resize_train")
     a = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -493,6 +493,8 @@ def main():
         if "base_padded" in only:  # configs[0] geometry with prompts of different lengths (sample 1 ends in 9 <pad>): key padding at Base size
             case_train(O.base_config(), "base", None, 2, 36, "base_c1_padded.npz", GRAD_KEYS, full_grads=False, sub_all=True, bf16_weights=True,
                        pad_tail=[0, 9])
+        if "train" in only:        # the fixture's training case (regenerated in round 6 so that the file carries every key the generator writes)
+            case_train(fx, "tiny", ov, 2, 12, "fixture_train.npz", GRAD_KEYS)
         if "resize_train" in only:  # training on a 128 x 192 image (grid 8 x 12, P = 96 > the trained 64): VERDICT r5 item 5
             case_train(fx, "tiny", ov, 2, 12, "fixture_resize_train.npz", GRAD_KEYS + RESIZE_KEYS, sub_all=True, image_hw=(128, 192))
         if "base_b2" in only:      # BASELINE config 1 as written: B = 2

@@ -662,7 +662,11 @@ def test_trained_weights_argmax_and_logits_parity(case):
     cosine -- 800 updates on a learnable synthetic task at Base width, 150 classes, L = 215; measured: loss 6.4 -> 0.03,
     median top-1 / top-2 margin of the reference 8.9 at a logits rms of 3.2), and the evaluation logits of the
     trained weights are compared with the fp32 restatement of the reference on the SAME weights: logits rel-L2 <= 2e-2 and
-    plain per-patch argmax agreement >= 99 %, on margins a trained model has."""
+    plain per-patch argmax agreement >= 99 %, on margins a trained model has.
+    What the comparison is against: the weights are HIP-trained, so no reference-GENERATED golden can exist
+    for them -- the other side is oracle/segofa_ref.py, whose agreement with the reference itself is pinned at max-abs 0.0 by the
+    goldens (tests/test_oracle_golden.py, oracle/gen_golden.py); the 150 / 171-class random-init tests assert 0.99 only on the
+    positions the reference decides (top-2 margin above three times the logits tolerance) and guard plain agreement at 0.95."""
     from ifseg_amd.tasks.mm_tasks import SegmentationTask
     from ifseg_amd.trainer import Trainer
     dev = torch.device("cuda:0")

@@ -1,5 +1,7 @@
 """HBM bytes per STEP by kernel from the two --pmc passes of tools/pmc_traffic.sh (FETCH_SIZE x2 on gfx950 + WRITE_SIZE).
-usage: pmc_step_traffic.py <rd dir> <wr dir> <steps in the run>"""
+The number of executed steps is COUNTED (one adam_kernel launch per step: the timed steps plus bench.py's warm-up, event-timed and
+host-timing passes), so launches / step here equal the kernel trace's (round 5's file divided by the --steps argument: 2 x).
+usage: pmc_step_traffic.py <rd dir> <wr dir>"""
 import csv, glob, collections, re, sys
 
 def short(k):
@@ -16,7 +18,8 @@ def tot(d, c):
     return acc, n
 
 rd, nr = tot(sys.argv[1], "FETCH_SIZE"); wr, nw = tot(sys.argv[2], "WRITE_SIZE")
-steps = float(sys.argv[3])
+steps = float(max(1, sum(v for k, v in nr.items() if "adam_kernel" in k)))
+print("executed steps in the run (adam_kernel launches): %d" % steps)
 rows = []
 for k in set(rd) | set(wr):
     r = 2 * rd.get(k, 0) * 1024 / steps; w = wr.get(k, 0) * 1024 / steps
