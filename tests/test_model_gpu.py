@@ -788,17 +788,30 @@ def test_parameters_stepped_from_outside_are_seen_by_the_next_forward(golden_dir
     assert _rel(le, o_eval) <= 2e-2
 
 
-def test_deferred_optimizer_is_bit_equal_and_the_next_forward_waits_for_its_slices():
+@pytest.mark.parametrize("delay", [False, True])
+def test_deferred_optimizer_is_bit_equal_and_the_next_forward_waits_for_its_slices(delay, monkeypatch):
     """Trainer.train_step(defer_optimizer=True): clip + Adam of update n run per parameter slice on their own stream while the
     forward of update n + 1 starts (trainer.py:865-907 / optim/adam.py:45-110 semantics unchanged).  Six updates with dropout
     (the masks depend on the step seed only) against the same six updates with the single launch on the main stream:
     parameters, fp32 masters, both Adam moments and the losses bit-equal; an evaluation right behind a deferred update sees
-    the updated weights (valid_step waits)."""
+    the updated weights (valid_step waits).
+    delay: every Adam slice is preceded by a ~1.5 ms sleep kernel on the stream it runs on, so the optimizer is
+    BEHIND the next forward instead of well ahead of it: a forward that reads a slice it did not wait for -- the FFN tail of
+    encoder layer l computes layer l + 1's pre-LN and reads that layer's gains -- would see stale parameters and the bits would
+    differ."""
     from ifseg_amd.criterions import SegCriterion
     from ifseg_amd.tasks.mm_tasks import SegmentationTask
     from ifseg_amd.trainer import Trainer
+    from ifseg_amd import hip as hip_mod
     dev = torch.device("cuda:0")
     task = SegmentationTask(num_seg_tokens=5, patch_image_size=128, arch="segofa_tiny")
+    if delay:
+        real = hip_mod.adam_step
+
+        def slow_adam(*a, **k):
+            torch.cuda._sleep(3_500_000)          # on torch's current stream = the stream the slice is launched on
+            return real(*a, **k)
+        monkeypatch.setattr(hip_mod, "adam_step", slow_adam)
 
     def make():
         torch.manual_seed(0)
@@ -883,8 +896,12 @@ def test_padded_prompts_vs_reference_golden(golden_dir):
             assert _rel(named[k[5:]].grad, torch.from_numpy(g[k])) <= 6e-2, k
     m.eval()
     with torch.no_grad():
-        lf, _ = m(**sample["net_input"], full_context_alignment=True)
+        lf, ex = m(**sample["net_input"], full_context_alignment=True)
     assert _rel(lf, torch.from_numpy(g["logits_full"])) <= 2e-2
+    # the mask the reference returns (encoder_module.py:730-752,838): True at <pad> source tokens, never at a patch position
+    pm = ex["encoder_returns"]["encoder_padding_mask"][0].cpu()
+    P_ = pm.shape[1] - batch["src_tokens"].shape[1]
+    assert not pm[:, :P_].any() and torch.equal(pm[:, P_:], batch["src_tokens"] == O.PAD)
 
 
 def test_training_on_a_resized_grid_vs_reference_golden(golden_dir):
