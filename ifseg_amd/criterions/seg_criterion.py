@@ -256,7 +256,7 @@ class SegCriterion(CriterionBase):
             model.engine.deferred_check(
                 getattr(self, bufs_name)["bad"], lambda t: ((t[0] != 0).clone(), t.zero_())[0],
                 "seg_criterion: target label outside [<seg_0>, <seg_%d>] (F.cross_entropy: target out of bounds)" % self.num_seg,
-                exc=IndexError)
+                exc=IndexError, native=(hip.CHECK_FLAG, 0, 1))
             n = self.num_seg
             ai, ap, al = stats[2:2 + n], stats[2 + n:2 + 2 * n], stats[2 + 2 * n:2 + 3 * n]
             metrics = {"area_intersect": ai, "area_pred_label": ap, "area_label": al, "area_union": ap + al - ai,

@@ -1008,6 +1008,56 @@ extern "C" int ifseg_nchw_to_nhwc_bf16(const void* in, int in_is_f32, void* out,
   return 0;
 }
 
+// ---- input validation without torch glue -----------------------------------------------------------
+// One launch per check, the verdict written straight into PINNED host memory (the engine reads it once the event behind the
+// launch has completed: HipEngine.deferred_check).  The torch composition it replaces -- compare, reduce, cast, copy -- was four
+// tiny kernels per check, three checks per step, all on the main queue between two steps.
+//   mode 0: any x[i] == value                      (int64: a <pad> source token where none is allowed, encoder_module.py:730-752)
+//   mode 1: rows of `row_len`: any x == value followed by x != value, or x[row start] == value  (padding that is not a suffix)
+//   mode 2: any x[i] == 0, x as bytes                (bool: a masked-out patch image, encoder_module.py:388-404 `patch_masks`)
+//   mode 3: *flag != 0, then *flag = 0               (int32 device flag raised by a kernel: the loss kernel's bad-label flag)
+namespace {
+__global__ __launch_bounds__(256) void check_inputs_kernel(const void* x, long long n, int mode, long long value, long long row_len,
+                                                           unsigned char* verdict) {
+  __shared__ int any;
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  int bad = 0;
+  if (mode == 3) {
+    if (threadIdx.x == 0) {
+      int* f = reinterpret_cast<int*>(const_cast<void*>(x));
+      bad = *f != 0;
+      *f = 0;
+    }
+  } else {
+    for (long long i = threadIdx.x; i < n; i += 256) {
+      if (mode == 2) {
+        bad |= reinterpret_cast<const unsigned char*>(x)[i] == 0;
+      } else {
+        const long long* t = reinterpret_cast<const long long*>(x);
+        if (mode == 0) bad |= t[i] == value;
+        else {
+          const long long c = i % row_len;
+          bad |= (c == 0 && t[i] == value) || (c + 1 < row_len && t[i] == value && t[i + 1] != value);
+        }
+      }
+    }
+  }
+  if (bad) any = 1;          // (benign race: every writer stores the same value)
+  __syncthreads();
+  if (threadIdx.x == 0) *verdict = any ? 1 : 0;
+}
+}  // namespace
+
+extern "C" int ifseg_check_inputs(const void* x, long long n, int mode, long long value, long long row_len,
+                                  unsigned char* verdict_host_pinned, void* stream) {
+  (void)hipGetLastError();
+  if (!x || !verdict_host_pinned || mode < 0 || mode > 3 || n < 0 || (mode == 1 && row_len <= 0)) return IFSEG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(check_inputs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, mode, value, row_len, verdict_host_pinned);
+  IFSEG_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---- rel-pos table <-> per-head delta tables ------------------------------------
 namespace {
 // out[h][i] = table[idx[i]][h] (idx < 0 -> 0)

@@ -21,7 +21,7 @@ GEMM_RELU, GEMM_OUT_F32, GEMM_ACCUMULATE = 1, 2, 4
 c_void_p, c_int, c_float, c_ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 
 
-ABI_VERSION = 17          # == IFSEG_ABI_VERSION of include/ifseg_hip.h (checked at load time and by __graft_entry__.build)
+ABI_VERSION = 18          # == IFSEG_ABI_VERSION of include/ifseg_hip.h (checked at load time and by __graft_entry__.build)
 
 
 def lib():
@@ -635,6 +635,16 @@ def ln_bwd(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx_add=None, g
                             c_int(ol), c_ll(ab), c_int(al), _drop_ref(drop, rpb or rows), _stream())
     _check(rc, "ln_bwd")
     return dx
+
+
+CHECK_ANY_EQ, CHECK_SUFFIX, CHECK_ANY_ZERO_BYTE, CHECK_FLAG = 0, 1, 2, 3
+
+
+def check_inputs(x, mode, verdict_pinned, slot, value=0, row_len=1):
+    """one-launch input validation (ifseg_check_inputs): verdict_pinned[slot] <- 0 / 1 in stream order"""
+    n = 1 if mode == CHECK_FLAG else x.numel()
+    _check(lib().ifseg_check_inputs(_ptr(x), c_ll(n), c_int(mode), c_ll(value), c_ll(row_len),
+                                    c_void_p(verdict_pinned.data_ptr() + slot), _stream()), "check_inputs")
 
 
 def reduce_parts(inp, out, outer, parts, n, accumulate=False, scale=1.0):

@@ -829,11 +829,14 @@ class HipEngine:
             self._wver += 1                 # an optimizer step follows: cached resized biases are stale
             hip.set_stream(prev)
 
-    def deferred_check(self, tensor, bad, message, exc=NotImplementedError):
+    def deferred_check(self, tensor, bad, message, exc=NotImplementedError, native=None):
         """Input validation without a device sync: `bad(tensor)` (a 0-d bool tensor) is evaluated on the stream and read
         back once its event has completed -- at the latest by the next call, i.e. the error surfaces one step late instead
         of draining the queue on every step (each batch is a new tensor, so a cache keyed on the tensor never hits with a
-        real data iterator).  The first call of a process checks synchronously."""
+        real data iterator).  The first call of a process checks synchronously.
+        `native` = (hip.CHECK_* mode, value, row_len): the same predicate as ONE launch that writes its verdict straight into
+        the pinned word (csrc/rowops.hip check_inputs_kernel) instead of compare + reduce + cast + copy torch kernels on the
+        main queue -- three checks per step, ~12 tiny kernels between the optimizer and the first kernel of the forward."""
         if torch.cuda.is_current_stream_capturing():
             return                                 # a captured forward replays validated inputs (checked at warm-up)
         if lab.get("SYNC_CHECKS"):
@@ -865,8 +868,26 @@ class HipEngine:
             if int(self._check_pin[slot]):
                 self._pending_checks = keep
                 raise msg[1](msg[0])
+        use_native = native is not None and tensor.is_cuda and tensor.is_contiguous()
+        first = message not in self._checked_kinds
+        if use_native:
+            slot = self._check_free.pop()
+            hip.check_inputs(tensor, native[0], self._check_pin, slot, native[1], native[2])
+            ev = torch.cuda.Event()
+            ev.record()
+            if first:                           # the first call of every kind of check is synchronous
+                self._checked_kinds.add(message)
+                ev.synchronize()
+                self._check_free.append(slot)
+                if int(self._check_pin[slot]):
+                    self._pending_checks = keep
+                    raise exc(message)
+            else:
+                keep.append((slot, ev, (message, exc)))
+            self._pending_checks = keep
+            return
         flag = bad(tensor)
-        if message not in self._checked_kinds:  # the first call of every kind of check is synchronous
+        if first:
             self._checked_kinds.add(message)
             if bool(flag):
                 raise exc(message)
@@ -897,11 +918,11 @@ class HipEngine:
             # the padding of a sample must be a suffix of its prompt (collate pads on the right): a valid key COUNT per sample
             self.deferred_check(src_tokens, lambda t: (t[:, :-1].eq(1) & t[:, 1:].ne(1)).any() | t[:, 0].eq(1).any(),
                                 "ifseg_amd HIP engine: <pad> tokens must form a suffix of every prompt (right padding)",
-                                exc=ValueError)
+                                exc=ValueError, native=(hip.CHECK_SUFFIX, 1, src_tokens.shape[1]))
         else:
             self.deferred_check(src_tokens, lambda t: t.eq(1).any(),
                                 "ifseg_amd HIP engine: padded source tokens need cfg.padded_prompts = True: every IFSeg sample carries the same unpadded prompt, so by "
-                                "default a step carries no per-sample key counts")
+                                "default a step carries no per-sample key counts", native=(hip.CHECK_ANY_EQ, 1, 1))
         B, L = src_tokens.shape
         C, Fd, H = cfg.embed_dim, cfg.ffn_dim, cfg.heads
         scaling = float(cfg.head_dim * cfg.attn_scale_factor) ** -0.5

@@ -382,7 +382,9 @@ class SegOFAModel(ModelBase):
                                    "(there is no CPU / PyTorch fallback)")
             if patch_masks is not None:
                 # validated without draining the queue (see HipEngine.deferred_check)
-                eng.deferred_check(patch_masks, lambda t: t.all().logical_not(), "masked-out patch images are not supported")
+                from ... import hip as _hip
+                eng.deferred_check(patch_masks, lambda t: t.all().logical_not(), "masked-out patch images are not supported",
+                                   native=(_hip.CHECK_ANY_ZERO_BYTE, 0, 1) if patch_masks.dtype == torch.bool else None)
             x, extra = self._run(src_tokens, patch_images, prev_output_tokens, bool(full_context_alignment), None)
         if aux_input is not None:
             # image-free branch (segofa.py:136-151): encoder on the artificial image, decoder with its defaults

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 17
+#define IFSEG_ABI_VERSION 18
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -343,6 +343,12 @@ int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamma, const fl
                       const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, void* dx2, int nblocks, int rows,
                       int C, int flags, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx, long long dx_bs, int lddx,
                       long long add_bs, int ldadd, long long dx2_bs, int lddx2, const ifseg_drop_args* drop2, void* stream);
+/* Input validation in one launch, the verdict (0 / 1) written to PINNED host memory in stream order (read it after an event):
+ * mode 0: any int64 x[i] == value; mode 1: rows of row_len int64: `value` entries that are not a suffix of their row (fairseq pads on
+ * the right: encoder_module.py:730-752); mode 2: any byte x[i] == 0 (the bool `patch_masks`); mode 3: *x (int32 device flag) != 0,
+ * and the flag is cleared.  Replaces compare + reduce + cast + copy torch kernels on the main queue between two steps. */
+int ifseg_check_inputs(const void* x, long long n, int mode, long long value, long long row_len,
+                       unsigned char* verdict_host_pinned, void* stream);
 /* fp32 master copy <- bf16 arena wherever bf16(master[i]) != p16[i] (an optimizer outside this library stepped the bf16
  * parameters: fp16_optimizer.py:198-222 writes the model copy); agreeing entries keep their fp32 value. */
 int ifseg_sync_master(float* master, const void* p16, long long n, void* stream);
