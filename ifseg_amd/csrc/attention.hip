@@ -1495,19 +1495,18 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(ReduceArgs r) {
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     if (t >= a.ntab) return;
-    const int np = a.tab_nparts[t] > 0 ? a.tab_nparts[t] : a.nparts;      // partial tables per head of this table
     if (blk < r.nbt[t] && a.tab_n[t] <= SMALL_TAB_MAX) {
       // small table (token offsets, bos row / column): one block per head sums the partials of every entry into LDS,
       // then thread r adds the entries of bucket r in entry order -- several entries may share a bucket (log-spaced
       // buckets beyond +-128), and a fixed order keeps the sum bit-reproducible (no atomics)
       const int n = a.tab_n[t], h = blk;
-      if (np <= 8) {
+      if (a.nparts <= 8) {
         // few partial tables (the batch-inner path hands over 4): a thread per entry, one pass -- the grouped passes below
         // cost two barriers per 32 entries (14 passes for the 429 offsets of a 215-token prompt).  Same order of additions.
         for (int j = tid; j < n; j += 256) {
-          const float* p = a.tab_part[t] + (long long)h * np * n + j;
+          const float* p = a.tab_part[t] + (long long)h * a.nparts * n + j;
           float sum = 0.f;
-          for (int q = 0; q < np; ++q) sum += p[(long long)q * n];
+          for (int q = 0; q < a.nparts; ++q) sum += p[(long long)q * n];
           tsmall[j] = sum;
         }
         __syncthreads();
@@ -1516,9 +1515,9 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(ReduceArgs r) {
         const int j = j0 + (tid & 31), g = tid >> 5;
         float sum = 0.f;
         if (j < n) {
-          const float* p = a.tab_part[t] + (long long)h * np * n + j;
+          const float* p = a.tab_part[t] + (long long)h * a.nparts * n + j;
 #pragma unroll 4
-          for (int q = g; q < np; q += 8) sum += p[(long long)q * n];
+          for (int q = g; q < a.nparts; q += 8) sum += p[(long long)q * n];
         }
         tred[g][tid & 31] = sum;
         __syncthreads();
@@ -1550,9 +1549,9 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(ReduceArgs r) {
       const int h = blk / nchunk, j = (blk - h * nchunk) * 32 + (tid & 31), g = tid >> 5;
       float sum = 0.f;
       if (j < n) {
-        const float* p = a.tab_part[t] + (long long)h * np * n + j;
+        const float* p = a.tab_part[t] + (long long)h * a.nparts * n + j;
 #pragma unroll 4
-        for (int q = g; q < np; q += 8) sum += p[(long long)q * n];
+        for (int q = g; q < a.nparts; q += 8) sum += p[(long long)q * n];
       }
       tred[g][tid & 31] = sum;
       __syncthreads();
@@ -1581,8 +1580,7 @@ extern "C" int ifseg_attn_bwd_reduce(const ifseg_attn_reduce_args* x, void* stre
   r.nbk = x->dpos_k_part ? (int)(((long long)x->S * x->C / 8 + 255) / 256) : 0;
   long long total = (long long)r.nbq + r.nbk + x->H;
   for (int t = 0; t < x->ntab; ++t) {
-    if (!x->tab_part[t] || !x->tab_idx[t] || !x->tab_acc[t] || x->tab_n[t] <= 0 || (x->nparts <= 0 && x->tab_nparts[t] <= 0) || x->tab_nparts[t] < 0)
-      return IFSEG_ERR_BAD_ARG;
+    if (!x->tab_part[t] || !x->tab_idx[t] || !x->tab_acc[t] || x->tab_n[t] <= 0 || x->nparts <= 0) return IFSEG_ERR_BAD_ARG;
     if (x->tab_nbucket[t] <= 0) return IFSEG_ERR_BAD_ARG;
     r.nbt[t] = x->tab_n[t] <= SMALL_TAB_MAX ? x->H : x->H * ((x->tab_n[t] + 31) / 32);
     total += r.nbt[t];

@@ -903,9 +903,8 @@ struct DbArgs {
   int tab_accumulate;         // partial delta tables: add to what they hold (slab pairs after the first)
   float dpq_scale;
   int P, gh, gw, Lt, causal;
-  float *drel2d, *drel1d, *drelx;     // [H][DB_NPARTS or gh][(2gh-1)(2gw-1)], [H][DB_NPARTS][2Lt-1], [H][DB_NPARTS][2]
+  float *drel2d, *drel1d, *drelx;     // [H][DB_NPARTS][(2gh-1)(2gw-1)], [H][DB_NPARTS][2Lt-1], [H][DB_NPARTS][2]
   int nb_q, nb_k, nb_2d;
-  int fuse2d;                         // the 2-D table's partials come out of the d pos_q pass: drel2d is [H][gh][...], nb_2d = 0
 };
 
 // A / B fragment of a transposed read of a [rows = contraction index][128-byte row] tile (vx layout): 16 rows from
@@ -924,7 +923,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int rbase, 
 // Two block ranges (d pos_q | d pos_k): small GEMMs with the contraction split over the four waves of a workgroup
 // (each wave stages its own tiles in its own LDS region: no block barrier inside the loop; the next step's global loads
 // are in flight under the current step's MFMAs) and a fixed-order sum of the four accumulators at the end.
-__global__ __launch_bounds__(256, 3) void attn_dbias_grads_kernel(DbArgs a) {
+__global__ __launch_bounds__(256) void attn_dbias_grads_kernel(DbArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char sm[32768];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -994,45 +993,7 @@ __global__ __launch_bounds__(256, 3) void attn_dbias_grads_kernel(DbArgs a) {
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr[s2][g].b, acc[1], 0, 0, 0);
           }
       }
-      if (a.fuse2d && i0 < a.P && j0 < a.P) {
-        // (32-wide grid) this tile is (grid row yi of queries) x (grid row yj of keys): its 63 diagonal sums ARE the entries
-        // (dy = yi - yj, dx = -31 .. 31) of this query row's partial 2-D table -- every (yi, yj) pair is one tile of one
-        // workgroup, so each entry is written exactly once and the separate table pass over sum_b dS is not needed.
-        // Lane d sums the diagonal x_i - x_j = d - 31 in a fixed order (x_i ascending, slab 0 before slab 1).
-        if (lane < 63) {
-          const int dx = lane - 31;
-          float t = 0.f;
-          // (four rows per trip: eight 2-byte reads in flight -- fully unrolled the 64 reads cost the kernel 60 VGPRs and a
-          // wave per SIMD, and the step 0.4 ms)
-#pragma unroll 1
-          for (int x0 = 0; x0 < 32; x0 += 4) {
-            float v[4][2];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int xi = x0 + u, xj = xi - dx;
-              const bool ok = xj >= 0 && xj < 32;
-              const int off = vx_off(xi, (ok ? xj : 0) * 2);      // slab 1's 64-byte half of the row: chunk index ^ 4
-              v[u][0] = ok ? bf2f(*reinterpret_cast<const bf16_t*>(tile + 4096 + off)) : 0.f;
-              v[u][1] = (ok && a.ng > 1) ? bf2f(*reinterpret_cast<const bf16_t*>(tile + 4096 + (off ^ 64))) : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { t += v[u][0]; t += v[u][1]; }
-          }
-          const int ndy = 2 * a.gh - 1, yi = i0 >> 5, dy = yi - (j0 >> 5);
-          float* o = a.drel2d + ((((long long)h * a.gh + yi) * ndy + (dy + a.gh - 1)) * 63 + lane);
-          *o = (a.tab_accumulate ? *o : 0.f) + t;
-        }
-      }
       __builtin_amdgcn_wave_barrier();
-    }
-    if (a.fuse2d && i0 < a.P && !a.tab_accumulate) {
-      // the table rows dy this query row has no live tile for (key rows outside the grid; causal: key rows below) are zeros
-      const int ndy = 2 * a.gh - 1, yi = i0 >> 5;
-      float* o = a.drel2d + ((long long)h * a.gh + yi) * ndy * 63;
-      for (int idx = tid; idx < ndy * 63; idx += 256) {
-        const int yj = yi - (idx / 63 - (a.gh - 1));
-        if (yj < 0 || yj >= a.gh || !live(yj * 32)) o[idx] = 0.f;
-      }
     }
     __syncthreads();                                   // (the tiles are dead: the sum reuses their LDS)
     // fixed-order sum of the four waves' accumulators, one column block at a time: [wave][r][lane]
@@ -1426,10 +1387,6 @@ extern "C" int ifseg_attn_dbias_grads(const ifseg_attn_dbias_args* x, void* stre
   a.nb_q = pos ? a.H * ((a.T + 31) / 32) : 0;
   a.nb_k = pos ? a.H * (a.Sp / 32) : 0;
   a.nb_2d = rel ? a.H * (2 * a.gh - 1) * DB_NPARTS : 0;
-  if (rel && x->rel2d_parts && x->rel2d_parts != DB_NPARTS) {
-    if (x->rel2d_parts != ifseg_attn_dbias_rel2d_parts(a.gh, a.gw, pos) || (a.P & 31)) return IFSEG_ERR_BAD_ARG;
-    a.fuse2d = 1; a.nb_2d = 0;
-  }
   // the kernels take the slabs (groups of four batch elements) two at a time: batches of more than eight per GPU run them
   // once per pair, later pairs adding to the first pair's results in launch order (deterministic)
   const int ng_all = x->ng;
@@ -1445,9 +1402,6 @@ extern "C" int ifseg_attn_dbias_grads(const ifseg_attn_dbias_args* x, void* stre
 }
 
 extern "C" int ifseg_attn_dbias_nparts(void) { return DB_NPARTS; }
-extern "C" int ifseg_attn_dbias_rel2d_parts(int grid_h, int grid_w, int has_pos) {
-  return (has_pos && grid_w == 32 && grid_h > 0) ? grid_h : DB_NPARTS;
-}
 
 extern "C" int ifseg_attn_dropout_mask(unsigned char* keep, int B, int H, int T, int S, float p, unsigned long long seed,
                                        const unsigned long long* seed_add, void* stream) {

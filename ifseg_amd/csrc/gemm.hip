@@ -505,9 +505,7 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, int M, i
   g.nrecA = (unsigned)nrA; g.nrecB = (unsigned)nrB;
   const int tiles128 = ((M + BM - 1) / BM) * ((N + 127) / 128);
   // narrow tiles when the output is narrow or there are too few 128-wide tiles to fill 256 CUs
-  // (IFSEG_GEMM_NARROW_MAX, laboratory: the N = 768 products -- 402 tiles of 128 x 128 -- as 804 tiles of 128 x 64)
-  static const int narrow_max = [] { const char* e = ifseg_lab_env("IFSEG_GEMM_NARROW_MAX"); return e ? atoi(e) : 384; }();
-  const bool narrow = layout == IFSEG_GEMM_NT && g.splitk == 1 && (N <= 64 || tiles128 < narrow_max);
+  const bool narrow = layout == IFSEG_GEMM_NT && g.splitk == 1 && (N <= 64 || tiles128 < 384);
   const int tiles = narrow ? ((M + BM - 1) / BM) * ((N + 63) / 64) : tiles128;
   dim3 grid(tiles, batch > 0 ? batch : 1, g.splitk), block(256);
   static const bool no_xcd_slices = ifseg_lab_env("IFSEG_GEMM_NO_XCD_SLICES") != nullptr;

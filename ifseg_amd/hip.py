@@ -21,7 +21,7 @@ GEMM_RELU, GEMM_OUT_F32, GEMM_ACCUMULATE = 1, 2, 4
 c_void_p, c_int, c_float, c_ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 
 
-ABI_VERSION = 19          # == IFSEG_ABI_VERSION of include/ifseg_hip.h (checked at load time and by __graft_entry__.build)
+ABI_VERSION = 18          # == IFSEG_ABI_VERSION of include/ifseg_hip.h (checked at load time and by __graft_entry__.build)
 
 
 def lib():
@@ -472,12 +472,6 @@ def dbias_nparts():
     return lib().ifseg_attn_dbias_nparts()
 
 
-def dbias_rel2d_parts(grid_h, grid_w, has_pos=True):
-    """partial 2-D tables per head attn_dbias_grads wants for this grid: grid_h on a 32-wide grid with abs-pos operands (the
-    d pos_q pass emits them, one per grid row of queries), dbias_nparts() otherwise"""
-    return lib().ifseg_attn_dbias_rel2d_parts(c_int(grid_h), c_int(grid_w), c_int(1 if has_pos else 0))
-
-
 def attn_fwd_bi(q, k, v, dense, out, lse, B, H, T, S, causal=False, P=None, gain=None, kv_len=None, drop=None):
     """out = gain softmax(q k^T + dense.D) v, four batch elements per workgroup (csrc/attention_bi.hip)"""
     a = _AttnBiArgs()
@@ -498,18 +492,15 @@ class _AttnDbiasArgs(ctypes.Structure):
                 ("pos_q", c_void_p), ("pos_k", c_void_p), ("ldpq", c_int), ("ldpk", c_int),
                 ("dpos_q_acc", c_void_p), ("dpos_k_acc", c_void_p), ("accumulate_pos", c_int), ("dpq_scale", c_float),
                 ("P", c_int), ("grid_h", c_int), ("grid_w", c_int),
-                ("drel2d", c_void_p), ("drel1d", c_void_p), ("drelx", c_void_p), ("causal", c_int),
-                ("rel2d_parts", c_int)]     # == ifseg_attn_dbias_args
+                ("drel2d", c_void_p), ("drel1d", c_void_p), ("drelx", c_void_p), ("causal", c_int)]     # == ifseg_attn_dbias_args
 
 
 def attn_dbias_grads(dbias, S, pos_q=None, pos_k=None, dpq_acc=None, dpk_acc=None, accumulate_pos=False, dpq_scale=1.0,
                      P=0, grid_h=0, grid_w=0, drel2d=None, drel1d=None, drelx=None, causal=False):
     """dbias [ng, H, T, Sp] bf16 -> abs-pos operand gradients (fp32 [T, C] / [S, C]) and delta-table gradients as
-    NP = dbias_nparts() partial tables per head (fp32 [H, NP2, (2gh-1)(2gw-1)], [H, NP, 2Lt-1], [H, NP, 2]); NP2 = NP or
-    dbias_rel2d_parts(gh, gw): the 2-D table's partials out of the d pos_q pass (no second read of sum_b dS)"""
+    NP = dbias_nparts() partial tables per head (fp32 [H, NP, (2gh-1)(2gw-1)], [H, NP, 2Lt-1], [H, NP, 2]) in one launch"""
     if drel2d is not None:
-        assert all(t.shape[1] == dbias_nparts() and t.is_contiguous() for t in (drel1d, drelx)) and drel2d.is_contiguous()
-        assert drel2d.shape[1] in (dbias_nparts(), dbias_rel2d_parts(grid_h, grid_w, pos_q is not None))
+        assert all(t.shape[1] == dbias_nparts() and t.is_contiguous() for t in (drel2d, drel1d, drelx))
     a = _AttnDbiasArgs()
     ng, H, T, Sp = dbias.shape
     a.dbias, a.ng, a.H, a.T, a.S, a.Sp = _p(dbias), ng, H, T, S, Sp
@@ -522,7 +513,6 @@ def attn_dbias_grads(dbias, S, pos_q=None, pos_k=None, dpq_acc=None, dpk_acc=Non
     a.P, a.grid_h, a.grid_w = P, grid_h, grid_w
     a.drel2d, a.drel1d, a.drelx = _p(drel2d), _p(drel1d), _p(drelx)
     a.causal = 1 if causal else 0
-    a.rel2d_parts = drel2d.shape[1] if drel2d is not None else 0
     _check(lib().ifseg_attn_dbias_grads(ctypes.byref(a), _stream()), "attn_dbias_grads")
 
 
@@ -865,12 +855,12 @@ class _AttnReduceArgs(ctypes.Structure):
                 ("dpos_q_part", c_void_p), ("dpos_k_part", c_void_p), ("dpos_q_acc", c_void_p), ("dpos_k_acc", c_void_p),
                 ("delta", c_void_p), ("gain", c_void_p), ("dgain", c_void_p), ("ntab", c_int),
                 ("tab_part", c_void_p * 3), ("tab_idx", c_void_p * 3), ("tab_acc", c_void_p * 3), ("tab_n", c_int * 3),
-                ("tab_nbucket", c_int * 3), ("tab_nparts", c_int * 3)]
+                ("tab_nbucket", c_int * 3)]
 
 
 def attn_bwd_reduce(B, H, T, S, C, dpq_part, dpk_part, dpq_acc, dpk_acc, accumulate_pos, delta, gain, dgain, nparts, tables):
     """every reduction behind attn_bwd's partial outputs in one launch (ifseg_attn_bwd_reduce); tables: list of
-    (part [H,nparts_i,n] fp32, idx [n] int32, acc [n_bucket,H] fp32)"""
+    (part [H,nparts,n] fp32, idx [n] int32, acc [n_bucket,H] fp32)"""
     assert all(t is None or t.dtype == torch.bfloat16 for t in (dpq_part, dpk_part)), "abs-pos partials are bf16"
     a = _AttnReduceArgs()
     a.B, a.H, a.T, a.S, a.C, a.nparts, a.accumulate_pos = B, H, T, S, C, nparts, 1 if accumulate_pos else 0
@@ -880,7 +870,6 @@ def attn_bwd_reduce(B, H, T, S, C, dpq_part, dpk_part, dpq_acc, dpk_acc, accumul
     for i, (part, idx, acc) in enumerate(tables):
         assert part.dtype == torch.float32 and acc.dtype == torch.float32 and idx.dtype == torch.int32 and acc.shape[1] == H
         a.tab_part[i], a.tab_idx[i], a.tab_acc[i], a.tab_n[i], a.tab_nbucket[i] = _p(part), _p(idx), _p(acc), idx.numel(), acc.shape[0]
-        a.tab_nparts[i] = part.shape[1]
     _check(lib().ifseg_attn_bwd_reduce(ctypes.byref(a), _stream()), "attn_bwd_reduce")
 
 

@@ -1760,10 +1760,8 @@ class HipEngine:
             timing["pairs"].append((t0, t1, 8.0 * 64 * T * S * B * H))
         parts = [None, None, None]
         if rel is not None:
-            # (the 2-D table's partials come out of the d pos_q pass on a 32-wide grid: one per grid row of queries)
-            np2 = hip.dbias_rel2d_parts(rel.P // rel.grid_w, rel.grid_w, pq is not None)
-            parts = [gbuf("g_relg%d_%d_%d" % (i, t.shape[1], np_), (H, np_, t.shape[1]), torch.float32)
-                     for i, (t, np_) in enumerate(zip((rel.rel2d, rel.rel1d, rel.relx), (np2, hip.dbias_nparts(), hip.dbias_nparts())))]
+            parts = [gbuf("g_relg%d_%d" % (i, t.shape[1]), (H, hip.dbias_nparts(), t.shape[1]), torch.float32)
+                     for i, t in enumerate((rel.rel2d, rel.rel1d, rel.relx))]
 
         def reductions():
             kw = {}

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 19
+#define IFSEG_ABI_VERSION 18
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -205,7 +205,6 @@ typedef struct ifseg_attn_reduce_args {
   float* tab_acc[3];                        /* fp32 [n_bucket_i, H] accumulators */
   int tab_n[3];
   int tab_nbucket[3];                       /* rows of tab_acc_i */
-  int tab_nparts[3];                        /* partial tables per head of table i when it differs from nparts (0 = nparts) */
 } ifseg_attn_reduce_args;
 int ifseg_attn_bwd_reduce(const ifseg_attn_reduce_args* args, void* stream);
 
@@ -285,16 +284,9 @@ typedef struct ifseg_attn_dbias_args {
   int P, grid_h, grid_w;
   float *drel2d, *drel1d, *drelx;
   int causal;                  /* dbias comes from a causal launch of ifseg_attn_bwd_bi: the blocks it skipped are not read */
-  int rel2d_parts;             /* partial tables per head in drel2d: 0 or NP = the table pass reads sum_b dS on its own;
-                                * ifseg_attn_dbias_rel2d_parts(grid_h, grid_w, 1) (= grid_h on a 32-wide grid): ONE pass -- the
-                                * d pos_q workgroup of a grid row of queries, which holds every 32 x 32 (query row, key row) tile
-                                * of sum_b dS in LDS anyway, also emits that tile's 63 diagonal sums = its share of the 2-D table,
-                                * one partial table per grid row; the table pass then only reads the text rows / columns */
 } ifseg_attn_dbias_args;
 int ifseg_attn_dbias_grads(const ifseg_attn_dbias_args* args, void* stream);
 int ifseg_attn_dbias_nparts(void);
-/* partial 2-D tables per head ifseg_attn_dbias_grads should be given for this grid (has_pos: pos_q / pos_k are passed) */
-int ifseg_attn_dbias_rel2d_parts(int grid_h, int grid_w, int has_pos);
 
 /* -------------------------------------------------------------- row ops */
 /* Row addressing used below: logical row r lives at element offset

@@ -66,9 +66,6 @@ def main(kind="enc"):
     print(kind, "bi dq (+ sum_b dS)      us %.1f" % timeit(lambda: bi(hip.ATTN_BWD_DQ)))
     print(kind, "bi dkv + dq             us %.1f" % timeit(lambda: bi(0)))
     print(kind, "dbias grads             us %.1f" % timeit(lambda: hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, causal=causal, **kw)))
-    if kw and hip.dbias_rel2d_parts(gh, gw) != hip.dbias_nparts():
-        kw1 = dict(kw, drel2d=torch.zeros(H, hip.dbias_rel2d_parts(gh, gw), n2d, device=dev))
-        print(kind, "dbias grads, one pass   us %.1f" % timeit(lambda: hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, causal=causal, **kw1)))
     print(kind, "  operands only         us %.1f" % timeit(lambda: hip.attn_dbias_grads(dbias, S, pos_q=pq, pos_k=pk, dpq_acc=dpq, dpk_acc=dpk, causal=causal, P=P)))
     if kw:
         print(kind, "  delta tables only     us %.1f" % timeit(lambda: hip.attn_dbias_grads(dbias, S, causal=causal, **kw)))

@@ -1,6 +1,6 @@
 """round 6, VERDICT r5 item 2(b): "round filling for N = 768, measured, not argued".  Stand-alone times (idle MI355X, M = 8480) of the
 forward products with N = 768 as 402 tiles of 128 x 128 (default), as 804 tiles of 128 x 64 (IFSEG_LAB=1 IFSEG_GEMM_NARROW_MAX=512 in a
-child process) and, for K = 3072, as a 2-way split-K (804 workgroups, fp32 slabs) + the reduction launch that sums them."""
+child process; the switch exists in commit f42f41a only: it was removed with the experiment) and, for K = 3072, as a 2-way split-K (804 workgroups, fp32 slabs) + the reduction launch that sums them."""
 import sys, os, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
