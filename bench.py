@@ -99,14 +99,14 @@ def _self_spawn(n, argv):
 PROF_STRIDE = 3
 
 
-TRAFFIC_JSON = os.environ.get("IFSEG_TRAFFIC_JSON", "profiles/round5_hbm_traffic.json")
+TRAFFIC_JSON = os.environ.get("IFSEG_TRAFFIC_JSON", "profiles/round6_hbm_traffic.json")
 
 
 def _pmc_traffic(kind):
     """HBM bytes per launch of a kernel family.  NOT measured in this run: read from the committed PMC collection
     (TRAFFIC_JSON: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 x2 correction on
     FETCH_SIZE, tools/pmc_traffic.sh); the bench line names the file in `traffic_source`.  None if not collected."""
-    for rel in (TRAFFIC_JSON, "profiles/round4_hbm_traffic.json"):
+    for rel in (TRAFFIC_JSON, "profiles/round5_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 return json.load(f)[kind]["bytes_per_launch"]
@@ -116,9 +116,16 @@ def _pmc_traffic(kind):
 
 
 def _traffic_source():
-    for rel in (TRAFFIC_JSON, "profiles/round4_hbm_traffic.json"):
-        if os.path.exists(os.path.join(ROOT, rel)):
-            return rel + " (rocprofv3 --pmc passes of this command, committed; not collected in this run)"
+    for rel in (TRAFFIC_JSON, "profiles/round5_hbm_traffic.json"):
+        path = os.path.join(ROOT, rel)
+        if os.path.exists(path):
+            at = None
+            try:
+                with open(path) as f:
+                    at = json.load(f).get("_collected_at")      # the commit whose tree the PMC passes ran (stamped when the file was committed)
+            except (OSError, ValueError):
+                pass
+            return rel + " (rocprofv3 --pmc passes of this command%s, committed; not collected in this run)" % (" at commit %s" % at if at else "")
     return None
 
 

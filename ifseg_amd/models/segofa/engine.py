@@ -950,11 +950,11 @@ class HipEngine:
             # aspect ratio; `--patch-image-size 640` on a 512-grid checkpoint in training): position tables / rel-pos biases are
             # bilinear-resized exactly like the reference.  Evaluation: the dense fp32 bias of csrc/resize.hip, cached per shape.
             # Training (round 6): the standard step below with dense biases from models/segofa/resized.py and their adjoints.
-            if pads:
-                raise NotImplementedError("ifseg_amd HIP engine: padded prompts on a resized feature grid are not supported")
+            # Padded prompts (round 6): the key counts go to the batch-inner kernels of the standard step, so an EVALUATION of a
+            # padded batch takes the standard step too (dense biases from resized.py) instead of the cached-bias slow path.
             if bag is not None:
                 raise NotImplementedError("ifseg_amd HIP engine: the image-free entry on a resized feature grid is not supported")
-            if not need_grad:
+            if not need_grad and not pads:
                 return self._forward_resized(src_tokens, feat, h, w, prev_output_tokens, full_context_alignment)
         resized = bool(slow)
         g = self._geometry(h, w, L)

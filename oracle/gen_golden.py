@@ -473,7 +473,7 @@ def main():
     ap.add_argument("--skip-base", action="store_true")
     ap.add_argument("--only-imfree", action="store_true")
     ap.add_argument("--only-eval", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of: train, optim, upgrade, lazy, base_b2, base_c3, padded, base_padded, resize_train")
+    ap.add_argument("--only", default="", help="comma list of: train, optim, upgrade, lazy, base_b2, base_c3, padded, base_padded, resize_train, resize_padded")
     a = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -497,6 +497,9 @@ def main():
             case_train(fx, "tiny", ov, 2, 12, "fixture_train.npz", GRAD_KEYS)
         if "resize_train" in only:  # training on a 128 x 192 image (grid 8 x 12, P = 96 > the trained 64): VERDICT r5 item 5
             case_train(fx, "tiny", ov, 2, 12, "fixture_resize_train.npz", GRAD_KEYS + RESIZE_KEYS, sub_all=True, image_hw=(128, 192))
+        if "resize_padded" in only:  # the two together: prompts of different lengths on a resized grid (round 6)
+            case_train(fx, "tiny", ov, 3, 12, "fixture_resize_padded.npz", GRAD_KEYS + RESIZE_KEYS, sub_all=True, image_hw=(128, 192),
+                       pad_tail=[0, 3, 5])
         if "base_b2" in only:      # BASELINE config 1 as written: B = 2
             case_train(O.base_config(), "base", None, 2, 36, "base_c1_b2.npz", GRAD_KEYS, full_grads=False, sub_all=True, bf16_weights=True)
         if "base_c3" in only:      # BASELINE config 3 geometry on one device: Base width, 150 classes, L = 215 (T_enc 1239)

@@ -971,6 +971,66 @@ def test_training_on_a_resized_grid_vs_reference_golden(golden_dir):
     assert _rel(lf, torch.from_numpy(g["logits_full"])) <= 2e-2
 
 
+def test_padded_prompts_on_a_resized_grid_vs_reference_golden(golden_dir):
+    """The two together (refused until round 6): prompts of different lengths (0 / 3 / 5 <pad> tokens) on a 128 x 192 image whose
+    feature grid (8 x 12) is not the trained one.  Training takes the standard step with the dense biases of
+    models/segofa/resized.py and per-sample key counts (ifseg_attn_bi_args.kv_len); the evaluation of such a batch takes the same
+    step instead of the cached-bias slow path.  tests/golden/fixture_resize_padded.npz is the REFERENCE's output
+    (oracle/gen_golden.py --only resize_padded): logits, loss, gradients, evaluation logits."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ifseg_amd.criterions import SegCriterion
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config()
+    sd = O.procedural_state_dict(ocfg)
+    g = np.load(os.path.join(golden_dir, "fixture_resize_padded.npz"))
+    B, hw = int(g["batch_size"]), tuple(int(v) for v in g["image_hw"])
+    batch = O.synthetic_batch(ocfg, B, int(g["src_len"]), image_hw=hw)
+    batch["src_tokens"] = torch.from_numpy(g["src_tokens"])
+    assert (batch["src_tokens"] == O.PAD).sum(1).tolist() == [0, 3, 5]
+    o_logits, o_loss, o_grads, _ = _oracle_all_grads(ocfg, sd, batch, hw)
+    assert np.abs(o_logits.numpy() - g["logits_causal"]).max() <= 1e-5 and abs(o_loss.item() - float(g["loss"])) <= 1e-5
+    crit = SegCriterion(unsupervised_segmentation=False, init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset)
+    sample = {"net_input": {k: batch[k].to(dev) for k in ("src_tokens", "patch_images", "patch_masks", "prev_output_tokens")},
+              "target": batch["target"].to(dev), "ntokens": 1, "nsentences": B}
+    m = _build(ocfg, sd, dev)
+    m.cfg.padded_prompts = True
+    m.train()
+    loss, _, logs = crit(m, sample)
+    logits = m.engine.ws["logits_pad"][:, :, : ocfg.num_seg_tokens].float().cpu()
+    ref = torch.from_numpy(g["logits_causal"])
+    print("padded prompts on a resized grid: logits rel-L2 %.4f (5 pads %.4f), loss %.5f vs %.5f"
+          % (_rel(logits, ref), _rel(logits[2], ref[2]), loss.item(), float(g["loss"])))
+    assert logits.shape == ref.shape and _rel(logits, ref) <= 2e-2 and abs(loss.item() - float(g["loss"])) <= 1e-2
+    assert (logits.argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.99
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(m.named_parameters())
+    gain_scale = max(v.abs().max().item() for k, v in o_grads.items() if k.endswith("c_attn"))
+    bad, n = [], 0
+    for k, og in sorted(o_grads.items()):
+        if k not in named or not named[k].requires_grad or og.norm() == 0 or k.endswith(("k_proj.bias", "pos_k_linear.bias")):
+            continue
+        hg = named[k].grad
+        if k.endswith("c_attn"):
+            assert (hg.float().cpu() - og).abs().max().item() <= 5e-2 * gain_scale, k
+            continue
+        n += 1
+        if _rel(hg, og) > 6e-2:
+            bad.append((round(_rel(hg, og), 4), k))
+    assert n > 100 and not bad, bad[:10]
+    for k in g.files:                                   # the reference's own gradients of the golden's keys
+        if k.startswith("grad:") and not k.endswith("c_attn"):
+            assert _rel(named[k[5:]].grad, torch.from_numpy(g[k])) <= 6e-2, k
+    m.eval()
+    with torch.no_grad():
+        lf, ex = m(**sample["net_input"], full_context_alignment=True)
+    assert _rel(lf, torch.from_numpy(g["logits_full"])) <= 2e-2
+    pm = ex["encoder_returns"]["encoder_padding_mask"][0].cpu()
+    P_ = pm.shape[1] - batch["src_tokens"].shape[1]
+    assert not pm[:, :P_].any() and torch.equal(pm[:, P_:], batch["src_tokens"] == O.PAD)
+
+
 def test_label_smoothing_runs_in_the_fused_criterion():
     """--label-smoothing > 0 (seg_criterion.py:142,265: F.cross_entropy(label_smoothing=eps)) stays on the fused loss kernel:
     loss, metrics and the gradient handed to the decoder equal the torch composition of the reference ops on the same logits."""

@@ -48,6 +48,36 @@ def test_fixture_logits_loss_and_grads(golden_dir):
     assert np.abs(g["logits_full"] - g["logits_causal"]).max() > 1e-3
 
 
+@pytest.mark.parametrize("name", ["fixture_padded.npz", "fixture_resize_train.npz", "fixture_resize_padded.npz"])
+def test_fixture_padded_and_resized_training_cases(golden_dir, name):
+    """The training goldens of the padded-prompt, resized-grid and padded + resized cases (the REFERENCE's logits, loss and
+    gradients): the oracle reproduces them on the CPU -- the same goldens pin the HIP path in tests/test_model_gpu.py."""
+    g = _load(golden_dir, name)
+    cfg = O.fixture_config()
+    sd = dict(O.procedural_state_dict(cfg))
+    hw = tuple(int(v) for v in g["image_hw"]) if "image_hw" in g.files else None
+    batch = O.synthetic_batch(cfg, int(g["batch_size"]), int(g["src_len"]), **({"image_hw": hw} if hw else {}))
+    if "src_tokens" in g.files:
+        batch["src_tokens"] = torch.from_numpy(g["src_tokens"])
+    keys = [k[5:] for k in g.files if k.startswith("grad:")]
+    for k in keys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    logits, extra = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"], None, batch["patch_masks"], False)
+    hp, wp = extra["encoder_returns"]["image_embed_shape"]
+    ih, iw = hw if hw else (128, 128)
+    loss, s, t = O.seg_loss(cfg, logits, batch["target"], hp, wp, ih, iw)
+    loss.backward()
+    assert np.abs(logits.detach().numpy() - g["logits_causal"]).max() <= 1e-5
+    assert abs(loss.item() - float(g["loss"])) <= 1e-6
+    assert len(keys) > 10
+    for k in keys:
+        ref = torch.from_numpy(g["grad:" + k])
+        assert (sd[k].grad - ref).norm() / ref.norm() <= 1e-5, k
+    with torch.no_grad():
+        full = O.segofa_forward(sd, cfg, batch["src_tokens"], batch["patch_images"], None, batch["patch_masks"], True)[0]
+    assert np.abs(full.numpy() - g["logits_full"]).max() <= 1e-5
+
+
 def test_fixture_resize_path(golden_dir):
     """P != orig grid: positional-embedding + double-bilinear rel-pos resize
     (encoder_module.py:360-368,802-808; decoder_module.py:541-548,603-627)."""
