@@ -330,17 +330,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, const bf1
 // row sums' multiply-adds differently in the two kernels).  DX2: the second output of ifseg_ln_bwd_drop,
 // dx2 = drop2(dx as stored in bf16) -- the same instantiation as the plain call, so the pair stays bit-identical to
 // ifseg_ln_bwd followed by ifseg_dropout.  (ln_bwd_kernel remains for the GELU / wide rows.)
-// DX2 only, optional (c != nullptr): the two row dots ifseg_ffn_ln_rowstats takes of dx2 -- the fc2 output gradient of the FFN block
-// that opens next in the backward -- from the row while it is in registers (dx2 as stored in bf16, the statements and the
-// lane / chunk order of ffn_ln_rowstats_kernel): c[row] = {sum_j dx2_j a_j, sum_j dx2_j (t[row][j] - wb_j)} / N
-struct RowStats { const bf16_t* t; int ldt; const float* coef; float* c; float inv_n; };
-
 template <int NCH, bool DX2>
 __global__ __launch_bounds__(256) void ln_bwd_lean_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* gamma,
                                                           const float* mean, const float* rstd, const bf16_t* dx_add,
                                                           bf16_t* dx, float* dgamma_part, float* dbeta_part, int rows, int C,
                                                           RowMap mdy, RowMap mx, RowMap mdx, RowMap madd, DropArgs drop, int pf32,
-                                                          bf16_t* dx2, RowMap mdx2, DropArgs drop2, RowStats rst) {
+                                                          bf16_t* dx2, RowMap mdx2, DropArgs drop2) {
   __shared__ float red[4 * (64 * 8 + 8)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C >> 3;
@@ -392,7 +387,6 @@ __global__ __launch_bounds__(256) void ln_bwd_lean_kernel(const bf16_t* dy, cons
       asm volatile("" : "+v"(rx[i].x), "+v"(rx[i].y), "+v"(rx[i].z), "+v"(rx[i].w), "+v"(rd[i].x), "+v"(rd[i].y), "+v"(rd[i].z), "+v"(rd[i].w));
     bf16_t* dxp = dx + mdx.off(row);
     const bf16_t* ap = dx_add ? dx_add + madd.off(row) : nullptr;
-    float q1 = 0.f, q2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + i * 64;
@@ -419,33 +413,9 @@ __global__ __launch_bounds__(256) void ln_bwd_lean_kernel(const bf16_t* dy, cons
           float d2[8];
           unpack8(pk, d2);                               // the adjoint sees dx as stored
           if (drop2.on) drop8(d2, drop2, (long long)row * nch + c, row);
-          const uint4 pk2 = pack8(d2);
-          *reinterpret_cast<uint4*>(dx2 + mdx2.off(row) + c * 8) = pk2;
-          rd[i] = pk2;                                   // (dy is dead: the row-dot pass below reads dx2 from its registers)
+          *reinterpret_cast<uint4*>(dx2 + mdx2.off(row) + c * 8) = pack8(d2);
         }
       }
-    }
-    if (DX2 && rst.c) {
-      // (a pass of its own behind the stores: inside the loop above its operands cost the kernel 36 VGPRs and ten spilled SGPRs)
-#pragma unroll
-      for (int i = 0; i < NCH; ++i)
-        asm volatile("" : "+v"(rd[i].x), "+v"(rd[i].y), "+v"(rd[i].z), "+v"(rd[i].w));
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        const int c = lane + i * 64;
-        if (c < nch) {
-          float dd[8], tv[8];
-          unpack8(rd[i], dd);
-          unpack8(*reinterpret_cast<const uint4*>(rst.t + (long long)row * rst.ldt + c * 8), tv);
-          const float4 a0 = *reinterpret_cast<const float4*>(rst.coef + c * 8), a1 = *reinterpret_cast<const float4*>(rst.coef + c * 8 + 4);
-          const float4 w0 = *reinterpret_cast<const float4*>(rst.coef + C + c * 8), w1 = *reinterpret_cast<const float4*>(rst.coef + C + c * 8 + 4);
-          const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { q1 += dd[e] * av[e]; q2 += dd[e] * (tv[e] - wv[e]); }
-        }
-      }
-      q1 = warp_sum(q1); q2 = warp_sum(q2);
-      if (lane == 0) { rst.c[2 * row] = q1 * rst.inv_n; rst.c[2 * row + 1] = q2 * rst.inv_n; }
     }
   }
   if (!dgamma_part) return;
@@ -763,7 +733,7 @@ extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, co
   ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 8.0 : 6.0));
   if (C <= 1024 && !(act_gelu & IFSEG_LN_GELU))
     hipLaunchKernelGGL((ln_bwd_lean_kernel<2, false>), g, dim3(256), 0, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C,
-                       mdy, mx, mdx, madd, dr, (act_gelu & IFSEG_LN_PARAMS_F32) ? 1 : 0, (bf16_t*)nullptr, RowMap{}, DropArgs{}, RowStats{});
+                       mdy, mx, mdx, madd, dr, (act_gelu & IFSEG_LN_PARAMS_F32) ? 1 : 0, (bf16_t*)nullptr, RowMap{}, DropArgs{});
   else if (C <= 1024) launch_ln_bwd<2, 1>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd, dr);
   else launch_ln_bwd<2, 4>(act_gelu, g, s, DY, X, G, mean, rstd, A, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C, mdy, mx, mdx, madd, dr);
   ifseg_prof_end(IFSEG_K_LN_BWD, s);
@@ -771,11 +741,11 @@ extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, co
   return 0;
 }
 
-static int ln_bwd_drop_impl(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
-                            const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, void* dx2, int nblocks,
-                            int rows, int C, int flags, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx,
-                            long long dx_bs, int lddx, long long add_bs, int ldadd, long long dx2_bs, int lddx2,
-                            const ifseg_drop_args* drop2, RowStats rst, void* stream) {
+extern "C" int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
+                                 const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, void* dx2, int nblocks,
+                                 int rows, int C, int flags, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx,
+                                 long long dx_bs, int lddx, long long add_bs, int ldadd, long long dx2_bs, int lddx2,
+                                 const ifseg_drop_args* drop2, void* stream) {
   (void)hipGetLastError();
   if (rows <= 0) return 0;
   if ((C & 7) || C > 1024 || nblocks <= 0) return IFSEG_ERR_BAD_SHAPE;
@@ -791,29 +761,10 @@ static int ln_bwd_drop_impl(const void* dy, const void* x, const void* gamma, co
   ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 10.0 : 8.0));
   hipLaunchKernelGGL((ln_bwd_lean_kernel<2, true>), dim3(nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
                      (const bf16_t*)gamma, mean, rstd, (const bf16_t*)dx_add, (bf16_t*)dx, dgamma_part, dbeta_part, rows, C,
-                     mdy, mx, mdx, madd, DropArgs{}, (flags & IFSEG_LN_PARAMS_F32) ? 1 : 0, (bf16_t*)dx2, mdx2, dr, rst);
+                     mdy, mx, mdx, madd, DropArgs{}, (flags & IFSEG_LN_PARAMS_F32) ? 1 : 0, (bf16_t*)dx2, mdx2, dr);
   ifseg_prof_end(IFSEG_K_LN_BWD, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
-}
-
-extern "C" int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
-                                 const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, void* dx2, int nblocks,
-                                 int rows, int C, int flags, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx,
-                                 long long dx_bs, int lddx, long long add_bs, int ldadd, long long dx2_bs, int lddx2,
-                                 const ifseg_drop_args* drop2, void* stream) {
-  return ln_bwd_drop_impl(dy, x, gamma, mean, rstd, dx_add, dx, dgamma_part, dbeta_part, dx2, nblocks, rows, C, flags, rpb, dy_bs, lddy,
-                          x_bs, ldx, dx_bs, lddx, add_bs, ldadd, dx2_bs, lddx2, drop2, RowStats{}, stream);
-}
-
-extern "C" int ifseg_ln_bwd_drop_rowstats(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
-                                          const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, void* dx2, int nblocks,
-                                          int rows, int C, int flags, int lddy, int ldx, int lddx, int ldadd, int lddx2,
-                                          const ifseg_drop_args* drop2, const void* t, int ldt, const float* coef, float* c, int N,
-                                          void* stream) {
-  if (!t || !coef || !c || N <= 0 || (ldt & 7) || ((size_t)coef & 15) || ((size_t)t & 15)) return IFSEG_ERR_BAD_ARG;
-  return ln_bwd_drop_impl(dy, x, gamma, mean, rstd, dx_add, dx, dgamma_part, dbeta_part, dx2, nblocks, rows, C, flags, 0, 0, lddy,
-                          0, ldx, 0, lddx, 0, ldadd, 0, lddx2, drop2, RowStats{(const bf16_t*)t, ldt, coef, c, 1.f / (float)N}, stream);
 }
 
 namespace {

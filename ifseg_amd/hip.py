@@ -21,7 +21,7 @@ GEMM_RELU, GEMM_OUT_F32, GEMM_ACCUMULATE = 1, 2, 4
 c_void_p, c_int, c_float, c_ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 
 
-ABI_VERSION = 19          # == IFSEG_ABI_VERSION of include/ifseg_hip.h (checked at load time and by __graft_entry__.build)
+ABI_VERSION = 18          # == IFSEG_ABI_VERSION of include/ifseg_hip.h (checked at load time and by __graft_entry__.build)
 
 
 def lib():
@@ -602,23 +602,11 @@ def ln_fwd_pair(x, gamma, beta, y, mean, rstd, gamma2, beta2, y2, mean2, rstd2, 
 LN_BWD_BLOCKS = int(lab.get("LN_BWD_BLOCKS", "768"))   # three resident blocks per CU (146-162 VGPRs): best of a 256..2048 sweep on MI355X
 
 
-def ln_bwd_drop(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx2, dx_add=None, drop2=None, rowstats=None):
+def ln_bwd_drop(dy, x, gamma, mean, rstd, dx, dgamma_part, dbeta_part, dx2, dx_add=None, drop2=None):
     """dx = [dx_add +] LN'(x; gamma)(dy) and dx2 = drop2(dx): the pre-LN backward that closes a block of the backward and the
-    fc2-dropout adjoint that opens the next one in one launch; rowstats = (t, coef, c, N): also ffn_ln_rowstats(dx2, t, coef, c, N)
-    of the FFN block dx2 opens (2-D row-major operands only)"""
+    fc2-dropout adjoint that opens the next one in one launch"""
     C = x.shape[-1]
     rows = x.numel() // C
-    if rowstats is not None:
-        t, coef, c, N = rowstats
-        ts = (dy, x, dx, dx2, t) + ((dx_add,) if dx_add is not None else ())
-        assert all(v.dim() == 2 and v.stride(1) == 1 for v in ts) and c.is_contiguous() and c.numel() == 2 * rows
-        rc = lib().ifseg_ln_bwd_drop_rowstats(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx_add), _ptr(dx),
-                                              _ptr(dgamma_part), _ptr(dbeta_part), _ptr(dx2), c_int(LN_BWD_BLOCKS), c_int(rows), c_int(C),
-                                              c_int(_ln_flags(gamma)), c_int(dy.stride(0)), c_int(x.stride(0)), c_int(dx.stride(0)),
-                                              c_int(dx_add.stride(0) if dx_add is not None else 0), c_int(dx2.stride(0)),
-                                              _drop_ref(drop2, rows), _ptr(_bf(t)), c_int(t.stride(0)), _ptr(coef), _ptr(c), c_int(N), _stream())
-        _check(rc, "ln_bwd_drop_rowstats")
-        return dx, dx2
     rpb = x.shape[1] if x.dim() == 3 else 0
     db_, dl = _map(dy, rpb)
     xb, xl = _map(x, rpb)

@@ -1543,11 +1543,8 @@ class HipEngine:
             return dx
         mu, rs = self._ln_stats(stats_tag, rows)
         part = self._ln_part(C, stats_tag)
-        # (round 6) ... and the two row dots ifseg_ffn_ln_rowstats takes of that adjoint, while the row is in registers
-        rst = nxt.get("rowstats") if all(v is None or (v.dim() == 2 and v.stride(1) == 1) for v in (dy, x, dx, dx_add)) else None
         hip.ln_bwd_drop(dy, x, self.Wf(pname + ".weight"), mu, rs, dx, part[0], part[1], nxt["out"], dx_add=dx_add,
-                        drop2=nxt["drop"], rowstats=rst)
-        self._rowstats_done = nxt["tg"] if rst is not None else None
+                        drop2=nxt["drop"])
         self._ln_red_tasks.append((part, self._fused(self.g16, pname + ".weight", 2, C), 2, hip.LN_BWD_BLOCKS, C, False))
         return dx
 
@@ -1559,12 +1556,7 @@ class HipEngine:
         bt, self._bt = self._bt, tg + "f"
         out = self.gbuf("g_drop_%d" % rows, (rows, self.cfg.embed_dim))
         self._bt = bt
-        rst = None
-        if self.ffn_ln_fused and s.get("t") is not None and not lab.get("NO_ROWSTATS_FUSE"):
-            C = self.cfg.embed_dim
-            rst = (s["t"].view(rows, C), self.ws[tg + "_fcoef"], self.buf(tg + "_fc12", (rows, 2), torch.float32), self.cfg.ffn_dim)
-        return dict(kind="drop", tg=tg, out=out, rowstats=rst,
-                    drop=(self.cfg.dropout, self._site_seed(self._site_id(s["site"])), self._dp(*s["site"]), s["rpb"]))
+        return dict(kind="drop", out=out, drop=(self.cfg.dropout, self._site_seed(self._site_id(s["site"])), self._dp(*s["site"]), s["rpb"]))
 
     def _bias_grad(self, dy2d, gout, accumulate=False):
         N = dy2d.shape[-1]
@@ -1610,10 +1602,7 @@ class HipEngine:
             self._linear_bwd(dbr, s["z"], W(p + "fc2.weight"), G(p + "fc2.weight"), G(p + "fc2.bias"), need_dx=False)
             mu, rs = self._ln_stats(tg + "_fln2", rows)
             cst = buf(tg + "_fc12", (rows, 2), torch.float32)
-            if dbr_pre is not None and getattr(self, "_rowstats_done", None) == tg:
-                self._rowstats_done = None          # the launch that produced dbr_pre left the row dots in cst
-            else:
-                hip.ffn_ln_rowstats(dbr, s["t"].view(rows, C), self.ws[tg + "_fcoef"], cst, Fd)
+            hip.ffn_ln_rowstats(dbr, s["t"].view(rows, C), self.ws[tg + "_fcoef"], cst, Fd)
             hip.linear_dx_gelu_ln_bwd(dbr, W(p + "fc2.weight"), du, s["u"], Wf(p + "ffn_layernorm.weight"), mu, rs, cst)
             self._ffn_pg_tasks.append((W(p + "fc2.weight"), G(p + "fc2.weight"), G(p + "fc2.bias"), Wf(p + "ffn_layernorm.weight"),
                                        Wf(p + "ffn_layernorm.bias"), G(p + "ffn_layernorm.weight"), G(p + "ffn_layernorm.bias"),
@@ -1935,7 +1924,6 @@ class HipEngine:
         scaling = float(cfg.head_dim * cfg.attn_scale_factor) ** -0.5
         W, Wf, G, buf = self.W, self.Wf, self.G, self.buf
         g = self._geometry(h, w, L)
-        self._rowstats_done = None
         self.mark("bwd_start")
         if ctx.get("g16_zeroed") is not None:
             # the gradient arena (218 MB for SegOFA-Base) was cleared on the side stream during the forward: the main stream only

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IFSEG_ABI_VERSION 19
+#define IFSEG_ABI_VERSION 18
 #define IFSEG_ERR_BAD_SHAPE (-2)
 #define IFSEG_ERR_BAD_ARG (-3)
 
@@ -343,14 +343,6 @@ int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamma, const fl
                       const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, void* dx2, int nblocks, int rows,
                       int C, int flags, int rpb, long long dy_bs, int lddy, long long x_bs, int ldx, long long dx_bs, int lddx,
                       long long add_bs, int ldadd, long long dx2_bs, int lddx2, const ifseg_drop_args* drop2, void* stream);
-/* ifseg_ln_bwd_drop on plain row-major operands (row r at r * ld) that ALSO emits ifseg_ffn_ln_rowstats of its second output:
- * c[r] = {sum_j dx2[r][j] coef[0][j], sum_j dx2[r][j] (t[r][j] - coef[1][j])} / N, t = the saved fc2 output of the FFN block whose
- * backward dx2 opens (J = C).  The row is in registers when dx2 is stored: one launch, one read of dx2 and two kernel boundaries
- * less on the main stream per FFN block (round 6). */
-int ifseg_ln_bwd_drop_rowstats(const void* dy, const void* x, const void* gamma, const float* mean, const float* rstd,
-                               const void* dx_add, void* dx, float* dgamma_part, float* dbeta_part, void* dx2, int nblocks, int rows,
-                               int C, int flags, int lddy, int ldx, int lddx, int ldadd, int lddx2, const ifseg_drop_args* drop2,
-                               const void* t, int ldt, const float* coef /* [2][C] */, float* c /* [rows][2] */, int N, void* stream);
 /* Input validation in one launch, the verdict (0 / 1) written to PINNED host memory in stream order (read it after an event):
  * mode 0: any int64 x[i] == value; mode 1: rows of row_len int64: `value` entries that are not a suffix of their row (fairseq pads on
  * the right: encoder_module.py:730-752); mode 2: any byte x[i] == 0 (the bool `patch_masks`); mode 3: *x (int32 device flag) != 0,
