@@ -913,8 +913,7 @@ class HipEngine:
             self.pack(dev)
         pads = bool(getattr(cfg, "padded_prompts", False))
         if pads:
-            if bag is not None:
-                raise NotImplementedError("ifseg_amd HIP engine: padded prompts in the image-free branch are not supported")
+            # (the image-free entry shares the encoder from the embeddings on: the same key counts -- fixture_imfree_padded.npz)
             # the padding of a sample must be a suffix of its prompt (collate pads on the right): a valid key COUNT per sample
             self.deferred_check(src_tokens, lambda t: (t[:, :-1].eq(1) & t[:, 1:].ne(1)).any() | t[:, 0].eq(1).any(),
                                 "ifseg_amd HIP engine: <pad> tokens must form a suffix of every prompt (right padding)",

@@ -241,7 +241,7 @@ def case_resize(cfg, arch, overrides, out_name):
                         seed=4321, src_len=12)
 
 
-def case_imfree(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys):
+def case_imfree(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys, pad_tail=None):
     """Image-free branch: SegOFAModel.forward(aux_input=...) + SegCriterion.compute_imfree_loss
     of the reference vs the restatement.  The reference's loss hard-codes a 32x32 -> 512x512 upsample
     (seg_criterion.py:236,249), so this case runs the small-width fixture on the full 32x32 patch grid."""
@@ -249,6 +249,11 @@ def case_imfree(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys):
     model, sd = build_reference(cfg, arch, overrides)
     crit = build_criterion(cfg)
     batch = O.synthetic_aux_batch(cfg, batch_size, src_len)
+    if pad_tail is not None:       # prompts of different lengths (right-padded) in the image-free step: the same encoder_padding_mask path
+        for b, n in enumerate(pad_tail):
+            if n:
+                batch["aux_input"]["src_tokens"][b, -n:] = O.PAD
+                batch["aux_input"]["src_tokens"][b, -n - 1] = O.EOS
     model.train()
     params = dict(model.named_parameters())
     for k in grad_keys:
@@ -273,6 +278,8 @@ def case_imfree(cfg, arch, overrides, batch_size, src_len, out_name, grad_keys):
     print("  oracle vs reference: logits max-abs %.3e  loss diff %.3e" % (err, abs(o_loss.item() - loss.item())))
     assert err <= 2e-5 and abs(o_loss.item() - loss.item()) <= 2e-6
     save = {"logits": ref_logits.numpy(), "loss": np.float64(loss.item()), "batch_size": batch_size, "src_len": src_len}
+    if pad_tail is not None:
+        save["src_tokens"] = batch["aux_input"]["src_tokens"].numpy()
     for k in grad_keys:
         g_ref, g_o = params[k].grad, sdg[k].grad
         rel = ((g_o - g_ref).norm() / (g_ref.norm() + 1e-30)).item()
@@ -473,7 +480,7 @@ def main():
     ap.add_argument("--skip-base", action="store_true")
     ap.add_argument("--only-imfree", action="store_true")
     ap.add_argument("--only-eval", action="store_true")
-    ap.add_argument("--only", default="", help="comma list of: train, optim, upgrade, lazy, base_b2, base_c3, padded, base_padded, resize_train, resize_padded")
+    ap.add_argument("--only", default="", help="comma list of: train, optim, upgrade, lazy, base_b2, base_c3, padded, base_padded, resize_train, resize_padded, imfree_padded")
     a = ap.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -500,6 +507,10 @@ def main():
         if "resize_padded" in only:  # the two together: prompts of different lengths on a resized grid (round 6)
             case_train(fx, "tiny", ov, 3, 12, "fixture_resize_padded.npz", GRAD_KEYS + RESIZE_KEYS, sub_all=True, image_hw=(128, 192),
                        pad_tail=[0, 3, 5])
+        if "imfree_padded" in only:  # the image-free step with prompts of different lengths (round 6)
+            fx512 = O.fixture_config(patch_image_size=512, orig_patch_image_size=512)
+            case_imfree(fx512, "tiny", ov, 2, 12, "fixture_imfree_padded.npz",
+                        [k for k in GRAD_KEYS if "token_rel_pos" not in k] + ["encoder.patch_layernorm_embedding.weight"], pad_tail=[0, 4])
         if "base_b2" in only:      # BASELINE config 1 as written: B = 2
             case_train(O.base_config(), "base", None, 2, 36, "base_c1_b2.npz", GRAD_KEYS, full_grads=False, sub_all=True, bf16_weights=True)
         if "base_c3" in only:      # BASELINE config 3 geometry on one device: Base width, 150 classes, L = 215 (T_enc 1239)

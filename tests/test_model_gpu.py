@@ -519,6 +519,73 @@ def test_image_free_branch_vs_reference_golden(golden_dir):
     assert _rel(alone, o_real) <= 2e-2
 
 
+def test_image_free_branch_with_padded_prompts_vs_reference_golden(golden_dir):
+    """The image-free step with prompts of different lengths (refused until round 6): the artificial image's encoder pass builds the
+    same encoder_padding_mask (encoder_module.py:566-606) -- here the same per-sample key counts as the supervised step.
+    tests/golden/fixture_imfree_padded.npz is the REFERENCE's output (oracle/gen_golden.py --only imfree_padded: sample 1 ends in
+    4 <pad> tokens)."""
+    from ifseg_amd.criterions import SegCriterion
+    dev = torch.device("cuda:0")
+    ocfg = O.fixture_config(patch_image_size=512, orig_patch_image_size=512)
+    sd = O.procedural_state_dict(ocfg)
+    g = np.load(os.path.join(golden_dir, "fixture_imfree_padded.npz"))
+    aux = O.synthetic_aux_batch(ocfg, 2, 12)
+    aux["aux_input"]["src_tokens"] = torch.from_numpy(g["src_tokens"])
+    assert (aux["aux_input"]["src_tokens"] == O.PAD).sum(1).tolist() == [0, 4]
+    real = O.synthetic_batch(ocfg, 2, 12)
+    sdg = {}
+    spec = O.state_dict_spec(ocfg)
+    for k, v in sd.items():
+        if not spec[k][1].startswith("alias:"):
+            sdg[k] = v.clone().requires_grad_(v.dtype.is_floating_point and "embed_images" not in k)
+    for k, (_, kind) in spec.items():
+        if kind.startswith("alias:"):
+            sdg[k] = sdg[kind[6:]]
+    o_logits, _ = O.segofa_forward_imfree(sdg, ocfg, aux["aux_input"])
+    o_loss = O.imfree_loss(ocfg, o_logits, aux["text2seg_target"])
+    o_loss.backward()
+    assert np.abs(o_logits.detach().numpy() - g["logits"]).max() <= 1e-5 and abs(o_loss.item() - float(g["loss"])) <= 1e-5
+    m = _build(ocfg, sd, dev)
+    m.cfg.padded_prompts = True
+    m.train()
+    crit = SegCriterion(init_seg_with_text=False, num_seg_tokens=ocfg.num_seg_tokens, seg_id_offset=ocfg.seg_id_offset, unsupervised_segmentation=True)
+    to = lambda d: {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+    sample = {"net_input": to({"src_tokens": real["src_tokens"], "src_lengths": torch.full((2,), 12),
+                               "patch_images": real["patch_images"], "patch_masks": real["patch_masks"],
+                               "prev_output_tokens": real["prev_output_tokens"]}),
+              "target": real["target"].to(dev), "aux_input": to(aux["aux_input"]),
+              "text2seg_target": aux["text2seg_target"].to(dev), "ntokens": 1, "nsentences": 2}
+    loss, sample_size, logs = crit(m, sample)
+    loss.backward()
+    torch.cuda.synchronize()
+    logits = m.engine._ws_grad["logits_pad"][:, :, : ocfg.num_seg_tokens].float().cpu()
+    ref = torch.from_numpy(g["logits"])
+    print("image-free, padded prompts: logits rel-L2 %.4f (padded sample %.4f)  loss %.5f vs %.5f"
+          % (_rel(logits, ref), _rel(logits[1], ref[1]), loss.item(), float(g["loss"])))
+    assert _rel(logits, ref) <= 2e-2 and abs(loss.item() - float(g["loss"])) <= 1e-2
+    named = dict(m.named_parameters())
+    gain_scale = max(v.grad.abs().max().item() for k, v in sdg.items() if k.endswith("c_attn") and v.grad is not None)
+    worst = []
+    for k, v in sorted(sdg.items()):
+        og = v.grad
+        if og is None or k not in named or not named[k].requires_grad or og.norm() == 0 or k.endswith(("k_proj.bias", "pos_k_linear.bias")):
+            continue
+        hg = named[k].grad
+        assert hg is not None, k
+        if k.endswith("c_attn"):
+            assert (hg.float().cpu() - og).abs().max().item() <= 5e-2 * gain_scale, k
+            continue
+        worst.append((_rel(hg, og), k))
+    worst.sort(reverse=True)
+    print("worst grads:", [(round(e, 4), k) for e, k in worst[:4]], "checked", len(worst))
+    assert len(worst) > 100
+    bad = [(e, k) for e, k in worst if e > (8e-2 if "token_rel_pos_table" in k else 6e-2)]
+    assert not bad, bad[:10]
+    for k in [f[5:] for f in g.files if f.startswith("grad:")]:          # the reference's own gradients
+        if not k.endswith("c_attn"):
+            assert _rel(named[k].grad, torch.from_numpy(g["grad:" + k])) <= 6e-2, k
+
+
 def test_eval_branch_vs_reference_golden(golden_dir):
     """BASELINE config 5 / SURVEY 8f row 4: SegCriterion eval branch on the device -- logits, metrics at the original
     150x200 resolution and the top-k neighbour smoothing (25 iterations, k=3) against the reference golden."""

@@ -164,6 +164,29 @@ def test_fixture_imfree_branch(golden_dir):
     assert torch.allclose(O.embed_bag_mean(sd["encoder.embed_tokens.weight"].detach(), flat, starts), ref, atol=1e-6)
 
 
+def test_fixture_imfree_branch_with_padded_prompts(golden_dir):
+    """the image-free step with prompts of different lengths: the oracle reproduces the reference's logits, loss and gradients"""
+    g = _load(golden_dir, "fixture_imfree_padded.npz")
+    cfg = O.fixture_config(patch_image_size=512, orig_patch_image_size=512)
+    sd = dict(O.procedural_state_dict(cfg))
+    aux = O.synthetic_aux_batch(cfg, int(g["batch_size"]), int(g["src_len"]))
+    aux["aux_input"]["src_tokens"] = torch.from_numpy(g["src_tokens"])
+    keys = [k[5:] for k in g.files if k.startswith("grad:")]
+    for k, (_, kind) in O.state_dict_spec(cfg).items():
+        if kind.startswith("alias:"):
+            sd[k] = sd[kind[6:]]
+    for k in keys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    logits, _ = O.segofa_forward_imfree(sd, cfg, aux["aux_input"])
+    loss = O.imfree_loss(cfg, logits, aux["text2seg_target"])
+    loss.backward()
+    assert np.abs(logits.detach().numpy() - g["logits"]).max() <= 1e-5 and abs(loss.item() - float(g["loss"])) <= 1e-6
+    assert len(keys) > 5
+    for k in keys:
+        ref = torch.from_numpy(g["grad:" + k])
+        assert (sd[k].grad - ref).norm() / ref.norm() <= 1e-5, k
+
+
 def test_fixture_eval_branch(golden_dir):
     """Eval branch of the criterion: top-k neighbour smoothing + metrics at the original image resolution
     (seg_criterion.py:197-213,289-347), restatement vs the reference's histograms and loss."""
