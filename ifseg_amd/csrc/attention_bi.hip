@@ -145,6 +145,41 @@ __device__ __forceinline__ void db_stage(const bf16_t* dbase, int p, int row0, i
   const int ir = min(row0 + row, rmax);
   lds_dma16_gs(dbase, (ir * Sp + col0 + c * 8) * 2, dst + p * 1024);
 }
+
+// ---- staging through BUFFER loads (round 6): the part of a piece's source address that changes from block to block -- the
+// streamed side's first row -- is wave-uniform, so it rides in the instruction's SCALAR offset; the per-lane part (row inside
+// the piece, swizzled chunk) is the same for every block, and rows past the end of the tensor are out of the descriptor's
+// range (zeros: their scores are -inf from the bias padding, their P is 0).  With global_load_lds every piece of every block
+// recomputed row, clamp, swizzle, multiply and add per lane: ~50 of a block's ~160 VALU instructions in kernels whose VALU
+// work is 3x their MFMA cycles.
+typedef int bi_v4i32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bi_v4i32 bi_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  bi_v4i32 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void lds_dma16_bs(bi_v4i32 rs, unsigned lds_base, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(voff), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+}
+// per-lane byte offsets of an operand tile's pieces [32 rows][64 bf16]: piece p = rows 8 p + (lane >> 3), chunk (lane & 7) ^
+// vx_swz(row); vx_swz(8 p + r) = vx_swz(r) ^ (2 (p & 1)), so even pieces share `even`, odd pieces `odd`; + the scalar (first row + 8 p) * ld * 2
+__device__ __forceinline__ void tile_voff(int lane, int ld, unsigned& even, unsigned& odd) {
+  const int r8 = lane >> 3, c0 = (lane & 7) ^ vx_swz(r8);
+  const unsigned rb = (unsigned)(r8 * ld) * 2u;
+  even = rb + ((unsigned)c0 << 4);
+  odd = rb + ((unsigned)(c0 ^ 2) << 4);
+}
+// per-lane byte offset of piece p of a bias tile whose first row is row0 (rows clamped to rmax) and whose columns start at col0
+__device__ __forceinline__ unsigned db_voff(int p, int row0, int rmax, int Sp, int col0, int lane) {
+  const int row = p * 16 + (lane >> 2);
+  const int c = (lane & 3) ^ db_swz(row);
+  return (unsigned)((min(row0 + row, rmax) * Sp + col0 + c * 8) * 2);
+}
 // four bf16 seeds of register group rg (8 bytes, requested with the block's other LDS reads) -> fp32, right before the MFMAs:
 // between the request and the first MFMA a block holds 8 registers of raw seeds instead of 16 of fp32 ones
 __device__ __forceinline__ void db_expand(const uint2& w, f32x16& s, int rg) {
@@ -219,7 +254,13 @@ __device__ __forceinline__ void attn_bi_fwd_body(const BiArgs& a) {
   const bf16_t* vb_ = a.v + (long long)bc * a.v_bs + h * 64;
   const bf16_t* db_ = a.D + (long long)h * a.Tp * a.Sp;
   const unsigned lds0 = lds_addr(smem);
-  const int r8 = lane >> 3, cp = lane & 7;
+  // this wave stages V (row block 0) or K (row block 1) of its batch element: rows 0 .. S-1, 64 columns of head h
+  const int ldkv = qb ? a.ldk : a.ldv;
+  const bi_v4i32 rsKV = bi_rsrc(qb ? kb_ : vb_, (unsigned)(((long long)(a.S - 1) * ldkv + 64) * 2));
+  const bi_v4i32 rsD = bi_rsrc(db_, (unsigned)((long long)a.Tp * a.Sp * 2));
+  unsigned ve, vo;                                            // (three loop-invariant per-lane offsets)
+  tile_voff(lane, ldkv, ve, vo);
+  const unsigned vD = db_voff(bl & 1, q0 + qb * 32, a.T - 1, a.Sp, 0, lane);
   const int kl = a.kv_len ? __builtin_amdgcn_readfirstlane(a.kv_len[bc]) : 0x7fffffff;
   AttnDrop dr{};
   unsigned rk = 0;
@@ -227,17 +268,11 @@ __device__ __forceinline__ void attn_bi_fwd_body(const BiArgs& a) {
   auto issue = [&](int it, int st) {
     const int j0 = sc.block(it) * 32;
     const unsigned base = lds0 + st * STG_DQ;
-    const bf16_t* src = qb ? kb_ : vb_;
-    const int ld = qb ? a.ldk : a.ldv;
     const unsigned dst = base + (qb ? ST_A : ST_B) + bl * 4096;
+    const unsigned s0 = (unsigned)(j0 * ldkv) * 2u, sp = (unsigned)ldkv * 16u;
 #pragma unroll
-    for (int piece = 0; piece < 4; ++piece) {
-      const int row = piece * 8 + r8;
-      const int c = cp ^ vx_swz(row);
-      const int jr = min(j0 + row, a.S - 1);
-      lds_dma16_gs(src, (jr * ld + c * 8) * 2, dst + piece * 1024);
-    }
-    if (bl < 2) db_stage(db_, bl, q0 + qb * 32, a.T - 1, a.Sp, j0, lane, base + ST_D + qb * 2048);
+    for (int piece = 0; piece < 4; ++piece) lds_dma16_bs(rsKV, dst + piece * 1024, (piece & 1) ? vo : ve, s0 + piece * sp);
+    if (bl < 2) lds_dma16_bs(rsD, base + ST_D + qb * 2048 + bl * 1024, vD, (unsigned)j0 * 2u);
   };
   f32x16 oacc[2];
 #pragma unroll
@@ -301,7 +336,12 @@ __device__ __forceinline__ void attn_bi_fwd_body(const BiArgs& a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) m4[e & 3] = fmaxf(m4[e & 3], s[e]);
     float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32)) * LOG2E;
+    {
+      // the row's other 16 keys sit in lane ^ 32: v_permlane32_swap hands both halves their partner's value in one VALU
+      // instruction (__shfl_xor is a ds_bpermute: an LDS round trip + s_waitcnt lgkmcnt(0) in the block's dependent chain)
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * LOG2E;
+    }
     if (__builtin_amdgcn_ballot_w64(mx > m_run + LAZY_MAX_SLACK)) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == NEG_INF) ? 0.f : m_new));
@@ -408,21 +448,21 @@ __device__ __forceinline__ void attn_bi_dq_body(const BiArgs& a) {
   // staging of block `it` into stage st: the four 1-KiB pieces of ONE operand tile of this wave's batch element (group 0:
   // V, group 1: K) and a quarter of this group's bias tile.  Lane l of a piece = row 8 p + (l >> 3), 16-byte position
   // l & 7, which holds source chunk (l & 7) ^ swizzle(row).
-  const int r8 = lane >> 3, cp = lane & 7;
+  const int ldkv = qb ? a.ldk : a.ldv;
+  const bi_v4i32 rsKV = bi_rsrc(qb ? kb_ : vb_, (unsigned)(((long long)(a.S - 1) * ldkv + 64) * 2));
+  const bi_v4i32 rsD = bi_rsrc(db_, (unsigned)((long long)a.Tp * a.Sp * 2));
+  // (three loop-invariant per-lane offsets: this kernel has the registers -- 176 of 256 at two waves per SIMD)
+  unsigned ve, vo;
+  tile_voff(lane, ldkv, ve, vo);
+  const unsigned vD = db_voff(bl & 1, q0 + qb * 32, a.T - 1, a.Sp, 0, lane);
   auto issue = [&](int it, int st) {
     const int j0 = sc.block(it) * 32;
     const unsigned base = lds0 + st * STG_DQ;
-    const bf16_t* src = qb ? kb_ : vb_;
-    const int ld = qb ? a.ldk : a.ldv;
     const unsigned dst = base + (qb ? ST_A : ST_B) + bl * 4096;
+    const unsigned s0 = (unsigned)(j0 * ldkv) * 2u, sp = (unsigned)ldkv * 16u;
 #pragma unroll
-    for (int piece = 0; piece < 4; ++piece) {
-      const int row = piece * 8 + r8;
-      const int c = cp ^ vx_swz(row);
-      const int jr = min(j0 + row, a.S - 1);
-      lds_dma16_gs(src, (jr * ld + c * 8) * 2, dst + piece * 1024);
-    }
-    if (bl < 2) db_stage(db_, bl, q0 + qb * 32, a.T - 1, a.Sp, j0, lane, base + ST_D + qb * 2048);
+    for (int piece = 0; piece < 4; ++piece) lds_dma16_bs(rsKV, dst + piece * 1024, (piece & 1) ? vo : ve, s0 + piece * sp);
+    if (bl < 2) lds_dma16_bs(rsD, base + ST_D + qb * 2048 + bl * 1024, vD, (unsigned)j0 * 2u);
   };
 
   f32x16 dq[2];
@@ -612,27 +652,26 @@ __device__ __forceinline__ void attn_bi_dkv_body(const BiArgs& a) {
   const float* eb_ = a.delta + ((long long)bc * a.H + h) * a.T;
   const bf16_t* db_ = a.D + (long long)h * a.Tp * a.Sp;
   const unsigned lds0 = lds_addr(smem);
-  const int r8 = lane >> 3, cp = lane & 7;
+  // group 0: the Q tile, group 1: the dO tile of this wave's batch element (rows 0 .. T-1, 64 columns of head h)
+  const int ldqo = kbw ? a.lddo : a.ldq;
+  const bi_v4i32 rsQO = bi_rsrc(kbw ? ob_ : qb_, (unsigned)(((long long)(a.T - 1) * ldqo + 64) * 2));
+  const bi_v4i32 rsD = bi_rsrc(db_, (unsigned)((long long)a.Tp * a.Sp * 2));
+  unsigned ve, vo;                                            // (loop-invariant per-lane offsets, see tile_voff / db_voff)
+  tile_voff(lane, ldqo, ve, vo);
+  const int jc = min(k0 + kbw * 32, a.Sp - 32);              // (a key block entirely in the padding: any valid address)
+  const unsigned vD = db_voff(bl & 1, 0, 0x7fffffff, a.Sp, jc, lane);
   auto issue = [&](int it, int st) {
     const int i0 = sc.block(it) * 32;
     const unsigned base = lds0 + st * STG_DKV;
-    // group 0: the Q tile, group 1: the dO tile of this wave's batch element; a quarter of this group's bias tile
-    const bf16_t* src = kbw ? ob_ : qb_;
-    const int ld = kbw ? a.lddo : a.ldq;
     const unsigned dst = base + (kbw ? ST_B : ST_A) + bl * 4096;
+    const unsigned s0 = (unsigned)(i0 * ldqo) * 2u, sp = (unsigned)ldqo * 16u;
 #pragma unroll
-    for (int piece = 0; piece < 4; ++piece) {
-      const int row = piece * 8 + r8;
-      const int c = cp ^ vx_swz(row);
-      const int ir = min(i0 + row, a.T - 1);
-      lds_dma16_gs(src, (ir * ld + c * 8) * 2, dst + piece * 1024);
-    }
+    for (int piece = 0; piece < 4; ++piece) lds_dma16_bs(rsQO, dst + piece * 1024, (piece & 1) ? vo : ve, s0 + piece * sp);
     if (bl < 2) {
       // bias tile [32 queries][32 keys of key block kbw].  The accumulators want four CONSECUTIVE QUERIES of one key per lane --
       // a column of this tile: read with the hardware transpose (ds_read_b64_tr_b16), four 8-byte reads per block.  (The
       // fp32 tile of round 4 served them with sixteen 4-byte reads; before that a second, transposed copy of the bias in HBM.)
-      const int jc = min(k0 + kbw * 32, a.Sp - 32);          // (a key block entirely in the padding: any valid address)
-      db_stage(db_, bl, i0, 0x7fffffff, a.Sp, jc, lane, base + ST_D + kbw * 2048);
+      lds_dma16_bs(rsD, base + ST_D + kbw * 2048 + bl * 1024, vD, (unsigned)(i0 * a.Sp) * 2u);
     }
     if (kbw == 0) {
       // lanes 0..31: lse, lanes 32..63: delta of this wave's batch element (LDS-DMA places lane i at base + 4 i)
