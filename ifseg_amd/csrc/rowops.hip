@@ -20,6 +20,13 @@ struct RowMap {  // logical row r -> element offset  (r / rpb) * bs + (r % rpb) 
     return rpb > 0 ? (long long)(r / rpb) * bs + (long long)(r % rpb) * ld : (long long)r * ld;
   }
 };
+// host side: a [B, rpb, C] view whose batches follow each other without a gap (bs == rpb * ld: every full-width activation
+// tensor of the engine) is the plain map r -> r * ld.  The kernels branch on rpb (uniform): the plain map skips an integer
+// division by a run-time value + 64-bit multiply-adds -- ~28 dependent VALU instructions per operand and ROW in front of the row's
+// first load (4-5 operands per LayerNorm launch).  Round 6.
+static inline RowMap row_map(int rpb, long long bs, int ld) {
+  return (rpb > 0 && bs == (long long)rpb * ld) ? RowMap{0, 0, ld} : RowMap{rpb, bs, ld};
+}
 
 __device__ __forceinline__ float gelu_f(float x) {
   return 0.5f * x * (1.f + erf_as(x, __expf(-0.5f * x * x)));
@@ -679,7 +686,7 @@ static int ln_fwd_impl(const void* x, const void* gamma, const void* beta, const
     if (drop->p < 0.f || drop->p >= 1.f || drop->rows_per_batch <= 0) return IFSEG_ERR_BAD_ARG;
     dr = DropArgs{1, drop->p, drop->seed, drop->drop_path_scale, drop->rows_per_batch, drop->seed_add};
   }
-  RowMap mx{rpb, x_bs, ldx}, my{rpb, y_bs, ldy}, mr{rpb, r_bs, ldr}, my2{rpb, y2_bs, ldy2};
+  RowMap mx = row_map(rpb, x_bs, ldx), my = row_map(rpb, y_bs, ldy), mr = row_map(rpb, r_bs, ldr), my2 = row_map(rpb, y2_bs, ldy2);
   dim3 g((rows + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
   const bf16_t *X = (const bf16_t*)x, *G = (const bf16_t*)gamma, *Bt = (const bf16_t*)beta, *R = (const bf16_t*)resid;
@@ -726,7 +733,7 @@ extern "C" int ifseg_ln_bwd(const void* dy, const void* x, const void* gamma, co
     if (drop->p < 0.f || drop->p >= 1.f || drop->rows_per_batch <= 0) return IFSEG_ERR_BAD_ARG;
     dr = DropArgs{1, drop->p, drop->seed, drop->drop_path_scale, drop->rows_per_batch, drop->seed_add};
   }
-  RowMap mdy{rpb, dy_bs, lddy}, mx{rpb, x_bs, ldx}, mdx{rpb, dx_bs, lddx}, madd{rpb, add_bs, ldadd};
+  RowMap mdy = row_map(rpb, dy_bs, lddy), mx = row_map(rpb, x_bs, ldx), mdx = row_map(rpb, dx_bs, lddx), madd = row_map(rpb, add_bs, ldadd);
   dim3 g(nblocks);
   hipStream_t s = (hipStream_t)stream;
   const bf16_t *DY = (const bf16_t*)dy, *X = (const bf16_t*)x, *G = (const bf16_t*)gamma, *A = (const bf16_t*)dx_add;
@@ -756,7 +763,7 @@ extern "C" int ifseg_ln_bwd_drop(const void* dy, const void* x, const void* gamm
     if (drop2->p < 0.f || drop2->p >= 1.f || drop2->rows_per_batch <= 0) return IFSEG_ERR_BAD_ARG;
     dr = DropArgs{1, drop2->p, drop2->seed, drop2->drop_path_scale, drop2->rows_per_batch, drop2->seed_add};
   }
-  RowMap mdy{rpb, dy_bs, lddy}, mx{rpb, x_bs, ldx}, mdx{rpb, dx_bs, lddx}, madd{rpb, add_bs, ldadd}, mdx2{rpb, dx2_bs, lddx2};
+  RowMap mdy = row_map(rpb, dy_bs, lddy), mx = row_map(rpb, x_bs, ldx), mdx = row_map(rpb, dx_bs, lddx), madd = row_map(rpb, add_bs, ldadd), mdx2 = row_map(rpb, dx2_bs, lddx2);
   hipStream_t s = (hipStream_t)stream;
   ifseg_prof_begin(IFSEG_K_LN_BWD, s, 0, (double)rows * C * (dx_add ? 10.0 : 8.0));
   hipLaunchKernelGGL((ln_bwd_lean_kernel<2, true>), dim3(nblocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
@@ -837,7 +844,7 @@ extern "C" int ifseg_colsum_bf16(const void* x, float* part, int nblk_rows, int 
   (void)hipGetLastError();
   if (M <= 0) return 0;
   if (N & 7) return IFSEG_ERR_BAD_SHAPE;
-  RowMap mx{rpb, x_bs, ldx};
+  RowMap mx = row_map(rpb, x_bs, ldx);
   const int rows_per_blk = (M + nblk_rows - 1) / nblk_rows;
   dim3 g((N / 8 + 255) / 256, nblk_rows);
   hipLaunchKernelGGL(colsum_kernel, g, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, part, M, N, mx, rows_per_blk);
@@ -884,7 +891,7 @@ extern "C" int ifseg_embed_rows(const void* table, const long long* ids, const v
   (void)hipGetLastError();
   if (n <= 0) return 0;
   if (C & 7) return IFSEG_ERR_BAD_SHAPE;
-  RowMap mo{rpb, o_bs, ldo};
+  RowMap mo = row_map(rpb, o_bs, ldo);
   const long long total = (long long)n * (C / 8);
   hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)table, ids, (const bf16_t*)add, (bf16_t*)out, n, C, mo);
@@ -928,7 +935,7 @@ extern "C" int ifseg_embed_bag_mean(const void* table, const long long* ids, con
   (void)hipGetLastError();
   if (B <= 0 || P <= 0) return 0;
   if ((C & 7) || maxlen <= 0) return IFSEG_ERR_BAD_SHAPE;
-  RowMap mo{rpb, o_bs, ldo};
+  RowMap mo = row_map(rpb, o_bs, ldo);
   const long long total = (long long)B * P * (C / 8);
   hipLaunchKernelGGL(embed_bag_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)table, ids, ends, (const bf16_t*)add, (bf16_t*)out, B, P, C, maxlen, mo);
@@ -1147,7 +1154,7 @@ extern "C" int ifseg_dropout(const void* x, const void* resid, void* out, long l
   if (rows <= 0) return 0;
   if ((C & 7) || p < 0.f || p >= 1.f || rows_per_batch <= 0) return IFSEG_ERR_BAD_ARG;
   const long long nchunks = rows * (C / 8);
-  RowMap mx{rpb, x_bs, ldx}, mr{rpb, r_bs, ldr}, mo{rpb, o_bs, ldo};
+  RowMap mx = row_map(rpb, x_bs, ldx), mr = row_map(rpb, r_bs, ldr), mo = row_map(rpb, o_bs, ldo);
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, (const bf16_t*)resid, (bf16_t*)out, nchunks, C, p, seed, drop_path_scale, rows_per_batch,
                      mx, mr, mo, seed_add);
