@@ -469,7 +469,7 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, int M, i
                      int lda, int ldb, int ldc, const void* bias, float alpha, int alpha_ncols,
                      const void* resid, int ldr, int flags, int batch, long long strideA,
                      long long strideB, long long strideC, long long strideR, int splitk, void* stream,
-                     const void* dot, int ldd, float* dot_out, int dot_T) {
+                     const void* dot, int ldd, float* dot_out, int dot_T, int prof_kind = -1) {
   (void)hipGetLastError();
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if ((N & 7) || (lda & 7) || (ldb & 7) || (ldc & 3) || (resid && (ldr & 3))) return IFSEG_ERR_BAD_SHAPE;
@@ -518,7 +518,8 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, int M, i
   if (layout < 0 || layout > 2) return IFSEG_ERR_BAD_ARG;
   if ((flags & IFSEG_GEMM_COLSUM) && layout != IFSEG_GEMM_TN) return IFSEG_ERR_BAD_ARG;
   const double nb = batch > 0 ? batch : 1;
-  ifseg_prof_begin(IFSEG_K_GEMM_NT + layout, s, 2.0 * M * N * K * nb, 2.0 * nb * ((double)M * K + (double)N * K + (double)M * N));
+  const int pk = prof_kind >= 0 ? prof_kind : IFSEG_K_GEMM_NT + layout;
+  ifseg_prof_begin(pk, s, 2.0 * M * N * K * nb, 2.0 * nb * ((double)M * K + (double)N * K + (double)M * N));
   const bool two_stage = (long long)tiles * g.splitk * (batch > 0 ? batch : 1) <= two_stage_max();
 #define LAUNCH2(AM, BKS, BNV)                                                                        \
   do {                                                                                               \
@@ -542,7 +543,7 @@ static int gemm_impl(int layout, const void* A, const void* B, void* C, int M, i
       }
       break;
   }
-  ifseg_prof_end(IFSEG_K_GEMM_NT + layout, s);
+  ifseg_prof_end(pk, s);
   IFSEG_CHECK_LAUNCH();
   return 0;
 }
@@ -635,6 +636,13 @@ extern "C" int ifseg_conv2d_nhwc_bf16(const void* in, const void* w, const void*
                                       int stride, int pad, int relu, void* stream) {
   (void)hipGetLastError();
   if ((Cin % 64) || (Cout & 7)) return IFSEG_ERR_BAD_SHAPE;
+  if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {
+    // a 1x1 stride-1 convolution on an NHWC image IS the F.linear product out[B H W, Cout] = in[B H W, Cin] . w[Cout, Cin]^T: the
+    // plain k-contiguous loader (k offset in the DMA's scalar offset, no per-piece bounds test or tap arithmetic), same tiles, same
+    // epilogue, same bits -- two of the three convolutions of every bottleneck (resnet.py:117-137).  Round 6.
+    return gemm_impl(IFSEG_GEMM_NT, in, w, out, B * H * W, Cout, Cin, Cin, Cin, Cout, shift, 1.f, 0, resid, Cout,
+                     relu ? IFSEG_GEMM_RELU : 0, 1, 0, 0, 0, 0, 1, stream, nullptr, 0, nullptr, 0, IFSEG_K_CONV);
+  }
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   GemmArgs g{};
   g.A = (const bf16_t*)in; g.B = (const bf16_t*)w; g.C = out;
