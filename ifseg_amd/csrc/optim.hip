@@ -107,7 +107,9 @@ extern "C" int ifseg_adam_step(float* p32, const void* g, float* m, float* v, vo
   (void)hipGetLastError();
   if (n <= 0) return 0;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, p32, (const bf16_t*)g, m, v,
+  // grid: two blocks per CU.  Sweep on MI355X over 109 M parameters (tools/adam_bench.py, profiles/round6_adam_grid.txt): 256 blocks
+  // 789 us, 512: 573, 768: 578, 1024: 588, 1536: 618, 2048 (until round 6): 620, 4096: 620 -- 5.33 TB/s against a torch copy's 5.0
+  hipLaunchKernelGGL(adam_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, p32, (const bf16_t*)g, m, v,
                      (bf16_t*)p16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, max_norm, sumsq, overflow, hyper);
   IFSEG_CHECK_LAUNCH();
   return 0;
