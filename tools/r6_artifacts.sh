@@ -1,6 +1,6 @@
 #!/bin/bash
 # everything profiles/round6_* of the final state is made from, in one gpurun call (tools/r6_collect.sh copies it into profiles/)
-# the tree that runs is commit 0484458 (+ this script)
+# the tree that runs is commit 013818c (+ this script)
 o=gpurun_out/r6_final; rm -rf $o; mkdir -p $o
 R=$GRAFT_REPO_ROOT
 timeout 2400 python -m pytest tests -m gpu -x -q > $o/pytest_gpu.txt 2>&1; tail -3 $o/pytest_gpu.txt
@@ -9,7 +9,7 @@ bash tools/pmc_traffic.sh > /dev/null 2>&1
 python tools/pmc_step_traffic.py gpurun_out/pmc_traffic/rd gpurun_out/pmc_traffic/wr > $o/step_traffic.txt 2>&1; head -3 $o/step_traffic.txt
 python - <<PY
 import json
-d = json.load(open("gpurun_out/hbm_traffic.json")); d["_collected_at"] = "0484458"
+d = json.load(open("gpurun_out/hbm_traffic.json")); d["_collected_at"] = "013818c"
 json.dump(d, open("profiles/round6_hbm_traffic.json", "w"), indent=1)
 PY
 cp profiles/round6_hbm_traffic.json $o/hbm_traffic.json
